@@ -1,0 +1,251 @@
+/*
+ * sbq.h -- C ABI of libsbq.so: the MI355X (gfx950) fake-quantization hot path.
+ *
+ * This is the drop-in boundary for Sparsebit's Quantizer/Observer/masker path.
+ * Every entry point takes raw DEVICE pointers, plain sizes and a hipStream_t
+ * (passed as void*); the caller owns and allocates every buffer (the library
+ * never allocates, frees or retains a pointer) and all launches are
+ * asynchronous on `stream`.  Every function returns an sbq_status (0 == OK).
+ *
+ * Reference interfaces replaced (paths relative to the Sparsebit tree):
+ *   - pybind module `fake_quant` (sparsebit/quantization/torch_extensions/
+ *     export.cc:3-8, fake_quant_tensor.h:9-36): the four functions
+ *     quant_pertensor_forward / quant_perchannel_forward /
+ *     quant_pertensor_backward / quant_perchannel_backward.
+ *   - the torch-op bodies of the observers
+ *     (sparsebit/quantization/observers/{base,minmax,mse,percentile}.py),
+ *     LSQ's init (sparsebit/quantization/quantizers/lsq.py:32-51) and the
+ *     unstructured L1 masker (sparsebit/sparse/sparsers/l1norm.py:14-26),
+ *     which have no native form in the reference.
+ *   - pybind module `cuda_kernel` vecquant4matmul / vecgroupquant4matmul
+ *     (large_language_models/llama/quantization/cuda/cuda_kernel.cpp:6-23).
+ *
+ * Tensor geometry.  A contiguous tensor quantized along `ch_axis` is described
+ * as [outer, C, inner]: C = shape[ch_axis], inner = prod(shape[ch_axis+1:]),
+ * outer = prod(shape[:ch_axis]).  Element i belongs to channel (i / inner) % C
+ * (the indexing of fake_quant_tensor.cu:181).  Per-tensor == C 1.
+ */
+#ifndef SBQ_H_
+#define SBQ_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+#pragma GCC visibility push(default)
+
+#define SBQ_VERSION 100 /* 0.1.0 */
+
+/* element types of data tensors */
+enum { SBQ_F32 = 0, SBQ_F16 = 1, SBQ_BF16 = 2 };
+/* type of the optional integer output of the forward QDQ */
+enum { SBQ_Q_NONE = 0, SBQ_Q_I8 = 1, SBQ_Q_I32 = 2 };
+/* rounding of x/scale: common.cuh:13-15,64-77 (Python always passes 0) */
+enum { SBQ_ROUND_HALF_EVEN = 0, SBQ_ROUND_HALF_UP = 1, SBQ_ROUND_HALF_DOWN = 2 };
+
+typedef enum {
+  SBQ_OK = 0,
+  SBQ_ERR_DTYPE = 1,     /* unsupported dtype (ref: ValueTypeException, common.cuh:45-49) */
+  SBQ_ERR_EMPTY = 2,     /* numel == 0 (ref: InvalidValueException, common.cuh:50-54) */
+  SBQ_ERR_NULL = 3,      /* required pointer is NULL */
+  SBQ_ERR_ARG = 4,       /* inconsistent sizes / ranges */
+  SBQ_ERR_WORKSPACE = 5, /* workspace too small or misaligned */
+  SBQ_ERR_LAUNCH = 6,    /* hipGetLastError() != hipSuccess after launch */
+  SBQ_ERR_ALIGN = 7      /* pointer not aligned to its element size */
+} sbq_status;
+
+int sbq_version(void);
+const char* sbq_strerror(int status);
+/* name of the last HIP error seen by this thread's failed launch ("" if none) */
+const char* sbq_last_hip_error(void);
+
+/* number of MSE shrink candidates (observers/mse.py:46: `for i in range(80)`) */
+#define SBQ_MSE_CANDIDATES 80
+/* radix-select digit: 3 passes of 11+11+10 bits over the 32-bit key */
+#define SBQ_RADIX_BINS 2048
+
+/* ------------------------------------------------------------------ *
+ * 1. Forward quantize-dequantize
+ *    y = (clamp(round(x / s) + round(zp), qmin, qmax) - round(zp)) * s
+ *    replaces fake_quant_tensor.cu:50-94 (per tensor), :170-224 (per channel);
+ *    arithmetic follows the CPU path quant_tensor.py:182-184 (zp rounded
+ *    half-to-even, everything in fp32).
+ *
+ *    x        data, dtype x_dtype, outer*C*inner elements
+ *    y        dequantized output, y_dtype == SBQ_F32 or == x_dtype (RNE cast)
+ *    q        optional integer tensor (NULL with SBQ_Q_NONE); SBQ_Q_I8 stores
+ *             the low 8 bits (needs qmax - qmin <= 255), SBQ_Q_I32 an int32
+ *    scale, zero_point   fp32, C elements (1 for per tensor)
+ * ------------------------------------------------------------------ */
+int sbq_quant_pertensor_forward(const void* x, int x_dtype, void* y, int y_dtype,
+                                void* q, int q_type,
+                                const float* scale, const float* zero_point,
+                                int64_t numel, int qmin, int qmax, int rounding,
+                                void* stream);
+
+int sbq_quant_perchannel_forward(const void* x, int x_dtype, void* y, int y_dtype,
+                                 void* q, int q_type,
+                                 const float* scale, const float* zero_point,
+                                 int64_t outer, int64_t C, int64_t inner,
+                                 int qmin, int qmax, int rounding, void* stream);
+
+/* Fused unstructured mask + QDQ: y = qdq(keep ? x : 0).
+ * keep = mask[i] != 0 when `mask` (1 byte/elem, torch.bool) is given, else
+ * keep = |x| > *thresh  (l1norm.py:24-25, strict).  Exactly one of mask/thresh
+ * must be non-NULL.  Replaces `weight * w_mask` (sparse/modules/conv.py:40,
+ * linear.py:31) followed by the weight quantizer. */
+int sbq_mask_quant_forward(const void* x, int x_dtype, void* y, int y_dtype,
+                           void* q, int q_type,
+                           const uint8_t* mask, const float* thresh,
+                           const float* scale, const float* zero_point,
+                           int64_t outer, int64_t C, int64_t inner,
+                           int qmin, int qmax, int rounding, void* stream);
+
+/* ------------------------------------------------------------------ *
+ * 2. Backward of the straight-through estimator (STE / LSQ)
+ *    replaces fake_quant_tensor.cu:97-167 and :227-308; semantics follow
+ *    MySTE.backward (quant_tensor.py:45-71) == kernel K3:
+ *      v  = round(x/s) + round(zp)
+ *      gx = qmin <= v <= qmax ? gy : 0
+ *      gs[c]  = sum gy * (v<qmin ? qmin-zp : v>qmax ? qmax-zp : round(x/s)-x/s)
+ *      gzp[c] = sum (qmin <= v <= qmax) ? 0 : -s*gy
+ *    gs/gzp may be NULL (not needed); both are fp32 with C elements and are
+ *    fully written (no pre-zeroing needed).  x, gy share x_dtype; gx has
+ *    gx_dtype (F32 or x_dtype).  workspace: sbq_backward_workspace_bytes().
+ * ------------------------------------------------------------------ */
+size_t sbq_backward_workspace_bytes(int64_t outer, int64_t C, int64_t inner);
+
+int sbq_quant_pertensor_backward(const void* x, const void* gy, int x_dtype,
+                                 void* gx, int gx_dtype, float* gs, float* gzp,
+                                 const float* scale, const float* zero_point,
+                                 int64_t numel, int qmin, int qmax, int rounding,
+                                 void* workspace, size_t workspace_bytes, void* stream);
+
+int sbq_quant_perchannel_backward(const void* x, const void* gy, int x_dtype,
+                                  void* gx, int gx_dtype, float* gs, float* gzp,
+                                  const float* scale, const float* zero_point,
+                                  int64_t outer, int64_t C, int64_t inner,
+                                  int qmin, int qmax, int rounding,
+                                  void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------ *
+ * 3. Observer reductions
+ * ------------------------------------------------------------------ */
+
+/* Per-channel statistics in one pass over x: min, max (NaN-propagating like
+ * torch.min/max; observers/minmax.py:14-25) and sum|x| in fp64 (LSQ init,
+ * lsq.py:44-47).  Any of the three outputs may be NULL.  C == 1: per tensor. */
+size_t sbq_stats_workspace_bytes(int64_t outer, int64_t C, int64_t inner);
+int sbq_channel_stats(const void* x, int x_dtype,
+                      int64_t outer, int64_t C, int64_t inner,
+                      float* min_out, float* max_out, double* abssum_out,
+                      void* workspace, size_t workspace_bytes, void* stream);
+
+/* scale / zero_point from min / max, observers/base.py:63-79:
+ *   symmetric: s = max(max(-min(min,0), max(max,0)) * 2 / (qmax-qmin), 1e-6), zp = 0
+ *   affine:    s = max((max(max,0) - min(min,0)) / (qmax-qmin), 1e-6),
+ *              zp = round(-min(min,0) / s)                                   */
+int sbq_qparams_from_minmax(const float* min_val, const float* max_val, int64_t C,
+                            int qmin, int qmax, int symmetric,
+                            float* scale_out, float* zero_point_out, void* stream);
+
+/* LSQ init: scale[c] = 2 * (abssum[c] / count) / sqrt(qmax)   (lsq.py:44-47) */
+int sbq_lsq_init_scale(const double* abssum, int64_t C, double count, int qmax,
+                       float* scale_out, void* stream);
+
+/* MSE observer (observers/mse.py:28-63).  Step 1 accumulates, for each channel
+ * and each of the 80 shrink candidates i, the sum of squared QDQ errors of this
+ * rank's data into sse[C][80] (fp64, ADDED to what is there: zero it first;
+ * all-reduce it across ranks with SUM between the two steps).  Step 2 picks,
+ * per channel, the first candidate with strictly smaller loss (fp32 loss =
+ * sse / count) and writes its scale / zero_point / index. */
+size_t sbq_mse_workspace_bytes(int64_t outer, int64_t C, int64_t inner);
+int sbq_mse_accumulate(const void* x, int x_dtype,
+                       int64_t outer, int64_t C, int64_t inner,
+                       const float* min_val, const float* max_val,
+                       int qmin, int qmax, int symmetric,
+                       double* sse, void* workspace, size_t workspace_bytes,
+                       void* stream);
+int sbq_mse_select(const double* sse, double count_per_channel,
+                   const float* min_val, const float* max_val, int64_t C,
+                   int qmin, int qmax, int symmetric,
+                   float* scale_out, float* zero_point_out, int32_t* best_index_out,
+                   void* stream);
+
+/* ------------------------------------------------------------------ *
+ * 4. Order statistics (percentile observer, unstructured-mask threshold)
+ *
+ * Keys: a float is mapped to a uint32 whose unsigned order equals the float
+ * order (-0 == +0, NaN largest like torch.kthvalue / torch.sort); with
+ * use_abs != 0 the key is that of |x|.
+ * ------------------------------------------------------------------ */
+
+/* Fast path, rows resident on chip: x is [C, inner] (inner <= SBQ_ROWSEL_MAX),
+ * one workgroup per row.  observers/percentile.py:16-46:
+ *   pos = count(x >= 0), neg = count(x < 0)
+ *   max[c] = pos ? kth(row, inner - max(round(pos*alpha), 0)) : 0
+ *   min[c] = neg ? kth(row, max(round(neg*alpha), 1))         : 0
+ * (k is 1-indexed k-th smallest; round == Python round, half to even). */
+#define SBQ_ROWSEL_MAX 16384
+int sbq_percentile_rows(const void* x, int x_dtype, int64_t C, int64_t inner,
+                        double alpha, float* min_out, float* max_out, void* stream);
+
+/* General path (any size, any [outer, C, inner] geometry, shardable):
+ * three-pass radix select.  Per pass the caller
+ *   1. zeroes hist (int64 [C][n_sel][SBQ_RADIX_BINS]),
+ *   2. calls sbq_radix_histogram on its shard (adds into hist),
+ *   3. (multi-GPU) all-reduces hist with SUM,
+ *   4. calls sbq_radix_advance, which picks each selector's bin and updates its
+ *      state {prefix, remaining k}.
+ * State is int64 [C][n_sel][2] = {prefix key bits found so far, k still to
+ * skip (1-indexed within the prefix bucket)}; initialise prefix = 0, k = rank.
+ * After pass 2 the prefix is the full 32-bit key; sbq_radix_finish converts it
+ * back to float.  n_sel selectors share one read of the data per pass (2 for
+ * percentile min+max, 1 for the mask threshold). */
+int sbq_radix_histogram(const void* x, int x_dtype,
+                        int64_t outer, int64_t C, int64_t inner,
+                        int use_abs, int pass, int n_sel, const int64_t* state,
+                        int64_t* hist, void* stream);
+int sbq_radix_advance(const int64_t* hist, int64_t C, int pass, int n_sel,
+                      int64_t* state, void* stream);
+int sbq_radix_finish(const int64_t* state, int64_t C, int n_sel, int use_abs,
+                     float* values_out /* [C][n_sel] */, void* stream);
+
+/* counts per channel: neg = count(x < 0), pos = count(x >= 0) (int64 [C] each,
+ * ADDED into the outputs) -- percentile.py:27-28 */
+int sbq_sign_counts(const void* x, int x_dtype, int64_t outer, int64_t C, int64_t inner,
+                    int64_t* neg_out, int64_t* pos_out, void* stream);
+
+/* mask[i] = |x[i]| > *thresh  (1 byte per element; l1norm.py:24-25) */
+int sbq_mask_from_threshold(const void* x, int x_dtype, int64_t numel,
+                            const float* thresh, uint8_t* mask_out, void* stream);
+
+/* ------------------------------------------------------------------ *
+ * 5. GPTQ 4-bit grouped mat-vec (config 4)
+ *    out[b,n] += sum_k (scales[n,g(k)] * nib(k,n) - zeros[n,g(k)]) * x[b,k]
+ *    replaces vecquant4matmul_cuda (cuda_kernel_4bit.cu:36-180).
+ *    qweight int32 [in/8, out] (8 input-channel nibbles per word, low first;
+ *    quant.py:187-260), scales/zeros fp32 [out, groups], x fp32 [batch, in],
+ *    out fp32 [batch, out] pre-filled with the bias (quant.py:285-289) and
+ *    accumulated in place.  group_size 0 == one group (cuda_kernel.cpp:10-16).
+ * ------------------------------------------------------------------ */
+size_t sbq_gptq_workspace_bytes(int64_t batch, int64_t in_features, int64_t out_features);
+int sbq_vecquant4matmul(const float* x, const int32_t* qweight, float* out,
+                        const float* scales, const float* zeros,
+                        int64_t batch, int64_t in_features, int64_t out_features,
+                        int64_t group_size,
+                        void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------ *
+ * 6. Launch tuning (benchmarks only; defaults are chosen per shape)
+ * ------------------------------------------------------------------ */
+/* knob 0: forward-QDQ variant override (-1 = auto). knob 1: grid cap (0 = auto) */
+int sbq_set_tuning(int knob, int value);
+
+#pragma GCC visibility pop
+#ifdef __cplusplus
+}
+#endif
+#endif /* SBQ_H_ */

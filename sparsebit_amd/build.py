@@ -1,0 +1,83 @@
+"""Ahead-of-time build of libsbq.so (HIP, gfx950 only) -- no import-time JIT.
+
+The reference JIT-compiles its extension when the package is imported
+(sparsebit/quantization/quantizers/quant_tensor.py:7-22); here the shared
+library is built once, in-tree, by `python -m sparsebit_amd.build` (or
+`__graft_entry__.build()`), and `sparsebit_amd.lib` only ever dlopens it.
+"""
+import concurrent.futures
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(CSRC, "build")
+LIB = os.path.join(HERE, "libsbq.so")
+ARCH = "gfx950"
+
+# -ffp-contract=off: the parity contract is op-for-op IEEE fp32 (no fused
+# multiply-add may be formed across the reference's separate torch ops).
+FLAGS = [
+    "--offload-arch=" + ARCH,
+    "-O3",
+    "-std=c++17",
+    "-ffp-contract=off",
+    "-fPIC",
+    "-fvisibility=hidden",
+    "-Wall",
+    "-Wno-unused-function",
+]
+
+
+def _hipcc():
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found: libsbq.so cannot be built")
+    return exe
+
+
+def sources():
+    return sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=True):
+    os.makedirs(OBJ, exist_ok=True)
+    hipcc = _hipcc()
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")]
+    headers.append(os.path.join(HERE, "..", "include", "sbq.h"))
+    headers.append(os.path.abspath(__file__))
+    jobs = []
+    objs = []
+    for src in sources():
+        obj = os.path.join(OBJ, src[:-4] + ".o")
+        objs.append(obj)
+        if force or _stale(obj, [os.path.join(CSRC, src)] + headers):
+            jobs.append([hipcc] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed:\n" + r.stdout)
+        if verbose and r.stdout.strip():
+            print(r.stdout)
+
+    with concurrent.futures.ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
+        list(ex.map(run, jobs))
+    if force or jobs or _stale(LIB, objs):
+        run([hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

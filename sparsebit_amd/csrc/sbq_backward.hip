@@ -1,0 +1,182 @@
+// sbq_backward.hip -- backward of the fake-quant straight-through estimator
+// (STE / LSQ) for gfx950.
+//
+// Replaces QuantizePerTensorBackwardCUDA / QuantizePerChannelBackwardCUDA
+// (sparsebit/quantization/torch_extensions/fake_quant_tensor.cu:97-132,227-270).
+// Semantics are those of the per-tensor kernel K3 == the pure-torch restatement
+// MySTE.backward (quant_tensor.py:45-71):
+//     v   = round(x/s) + round(zp)
+//     gx  = (qmin <= v <= qmax) ? gy : 0
+//     gs += gy * (v < qmin ? qmin - zp : v > qmax ? qmax - zp : round(x/s) - x/s)
+//     gzp += (qmin <= v <= qmax) ? 0 : -s * gy
+// Deliberate differences from the reference CUDA code, which is not a usable
+// oracle here: (1) its BlockReduceSum sits inside divergent grid-stride loops and
+// assumes 32-lane warps (UB on any GPU, wrong on wave64); (2) the per-channel
+// kernel tests `vq < qmax` for gzp (off by one vs the per-tensor `<=`,
+// fake_quant_tensor.cu:264 vs :127) -- we use `<=` in both; (3) it accumulates
+// with float atomicAdd onto one scalar (non-deterministic) -- here every chunk
+// writes one fp64 partial and a second kernel folds them in a fixed order.
+#include "sbq_common.hpp"
+
+namespace sbq {
+namespace {
+
+constexpr uint32_t kBwdChunk = kBlock * kPack * 4;  // 8192 elements per workgroup
+
+struct GradPartial {
+  double gs, gzp;
+};
+
+template <typename T, typename Tg, bool VEC>
+__global__ __launch_bounds__(kBlock) void ste_backward_kernel(
+    const void* __restrict__ x, const void* __restrict__ gy, void* __restrict__ gx,
+    const float* __restrict__ scale, const float* __restrict__ zero_point,
+    GradPartial* __restrict__ part, const ChunkGeom g, float qlo, float qhi, int rounding) {
+  __shared__ double s_d[kWavesPerBlock];
+  const uint32_t bid = blockIdx.x;
+  const ChunkPos cp = chunk_pos(g, bid);
+  const float s = scale[cp.c];
+  const float zp = __builtin_rintf(zero_point[cp.c]);
+  float gs = 0.0f, gz = 0.0f;
+
+  auto one = [&](float xv, float gyv) -> float {
+    const float t = xv / s;
+    float r;
+    if (rounding == SBQ_ROUND_HALF_EVEN) r = __builtin_rintf(t);
+    else if (rounding == SBQ_ROUND_HALF_UP) r = __builtin_floorf(t + 0.5f);
+    else r = __builtin_ceilf(t - 0.5f);
+    const float v = r + zp;
+    const bool below = v < qlo, above = v > qhi;
+    const bool inside = !(below || above);  // NaN counts as inside, like the reference's int compare of 0
+    float pgs = (r - t) * gyv;
+    if (above) pgs = (qhi - zp) * gyv;
+    if (below) pgs = (qlo - zp) * gyv;
+    gs += pgs;
+    gz += inside ? 0.0f : (-s * gyv);
+    return inside ? gyv : 0.0f;
+  };
+
+  if constexpr (VEC) {
+    const int64_t vend = cp.begin + ((cp.end - cp.begin) / kPack) * kPack;
+    for (int64_t e = cp.begin + static_cast<int64_t>(threadIdx.x) * kPack; e < vend;
+         e += static_cast<int64_t>(kBlock) * kPack) {
+      float xv[kPack], gv[kPack], o[kPack];
+      load_pack<T, true>(x, cp.row_base + e, xv);
+      load_pack<T, true>(gy, cp.row_base + e, gv);
+#pragma unroll
+      for (int q = 0; q < kPack; ++q) o[q] = one(xv[q], gv[q]);
+      store_pack<Tg, true>(gx, cp.row_base + e, o);
+    }
+    for (int64_t e = vend + threadIdx.x; e < cp.end; e += kBlock) {
+      const float o = one(Elem<T>::load1(x, cp.row_base + e), Elem<T>::load1(gy, cp.row_base + e));
+      Elem<Tg>::store1(gx, cp.row_base + e, o);
+    }
+  } else {
+    for (int64_t e = cp.begin + threadIdx.x; e < cp.end; e += kBlock) {
+      const float o = one(Elem<T>::load1(x, cp.row_base + e), Elem<T>::load1(gy, cp.row_base + e));
+      Elem<Tg>::store1(gx, cp.row_base + e, o);
+    }
+  }
+  if (part) {
+    const double a = block_reduce(static_cast<double>(gs), Sum(), s_d);
+    const double b = block_reduce(static_cast<double>(gz), Sum(), s_d);
+    if (threadIdx.x == 0) part[bid] = GradPartial{a, b};
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void ste_fold_kernel(const GradPartial* __restrict__ part,
+                                                          uint32_t chunks_per_chan,
+                                                          float* __restrict__ gs_out,
+                                                          float* __restrict__ gzp_out) {
+  __shared__ double s_d[kWavesPerBlock];
+  const uint32_t c = blockIdx.x;
+  const GradPartial* p = part + static_cast<size_t>(c) * chunks_per_chan;
+  double a = 0.0, b = 0.0;
+  for (uint32_t i = threadIdx.x; i < chunks_per_chan; i += kBlock) {
+    a += p[i].gs;
+    b += p[i].gzp;
+  }
+  a = block_reduce(a, Sum(), s_d);
+  b = block_reduce(b, Sum(), s_d);
+  if (threadIdx.x == 0) {
+    if (gs_out) gs_out[c] = static_cast<float>(a);
+    if (gzp_out) gzp_out[c] = static_cast<float>(b);
+  }
+}
+
+int ste_backward(const void* x, const void* gy, int x_dtype, void* gx, int gx_dtype, float* gs,
+                 float* gzp, const float* scale, const float* zp, int64_t outer, int64_t C,
+                 int64_t inner, int qmin, int qmax, int rounding, void* workspace,
+                 size_t workspace_bytes, void* stream) {
+  if (!valid_dtype(x_dtype) || !valid_dtype(gx_dtype)) return SBQ_ERR_DTYPE;
+  if (gx_dtype != SBQ_F32 && gx_dtype != x_dtype) return SBQ_ERR_DTYPE;
+  if (outer < 0 || C < 0 || inner < 0) return SBQ_ERR_ARG;
+  if (outer == 0 || C == 0 || inner == 0) return SBQ_ERR_EMPTY;
+  if (!x || !gy || !gx || !scale || !zp) return SBQ_ERR_NULL;
+  if (qmin > qmax || rounding < 0 || rounding > 2) return SBQ_ERR_ARG;
+  if (!geom_ok(outer, C, inner, kBwdChunk)) return SBQ_ERR_ARG;
+  if ((reinterpret_cast<uintptr_t>(x) % dtype_size(x_dtype)) ||
+      (reinterpret_cast<uintptr_t>(gy) % dtype_size(x_dtype)) ||
+      (reinterpret_cast<uintptr_t>(gx) % dtype_size(gx_dtype)))
+    return SBQ_ERR_ALIGN;
+  const ChunkGeom g = make_geom(outer, C, inner, kBwdChunk);
+  const bool want_param_grads = gs || gzp;
+  GradPartial* part = nullptr;
+  if (want_param_grads) {
+    const size_t need = static_cast<size_t>(g.chunks_per_chan) * g.C * sizeof(GradPartial);
+    if (!workspace) return SBQ_ERR_NULL;
+    if (workspace_bytes < need || !aligned16(workspace)) return SBQ_ERR_WORKSPACE;
+    part = static_cast<GradPartial*>(workspace);
+  }
+  hipStream_t st = as_stream(stream);
+  const uint32_t grid = g.chunks_per_chan * g.C;
+  const bool vec = pack_friendly(x, C, outer, inner) && aligned16(gy) && aligned16(gx);
+  const float qlo = static_cast<float>(qmin), qhi = static_cast<float>(qmax);
+  int rc = dispatch_dtype(x_dtype, [&](auto tag) {
+    using T = decltype(tag);
+    auto go = [&](auto gtag) {
+      using Tg = decltype(gtag);
+      if (vec)
+        ste_backward_kernel<T, Tg, true><<<grid, kBlock, 0, st>>>(x, gy, gx, scale, zp, part, g, qlo, qhi, rounding);
+      else
+        ste_backward_kernel<T, Tg, false><<<grid, kBlock, 0, st>>>(x, gy, gx, scale, zp, part, g, qlo, qhi, rounding);
+    };
+    if (gx_dtype == SBQ_F32) go(F32());
+    else go(T());
+  });
+  if (rc != SBQ_OK) return rc;
+  rc = check_launch();
+  if (rc != SBQ_OK || !want_param_grads) return rc;
+  ste_fold_kernel<<<g.C, kBlock, 0, st>>>(part, g.chunks_per_chan, gs, gzp);
+  return check_launch();
+}
+
+}  // namespace
+}  // namespace sbq
+
+extern "C" {
+
+size_t sbq_backward_workspace_bytes(int64_t outer, int64_t C, int64_t inner) {
+  using namespace sbq;
+  if (!geom_ok(outer, C, inner, kBwdChunk)) return 0;
+  const ChunkGeom g = make_geom(outer, C, inner, kBwdChunk);
+  return static_cast<size_t>(g.chunks_per_chan) * g.C * sizeof(GradPartial);
+}
+
+int sbq_quant_pertensor_backward(const void* x, const void* gy, int x_dtype, void* gx, int gx_dtype,
+                                 float* gs, float* gzp, const float* scale, const float* zero_point,
+                                 int64_t numel, int qmin, int qmax, int rounding, void* workspace,
+                                 size_t workspace_bytes, void* stream) {
+  return sbq::ste_backward(x, gy, x_dtype, gx, gx_dtype, gs, gzp, scale, zero_point, 1, 1, numel,
+                           qmin, qmax, rounding, workspace, workspace_bytes, stream);
+}
+
+int sbq_quant_perchannel_backward(const void* x, const void* gy, int x_dtype, void* gx, int gx_dtype,
+                                  float* gs, float* gzp, const float* scale, const float* zero_point,
+                                  int64_t outer, int64_t C, int64_t inner, int qmin, int qmax,
+                                  int rounding, void* workspace, size_t workspace_bytes, void* stream) {
+  return sbq::ste_backward(x, gy, x_dtype, gx, gx_dtype, gs, gzp, scale, zero_point, outer, C, inner,
+                           qmin, qmax, rounding, workspace, workspace_bytes, stream);
+}
+
+}  // extern "C"

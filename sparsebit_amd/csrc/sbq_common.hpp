@@ -1,0 +1,327 @@
+// sbq_common.hpp -- shared device/host helpers for libsbq (gfx950 only).
+//
+// Everything here is written for CDNA4: 64-lane wavefronts, 16-byte per-lane
+// global accesses, DPP/shuffle wave reductions and LDS cross-wave reductions.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/sbq.h"
+
+namespace sbq {
+
+constexpr int kWave = 64;       // gfx950 wavefront
+constexpr int kBlock = 256;     // 4 waves: one per SIMD of a CU
+constexpr int kWavesPerBlock = kBlock / kWave;
+
+// ---- 16-byte vector payloads -------------------------------------------------
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// Element tags.  Storage is raw bits; conversion is explicit so that the
+// arithmetic is always IEEE fp32 exactly like the reference's CPU path.
+struct F32 { using storage = float;    static constexpr int id = SBQ_F32;  };
+struct F16 { using storage = uint16_t; static constexpr int id = SBQ_F16;  };
+struct BF16 { using storage = uint16_t; static constexpr int id = SBQ_BF16; };
+
+template <typename T> struct Elem;
+
+template <> struct Elem<F32> {
+  static constexpr int kVec = 4;  // elements per 16 bytes
+  static __device__ __forceinline__ float load1(const void* p, int64_t i) {
+    return static_cast<const float*>(p)[i];
+  }
+  static __device__ __forceinline__ void store1(void* p, int64_t i, float v) {
+    static_cast<float*>(p)[i] = v;
+  }
+};
+
+template <> struct Elem<F16> {
+  static constexpr int kVec = 8;
+  static __device__ __forceinline__ float from_bits(uint16_t b) {
+    _Float16 h;
+    __builtin_memcpy(&h, &b, 2);
+    return static_cast<float>(h);
+  }
+  static __device__ __forceinline__ uint16_t to_bits(float v) {
+    _Float16 h = static_cast<_Float16>(v);  // v_cvt_f16_f32, RNE
+    uint16_t b;
+    __builtin_memcpy(&b, &h, 2);
+    return b;
+  }
+  static __device__ __forceinline__ float load1(const void* p, int64_t i) {
+    return from_bits(static_cast<const uint16_t*>(p)[i]);
+  }
+  static __device__ __forceinline__ void store1(void* p, int64_t i, float v) {
+    static_cast<uint16_t*>(p)[i] = to_bits(v);
+  }
+};
+
+template <> struct Elem<BF16> {
+  static constexpr int kVec = 8;
+  static __device__ __forceinline__ float from_bits(uint16_t b) {
+    return __builtin_bit_cast(float, static_cast<uint32_t>(b) << 16);
+  }
+  static __device__ __forceinline__ uint16_t to_bits(float v) {
+    __bf16 h = static_cast<__bf16>(v);  // v_cvt_pk_bf16_f32 on gfx950, RNE
+    return __builtin_bit_cast(uint16_t, h);
+  }
+  static __device__ __forceinline__ float load1(const void* p, int64_t i) {
+    return from_bits(static_cast<const uint16_t*>(p)[i]);
+  }
+  static __device__ __forceinline__ void store1(void* p, int64_t i, float v) {
+    static_cast<uint16_t*>(p)[i] = to_bits(v);
+  }
+};
+
+// A "pack" is the per-lane unit of work of the streaming kernels: 8 elements.
+// 16-bit types: one 16-byte access; fp32: two.
+constexpr int kPack = 8;
+
+template <bool NT>
+__device__ __forceinline__ u32x4 ld16(const void* p) {
+  if constexpr (NT) return __builtin_nontemporal_load(static_cast<const u32x4*>(p));
+  else return *static_cast<const u32x4*>(p);
+}
+template <bool NT>
+__device__ __forceinline__ void st16(void* p, u32x4 v) {
+  if constexpr (NT) __builtin_nontemporal_store(v, static_cast<u32x4*>(p));
+  else *static_cast<u32x4*>(p) = v;
+}
+template <bool NT>
+__device__ __forceinline__ u32x2 ld8(const void* p) {
+  if constexpr (NT) return __builtin_nontemporal_load(static_cast<const u32x2*>(p));
+  else return *static_cast<const u32x2*>(p);
+}
+template <bool NT>
+__device__ __forceinline__ void st8(void* p, u32x2 v) {
+  if constexpr (NT) __builtin_nontemporal_store(v, static_cast<u32x2*>(p));
+  else *static_cast<u32x2*>(p) = v;
+}
+
+// load 8 consecutive elements starting at element index i (i % 8 == 0, base
+// 16-byte aligned) as fp32
+template <typename T, bool NT>
+__device__ __forceinline__ void load_pack(const void* base, int64_t i, float (&v)[kPack]) {
+  if constexpr (T::id == SBQ_F32) {
+    const char* p = static_cast<const char*>(base) + i * 4;
+    u32x4 a = ld16<NT>(p), b = ld16<NT>(p + 16);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      v[j] = __builtin_bit_cast(float, a[j]);
+      v[4 + j] = __builtin_bit_cast(float, b[j]);
+    }
+  } else {
+    const char* p = static_cast<const char*>(base) + i * 2;
+    u32x4 a = ld16<NT>(p);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      v[2 * j] = Elem<T>::from_bits(static_cast<uint16_t>(a[j] & 0xffffu));
+      v[2 * j + 1] = Elem<T>::from_bits(static_cast<uint16_t>(a[j] >> 16));
+    }
+  }
+}
+
+template <typename T, bool NT>
+__device__ __forceinline__ void store_pack(void* base, int64_t i, const float (&v)[kPack]) {
+  if constexpr (T::id == SBQ_F32) {
+    char* p = static_cast<char*>(base) + i * 4;
+    u32x4 a, b;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      a[j] = __builtin_bit_cast(uint32_t, v[j]);
+      b[j] = __builtin_bit_cast(uint32_t, v[4 + j]);
+    }
+    st16<NT>(p, a);
+    st16<NT>(p + 16, b);
+  } else {
+    char* p = static_cast<char*>(base) + i * 2;
+    u32x4 a;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      uint32_t lo = Elem<T>::to_bits(v[2 * j]);
+      uint32_t hi = Elem<T>::to_bits(v[2 * j + 1]);
+      a[j] = lo | (hi << 16);
+    }
+    st16<NT>(p, a);
+  }
+}
+
+// ---- wave / block reductions ---------------------------------------------------
+template <typename V, typename Op>
+__device__ __forceinline__ V wave_reduce(V v, Op op) {
+#pragma unroll
+  for (int m = kWave / 2; m > 0; m >>= 1) v = op(v, __shfl_xor(v, m, kWave));
+  return v;
+}
+
+// Reduce across the 4 waves of a 256-thread block.  `slot` is LDS scratch with
+// at least kWavesPerBlock entries; result valid in every thread.
+template <typename V, typename Op>
+__device__ __forceinline__ V block_reduce(V v, Op op, V* slot) {
+  v = wave_reduce(v, op);
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wid = threadIdx.x / kWave;
+  __syncthreads();  // protect slot reuse
+  if (lane == 0) slot[wid] = v;
+  __syncthreads();
+  V r = slot[0];
+#pragma unroll
+  for (int w = 1; w < kWavesPerBlock; ++w) r = op(r, slot[w]);
+  return r;
+}
+
+// torch.min / torch.max semantics: NaN wins.
+struct NanMin {
+  __device__ __forceinline__ float operator()(float a, float b) const {
+    return (a != a || a < b) ? a : ((b != b) ? b : (b < a ? b : a));
+  }
+};
+struct NanMax {
+  __device__ __forceinline__ float operator()(float a, float b) const {
+    return (a != a || a > b) ? a : ((b != b) ? b : (b > a ? b : a));
+  }
+};
+struct Sum {
+  template <typename V>
+  __device__ __forceinline__ V operator()(V a, V b) const { return a + b; }
+};
+
+// ---- the QDQ scalar core ---------------------------------------------------------
+// quant_tensor.py:182-184:  zp = round(zp); q = clamp(round(x/s) + zp, qmin, qmax);
+// dq = (q - zp) * s -- every step an individually rounded IEEE fp32 operation
+// (build with -ffp-contract=off).  `zp` is already rounded, qlo/qhi are floats.
+template <int ROUND>
+__device__ __forceinline__ float round_mode(float t) {
+  if constexpr (ROUND == SBQ_ROUND_HALF_EVEN) return __builtin_rintf(t);  // v_rndne_f32
+  else if constexpr (ROUND == SBQ_ROUND_HALF_UP) return __builtin_floorf(t + 0.5f);
+  else return __builtin_ceilf(t - 0.5f);
+}
+
+template <int ROUND>
+__device__ __forceinline__ float quant_level(float x, float s, float zp, float qlo, float qhi) {
+  float t = x / s;  // IEEE-correct division (v_div_scale/fmas/fixup)
+  float v = round_mode<ROUND>(t) + zp;
+  // torch.clamp propagates NaN; med3/min/max would drop it
+  float c = __builtin_fminf(__builtin_fmaxf(v, qlo), qhi);
+  return (v != v) ? v : c;
+}
+
+__device__ __forceinline__ float dequant_level(float q, float s, float zp) {
+  return (q - zp) * s;
+}
+
+// observers/base.py:63-79 in fp32, op for op.
+__device__ __forceinline__ void qparams_from_minmax(float mn, float mx, float qrange,
+                                                    bool symmetric, float& scale, float& zp) {
+  NanMin nmin;
+  NanMax nmax;
+  float mn_neg = nmin(mn, 0.0f);  // torch.minimum: NaN propagates
+  float mx_pos = nmax(mx, 0.0f);
+  if (symmetric) {
+    mx_pos = nmax(-mn_neg, mx_pos);
+    float s = (mx_pos * 2.0f) / qrange;
+    scale = nmax(s, 1e-6f);
+    zp = 0.0f;
+  } else {
+    float s = (mx_pos - mn_neg) / qrange;
+    scale = nmax(s, 1e-6f);
+    zp = __builtin_rintf(-mn_neg / scale);
+  }
+}
+
+// ---- order-preserving float <-> uint32 key --------------------------------------
+__device__ __forceinline__ uint32_t float_key(float f, bool use_abs) {
+  uint32_t u = __builtin_bit_cast(uint32_t, f);
+  if (use_abs) u &= 0x7fffffffu;
+  if (f != f) return 0xffffffffu;          // NaN sorts last (torch.sort / kthvalue)
+  if (u == 0x80000000u) u = 0;             // -0 == +0
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float key_float(uint32_t k) {
+  if (k == 0xffffffffu) return __builtin_nanf("");
+  uint32_t u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+  return __builtin_bit_cast(float, u);
+}
+
+// ---- host side ---------------------------------------------------------------------
+int check_launch();  // hipGetLastError -> sbq_status, records the error string
+int knob(int which);
+inline hipStream_t as_stream(void* s) { return static_cast<hipStream_t>(s); }
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+inline size_t dtype_size(int dt) { return dt == SBQ_F32 ? 4 : 2; }
+inline bool valid_dtype(int dt) { return dt == SBQ_F32 || dt == SBQ_F16 || dt == SBQ_BF16; }
+inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+
+// ---- chunk geometry shared by the reductions ------------------------------------
+// A row is one (outer index, channel) run of `inner` contiguous elements.  It is
+// cut into chunks of `chunk_elems` elements; a workgroup handles one chunk and the
+// linear block id enumerates [channel][outer][chunk-in-row].
+struct ChunkGeom {
+  int64_t inner;
+  uint32_t C;
+  uint32_t outer;
+  uint32_t chunks_per_row;
+  uint32_t chunk_elems;      // elements per chunk (multiple of 8)
+  uint32_t chunks_per_chan;  // outer * chunks_per_row
+};
+
+inline bool geom_ok(int64_t outer, int64_t C, int64_t inner, uint32_t chunk) {
+  if (outer <= 0 || C <= 0 || inner <= 0) return false;
+  if (outer >= (1ll << 31) || C >= (1ll << 31)) return false;
+  const int64_t cpr = ceil_div(inner, chunk);
+  if (cpr * outer >= (1ll << 31)) return false;
+  if (cpr * outer * C >= (1ll << 31)) return false;
+  return true;
+}
+
+inline ChunkGeom make_geom(int64_t outer, int64_t C, int64_t inner, uint32_t chunk) {
+  ChunkGeom g;
+  g.inner = inner;
+  g.C = static_cast<uint32_t>(C);
+  g.outer = static_cast<uint32_t>(outer);
+  g.chunk_elems = chunk;
+  g.chunks_per_row = static_cast<uint32_t>(ceil_div(inner, chunk));
+  g.chunks_per_chan = g.outer * g.chunks_per_row;
+  return g;
+}
+
+// decode blockIdx.x -> (channel, first element of the chunk, one-past-last)
+struct ChunkPos {
+  uint32_t c;
+  int64_t row_base, begin, end;
+};
+__device__ __forceinline__ ChunkPos chunk_pos(const ChunkGeom& g, uint32_t bid) {
+  ChunkPos p;
+  p.c = bid / g.chunks_per_chan;
+  const uint32_t j = bid - p.c * g.chunks_per_chan;
+  const uint32_t o = j / g.chunks_per_row;
+  const uint32_t k = j - o * g.chunks_per_row;
+  p.row_base = (static_cast<int64_t>(o) * g.C + p.c) * g.inner;
+  p.begin = static_cast<int64_t>(k) * g.chunk_elems;
+  p.end = p.begin + g.chunk_elems;
+  if (p.end > g.inner) p.end = g.inner;
+  return p;
+}
+
+template <typename F>
+inline int dispatch_dtype(int dt, F&& f) {
+  if (dt == SBQ_F32) f(F32());
+  else if (dt == SBQ_F16) f(F16());
+  else if (dt == SBQ_BF16) f(BF16());
+  else return SBQ_ERR_DTYPE;
+  return SBQ_OK;
+}
+
+// can the rows be read as whole 16-byte packs?  (a single row may have a ragged
+// tail, which the kernels read element-wise)
+inline bool pack_friendly(const void* x, int64_t C, int64_t outer, int64_t inner) {
+  if (!aligned16(x)) return false;
+  if (inner % kPack == 0) return true;
+  return C == 1 && outer == 1;
+}
+
+}  // namespace sbq

@@ -1,0 +1,400 @@
+// sbq_observe.hip -- observer reductions for gfx950: per-channel min / max /
+// sum|x| in one pass, scale/zero-point from min/max, LSQ scale init and the
+// 80-candidate MSE search.
+//
+// Replaces the torch-op bodies of
+//   sparsebit/quantization/observers/minmax.py:14-25     (min / max)
+//   sparsebit/quantization/observers/base.py:63-79       (calc_qparams_with_minmax)
+//   sparsebit/quantization/observers/mse.py:28-63        (MSE search)
+//   sparsebit/quantization/quantizers/lsq.py:44-47       (LSQ init)
+// and removes DataCache's torch.cat/transpose copy (observers/base.py:21-36):
+// the kernels index the original [outer, C, inner] tensor in place.
+//
+// Structure: HBM-bound read-once reductions.  A workgroup reduces one "chunk"
+// (a run of packs inside one channel row) with 16-byte loads, 64-lane shuffle
+// reductions and a 4-entry LDS cross-wave step, and writes ONE partial record;
+// a second tiny kernel folds the partials of a channel in a fixed order, so the
+// results are deterministic (no float atomics).
+#include "sbq_common.hpp"
+
+namespace sbq {
+namespace {
+
+constexpr uint32_t kStatsChunk = kBlock * kPack * 4;  // 8192 elements, 4 packs per lane
+constexpr uint32_t kMseChunk = kBlock * kPack * 2;    // 4096 elements, 2 packs per lane (registers)
+
+struct StatPartial {
+  float mn, mx;
+  double abssum;
+};
+
+struct MinF { __device__ __forceinline__ float operator()(float a, float b) const { return __builtin_fminf(a, b); } };
+struct MaxF { __device__ __forceinline__ float operator()(float a, float b) const { return __builtin_fmaxf(a, b); } };
+struct OrI { __device__ __forceinline__ int operator()(int a, int b) const { return a | b; } };
+
+// ---- stage 1: one partial {min, max, sum|x|} per chunk ---------------------------
+// min/max use the NaN-dropping v_min/v_max plus a separate "saw a NaN" flag, which
+// reproduces torch's NaN-propagating result at 1 op per element instead of 5.
+template <typename T, bool VEC>
+__global__ __launch_bounds__(kBlock) void stats_partial_kernel(const void* __restrict__ x,
+                                                               StatPartial* __restrict__ part,
+                                                               const ChunkGeom g) {
+  __shared__ float s_f[kWavesPerBlock];
+  __shared__ double s_d[kWavesPerBlock];
+  __shared__ int s_i[kWavesPerBlock];
+  const uint32_t bid = blockIdx.x;
+  const ChunkPos cp = chunk_pos(g, bid);
+  const int64_t row_base = cp.row_base, begin = cp.begin, end = cp.end;
+
+  float mn = __builtin_inff(), mx = -__builtin_inff(), as = 0.0f;
+  int nan = 0;
+  if constexpr (VEC) {
+    const int64_t vend = begin + ((end - begin) / kPack) * kPack;
+    constexpr int U = 4;
+    for (int64_t base = begin; base < vend; base += static_cast<int64_t>(kBlock) * kPack * U) {
+      float v[U][kPack];
+      bool ok[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        int64_t e = base + (static_cast<int64_t>(u) * kBlock + threadIdx.x) * kPack;
+        ok[u] = e < vend;
+        if (!ok[u]) e = vend - kPack;
+        load_pack<T, true>(x, row_base + e, v[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (!ok[u]) continue;
+#pragma unroll
+        for (int q = 0; q < kPack; ++q) {
+          const float f = v[u][q];
+          mn = __builtin_fminf(mn, f);
+          mx = __builtin_fmaxf(mx, f);
+          nan |= (f != f);
+          as += __builtin_fabsf(f);
+        }
+      }
+    }
+    // ragged tail of a per-tensor row (< 8 elements)
+    for (int64_t e = vend + threadIdx.x; e < end; e += kBlock) {
+      const float f = Elem<T>::load1(x, row_base + e);
+      mn = __builtin_fminf(mn, f);
+      mx = __builtin_fmaxf(mx, f);
+      nan |= (f != f);
+      as += __builtin_fabsf(f);
+    }
+  } else {
+    for (int64_t e = begin + threadIdx.x; e < end; e += kBlock) {
+      const float f = Elem<T>::load1(x, row_base + e);
+      mn = __builtin_fminf(mn, f);
+      mx = __builtin_fmaxf(mx, f);
+      nan |= (f != f);
+      as += __builtin_fabsf(f);
+    }
+  }
+  mn = block_reduce(mn, MinF(), s_f);
+  mx = block_reduce(mx, MaxF(), s_f);
+  nan = block_reduce(nan, OrI(), s_i);
+  const double asd = block_reduce(static_cast<double>(as), Sum(), s_d);
+  if (threadIdx.x == 0) {
+    StatPartial p;
+    p.mn = nan ? __builtin_nanf("") : mn;
+    p.mx = nan ? __builtin_nanf("") : mx;
+    p.abssum = asd;
+    part[bid] = p;
+  }
+}
+
+// ---- stage 2: fold a channel's partials (fixed order => deterministic) ------------
+__global__ __launch_bounds__(kBlock) void stats_finish_kernel(const StatPartial* __restrict__ part,
+                                                              uint32_t chunks_per_chan,
+                                                              float* __restrict__ min_out,
+                                                              float* __restrict__ max_out,
+                                                              double* __restrict__ abssum_out) {
+  __shared__ float s_f[kWavesPerBlock];
+  __shared__ double s_d[kWavesPerBlock];
+  const uint32_t c = blockIdx.x;
+  const StatPartial* p = part + static_cast<size_t>(c) * chunks_per_chan;
+  float mn = __builtin_inff(), mx = -__builtin_inff();
+  double as = 0.0;
+  NanMin nmin;
+  NanMax nmax;
+  for (uint32_t i = threadIdx.x; i < chunks_per_chan; i += kBlock) {
+    mn = nmin(mn, p[i].mn);
+    mx = nmax(mx, p[i].mx);
+    as += p[i].abssum;
+  }
+  mn = block_reduce(mn, nmin, s_f);
+  mx = block_reduce(mx, nmax, s_f);
+  as = block_reduce(as, Sum(), s_d);
+  if (threadIdx.x == 0) {
+    if (min_out) min_out[c] = mn;
+    if (max_out) max_out[c] = mx;
+    if (abssum_out) abssum_out[c] = as;
+  }
+}
+
+__global__ void qparams_kernel(const float* __restrict__ mn, const float* __restrict__ mx, int64_t C,
+                               float qrange, int symmetric, float* __restrict__ scale,
+                               float* __restrict__ zp) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= C) return;
+  float s, z;
+  qparams_from_minmax(mn[i], mx[i], qrange, symmetric != 0, s, z);
+  scale[i] = s;
+  zp[i] = z;
+}
+
+// lsq.py:44-47: scale = 2 * mean(|x|) / sqrt(qmax); torch computes the mean and
+// both scalings in fp32 (the Python scalar sqrt(qmax) is rounded to fp32).
+__global__ void lsq_init_kernel(const double* __restrict__ abssum, int64_t C, double count,
+                                float sqrt_qmax, float* __restrict__ scale) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= C) return;
+  const float mean = static_cast<float>(abssum[i] / count);
+  scale[i] = (2.0f * mean) / sqrt_qmax;
+}
+
+// ---- MSE search -------------------------------------------------------------------
+// mse.py:46-49: candidate i shrinks (min, max) by the fp32 factor (1 - 0.01 i).
+__device__ __forceinline__ void mse_candidate(float mn, float mx, int i, float qrange, bool symmetric,
+                                              float& s, float& z) {
+  const float f = static_cast<float>(1.0 - static_cast<double>(i) * 0.01);
+  qparams_from_minmax(mn * f, mx * f, qrange, symmetric, s, z);
+}
+
+// One workgroup keeps a 4096-element chunk of one channel in registers and walks
+// the 80 candidates over it: x is read from HBM once, not 80 times (the reference
+// makes 80 x 4 full passes).  Output: part[bid][80] fp64 partial sums of (x-dq)^2.
+template <typename T, bool VEC>
+__global__ __launch_bounds__(kBlock) void mse_partial_kernel(
+    const void* __restrict__ x, const float* __restrict__ min_val, const float* __restrict__ max_val,
+    double* __restrict__ part, const ChunkGeom g, float qrange, float qlo, float qhi, int symmetric) {
+  __shared__ float s_scale[SBQ_MSE_CANDIDATES];
+  __shared__ float s_zp[SBQ_MSE_CANDIDATES];
+  __shared__ float s_acc[SBQ_MSE_CANDIDATES][kWavesPerBlock];
+  const uint32_t bid = blockIdx.x;
+  const ChunkPos cp = chunk_pos(g, bid);
+  const uint32_t c = cp.c;
+  const int64_t row_base = cp.row_base, begin = cp.begin, end = cp.end;
+
+  if (threadIdx.x < SBQ_MSE_CANDIDATES) {
+    float s, z;
+    mse_candidate(min_val[c], max_val[c], threadIdx.x, qrange, symmetric != 0, s, z);
+    s_scale[threadIdx.x] = s;
+    s_zp[threadIdx.x] = z;  // already integral (rint) or 0
+  }
+
+  constexpr int E = 2 * kPack;  // elements per lane
+  float v[E];
+  bool ok[E];
+  if constexpr (VEC) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      int64_t e = begin + (static_cast<int64_t>(u) * kBlock + threadIdx.x) * kPack;
+      const bool in = e + kPack <= end;  // chunk and inner are multiples of 8 here
+      if (!in) e = begin;
+      float t[kPack];
+      load_pack<T, true>(x, row_base + e, t);
+#pragma unroll
+      for (int q = 0; q < kPack; ++q) {
+        v[u * kPack + q] = t[q];
+        ok[u * kPack + q] = in;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int q = 0; q < E; ++q) {
+      const int64_t e = begin + static_cast<int64_t>(q) * kBlock + threadIdx.x;
+      ok[q] = e < end;
+      v[q] = ok[q] ? Elem<T>::load1(x, row_base + e) : 0.0f;
+    }
+  }
+  __syncthreads();
+
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wid = threadIdx.x / kWave;
+  for (int i = 0; i < SBQ_MSE_CANDIDATES; ++i) {
+    const float s = s_scale[i];
+    const float z = s_zp[i];
+    float acc = 0.0f;
+#pragma unroll
+    for (int q = 0; q < E; ++q) {
+      const float lv = quant_level<SBQ_ROUND_HALF_EVEN>(v[q], s, z, qlo, qhi);
+      const float d = v[q] - dequant_level(lv, s, z);
+      const float sq = d * d;
+      acc += ok[q] ? sq : 0.0f;
+    }
+    acc = wave_reduce(acc, Sum());
+    if (lane == 0) s_acc[i][wid] = acc;
+  }
+  __syncthreads();
+  if (threadIdx.x < SBQ_MSE_CANDIDATES) {
+    double t = 0.0;
+#pragma unroll
+    for (int w = 0; w < kWavesPerBlock; ++w) t += static_cast<double>(s_acc[threadIdx.x][w]);
+    part[static_cast<size_t>(bid) * SBQ_MSE_CANDIDATES + threadIdx.x] = t;
+  }
+}
+
+// sse[c][i] += sum over the channel's chunks, fixed order.
+__global__ __launch_bounds__(kBlock) void mse_fold_kernel(const double* __restrict__ part,
+                                                          uint32_t chunks_per_chan,
+                                                          double* __restrict__ sse) {
+  __shared__ double s_d[kWavesPerBlock];
+  const uint32_t c = blockIdx.x;
+  const double* p = part + static_cast<size_t>(c) * chunks_per_chan * SBQ_MSE_CANDIDATES;
+  for (int i = 0; i < SBQ_MSE_CANDIDATES; ++i) {
+    double t = 0.0;
+    for (uint32_t j = threadIdx.x; j < chunks_per_chan; j += kBlock)
+      t += p[static_cast<size_t>(j) * SBQ_MSE_CANDIDATES + i];
+    t = block_reduce(t, Sum(), s_d);
+    if (threadIdx.x == 0) sse[static_cast<size_t>(c) * SBQ_MSE_CANDIDATES + i] += t;
+  }
+}
+
+// mse.py:51-61: keep the first candidate whose fp32 loss is strictly smaller.
+__global__ void mse_select_kernel(const double* __restrict__ sse, double count,
+                                  const float* __restrict__ min_val, const float* __restrict__ max_val,
+                                  int64_t C, float qrange, int symmetric, float* __restrict__ scale,
+                                  float* __restrict__ zp, int32_t* __restrict__ best_index) {
+  const int64_t c = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float loss_min = 1e10f;
+  int best = -1;
+  for (int i = 0; i < SBQ_MSE_CANDIDATES; ++i) {
+    const float loss = static_cast<float>(sse[c * SBQ_MSE_CANDIDATES + i] / count);
+    if (loss < loss_min) {
+      loss_min = loss;
+      best = i;
+    }
+  }
+  float s = 1.0f, z = 0.0f;  // mse.py:34-39 initial values
+  if (best >= 0) mse_candidate(min_val[c], max_val[c], best, qrange, symmetric != 0, s, z);
+  scale[c] = s;
+  zp[c] = z;
+  if (best_index) best_index[c] = best;
+}
+
+}  // namespace
+}  // namespace sbq
+
+extern "C" {
+
+size_t sbq_stats_workspace_bytes(int64_t outer, int64_t C, int64_t inner) {
+  using namespace sbq;
+  if (!geom_ok(outer, C, inner, kStatsChunk)) return 0;
+  const ChunkGeom g = make_geom(outer, C, inner, kStatsChunk);
+  return static_cast<size_t>(g.chunks_per_chan) * g.C * sizeof(StatPartial);
+}
+
+int sbq_channel_stats(const void* x, int x_dtype, int64_t outer, int64_t C, int64_t inner,
+                      float* min_out, float* max_out, double* abssum_out,
+                      void* workspace, size_t workspace_bytes, void* stream) {
+  using namespace sbq;
+  if (!valid_dtype(x_dtype)) return SBQ_ERR_DTYPE;
+  if (outer < 0 || C < 0 || inner < 0) return SBQ_ERR_ARG;
+  if (outer == 0 || C == 0 || inner == 0) return SBQ_ERR_EMPTY;
+  if (!x || !workspace) return SBQ_ERR_NULL;
+  if (!geom_ok(outer, C, inner, kStatsChunk)) return SBQ_ERR_ARG;
+  if (reinterpret_cast<uintptr_t>(x) % dtype_size(x_dtype)) return SBQ_ERR_ALIGN;
+  const ChunkGeom g = make_geom(outer, C, inner, kStatsChunk);
+  const size_t need = static_cast<size_t>(g.chunks_per_chan) * g.C * sizeof(StatPartial);
+  if (workspace_bytes < need || !aligned16(workspace)) return SBQ_ERR_WORKSPACE;
+  hipStream_t st = as_stream(stream);
+  StatPartial* part = static_cast<StatPartial*>(workspace);
+  const uint32_t grid = g.chunks_per_chan * g.C;
+  const bool vec = pack_friendly(x, C, outer, inner);
+  int rc = dispatch_dtype(x_dtype, [&](auto tag) {
+    using T = decltype(tag);
+    if (vec) stats_partial_kernel<T, true><<<grid, kBlock, 0, st>>>(x, part, g);
+    else stats_partial_kernel<T, false><<<grid, kBlock, 0, st>>>(x, part, g);
+  });
+  if (rc != SBQ_OK) return rc;
+  rc = check_launch();
+  if (rc != SBQ_OK) return rc;
+  stats_finish_kernel<<<g.C, kBlock, 0, st>>>(part, g.chunks_per_chan, min_out, max_out, abssum_out);
+  return check_launch();
+}
+
+int sbq_qparams_from_minmax(const float* min_val, const float* max_val, int64_t C, int qmin, int qmax,
+                            int symmetric, float* scale_out, float* zero_point_out, void* stream) {
+  using namespace sbq;
+  if (C < 0) return SBQ_ERR_ARG;
+  if (C == 0) return SBQ_ERR_EMPTY;
+  if (!min_val || !max_val || !scale_out || !zero_point_out) return SBQ_ERR_NULL;
+  if (qmin >= qmax) return SBQ_ERR_ARG;
+  const float qrange = static_cast<float>(qmax - qmin);
+  qparams_kernel<<<static_cast<uint32_t>(ceil_div(C, kBlock)), kBlock, 0, as_stream(stream)>>>(
+      min_val, max_val, C, qrange, symmetric, scale_out, zero_point_out);
+  return check_launch();
+}
+
+int sbq_lsq_init_scale(const double* abssum, int64_t C, double count, int qmax, float* scale_out,
+                       void* stream) {
+  using namespace sbq;
+  if (C < 0 || count <= 0 || qmax <= 0) return SBQ_ERR_ARG;
+  if (C == 0) return SBQ_ERR_EMPTY;
+  if (!abssum || !scale_out) return SBQ_ERR_NULL;
+  const float sq = static_cast<float>(__builtin_sqrt(static_cast<double>(qmax)));
+  lsq_init_kernel<<<static_cast<uint32_t>(ceil_div(C, kBlock)), kBlock, 0, as_stream(stream)>>>(
+      abssum, C, count, sq, scale_out);
+  return check_launch();
+}
+
+size_t sbq_mse_workspace_bytes(int64_t outer, int64_t C, int64_t inner) {
+  using namespace sbq;
+  if (!geom_ok(outer, C, inner, kMseChunk)) return 0;
+  const ChunkGeom g = make_geom(outer, C, inner, kMseChunk);
+  return static_cast<size_t>(g.chunks_per_chan) * g.C * SBQ_MSE_CANDIDATES * sizeof(double);
+}
+
+int sbq_mse_accumulate(const void* x, int x_dtype, int64_t outer, int64_t C, int64_t inner,
+                       const float* min_val, const float* max_val, int qmin, int qmax, int symmetric,
+                       double* sse, void* workspace, size_t workspace_bytes, void* stream) {
+  using namespace sbq;
+  if (!valid_dtype(x_dtype)) return SBQ_ERR_DTYPE;
+  if (outer < 0 || C < 0 || inner < 0) return SBQ_ERR_ARG;
+  if (outer == 0 || C == 0 || inner == 0) return SBQ_ERR_EMPTY;
+  if (!x || !min_val || !max_val || !sse || !workspace) return SBQ_ERR_NULL;
+  if (qmin >= qmax) return SBQ_ERR_ARG;
+  if (!geom_ok(outer, C, inner, kMseChunk)) return SBQ_ERR_ARG;
+  if (reinterpret_cast<uintptr_t>(x) % dtype_size(x_dtype)) return SBQ_ERR_ALIGN;
+  const ChunkGeom g = make_geom(outer, C, inner, kMseChunk);
+  const size_t need = static_cast<size_t>(g.chunks_per_chan) * g.C * SBQ_MSE_CANDIDATES * sizeof(double);
+  if (workspace_bytes < need || !aligned16(workspace)) return SBQ_ERR_WORKSPACE;
+  hipStream_t st = as_stream(stream);
+  double* part = static_cast<double*>(workspace);
+  const uint32_t grid = g.chunks_per_chan * g.C;
+  const bool vec = aligned16(x) && inner % kPack == 0;
+  const float qrange = static_cast<float>(qmax - qmin);
+  const float qlo = static_cast<float>(qmin), qhi = static_cast<float>(qmax);
+  int rc = dispatch_dtype(x_dtype, [&](auto tag) {
+    using T = decltype(tag);
+    if (vec)
+      mse_partial_kernel<T, true><<<grid, kBlock, 0, st>>>(x, min_val, max_val, part, g, qrange, qlo, qhi, symmetric);
+    else
+      mse_partial_kernel<T, false><<<grid, kBlock, 0, st>>>(x, min_val, max_val, part, g, qrange, qlo, qhi, symmetric);
+  });
+  if (rc != SBQ_OK) return rc;
+  rc = check_launch();
+  if (rc != SBQ_OK) return rc;
+  mse_fold_kernel<<<g.C, kBlock, 0, st>>>(part, g.chunks_per_chan, sse);
+  return check_launch();
+}
+
+int sbq_mse_select(const double* sse, double count_per_channel, const float* min_val,
+                   const float* max_val, int64_t C, int qmin, int qmax, int symmetric,
+                   float* scale_out, float* zero_point_out, int32_t* best_index_out, void* stream) {
+  using namespace sbq;
+  if (C < 0 || count_per_channel <= 0) return SBQ_ERR_ARG;
+  if (C == 0) return SBQ_ERR_EMPTY;
+  if (!sse || !min_val || !max_val || !scale_out || !zero_point_out) return SBQ_ERR_NULL;
+  if (qmin >= qmax) return SBQ_ERR_ARG;
+  const float qrange = static_cast<float>(qmax - qmin);
+  mse_select_kernel<<<static_cast<uint32_t>(ceil_div(C, kWave)), kWave, 0, as_stream(stream)>>>(
+      sse, count_per_channel, min_val, max_val, C, qrange, symmetric, scale_out, zero_point_out,
+      best_index_out);
+  return check_launch();
+}
+
+}  // extern "C"

@@ -1,0 +1,410 @@
+// sbq_select.hip -- exact order statistics on gfx950: the percentile observer's
+// k-th values and the unstructured-mask threshold, plus the mask itself.
+//
+// Replaces
+//   sparsebit/quantization/observers/percentile.py:16-46  (2*C torch.kthvalue calls
+//       in a Python loop after a torch.cat/transpose copy),
+//   sparsebit/sparse/sparsers/l1norm.py:18-26             (full torch.sort for ONE
+//       order statistic, then `abs(w) > thresh`).
+//
+// Two selection engines, both exact and atomics-free in their results:
+//   * rows: a [C, inner] weight whose row fits in LDS (<= 16384 keys = 64 KiB).
+//     One workgroup per row loads the row ONCE (16-byte loads), converts it to
+//     order-preserving uint32 keys in LDS and finds both k-th keys by a 32-step
+//     MSB-first bisection; each step is one LDS sweep + one block-wide count.
+//   * radix: any size / geometry / sharding.  Three passes (11+11+10 key bits);
+//     per pass one HBM sweep builds a 2048-bin histogram per (channel, selector)
+//     in LDS with integer atomics (order independent => deterministic), flushed
+//     with 64-bit global atomics.  Histograms are plain int64 so that shards on
+//     different GPUs are combined exactly with one SUM all-reduce per pass.
+#include "sbq_common.hpp"
+
+namespace sbq {
+namespace {
+
+struct SumU { __device__ __forceinline__ uint32_t operator()(uint32_t a, uint32_t b) const { return a + b; } };
+
+// ---------------------------------------------------------------------------------
+// rows engine
+// ---------------------------------------------------------------------------------
+template <typename T, bool VEC>
+__global__ __launch_bounds__(kBlock) void percentile_rows_kernel(const void* __restrict__ x,
+                                                                 uint32_t inner, double alpha,
+                                                                 float* __restrict__ min_out,
+                                                                 float* __restrict__ max_out) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  uint32_t* keys = reinterpret_cast<uint32_t*>(smem);        // [inner]
+  uint32_t* red = keys + ((inner + 3u) & ~3u);                // [2][kWavesPerBlock]
+  const uint32_t row = blockIdx.x;
+  const int64_t base = static_cast<int64_t>(row) * inner;
+
+  uint32_t neg = 0, pos = 0;
+  if constexpr (VEC) {
+    for (uint32_t p = threadIdx.x; p < inner / kPack; p += kBlock) {
+      float v[kPack];
+      load_pack<T, true>(x, base + static_cast<int64_t>(p) * kPack, v);
+#pragma unroll
+      for (int j = 0; j < kPack; ++j) {
+        neg += v[j] < 0.0f;
+        pos += v[j] >= 0.0f;
+        keys[p * kPack + j] = float_key(v[j], false);
+      }
+    }
+  } else {
+    for (uint32_t e = threadIdx.x; e < inner; e += kBlock) {
+      const float f = Elem<T>::load1(x, base + e);
+      neg += f < 0.0f;
+      pos += f >= 0.0f;
+      keys[e] = float_key(f, false);
+    }
+  }
+  neg = block_reduce(neg, SumU(), red);
+  pos = block_reduce(pos, SumU(), red);  // block_reduce syncs: keys[] are visible after this
+
+  // percentile.py:36-43 (1-indexed k-th smallest; Python round == rint on a double)
+  const double rp = __builtin_rint(static_cast<double>(pos) * alpha);
+  const double rn = __builtin_rint(static_cast<double>(neg) * alpha);
+  int64_t k_max = static_cast<int64_t>(inner) - static_cast<int64_t>(rp > 0.0 ? rp : 0.0);
+  int64_t k_min = static_cast<int64_t>(rn > 1.0 ? rn : 1.0);
+  // torch.kthvalue raises for k outside [1, n]; clamp instead of faulting
+  if (k_max < 1) k_max = 1;
+  if (k_min > inner) k_min = inner;
+
+  // MSB-first bisection for two ranks at once.  Invariant: `pre` holds the decided
+  // high bits of the answer; `k` is the rank inside the bucket of keys sharing them.
+  uint32_t pre0 = 0, pre1 = 0;
+  uint32_t k0 = static_cast<uint32_t>(k_min), k1 = static_cast<uint32_t>(k_max);
+  for (int bit = 31; bit >= 0; --bit) {
+    const uint32_t hi_mask = bit == 31 ? 0u : ~((2u << bit) - 1u);  // bits above `bit`
+    const uint32_t b = 1u << bit;
+    uint32_t c0 = 0, c1 = 0;  // keys in the bucket whose `bit` is 0
+    for (uint32_t e = threadIdx.x; e < inner; e += kBlock) {
+      const uint32_t kk = keys[e];
+      c0 += ((kk & hi_mask) == pre0) & !(kk & b);
+      c1 += ((kk & hi_mask) == pre1) & !(kk & b);
+    }
+    // pack the two counts (each <= 16384) into one reduction
+    const uint32_t packed = block_reduce(c0 | (c1 << 16), SumU(), red);
+    c0 = packed & 0xffffu;
+    c1 = packed >> 16;
+    if (k0 > c0) { k0 -= c0; pre0 |= b; }
+    if (k1 > c1) { k1 -= c1; pre1 |= b; }
+  }
+  if (threadIdx.x == 0) {
+    min_out[row] = neg > 0 ? key_float(pre0) : 0.0f;
+    max_out[row] = pos > 0 ? key_float(pre1) : 0.0f;
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// radix engine
+// ---------------------------------------------------------------------------------
+using RadixGeom = ChunkGeom;
+
+constexpr uint32_t kRadixChunk = kBlock * kPack * 8;  // 16384 elements per workgroup
+constexpr int kMaxSel = 2;
+
+__device__ __forceinline__ int pass_shift(int pass) { return pass == 0 ? 21 : (pass == 1 ? 10 : 0); }
+__device__ __forceinline__ uint32_t pass_bins(int pass) { return pass == 2 ? 1024u : 2048u; }
+
+template <typename T, bool VEC>
+__global__ __launch_bounds__(kBlock) void radix_hist_kernel(const void* __restrict__ x,
+                                                            const int64_t* __restrict__ state,
+                                                            unsigned long long* __restrict__ hist,
+                                                            const RadixGeom g, int use_abs, int pass,
+                                                            int n_sel) {
+  __shared__ uint32_t lh[kMaxSel][SBQ_RADIX_BINS];
+  const uint32_t bid = blockIdx.x;
+  const ChunkPos cp = chunk_pos(g, bid);
+  const uint32_t c = cp.c;
+  const int64_t row_base = cp.row_base, begin = cp.begin, end = cp.end;
+
+  for (uint32_t i = threadIdx.x; i < kMaxSel * SBQ_RADIX_BINS; i += kBlock) (&lh[0][0])[i] = 0;
+  const int shift = pass_shift(pass);
+  const uint32_t dmask = pass_bins(pass) - 1u;
+  // high bits already decided by earlier passes
+  const uint32_t known = pass == 0 ? 0u : (pass == 1 ? 0xffe00000u : 0xfffffc00u);
+  uint32_t pre[kMaxSel];
+#pragma unroll
+  for (int s = 0; s < kMaxSel; ++s)
+    pre[s] = s < n_sel ? static_cast<uint32_t>(state[(static_cast<size_t>(c) * n_sel + s) * 2]) : 0u;
+  __syncthreads();
+
+  auto visit = [&](float f) {
+    const uint32_t kk = float_key(f, use_abs != 0);
+    const uint32_t d = (kk >> shift) & dmask;
+#pragma unroll
+    for (int s = 0; s < kMaxSel; ++s)
+      if (s < n_sel && (kk & known) == pre[s]) atomicAdd(&lh[s][d], 1u);
+  };
+
+  if constexpr (VEC) {
+    const int64_t vend = begin + ((end - begin) / kPack) * kPack;
+    for (int64_t e = begin + static_cast<int64_t>(threadIdx.x) * kPack; e < vend;
+         e += static_cast<int64_t>(kBlock) * kPack) {
+      float v[kPack];
+      load_pack<T, true>(x, row_base + e, v);
+#pragma unroll
+      for (int q = 0; q < kPack; ++q) visit(v[q]);
+    }
+    for (int64_t e = vend + threadIdx.x; e < end; e += kBlock) visit(Elem<T>::load1(x, row_base + e));
+  } else {
+    for (int64_t e = begin + threadIdx.x; e < end; e += kBlock) visit(Elem<T>::load1(x, row_base + e));
+  }
+  __syncthreads();
+  for (int s = 0; s < n_sel; ++s) {
+    unsigned long long* gh = hist + (static_cast<size_t>(c) * n_sel + s) * SBQ_RADIX_BINS;
+    for (uint32_t i = threadIdx.x; i < SBQ_RADIX_BINS; i += kBlock) {
+      const uint32_t v = lh[s][i];
+      if (v) atomicAdd(&gh[i], static_cast<unsigned long long>(v));
+    }
+  }
+}
+
+// one workgroup per (channel, selector): find the bin holding rank k
+__global__ __launch_bounds__(kBlock) void radix_advance_kernel(const int64_t* __restrict__ hist,
+                                                               int pass, int64_t* __restrict__ state) {
+  __shared__ int64_t seg[kBlock];
+  const size_t cs = blockIdx.x;
+  const int64_t* h = hist + cs * SBQ_RADIX_BINS;
+  constexpr int kPer = SBQ_RADIX_BINS / kBlock;  // 8 bins per thread
+  int64_t t = 0;
+#pragma unroll
+  for (int i = 0; i < kPer; ++i) t += h[threadIdx.x * kPer + i];
+  seg[threadIdx.x] = t;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int64_t k = state[cs * 2 + 1];
+    uint32_t pre = static_cast<uint32_t>(state[cs * 2]);
+    int sidx = 0;
+    for (; sidx < kBlock - 1; ++sidx) {
+      if (k <= seg[sidx]) break;
+      k -= seg[sidx];
+    }
+    int b = sidx * kPer;
+    const int last = sidx * kPer + kPer - 1;
+    for (; b < last; ++b) {
+      if (k <= h[b]) break;
+      k -= h[b];
+    }
+    pre |= static_cast<uint32_t>(b) << pass_shift(pass);
+    state[cs * 2] = static_cast<int64_t>(pre);
+    state[cs * 2 + 1] = k;
+  }
+}
+
+__global__ void radix_finish_kernel(const int64_t* __restrict__ state, int64_t n, float* __restrict__ out) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  out[i] = key_float(static_cast<uint32_t>(state[i * 2]));
+}
+
+template <typename T, bool VEC>
+__global__ __launch_bounds__(kBlock) void sign_count_kernel(const void* __restrict__ x,
+                                                            unsigned long long* __restrict__ neg_out,
+                                                            unsigned long long* __restrict__ pos_out,
+                                                            const RadixGeom g) {
+  __shared__ uint32_t red[kWavesPerBlock];
+  const uint32_t bid = blockIdx.x;
+  const ChunkPos cp = chunk_pos(g, bid);
+  const uint32_t c = cp.c;
+  const int64_t row_base = cp.row_base, begin = cp.begin, end = cp.end;
+  uint32_t neg = 0, pos = 0;
+  auto visit = [&](float f) {
+    neg += f < 0.0f;
+    pos += f >= 0.0f;
+  };
+  if constexpr (VEC) {
+    const int64_t vend = begin + ((end - begin) / kPack) * kPack;
+    for (int64_t e = begin + static_cast<int64_t>(threadIdx.x) * kPack; e < vend;
+         e += static_cast<int64_t>(kBlock) * kPack) {
+      float v[kPack];
+      load_pack<T, true>(x, row_base + e, v);
+#pragma unroll
+      for (int q = 0; q < kPack; ++q) visit(v[q]);
+    }
+    for (int64_t e = vend + threadIdx.x; e < end; e += kBlock) visit(Elem<T>::load1(x, row_base + e));
+  } else {
+    for (int64_t e = begin + threadIdx.x; e < end; e += kBlock) visit(Elem<T>::load1(x, row_base + e));
+  }
+  neg = block_reduce(neg, SumU(), red);
+  pos = block_reduce(pos, SumU(), red);
+  if (threadIdx.x == 0) {
+    if (neg) atomicAdd(&neg_out[c], static_cast<unsigned long long>(neg));
+    if (pos) atomicAdd(&pos_out[c], static_cast<unsigned long long>(pos));
+  }
+}
+
+// mask[i] = |x[i]| > thresh   (l1norm.py:24-25)
+template <typename T>
+__global__ __launch_bounds__(kBlock) void mask_pack_kernel(const void* __restrict__ x,
+                                                           const float* __restrict__ thresh,
+                                                           uint8_t* __restrict__ mask, uint32_t packs) {
+  const float thr = *thresh;
+  for (uint32_t p = blockIdx.x * kBlock + threadIdx.x; p < packs; p += gridDim.x * kBlock) {
+    float v[kPack];
+    load_pack<T, true>(x, static_cast<int64_t>(p) * kPack, v);
+    u32x2 w;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      uint32_t acc = 0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc |= (__builtin_fabsf(v[4 * h + j]) > thr ? 1u : 0u) << (8 * j);
+      w[h] = acc;
+    }
+    st8<true>(mask + static_cast<int64_t>(p) * kPack, w);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void mask_scalar_kernel(const void* __restrict__ x,
+                                                             const float* __restrict__ thresh,
+                                                             uint8_t* __restrict__ mask, int64_t begin,
+                                                             int64_t end) {
+  const float thr = *thresh;
+  for (int64_t i = begin + static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < end;
+       i += static_cast<int64_t>(gridDim.x) * kBlock)
+    mask[i] = __builtin_fabsf(Elem<T>::load1(x, i)) > thr ? 1 : 0;
+}
+
+bool radix_geom(int64_t outer, int64_t C, int64_t inner, RadixGeom& g) {
+  if (!geom_ok(outer, C, inner, kRadixChunk)) return false;
+  g = make_geom(outer, C, inner, kRadixChunk);
+  return true;
+}
+
+}  // namespace
+}  // namespace sbq
+
+extern "C" {
+
+int sbq_percentile_rows(const void* x, int x_dtype, int64_t C, int64_t inner, double alpha,
+                        float* min_out, float* max_out, void* stream) {
+  using namespace sbq;
+  if (!valid_dtype(x_dtype)) return SBQ_ERR_DTYPE;
+  if (C < 0 || inner < 0) return SBQ_ERR_ARG;
+  if (C == 0 || inner == 0) return SBQ_ERR_EMPTY;
+  if (!x || !min_out || !max_out) return SBQ_ERR_NULL;
+  if (inner > SBQ_ROWSEL_MAX || C >= (1ll << 31)) return SBQ_ERR_ARG;
+  if (!(alpha >= 0.0 && alpha <= 1.0)) return SBQ_ERR_ARG;
+  if (reinterpret_cast<uintptr_t>(x) % dtype_size(x_dtype)) return SBQ_ERR_ALIGN;
+  const bool vec = aligned16(x) && inner % kPack == 0;
+  const size_t lds = ((static_cast<size_t>(inner) + 3) & ~size_t(3)) * 4 + 2 * kWavesPerBlock * 4 + 16;
+  hipStream_t st = as_stream(stream);
+  int rc = dispatch_dtype(x_dtype, [&](auto tag) {
+    using T = decltype(tag);
+    if (vec)
+      percentile_rows_kernel<T, true><<<static_cast<uint32_t>(C), kBlock, lds, st>>>(
+          x, static_cast<uint32_t>(inner), alpha, min_out, max_out);
+    else
+      percentile_rows_kernel<T, false><<<static_cast<uint32_t>(C), kBlock, lds, st>>>(
+          x, static_cast<uint32_t>(inner), alpha, min_out, max_out);
+  });
+  if (rc != SBQ_OK) return rc;
+  return check_launch();
+}
+
+int sbq_radix_histogram(const void* x, int x_dtype, int64_t outer, int64_t C, int64_t inner,
+                        int use_abs, int pass, int n_sel, const int64_t* state, int64_t* hist,
+                        void* stream) {
+  using namespace sbq;
+  if (!valid_dtype(x_dtype)) return SBQ_ERR_DTYPE;
+  if (outer < 0 || C < 0 || inner < 0) return SBQ_ERR_ARG;
+  if (outer == 0 || C == 0 || inner == 0) return SBQ_ERR_EMPTY;
+  if (!x || !state || !hist) return SBQ_ERR_NULL;
+  if (pass < 0 || pass > 2 || n_sel < 1 || n_sel > kMaxSel) return SBQ_ERR_ARG;
+  if (reinterpret_cast<uintptr_t>(x) % dtype_size(x_dtype)) return SBQ_ERR_ALIGN;
+  RadixGeom g;
+  if (!radix_geom(outer, C, inner, g)) return SBQ_ERR_ARG;
+  const bool vec = pack_friendly(x, C, outer, inner);
+  hipStream_t st = as_stream(stream);
+  const uint32_t grid = g.chunks_per_chan * g.C;
+  unsigned long long* h = reinterpret_cast<unsigned long long*>(hist);
+  int rc = dispatch_dtype(x_dtype, [&](auto tag) {
+    using T = decltype(tag);
+    if (vec) radix_hist_kernel<T, true><<<grid, kBlock, 0, st>>>(x, state, h, g, use_abs, pass, n_sel);
+    else radix_hist_kernel<T, false><<<grid, kBlock, 0, st>>>(x, state, h, g, use_abs, pass, n_sel);
+  });
+  if (rc != SBQ_OK) return rc;
+  return check_launch();
+}
+
+int sbq_radix_advance(const int64_t* hist, int64_t C, int pass, int n_sel, int64_t* state, void* stream) {
+  using namespace sbq;
+  if (C < 0) return SBQ_ERR_ARG;
+  if (C == 0) return SBQ_ERR_EMPTY;
+  if (!hist || !state) return SBQ_ERR_NULL;
+  if (pass < 0 || pass > 2 || n_sel < 1 || n_sel > kMaxSel || C * n_sel >= (1ll << 31)) return SBQ_ERR_ARG;
+  radix_advance_kernel<<<static_cast<uint32_t>(C * n_sel), kBlock, 0, as_stream(stream)>>>(hist, pass, state);
+  return check_launch();
+}
+
+int sbq_radix_finish(const int64_t* state, int64_t C, int n_sel, int use_abs, float* values_out,
+                     void* stream) {
+  using namespace sbq;
+  (void)use_abs;  // keys of |x| are non-negative floats: the inverse map is the same
+  if (C < 0) return SBQ_ERR_ARG;
+  if (C == 0) return SBQ_ERR_EMPTY;
+  if (!state || !values_out) return SBQ_ERR_NULL;
+  if (n_sel < 1 || n_sel > kMaxSel) return SBQ_ERR_ARG;
+  const int64_t n = C * n_sel;
+  radix_finish_kernel<<<static_cast<uint32_t>(ceil_div(n, kBlock)), kBlock, 0, as_stream(stream)>>>(
+      state, n, values_out);
+  return check_launch();
+}
+
+int sbq_sign_counts(const void* x, int x_dtype, int64_t outer, int64_t C, int64_t inner,
+                    int64_t* neg_out, int64_t* pos_out, void* stream) {
+  using namespace sbq;
+  if (!valid_dtype(x_dtype)) return SBQ_ERR_DTYPE;
+  if (outer < 0 || C < 0 || inner < 0) return SBQ_ERR_ARG;
+  if (outer == 0 || C == 0 || inner == 0) return SBQ_ERR_EMPTY;
+  if (!x || !neg_out || !pos_out) return SBQ_ERR_NULL;
+  if (reinterpret_cast<uintptr_t>(x) % dtype_size(x_dtype)) return SBQ_ERR_ALIGN;
+  RadixGeom g;
+  if (!radix_geom(outer, C, inner, g)) return SBQ_ERR_ARG;
+  const bool vec = pack_friendly(x, C, outer, inner);
+  hipStream_t st = as_stream(stream);
+  const uint32_t grid = g.chunks_per_chan * g.C;
+  unsigned long long* ng = reinterpret_cast<unsigned long long*>(neg_out);
+  unsigned long long* ps = reinterpret_cast<unsigned long long*>(pos_out);
+  int rc = dispatch_dtype(x_dtype, [&](auto tag) {
+    using T = decltype(tag);
+    if (vec) sign_count_kernel<T, true><<<grid, kBlock, 0, st>>>(x, ng, ps, g);
+    else sign_count_kernel<T, false><<<grid, kBlock, 0, st>>>(x, ng, ps, g);
+  });
+  if (rc != SBQ_OK) return rc;
+  return check_launch();
+}
+
+int sbq_mask_from_threshold(const void* x, int x_dtype, int64_t numel, const float* thresh,
+                            uint8_t* mask_out, void* stream) {
+  using namespace sbq;
+  if (!valid_dtype(x_dtype)) return SBQ_ERR_DTYPE;
+  if (numel < 0) return SBQ_ERR_ARG;
+  if (numel == 0) return SBQ_ERR_EMPTY;
+  if (!x || !thresh || !mask_out) return SBQ_ERR_NULL;
+  if (reinterpret_cast<uintptr_t>(x) % dtype_size(x_dtype)) return SBQ_ERR_ALIGN;
+  hipStream_t st = as_stream(stream);
+  const bool vec = aligned16(x) && (reinterpret_cast<uintptr_t>(mask_out) & 7u) == 0 &&
+                   numel / kPack < (1ll << 31);
+  const int64_t body = vec ? (numel / kPack) * kPack : 0;
+  int rc = dispatch_dtype(x_dtype, [&](auto tag) {
+    using T = decltype(tag);
+    if (body > 0) {
+      const uint32_t packs = static_cast<uint32_t>(body / kPack);
+      uint32_t grid = (packs + kBlock - 1) / kBlock;
+      if (grid > 4096u) grid = 4096u;
+      mask_pack_kernel<T><<<grid, kBlock, 0, st>>>(x, thresh, mask_out, packs);
+    }
+    if (body < numel) {
+      int64_t blocks = ceil_div(numel - body, kBlock);
+      if (blocks > 4096) blocks = 4096;
+      mask_scalar_kernel<T><<<static_cast<uint32_t>(blocks), kBlock, 0, st>>>(x, thresh, mask_out, body, numel);
+    }
+  });
+  if (rc != SBQ_OK) return rc;
+  return check_launch();
+}
+
+}  // extern "C"

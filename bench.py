@@ -1,0 +1,256 @@
+"""Headline benchmark: per-channel int8 QDQ of a 4096 x 4096 bf16 weight on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+
+One "step" = one pass of the hot path over one weight: sbq_quant_perchannel_forward
+(bf16 in -> bf16 out, per-channel symmetric int8, scales from the minmax observer), called
+through the C ABI with caller-allocated buffers that are already resident in HBM.  To keep
+the number an HBM number, the steps rotate over 12 distinct input/output pairs (805 MB,
+larger than the 256 MiB Infinity Cache); the cache-resident rate is reported separately.
+Multi-GPU is weak scaling with no data-path collective: each rank quantizes its own
+weights; the observer statistic all-reduce (RCCL) is timed beside it.
+
+Prints ONE JSON line on rank 0 (contract: see the round prompt / DESIGN.md section 6).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+ROWS = COLS = 4096
+NBUF = 12
+QMIN, QMAX = -128, 127
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+BYTES_PER_ELEM = 4  # algorithmic: 2 B read + 2 B written (bf16 -> bf16), SURVEY.md 8(d)
+
+
+def make_weight(seed):
+    """randn * logspace(-2, 1) row scales, bf16."""
+    g = torch.Generator().manual_seed(seed)
+    w = torch.randn(ROWS, COLS, generator=g) * torch.logspace(-2, 1, ROWS).unsqueeze(1)
+    return w.bfloat16()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=500)
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    assert torch.cuda.is_available(), "bench.py measures the HIP path: it needs an MI355X"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    import torch.distributed as dist
+
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
+
+    from sparsebit_amd import dist as sbq_dist
+    from sparsebit_amd import lib as L
+    from sparsebit_amd import ops
+    from sparsebit_amd.common import Backend
+    from sparsebit_amd.config import quantizer_config
+    from sparsebit_amd.quantizers import build_quantizer
+
+    lib = L.load()  # raises if libsbq.so / a symbol is missing: no fallback
+
+    # ---- data: NBUF distinct weights per rank, resident in HBM ---------------------------
+    host = make_weight(1000 * rank)
+    xs = [host.to(dev)]
+    for i in range(1, NBUF):
+        xs.append(torch.roll(xs[0], shifts=i, dims=1).contiguous())  # same row statistics, distinct buffers
+    ys = [torch.empty_like(x) for x in xs]
+
+    # ---- calibration through the product API (minmax observer -> scale / zero_point) ------
+    q = build_quantizer(quantizer_config("per-channel-symmetric", 8, observer="MINMAX"))
+    q.set_backend(Backend.VIRTUAL)
+    q.update_observer(xs[0])
+    scale, zp = q.calc_qparams()
+    scale = scale.reshape(-1).contiguous()
+    zp = zp.reshape(-1).contiguous()
+
+    stream = torch.cuda.current_stream(dev)
+    st = L.stream_ptr(dev)
+    xp = [L.ptr(x) for x in xs]
+    yp = [L.ptr(y) for y in ys]
+    sp, zpp = L.ptr(scale), L.ptr(zp)
+    fwd = lib.sbq_quant_perchannel_forward
+
+    def step(i):
+        j = i % NBUF
+        rc = fwd(xp[j], L.BF16, yp[j], L.BF16, None, L.Q_NONE, sp, zpp, 1, ROWS, COLS, QMIN, QMAX, 0, st)
+        if rc:
+            L.check(rc)
+
+    def sync_all():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    # ---- parity gate inside the benchmark (rank 0): the timed kernel == oracle --------------
+    parity = None
+    if rank == 0:
+        from oracle import oracle as O
+
+        step(0)
+        torch.cuda.synchronize(dev)
+        rows = [0, 1, 255, 2048, 4095]
+        xf = host.float().numpy()[rows]
+        s_ref, z_ref = O.qparams_from_minmax(*O.minmax(xf, 0, True), QMIN, QMAX, True)
+        dq_ref, _ = O.qdq(xf, s_ref, z_ref, QMIN, QMAX, 0)
+        got = ys[0][rows].float().cpu().numpy()
+        want = torch.from_numpy(dq_ref).bfloat16().float().numpy()
+        parity = bool((got == want).all()) and bool((scale[rows].cpu().numpy() == s_ref).all())
+        assert parity, "timed kernel does not match the oracle"
+
+    # ---- timed region ------------------------------------------------------------------------
+    for i in range(args.warmup):
+        step(i)
+    sync_all()
+    e0 = torch.cuda.Event(enable_timing=True)
+    e1 = torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record(stream)  # the kernels are launched on this very stream
+    for i in range(args.steps):
+        step(i)
+    e1.record(stream)
+    sync_all()
+    t1 = time.perf_counter()
+    wall = t1 - t0
+    kern_us = e0.elapsed_time(e1) * 1e3 / args.steps  # avg launch-to-launch duration on the GPU
+    if world > 1:
+        t = torch.tensor([wall, kern_us], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall, kern_us = t.tolist()
+
+    n_elem = ROWS * COLS
+    value = world * args.steps * n_elem / wall
+    achieved = n_elem * BYTES_PER_ELEM / (kern_us * 1e-6) / 1e9
+
+    # ---- secondary measurements (outside the timed region) -------------------------------------
+    def timed(fn, iters):
+        for i in range(10):
+            fn(i)
+        torch.cuda.synchronize(dev)
+        a = torch.cuda.Event(enable_timing=True)
+        b = torch.cuda.Event(enable_timing=True)
+        a.record(stream)
+        for i in range(iters):
+            fn(i)
+        b.record(stream)
+        torch.cuda.synchronize(dev)
+        return a.elapsed_time(b) * 1e3 / iters
+
+    extras = {}
+    warm_us = timed(lambda i: step(0), 200)
+    extras["cache_resident_us"] = round(warm_us, 3)
+    extras["cache_resident_GBps"] = round(n_elem * BYTES_PER_ELEM / warm_us / 1e3, 1)
+    y32 = torch.empty(ROWS, COLS, dtype=torch.float32, device=dev)
+
+    def step_f32(i):
+        fwd(xp[i % NBUF], L.BF16, L.ptr(y32), L.F32, None, L.Q_NONE, sp, zpp, 1, ROWS, COLS, QMIN, QMAX, 0, st)
+
+    f32_us = timed(step_f32, 100)
+    extras["bf16_to_fp32_us"] = round(f32_us, 3)
+    extras["bf16_to_fp32_GBps"] = round(n_elem * 6 / f32_us / 1e3, 1)
+    obs_us = timed(lambda i: ops.channel_stats(xs[i % NBUF], 0, True), 100)
+    extras["minmax_observer_us"] = round(obs_us, 3)
+    extras["minmax_observer_GBps"] = round(n_elem * 2 / obs_us / 1e3, 1)
+
+    # observer statistic exchange: ONE MAX all-reduce of [max, -min, nan flags] for C = 4096
+    mn, mx, _ = ops.channel_stats(xs[0], 0, True)
+    with sbq_dist.sharded_calibration():
+        ar_us = timed(lambda i: sbq_dist.allreduce_minmax(mn, mx), 50) if world > 1 else 0.0
+    extras["observer_allreduce_us"] = round(ar_us, 2)
+    extras["observer_allreduce_bytes"] = 4 * 4 * ROWS if world > 1 else 0
+
+    # ---- CPU baseline: the reference's CPU fake-quant ops on this box's host cores -----------
+    cpu_baseline = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import torch_port
+
+        cores = os.cpu_count() or 1
+        torch.set_num_threads(cores)
+        xcpu = host.float()
+        s_cpu = scale.cpu().reshape(-1, 1)
+        z_cpu = zp.cpu().reshape(-1, 1)
+        torch_port.ort_fake_quant_cpu(xcpu, s_cpu, z_cpu, QMIN, QMAX)  # warm-up
+        best = float("inf")
+        t_begin = time.perf_counter()
+        reps = 0
+        while reps < 5 or (time.perf_counter() - t_begin < 10.0 and reps < 200):
+            a = time.perf_counter()
+            out = torch_port.ort_fake_quant_cpu(xcpu, s_cpu, z_cpu, QMIN, QMAX)
+            best = min(best, time.perf_counter() - a)
+            reps += 1
+        same = bool((out.bfloat16() == ys[0].cpu()).all())
+        cpu_baseline = {
+            "value": round(n_elem / best, 1),
+            "unit": "elements/s",
+            "cores": torch.get_num_threads(),
+            "kind": "port",
+            "sample": "full 4096x4096 weight (fp32 upcast of the same bf16 data), best of %d runs of the "
+                      "reference's CPU ops (quant_tensor.py:182-184) in torch, %.1f ms" % (reps, best * 1e3),
+            "matches_gpu_output": same,
+        }
+
+    if rank == 0:
+        line = {
+            "metric": "per-channel int8 QDQ throughput, 4096x4096 bf16 weight",
+            "value": value,
+            "unit": "elements/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": wall * 1e3 / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",  # arithmetic type of the path (bf16 storage in and out)
+            "data": "synthetic",
+            "config": {
+                "workload": "per-channel symmetric int8 QDQ of one 4096x4096 bf16 weight per step (bf16 out), "
+                            "minmax-observer scales, %d rotating HBM-resident buffer pairs (%d MB) per GPU"
+                            % (NBUF, NBUF * 2 * n_elem * 2 // 2 ** 20),
+                "elements_per_step_per_gpu": n_elem,
+                "parallelism": "replicated weights, %d rank(s), no data-path collective" % world,
+            },
+            "roofline": {
+                "bound": "hbm",
+                "achieved": round(achieved, 1),
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "traffic": None,
+                "kernel": "sbq::qdq_pack_kernel<BF16,BF16,...>",
+                "kernel_avg_us": round(kern_us, 3),
+                "algorithmic_bytes_per_launch": n_elem * BYTES_PER_ELEM,
+            },
+            "cpu_baseline": cpu_baseline,
+            "parity_checked": parity,
+            "extras": extras,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,357 @@
+"""Functional layer over the C ABI (include/sbq.h): torch tensors in, torch tensors out.
+
+Every function here launches HIP kernels from libsbq.so on the current torch
+stream of the tensor's device.  Operands must already be in HBM; there is no CPU
+path (lib.require_device raises).  Outputs are allocated here with torch because
+the C ABI is caller-allocates (the reference's native layer allocated with
+at::empty_like, fake_quant_tensor.cu:80,211).
+"""
+import torch
+
+from . import lib as L
+
+
+def geometry(shape, ch_axis, per_channel):
+    """[outer, C, inner] of a contiguous tensor quantized along ch_axis (C == 1: per tensor)."""
+    numel = 1
+    for s in shape:
+        numel *= int(s)
+    if not per_channel:
+        return 1, 1, numel
+    outer = 1
+    for s in shape[:ch_axis]:
+        outer *= int(s)
+    inner = 1
+    for s in shape[ch_axis + 1:]:
+        inner *= int(s)
+    return outer, int(shape[ch_axis]), inner
+
+
+_workspaces = {}
+
+
+def _workspace(device, nbytes):
+    """Grow-only scratch buffer per (device, stream): reductions write their partials here."""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    buf = _workspaces.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _workspaces[key] = buf
+    return buf
+
+
+def _f32c(t, device):
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.reshape(-1).contiguous()
+
+
+def _check_qparams(scale, zero_point, C):
+    if scale.numel() != C or zero_point.numel() != C:
+        raise L.SbqError("scale/zero_point must have %d element(s), got %d/%d" % (C, scale.numel(), zero_point.numel()))
+
+
+# ---------------------------------------------------------------------------------
+# forward QDQ
+# ---------------------------------------------------------------------------------
+def fake_quant(x, scale, zero_point, qmin, qmax, ch_axis=0, out_dtype=None, return_q=None,
+               rounding=L.ROUND_HALF_EVEN, mask=None, thresh=None):
+    """y = (clamp(round(x/s) + round(zp), qmin, qmax) - round(zp)) * s   [quant_tensor.py:182-184]
+
+    scale.numel() > 1 selects per-channel along ch_axis.  out_dtype: torch.float32
+    (the reference's output type) or x.dtype.  return_q: None | torch.int8 | torch.uint8 |
+    torch.int32 -> also return the integer tensor.  mask (torch.bool/uint8) or thresh
+    (0-d fp32 tensor) fuse the unstructured-sparsity multiply in front of the QDQ.
+    """
+    dev = L.require_device(x, scale, zero_point, mask, thresh)
+    lib = L.load()
+    x = x.contiguous()
+    per_channel = scale.numel() > 1
+    outer, C, inner = geometry(x.shape, ch_axis, per_channel)
+    scale = _f32c(scale, dev)
+    zero_point = _f32c(zero_point, dev)
+    _check_qparams(scale, zero_point, C)
+    out_dtype = out_dtype or torch.float32
+    if out_dtype not in (torch.float32, x.dtype):
+        raise L.SbqError("out_dtype must be float32 or the input dtype")
+    y = torch.empty(x.shape, dtype=out_dtype, device=dev)
+    q = None
+    q_type = L.Q_NONE
+    if return_q is not None:
+        if return_q in (torch.int8, torch.uint8):
+            q_type = L.Q_I8
+        elif return_q == torch.int32:
+            q_type = L.Q_I32
+        else:
+            raise L.SbqError("return_q must be int8, uint8 or int32")
+        q = torch.empty(x.shape, dtype=return_q, device=dev)
+    if x.numel() == 0:
+        L.check(2)
+    with torch.cuda.device(dev):
+        st = L.stream_ptr(dev)
+        if mask is None and thresh is None:
+            if per_channel:
+                rc = lib.sbq_quant_perchannel_forward(L.ptr(x), L.dtype_id(x), L.ptr(y), L.dtype_id(y), L.ptr(q), q_type,
+                                                      L.ptr(scale), L.ptr(zero_point), outer, C, inner,
+                                                      int(qmin), int(qmax), rounding, st)
+            else:
+                rc = lib.sbq_quant_pertensor_forward(L.ptr(x), L.dtype_id(x), L.ptr(y), L.dtype_id(y), L.ptr(q), q_type,
+                                                     L.ptr(scale), L.ptr(zero_point), x.numel(),
+                                                     int(qmin), int(qmax), rounding, st)
+        else:
+            if mask is not None:
+                if mask.shape != x.shape:
+                    raise L.SbqError("mask must have the shape of x")
+                mask = mask.contiguous()
+                if mask.dtype == torch.bool:
+                    mask = mask.view(torch.uint8)
+                elif mask.dtype != torch.uint8:
+                    raise L.SbqError("mask must be bool or uint8")
+            if thresh is not None:
+                thresh = _f32c(thresh, dev)
+            rc = lib.sbq_mask_quant_forward(L.ptr(x), L.dtype_id(x), L.ptr(y), L.dtype_id(y), L.ptr(q), q_type,
+                                            L.ptr(mask), L.ptr(thresh), L.ptr(scale), L.ptr(zero_point),
+                                            outer, C, inner, int(qmin), int(qmax), rounding, st)
+    L.check(rc)
+    return (y, q) if return_q is not None else y
+
+
+# ---------------------------------------------------------------------------------
+# STE backward
+# ---------------------------------------------------------------------------------
+def fake_quant_backward(x, gy, scale, zero_point, qmin, qmax, ch_axis=0, need_gs=True, need_gzp=True,
+                        gx_dtype=None, rounding=L.ROUND_HALF_EVEN):
+    """-> (gx, gs | None, gzp | None); gs/gzp are flat fp32 [C]  (fake_quant_tensor.cu:97-132)."""
+    dev = L.require_device(x, gy, scale, zero_point)
+    lib = L.load()
+    x = x.contiguous()
+    gy = gy.contiguous()
+    if gy.dtype != x.dtype:
+        gy = gy.to(x.dtype)
+    per_channel = scale.numel() > 1
+    outer, C, inner = geometry(x.shape, ch_axis, per_channel)
+    scale = _f32c(scale, dev)
+    zero_point = _f32c(zero_point, dev)
+    _check_qparams(scale, zero_point, C)
+    gx = torch.empty(x.shape, dtype=gx_dtype or x.dtype, device=dev)
+    gs = torch.empty(C, dtype=torch.float32, device=dev) if need_gs else None
+    gzp = torch.empty(C, dtype=torch.float32, device=dev) if need_gzp else None
+    if x.numel() == 0:
+        L.check(2)
+    with torch.cuda.device(dev):
+        nbytes = lib.sbq_backward_workspace_bytes(outer, C, inner)
+        ws = _workspace(dev, nbytes)
+        rc = lib.sbq_quant_perchannel_backward(L.ptr(x), L.ptr(gy), L.dtype_id(x), L.ptr(gx), L.dtype_id(gx),
+                                               L.ptr(gs), L.ptr(gzp), L.ptr(scale), L.ptr(zero_point),
+                                               outer, C, inner, int(qmin), int(qmax), rounding,
+                                               L.ptr(ws), ws.numel(), L.stream_ptr(dev))
+    L.check(rc)
+    return gx, gs, gzp
+
+
+# ---------------------------------------------------------------------------------
+# observer reductions
+# ---------------------------------------------------------------------------------
+def channel_stats(x, ch_axis=0, per_channel=True, want_min=True, want_max=True, want_abssum=False):
+    """-> (min [C] fp32 | None, max [C] fp32 | None, abssum [C] fp64 | None) in one read of x."""
+    dev = L.require_device(x)
+    lib = L.load()
+    x = x.contiguous()
+    outer, C, inner = geometry(x.shape, ch_axis, per_channel)
+    mn = torch.empty(C, dtype=torch.float32, device=dev) if want_min else None
+    mx = torch.empty(C, dtype=torch.float32, device=dev) if want_max else None
+    ab = torch.empty(C, dtype=torch.float64, device=dev) if want_abssum else None
+    if x.numel() == 0:
+        L.check(2)
+    with torch.cuda.device(dev):
+        ws = _workspace(dev, lib.sbq_stats_workspace_bytes(outer, C, inner))
+        rc = lib.sbq_channel_stats(L.ptr(x), L.dtype_id(x), outer, C, inner, L.ptr(mn), L.ptr(mx), L.ptr(ab),
+                                   L.ptr(ws), ws.numel(), L.stream_ptr(dev))
+    L.check(rc)
+    return mn, mx, ab
+
+
+def qparams_from_minmax(min_val, max_val, qmin, qmax, symmetric):
+    """observers/base.py:63-79 on device -> (scale, zero_point), shaped like min_val."""
+    dev = L.require_device(min_val, max_val)
+    lib = L.load()
+    shape = min_val.shape
+    mn = _f32c(min_val, dev)
+    mx = _f32c(max_val, dev)
+    scale = torch.empty_like(mn)
+    zp = torch.empty_like(mn)
+    with torch.cuda.device(dev):
+        rc = lib.sbq_qparams_from_minmax(L.ptr(mn), L.ptr(mx), mn.numel(), int(qmin), int(qmax), int(bool(symmetric)),
+                                         L.ptr(scale), L.ptr(zp), L.stream_ptr(dev))
+    L.check(rc)
+    return scale.reshape(shape), zp.reshape(shape)
+
+
+def lsq_init_scale(abssum, count, qmax):
+    dev = L.require_device(abssum)
+    lib = L.load()
+    ab = abssum.reshape(-1).contiguous()
+    if ab.dtype != torch.float64:
+        ab = ab.double()
+    scale = torch.empty(ab.numel(), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.sbq_lsq_init_scale(L.ptr(ab), ab.numel(), float(count), int(qmax), L.ptr(scale), L.stream_ptr(dev))
+    L.check(rc)
+    return scale
+
+
+def mse_accumulate(x, min_val, max_val, qmin, qmax, symmetric, sse, ch_axis=0, per_channel=True):
+    """sse[C][80] (fp64) += sum of squared QDQ error of x for each shrink candidate (mse.py:46-61)."""
+    dev = L.require_device(x, min_val, max_val, sse)
+    lib = L.load()
+    x = x.contiguous()
+    outer, C, inner = geometry(x.shape, ch_axis, per_channel)
+    mn = _f32c(min_val, dev)
+    mx = _f32c(max_val, dev)
+    if sse.dtype != torch.float64 or sse.numel() != C * L.MSE_CANDIDATES or not sse.is_contiguous():
+        raise L.SbqError("sse must be a contiguous float64 [C, 80] tensor")
+    if mn.numel() != C or mx.numel() != C:
+        raise L.SbqError("min/max must have C elements")
+    with torch.cuda.device(dev):
+        ws = _workspace(dev, lib.sbq_mse_workspace_bytes(outer, C, inner))
+        rc = lib.sbq_mse_accumulate(L.ptr(x), L.dtype_id(x), outer, C, inner, L.ptr(mn), L.ptr(mx), int(qmin), int(qmax),
+                                    int(bool(symmetric)), L.ptr(sse), L.ptr(ws), ws.numel(), L.stream_ptr(dev))
+    L.check(rc)
+    return sse
+
+
+def mse_select(sse, count_per_channel, min_val, max_val, qmin, qmax, symmetric):
+    """-> (scale [C], zero_point [C], best_index int32 [C])"""
+    dev = L.require_device(sse, min_val, max_val)
+    lib = L.load()
+    mn = _f32c(min_val, dev)
+    mx = _f32c(max_val, dev)
+    C = mn.numel()
+    scale = torch.empty(C, dtype=torch.float32, device=dev)
+    zp = torch.empty(C, dtype=torch.float32, device=dev)
+    best = torch.empty(C, dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.sbq_mse_select(L.ptr(sse), float(count_per_channel), L.ptr(mn), L.ptr(mx), C, int(qmin), int(qmax),
+                                int(bool(symmetric)), L.ptr(scale), L.ptr(zp), L.ptr(best), L.stream_ptr(dev))
+    L.check(rc)
+    return scale, zp, best
+
+
+# ---------------------------------------------------------------------------------
+# order statistics
+# ---------------------------------------------------------------------------------
+def percentile_rows(x2d, alpha):
+    """x2d [C, inner] (inner <= 16384) -> (min [C], max [C]) per percentile.py:16-46."""
+    dev = L.require_device(x2d)
+    lib = L.load()
+    x2d = x2d.contiguous()
+    C, inner = x2d.shape
+    mn = torch.empty(C, dtype=torch.float32, device=dev)
+    mx = torch.empty(C, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.sbq_percentile_rows(L.ptr(x2d), L.dtype_id(x2d), C, inner, float(alpha), L.ptr(mn), L.ptr(mx),
+                                     L.stream_ptr(dev))
+    L.check(rc)
+    return mn, mx
+
+
+def sign_counts(x, neg, pos, ch_axis=0, per_channel=True):
+    """neg/pos (int64 [C]) += count(x < 0) / count(x >= 0)"""
+    dev = L.require_device(x, neg, pos)
+    lib = L.load()
+    x = x.contiguous()
+    outer, C, inner = geometry(x.shape, ch_axis, per_channel)
+    with torch.cuda.device(dev):
+        rc = lib.sbq_sign_counts(L.ptr(x), L.dtype_id(x), outer, C, inner, L.ptr(neg), L.ptr(pos), L.stream_ptr(dev))
+    L.check(rc)
+
+
+def radix_histogram(x, state, hist, pass_, n_sel, use_abs, ch_axis=0, per_channel=True):
+    dev = L.require_device(x, state, hist)
+    lib = L.load()
+    x = x.contiguous()
+    outer, C, inner = geometry(x.shape, ch_axis, per_channel)
+    with torch.cuda.device(dev):
+        rc = lib.sbq_radix_histogram(L.ptr(x), L.dtype_id(x), outer, C, inner, int(bool(use_abs)), int(pass_), int(n_sel),
+                                     L.ptr(state), L.ptr(hist), L.stream_ptr(dev))
+    L.check(rc)
+
+
+def radix_advance(hist, state, pass_, n_sel, C):
+    dev = L.require_device(hist, state)
+    lib = L.load()
+    with torch.cuda.device(dev):
+        rc = lib.sbq_radix_advance(L.ptr(hist), int(C), int(pass_), int(n_sel), L.ptr(state), L.stream_ptr(dev))
+    L.check(rc)
+
+
+def radix_finish(state, n_sel, C, use_abs):
+    dev = L.require_device(state)
+    lib = L.load()
+    out = torch.empty((C, n_sel), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.sbq_radix_finish(L.ptr(state), int(C), int(n_sel), int(bool(use_abs)), L.ptr(out), L.stream_ptr(dev))
+    L.check(rc)
+    return out
+
+
+class HipSelectBackend:
+    """The three primitives of the sharded exact selection protocol (select.py), on HIP."""
+
+    def new_state(self, ranks, device):
+        # ranks: python nested list [C][n_sel] of 1-indexed ranks
+        C, n_sel = len(ranks), len(ranks[0])
+        st = torch.zeros((C, n_sel, 2), dtype=torch.int64)
+        st[:, :, 1] = torch.tensor(ranks, dtype=torch.int64)
+        return st.to(device)
+
+    def new_hist(self, C, n_sel, device):
+        return torch.zeros((C, n_sel, L.RADIX_BINS), dtype=torch.int64, device=device)
+
+    def histogram(self, x, state, hist, pass_, n_sel, use_abs, ch_axis, per_channel):
+        radix_histogram(x, state, hist, pass_, n_sel, use_abs, ch_axis, per_channel)
+
+    def advance(self, hist, state, pass_, n_sel, C):
+        radix_advance(hist, state, pass_, n_sel, C)
+
+    def finish(self, state, n_sel, C, use_abs):
+        return radix_finish(state, n_sel, C, use_abs)
+
+
+def mask_from_threshold(x, thresh):
+    """mask = |x| > thresh as torch.bool (l1norm.py:24-25)"""
+    dev = L.require_device(x, thresh)
+    lib = L.load()
+    x = x.contiguous()
+    thresh = _f32c(thresh, dev)
+    mask = torch.empty(x.shape, dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.sbq_mask_from_threshold(L.ptr(x), L.dtype_id(x), x.numel(), L.ptr(thresh), L.ptr(mask), L.stream_ptr(dev))
+    L.check(rc)
+    return mask.view(torch.bool)
+
+
+# ---------------------------------------------------------------------------------
+# GPTQ 4-bit mat-vec
+# ---------------------------------------------------------------------------------
+def vecquant4matmul(x, qweight, out, scales, zeros, group_size=0):
+    """out[b,n] += sum_k (scales[n,g]*nib - zeros[n,g]) * x[b,k], in place (cuda_kernel.cpp:6-23)."""
+    dev = L.require_device(x, qweight, out, scales, zeros)
+    lib = L.load()
+    if x.dtype != torch.float32 or out.dtype != torch.float32 or qweight.dtype != torch.int32:
+        raise L.SbqError("vecquant4matmul: x/out must be float32 and qweight int32")
+    if not (x.is_contiguous() and out.is_contiguous() and qweight.is_contiguous()):
+        raise L.SbqError("vecquant4matmul: tensors must be contiguous")
+    in_f = x.shape[-1]
+    batch = x.numel() // in_f
+    out_f = qweight.shape[1]
+    if out.shape[-1] != out_f:
+        raise L.SbqError("output channel must be the same with input2 out_channel")
+    scales = _f32c(scales, dev)
+    zeros = _f32c(zeros, dev)
+    with torch.cuda.device(dev):
+        ws = _workspace(dev, lib.sbq_gptq_workspace_bytes(batch, in_f, out_f))
+        rc = lib.sbq_vecquant4matmul(L.ptr(x), L.ptr(qweight), L.ptr(out), L.ptr(scales), L.ptr(zeros), batch, in_f, out_f,
+                                     int(group_size), L.ptr(ws), ws.numel(), L.stream_ptr(dev))
+    L.check(rc)
+    return out

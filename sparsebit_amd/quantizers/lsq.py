@@ -1,0 +1,106 @@
+"""LSQ quantizer (mirrors sparsebit/quantization/quantizers/lsq.py:13-76).
+
+Init: scale = 2 * mean|x| / sqrt(qmax) from ONE fused min/max/sum|x| reduction of the
+cached data (the reference materialises a channel-first copy and makes three torch
+passes); forward: the same STE kernel with the LSQ gradient scaling.  A fused
+mask + LSQ forward for sparse QAT is `forward_masked`.
+"""
+import math
+import warnings
+
+import torch
+import torch.nn as nn
+
+from . import Quantizer as BaseQuantizer
+from . import register_quantizer
+from .. import dist as sbq_dist
+from .. import ops
+from .quant_tensor import STE, fake_quant_factory
+
+
+class gs_scaling(torch.autograd.Function):
+    """identity forward, grad * ratio backward (lsq.py:13-21)"""
+
+    @staticmethod
+    def forward(ctx, x, ratio):
+        ctx.ratio = ratio
+        return x
+
+    @staticmethod
+    def backward(ctx, grad):
+        return grad * ctx.ratio, None
+
+
+@register_quantizer
+class Quantizer(BaseQuantizer):
+    TYPE = "LSQ"
+
+    def __init__(self, config):
+        super(Quantizer, self).__init__(config)
+        self.init_params = False  # LSQ initialises from calibration data
+
+    def calc_qparams(self):
+        if self.fake_fused:
+            return self.scale, self.zero_point
+        if not self.init_params:
+            shards = self.observer._shards()
+            ch_axis, perch = self.qdesc.ch_axis, self.is_perchannel
+            # lsq.py:39-43 needs the global minimum; lsq.py:44-47 the per-channel mean|x|:
+            # one pass gives both (per-channel stats also yield the global min)
+            mn = ab = None
+            n_local = 0
+            C = shards[0].shape[ch_axis] if perch else 1
+            for x in shards:
+                a, _, s = ops.channel_stats(x, ch_axis, perch, want_min=True, want_max=False, want_abssum=True)
+                mn = a if mn is None else torch.minimum(mn, a)
+                ab = s if ab is None else ab + s
+                n_local += x.numel() // C
+            if sbq_dist.active():
+                mn, _ = sbq_dist.allreduce_minmax(mn, mn)
+                sbq_dist.allreduce_sum_(ab)
+            n = sbq_dist.allreduce_count(n_local)
+            if bool(mn.min() < 0) and not self.qdesc.is_symmetric:
+                warnings.warn("Found data less than 0, reset quantizer scheme as symmetric")
+                self.qdesc.set_symmetric(True)
+            scale = ops.lsq_init_scale(ab, n, self.qdesc.qmax)
+            if not perch:
+                scale = scale.reshape(())
+            self.observer.data_cache.reset()
+            self.scale = nn.Parameter(self._broadcast_qparams(scale.to(self.device)))
+            self.zero_point = self._broadcast_qparams(torch.zeros_like(self.scale))
+            self.init_params = True
+        return self.scale, self.zero_point
+
+    def _qparams_preprocess(self, x):
+        if self.export_onnx:
+            return (
+                torch.tensor(self.scale.abs().detach().cpu().numpy(), device=self.device),
+                torch.tensor(
+                    torch.clamp(self.zero_point, self.qdesc.qmin, self.qdesc.qmax).detach().cpu().numpy(),
+                    device=self.device,
+                ),
+            )
+        scale = self.scale.abs()
+        zero_point = torch.clamp(self.zero_point, self.qdesc.qmin, self.qdesc.qmax)
+        return scale, zero_point
+
+    def _gs_ratio(self, x):
+        if self.is_perchannel:
+            num_perchannel = x.numel() / x.shape[self.qdesc.ch_axis]
+            return 1.0 / math.sqrt(num_perchannel * self.qdesc.qmax)
+        return 1.0 / math.sqrt(x.numel() * self.qdesc.qmax)
+
+    def _forward(self, x, scale, zero_point):
+        scale = gs_scaling.apply(scale, self._gs_ratio(x))
+        return STE.apply(x, scale, zero_point, self.qdesc, self.backend)
+
+    def forward_masked(self, x, mask=None, thresh=None, out_dtype=None):
+        """Inference-side fused `quantizer(x * mask)`: one kernel, one read of x
+        (sparse/modules/conv.py:40 + this quantizer).  mask: torch.bool like x, or
+        thresh: 0-d tensor with keep = |x| > thresh."""
+        if not self.is_enable:
+            return x * mask if mask is not None else torch.where(x.abs() > thresh, x, torch.zeros_like(x))
+        scale, zero_point = self._qparams_preprocess(x)
+        qmin, qmax = self.qdesc.qrange
+        return ops.fake_quant(x, scale.detach(), zero_point, qmin, qmax, self.qdesc.ch_axis,
+                              out_dtype=out_dtype or torch.float32, mask=mask, thresh=thresh)

@@ -1,0 +1,124 @@
+"""Fake-quant dispatch + straight-through estimator on the HIP path.
+
+Mirrors sparsebit/quantization/quantizers/quant_tensor.py: `fake_quant_kernel` is
+the object with the reference pybind module's four functions (export.cc:3-8),
+`ort_fake_quant` / `trt_fake_quant` / `fake_quant_factory` / `STE` /
+`torch_fake_quant` keep their names, arguments and checks.  The GPU branch of the
+reference is the only branch here: CPU tensors are rejected (no fallback).
+"""
+import numpy as np
+import torch
+
+from .. import fake_quant as fake_quant_kernel
+from .. import lib as L
+from .. import ops
+from ..common import Backend
+
+
+def _same_device(x_f, scale, zero_point):
+    assert (
+        x_f.device == scale.device == zero_point.device
+    ), "input, scale and zero_point of quantizer must be on same device!"
+
+
+def ort_fake_quant(x_f, scale, zero_point, qdesc, out_dtype=None):
+    """quant_tensor.py:159-185 (GPU branch).  bf16/fp16/fp32 in; fp32 out by default like
+    the reference (it upcasts fp16 itself, :165-166)."""
+    _same_device(x_f, scale, zero_point)
+    qmin, qmax = qdesc.qrange
+    return ops.fake_quant(x_f, scale, zero_point, qmin, qmax, qdesc.ch_axis, out_dtype=out_dtype or _default_out(x_f))
+
+
+def trt_fake_quant(x_f, scale, zero_point, qdesc, out_dtype=None):
+    """quant_tensor.py:128-156 (GPU branch): symmetric only."""
+    _same_device(x_f, scale, zero_point)
+    assert abs(zero_point).sum() == 0, "tensorrt only support symmetric quant, but zp={}".format(zero_point)
+    qmin, qmax = qdesc.qrange
+    return ops.fake_quant(x_f, scale, zero_point, qmin, qmax, qdesc.ch_axis, out_dtype=out_dtype or _default_out(x_f))
+
+
+_keep_dtype = False
+
+
+def keep_input_dtype(flag=True):
+    """Perf mode: return the dequantized tensor in the input dtype (bf16 in -> bf16 out,
+    = RNE cast of the fp32 result, 4 B/element of HBM traffic instead of 6).  Default
+    off: the reference always returns fp32."""
+    global _keep_dtype
+    _keep_dtype = bool(flag)
+
+
+def _default_out(x):
+    return x.dtype if _keep_dtype else torch.float32
+
+
+fake_quant_factory = {
+    Backend.VIRTUAL: ort_fake_quant,
+    Backend.ONNXRUNTIME: ort_fake_quant,
+    Backend.TENSORRT: trt_fake_quant,
+}
+
+
+class STE(torch.autograd.Function):
+    """quant_tensor.py:74-125; backward through sbq_quant_*_backward."""
+
+    @staticmethod
+    def forward(ctx, x, scale, zero_point, qdesc, backend):
+        x_fq = fake_quant_factory[backend](x, scale, zero_point, qdesc)
+        ctx.save_for_backward(x, scale, zero_point)
+        ctx.qdesc = qdesc
+        return x_fq
+
+    @staticmethod
+    def backward(ctx, gout):
+        x, scale, zero_point = ctx.saved_tensors
+        qdesc = ctx.qdesc
+        qmin, qmax = qdesc.qrange
+        need_gs = ctx.needs_input_grad[1]
+        need_gzp = ctx.needs_input_grad[2]
+        gx, gs, gzp = ops.fake_quant_backward(
+            x, gout, scale, zero_point.float(), qmin, qmax, qdesc.ch_axis, need_gs, need_gzp, gx_dtype=x.dtype
+        )
+        if gs is not None:
+            gs = gs.reshape(scale.shape)
+        if gzp is not None:
+            gzp = gzp.reshape(zero_point.shape)
+        return gx, gs, gzp, None, None
+
+
+def trt_dqrange(scale, zero_point, qdesc):
+    assert abs(zero_point).sum() == 0, "tensorrt only support symmetric quant, but zp={}".format(zero_point)
+    qmin, qmax = qdesc.qrange
+    return (scale * qmin, scale * qmax)
+
+
+def ort_dqrange(scale, zero_point, qdesc):
+    qmin, qmax = qdesc.qrange
+    return ((qmin - zero_point) * scale, (qmax - zero_point) * scale)
+
+
+fake_qrange_factory = {
+    Backend.VIRTUAL: ort_dqrange,
+    Backend.ONNXRUNTIME: ort_dqrange,
+    Backend.TENSORRT: trt_dqrange,
+}
+
+
+def torch_fake_quant(x_f, scale, zero_point, qdesc):
+    """Export-only branch, kept on torch builtins so torch.onnx.export emits
+    QuantizeLinear/DequantizeLinear exactly as with the reference (quant_tensor.py:220-249):
+    the HIP kernel is never traced."""
+    if qdesc._type.startswith("uint"):
+        lower_bound, upper_bound = (0, 255)
+    else:
+        lower_bound, upper_bound = (-128, 127)
+    if scale.numel() > 1:
+        ch_axis = int(np.argmax(list(scale.shape)))
+        scale = scale.reshape(-1).detach().to(x_f.device)
+        zero_point = zero_point.reshape(-1).int().to(x_f.device)
+        return torch.fake_quantize_per_channel_affine(x_f, scale, zero_point, ch_axis, lower_bound, upper_bound)
+    if scale.numel() == 1:
+        return torch.fake_quantize_per_tensor_affine(
+            x_f, scale.item(), zero_point.int().item(), lower_bound, upper_bound
+        )
+    raise TypeError("scale / zeropoint is not allowed to be an empty tensor")

@@ -1,0 +1,521 @@
+"""GPU parity tests: the HIP path (through the C ABI) against
+  * the golden vectors produced by the real reference (tests/golden/ref_golden.npz),
+  * the CPU oracle on seeded inputs,
+  * size-independent properties at BASELINE.json's full size (4096 x 4096).
+
+Bar: integer tensor bit-exact; dequantized float bit-exact too (the contract allows 1e-6
+relative; we assert 0 ulp, zeros compared by value); LSQ init / gradient sums within the
+stated tolerance.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_cases, rel_err
+from helpers import all_x, case_config, dev_tensor, same_values
+
+pytestmark = pytest.mark.gpu
+
+QUANT_CASES = golden_cases("")
+DTYPES = [torch.float32, torch.bfloat16, torch.float16]
+
+
+def _meta(golden, name):
+    qmin, qmax, ch_axis, perch, sym = golden[name + "/meta"].tolist()
+    return int(qmin), int(qmax), int(ch_axis), bool(perch), bool(sym)
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from sparsebit_amd import ops as o
+
+    return o
+
+
+# --------------------------------------------------------------------------------------
+# forward QDQ
+# --------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", QUANT_CASES)
+def test_qdq_kernel_vs_reference_golden(golden, oracle, ops, name):
+    """HIP QDQ with the reference's own scale / zero_point == the reference's output."""
+    qmin, qmax, ch_axis, perch, sym = _meta(golden, name)
+    x = golden[name + "/x"]
+    scale, zp = golden[name + "/scale"], golden[name + "/zero_point"]
+    ref_dq = golden[name + "/dq"]
+    _, ref_q = oracle.qdq(x, scale, zp, qmin, qmax, ch_axis)
+    for dt in (torch.float32, torch.bfloat16):  # golden inputs are bf16-representable
+        xd = dev_tensor(x, dt)
+        y, q = ops.fake_quant(xd, dev_tensor(scale), dev_tensor(zp), qmin, qmax, ch_axis, return_q=torch.int32)
+        assert y.dtype == torch.float32
+        assert same_values(y.cpu().numpy(), ref_dq), (name, dt, rel_err(y.cpu().numpy(), ref_dq))
+        assert np.array_equal(q.cpu().numpy(), ref_q), (name, dt)
+    # perf mode: bf16 out == RNE cast of the fp32 reference result
+    y16 = ops.fake_quant(dev_tensor(x, torch.bfloat16), dev_tensor(scale), dev_tensor(zp), qmin, qmax, ch_axis,
+                         out_dtype=torch.bfloat16)
+    want = torch.from_numpy(ref_dq).bfloat16()
+    assert same_values(y16.float().cpu().numpy(), want.float().numpy())
+    # int8 / uint8 storage of q
+    if qmax - qmin <= 255:
+        qt = torch.int8 if qmin < 0 else torch.uint8
+        _, q8 = ops.fake_quant(dev_tensor(x), dev_tensor(scale), dev_tensor(zp), qmin, qmax, ch_axis, return_q=qt)
+        assert np.array_equal(q8.cpu().numpy().astype(np.int32), ref_q)
+
+
+@pytest.mark.parametrize("name", QUANT_CASES)
+def test_quantizer_end_to_end_vs_reference_golden(golden, name):
+    """build_quantizer -> update_observer -> calc_qparams -> forward, like the reference's
+    calibration flow (tools/calibration.py:102-135), against the reference's own results."""
+    from sparsebit_amd.quantizers import build_quantizer
+
+    cfg, backend = case_config(name)
+    qmin, qmax, ch_axis, perch, sym = _meta(golden, name)
+    q = build_quantizer(cfg)
+    q.set_backend(backend)
+    xs = all_x(golden, name)
+    for x in xs:
+        q.update_observer(dev_tensor(x))
+    scale, zp = q.calc_qparams()
+    assert q.qdesc.qmin == qmin and q.qdesc.qmax == qmax and q.qdesc.ch_axis == ch_axis
+    assert q.qdesc.is_symmetric == sym
+    kind = name.split("/")[0]
+    s = scale.detach().reshape(-1).cpu().numpy()
+    z = zp.detach().reshape(-1).cpu().numpy()
+    if kind == "lsq":
+        # fp32 mean vs the reference's blocked fp32 sum: the contract's 1e-6 relative
+        assert rel_err(s, golden[name + "/scale"]) <= 1e-6, rel_err(s, golden[name + "/scale"])
+        assert isinstance(q.scale, torch.nn.Parameter)
+        assert np.all(z == 0)
+        return
+    assert np.array_equal(s, golden[name + "/scale"]), (s, golden[name + "/scale"])
+    assert same_values(z, golden[name + "/zero_point"])
+    if kind != "mse":
+        assert np.array_equal(q.observer.min_val.reshape(-1).cpu().numpy(), golden[name + "/min_val"])
+        assert np.array_equal(q.observer.max_val.reshape(-1).cpu().numpy(), golden[name + "/max_val"])
+    want_shape = [1] * xs[0].ndim  # Quantizer._broadcast_qparams (quantizers/base.py:97-100)
+    if perch:
+        want_shape[ch_axis] = golden[name + "/scale"].size
+    assert list(scale.shape) == want_shape
+    q.enable_quant()
+    dq = q(dev_tensor(xs[0]))
+    assert same_values(dq.cpu().numpy(), golden[name + "/dq"])
+
+
+def test_hand_kats(golden, ops):
+    x = golden["kat/x"]
+    for key, s, zp, lo, hi in (("kat/int8_s1_zp0", 1.0, 0.0, -128, 127), ("kat/uint8_s1_zp3.5", 1.0, 3.5, 0, 255),
+                                ("kat/uint8_s0.3_zp2.5", 0.3, 2.5, 0, 255)):
+        y = ops.fake_quant(dev_tensor(x), dev_tensor([s]), dev_tensor([zp]), lo, hi)
+        assert same_values(y.cpu().numpy(), golden[key]), key
+    y, q = ops.fake_quant(dev_tensor(x[:11]), dev_tensor([1.0]), dev_tensor([0.0]), -128, 127, return_q=torch.int32)
+    assert q.cpu().tolist() == [0, 2, 2, 0, -2, -2, 126, 127, 127, -128, -128]
+    y = ops.fake_quant(dev_tensor(golden["kat/tie_x"]), dev_tensor(golden["kat/tie_s"]), dev_tensor([0.0]), -128, 127)
+    assert same_values(y.cpu().numpy(), golden["kat/tie_dq"])
+
+
+SHAPES = [
+    ((512, 1024), 0),  # ROWS path, whole slabs
+    ((96, 2304), 0),  # ROWS path, ragged last slab
+    ((64, 3, 7, 7), 0),  # inner = 147: scalar path
+    ((37, 40), 0),  # FLAT path (short rows)
+    ((4, 24, 6, 10), 1),  # NCHW activation per channel, outer > 1
+    ((3, 50, 64), 2),  # NLC per channel
+    ((1, 1), 0),
+]
+
+
+@pytest.mark.parametrize("shape,ch_axis", SHAPES)
+@pytest.mark.parametrize("scheme", ["sym8", "aff8", "sym4", "aff4"])
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_qdq_random_vs_oracle(oracle, ops, shape, ch_axis, scheme, dtype):
+    g = torch.Generator().manual_seed(sum(shape) * 131 + len(scheme) + ord(scheme[0]) + int(scheme[3:]))
+    x = torch.randn(*shape, generator=g) * 3
+    x = x.to(dtype)
+    xf = x.float().numpy()
+    qmin, qmax = {"sym8": (-128, 127), "aff8": (0, 255), "sym4": (-8, 7), "aff4": (0, 15)}[scheme]
+    for perch in (True, False):
+        mn, mx = oracle.minmax(xf, ch_axis, perch)
+        s, z = oracle.qparams_from_minmax(mn, mx, qmin, qmax, scheme.startswith("sym"))
+        if scheme.startswith("aff"):
+            z = z + np.float32(0.5) * (np.arange(z.size) % 2).astype(np.float32)  # zp on .5: half-to-even rounding
+        ref_dq, ref_q = oracle.qdq(xf, s, z, qmin, qmax, ch_axis)
+        y, q = ops.fake_quant(x.cuda(), dev_tensor(s), dev_tensor(z), qmin, qmax, ch_axis, return_q=torch.int32)
+        assert same_values(y.cpu().numpy(), ref_dq)
+        assert np.array_equal(q.cpu().numpy(), ref_q)
+        if dtype != torch.float32:
+            y16 = ops.fake_quant(x.cuda(), dev_tensor(s), dev_tensor(z), qmin, qmax, ch_axis, out_dtype=dtype)
+            assert same_values(y16.float().cpu().numpy(), torch.from_numpy(ref_dq).to(dtype).float().numpy())
+
+
+def test_qdq_edge_values_and_alignment(oracle, ops):
+    """ties at k+0.5, signed zeros, denormals, beyond-clamp values, inf / NaN, a zero row
+    (scale floor 1e-6), odd pointer offsets, ragged per-tensor tails."""
+    s = np.array([0.0123, 1e-6, 1.0, 3.7e5], dtype=np.float32)
+    k = np.arange(-140, 140, dtype=np.float32)
+    rows = []
+    for sc in s:
+        special = np.array([0.0, -0.0, 1e-40, -1e-40, 1e-30, 3e38, -3e38, np.inf, -np.inf, np.nan], np.float32)
+        rows.append(np.concatenate([(k + 0.5) * sc, k * sc, special, np.zeros(6, np.float32)]))
+    x = np.stack(rows).astype(np.float32)  # [4, 576]
+    z = np.array([0, 0, 3.5, -2.5], dtype=np.float32)
+    for (qmin, qmax) in ((-128, 127), (0, 255)):
+        ref_dq, ref_q = oracle.qdq(x, s, z, qmin, qmax, 0)
+        y, q = ops.fake_quant(dev_tensor(x), dev_tensor(s), dev_tensor(z), qmin, qmax, 0, return_q=torch.int32)
+        assert same_values(y.cpu().numpy(), ref_dq)
+        finite = ~np.isnan(x)
+        assert np.array_equal(q.cpu().numpy()[finite], ref_q[finite])
+    # per-tensor with a ragged tail and a misaligned base pointer (storage offset 1 element)
+    g = torch.Generator().manual_seed(5)
+    for n in (1, 7, 8, 9, 2049, 40003):
+        for dt in DTYPES:
+            base = (torch.randn(n + 3, generator=g) * 4).to(dt).cuda()
+            for off in (0, 1, 3):
+                xv = base[off:off + n]
+                xf = xv.float().cpu().numpy()
+                ref_dq, ref_q = oracle.qdq(xf, [0.031], [1.0], -128, 127)
+                y, q = ops.fake_quant(xv, dev_tensor([0.031]), dev_tensor([1.0]), -128, 127, return_q=torch.int32)
+                assert same_values(y.cpu().numpy(), ref_dq), (n, dt, off)
+                assert np.array_equal(q.cpu().numpy(), ref_q)
+
+
+def test_rounding_modes(ops):
+    """common.cuh:64-77: half-even (0), half-up floor(v+.5) (1), half-down ceil(v-.5) (2)."""
+    x = torch.tensor([0.5, 1.5, 2.5, -0.5, -1.5, -2.5, 0.4, -0.6], device="cuda")
+    one, zero = dev_tensor([1.0]), dev_tensor([0.0])
+    from sparsebit_amd import fake_quant as fq
+
+    assert fq.quant_pertensor_forward(x, one, zero, -128, 127, 0).tolist() == [0, 2, 2, 0, -2, -2, 0, -1]
+    assert fq.quant_pertensor_forward(x, one, zero, -128, 127, 1).tolist() == [1, 2, 3, 0, -1, -2, 0, -1]
+    assert fq.quant_pertensor_forward(x, one, zero, -128, 127, 2).tolist() == [0, 1, 2, -1, -2, -3, 0, -1]
+
+
+def test_errors_and_no_cpu_fallback(ops):
+    from sparsebit_amd import lib as L
+
+    one, zero = dev_tensor([1.0]), dev_tensor([0.0])
+    with pytest.raises(L.SbqError):  # CPU tensors are rejected: there is no fallback path
+        ops.fake_quant(torch.randn(8), torch.ones(1), torch.zeros(1), -128, 127)
+    with pytest.raises(L.SbqError):  # reference: InvalidValueException "Tensor is empty" (common.cuh:50-54)
+        ops.fake_quant(torch.empty(0, device="cuda"), one, zero, -128, 127)
+    with pytest.raises(L.SbqError):  # reference: ValueTypeException (common.cuh:45-49)
+        ops.fake_quant(torch.zeros(8, dtype=torch.float64, device="cuda"), one, zero, -128, 127)
+    with pytest.raises(L.SbqError):
+        ops.fake_quant(torch.zeros(4, 8, device="cuda"), dev_tensor([1.0, 1.0]), dev_tensor([0.0, 0.0]), -128, 127, 0)
+    lib = L.load()
+    assert lib.sbq_quant_pertensor_forward(None, 0, None, 0, None, 0, None, None, 8, -128, 127, 0, None) == 3
+    assert lib.sbq_strerror(2).decode().startswith("Kernel Failure, Tensor is empty")
+
+
+# --------------------------------------------------------------------------------------
+# full size (BASELINE.json: per-channel 4096 x 4096 bf16): properties + oracle on a sample
+# --------------------------------------------------------------------------------------
+def test_full_size_4096_properties(oracle, ops):
+    g = torch.Generator().manual_seed(0)
+    w = torch.randn(4096, 4096, generator=g) * torch.logspace(-2, 1, 4096).unsqueeze(1)
+    x = w.bfloat16().cuda()
+    from sparsebit_amd.config import quantizer_config
+    from sparsebit_amd.common import Backend
+    from sparsebit_amd.quantizers import build_quantizer
+
+    q = build_quantizer(quantizer_config("per-channel-symmetric", 8))
+    q.set_backend(Backend.VIRTUAL)
+    q.update_observer(x)
+    scale, zp = q.calc_qparams()
+    # observer == oracle on all 4096 channels (cheap: one pass on the CPU)
+    xf = x.float().cpu().numpy()
+    mn, mx = oracle.minmax(xf, 0, True)
+    s_ref, z_ref = oracle.qparams_from_minmax(mn, mx, -128, 127, True)
+    assert np.array_equal(scale.reshape(-1).cpu().numpy(), s_ref)
+    y, qi = ops.fake_quant(x, scale, zp, -128, 127, 0, return_q=torch.int8)
+    y16 = ops.fake_quant(x, scale, zp, -128, 127, 0, out_dtype=torch.bfloat16)
+    # (1) integer range, (2) dq == q * scale exactly, (3) bf16 output is the RNE cast,
+    # (4) idempotence: QDQ of an fp32 QDQ result is itself, (5) every row reaches +-127 or -128
+    assert int(qi.min()) >= -128 and int(qi.max()) <= 127
+    assert torch.equal(y, qi.float() * scale.reshape(-1, 1))
+    assert torch.equal(y16, y.bfloat16())
+    y2 = ops.fake_quant(y, scale, zp, -128, 127, 0)
+    assert torch.equal(y2, y)
+    assert bool((qi.abs().amax(1) >= 127).all())
+    # (6) the oracle on a sample of rows, bit for bit
+    rows = np.array([0, 1, 17, 255, 1024, 2047, 2048, 3333, 4095])
+    ref_dq, ref_q = oracle.qdq(xf[rows], s_ref[rows], z_ref[rows], -128, 127, 0)
+    assert same_values(y[rows].cpu().numpy(), ref_dq)
+    assert np.array_equal(qi[rows].cpu().numpy().astype(np.int32), ref_q)
+    # (7) checksum of checksums against the oracle over the whole tensor
+    ref_all, _ = oracle.qdq(xf, s_ref, z_ref, -128, 127, 0)
+    assert same_values(y.cpu().numpy(), ref_all)
+
+
+# --------------------------------------------------------------------------------------
+# observers on random data vs the oracle
+# --------------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape,ch_axis", SHAPES + [((3, 8192 + 24), 0), ((1, 70001), 0)])
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_channel_stats_vs_oracle(oracle, ops, shape, ch_axis, dtype):
+    g = torch.Generator().manual_seed(11)
+    x = (torch.randn(*shape, generator=g) * 2).to(dtype)
+    xf = x.float().numpy()
+    for perch in (True, False):
+        mn, mx, ab = ops.channel_stats(x.cuda(), ch_axis, perch, want_abssum=True)
+        rmn, rmx = oracle.minmax(xf, ch_axis, perch)
+        assert np.array_equal(mn.cpu().numpy(), rmn) and np.array_equal(mx.cpu().numpy(), rmx)
+        axes = tuple(i for i in range(x.ndim) if not (perch and i == ch_axis))
+        want = np.abs(xf.astype(np.float64)).sum(axis=axes).reshape(-1)
+        assert np.allclose(ab.cpu().numpy(), want, rtol=1e-6)
+    # NaN propagates like torch.min / torch.max
+    xn = x.clone().float()
+    xn.view(-1)[xn.numel() // 2] = float("nan")
+    mn, mx, _ = ops.channel_stats(xn.cuda(), ch_axis, False)
+    assert np.isnan(mn.item()) and np.isnan(mx.item())
+
+
+@pytest.mark.parametrize("sym", [True, False])
+def test_qparams_kernel_vs_oracle(oracle, ops, sym):
+    g = np.random.default_rng(3)
+    mn = np.concatenate([g.normal(size=500).astype(np.float32) * 3, [0, 1, -1, 0, np.nan, -np.inf, 1e-30]]).astype(np.float32)
+    mx = np.concatenate([g.normal(size=500).astype(np.float32) * 3, [0, 3, 3, 1e-9, 1.0, np.inf, 2e-30]]).astype(np.float32)
+    for qmin, qmax in ((-128, 127), (0, 255), (-8, 7), (0, 15), (-32768, 32767)):
+        s, z = ops.qparams_from_minmax(dev_tensor(mn), dev_tensor(mx), qmin, qmax, sym)
+        rs, rz = oracle.qparams_from_minmax(mn, mx, qmin, qmax, sym)
+        assert same_values(s.cpu().numpy(), rs) and same_values(z.cpu().numpy(), rz)
+
+
+@pytest.mark.parametrize("shape,ch_axis,perch", [((64, 96), 0, True), ((32, 16, 3, 3), 0, True), ((24, 3, 7, 7), 0, True),
+                                                  ((5, 4096 + 8), 0, True), ((4, 8, 6, 6), 1, True), ((3, 17, 48), 2, False),
+                                                  ((2, 33333), 0, False)])
+@pytest.mark.parametrize("scheme", [("sym", -128, 127), ("aff", 0, 255), ("sym", -8, 7)])
+def test_mse_observer_vs_oracle(oracle, ops, shape, ch_axis, perch, scheme):
+    """Per-channel MSE follows the CUDA-kernel semantics.  Candidate index must
+    equal the oracle's unless the two candidates' fp64 losses agree to 1e-7 relative (fp32
+    summation order is free; the reference's own order is unspecified)."""
+    kind, qmin, qmax = scheme
+    g = torch.Generator().manual_seed(21)
+    x = (torch.randn(*shape, generator=g) * 1.7).bfloat16()
+    xf = x.float().numpy()
+    from sparsebit_amd.config import quantizer_config
+    from sparsebit_amd.observers import build_observer
+    from sparsebit_amd.quantizers.quant_descriptor import QuantDescriptor
+
+    bit = {127: 8, 255: 8, 7: 4}[qmax]
+    name = "per-%s-%s" % ("channel" if perch else "tensor", "symmetric" if kind == "sym" else "affine")
+    layout = {0: None, 1: "NCHW", 2: "NLC"}[ch_axis]
+    cfg = quantizer_config(name, bit, observer="MSE", target="weight" if layout is None else "feature", layout=layout or "NCHW")
+    obs = build_observer(cfg, QuantDescriptor(cfg))
+    obs.data_cache.update(x.cuda())
+    s, z = obs.calc_qparams()
+    rs, rz, rbest, rsse = oracle.mse(xf, qmin, qmax, kind == "sym", ch_axis, perch)
+    best = obs.best_index.cpu().numpy()
+    for c in np.nonzero(best != rbest)[0]:
+        a, b = rsse[c, best[c]], rsse[c, rbest[c]]
+        assert abs(a - b) <= 1e-7 * max(a, b), (c, best[c], rbest[c], a, b)
+    same = best == rbest
+    assert same.mean() > 0.97
+    assert np.array_equal(s.reshape(-1).cpu().numpy()[same], rs[same])
+    assert same_values(z.reshape(-1).cpu().numpy()[same], rz[same])
+
+
+@pytest.mark.parametrize("shape", [(64, 96), (16, 4096), (7, 16384), (33, 147), (5, 1)])
+@pytest.mark.parametrize("alpha", [1e-3, 0.05, 0.5, 0.0, 1.0])
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_percentile_rows_vs_oracle(oracle, ops, shape, alpha, dtype):
+    g = torch.Generator().manual_seed(31)
+    x = (torch.randn(*shape, generator=g)).to(dtype)
+    x[0] = x[0].abs()  # a row without negatives -> min stays 0
+    if shape[0] > 2:
+        x[1] = -x[1].abs() - 1  # a row without non-negatives -> max stays 0
+    x.view(-1)[::7] = x.view(-1)[0]  # many duplicates
+    mn, mx = ops.percentile_rows(x.cuda(), alpha)
+    rmn, rmx = oracle.percentile(x.float().numpy(), alpha, 0, True)
+    assert same_values(mn.cpu().numpy(), rmn) and same_values(mx.cpu().numpy(), rmx)
+
+
+@pytest.mark.parametrize("case", [((3, 50, 64), 2, False), ((4, 8, 6, 6), 1, True), ((2, 70001), 0, False),
+                                  ((6, 20000), 0, True), ((3, 17, 48), 2, True)])
+@pytest.mark.parametrize("alpha", [1e-3, 0.01, 0.3])
+def test_percentile_radix_path_vs_oracle(oracle, case, alpha):
+    """The general (shardable) radix path: several cached batches, per tensor and per channel."""
+    shape, ch_axis, perch = case
+    from sparsebit_amd.config import quantizer_config
+    from sparsebit_amd.observers import build_observer
+    from sparsebit_amd.quantizers.quant_descriptor import QuantDescriptor
+
+    g = torch.Generator().manual_seed(41)
+    xs = [torch.randn(*shape, generator=g).bfloat16() for _ in range(3)]
+    layout = {0: None, 1: "NCHW", 2: "NLC"}[ch_axis]
+    name = "per-%s-affine" % ("channel" if perch else "tensor")
+    cfg = quantizer_config(name, 8, observer="PERCENTILE", target="weight" if layout is None else "feature",
+                           layout=layout or "NCHW", alpha=alpha)
+    obs = build_observer(cfg, QuantDescriptor(cfg))
+    use = xs if layout is not None else xs[:1]
+    for x in use:
+        obs.data_cache.update(x.cuda())
+    mn, mx = obs.calc_minmax()
+    if perch:
+        # per channel over the union of batches (documented deviation from reference quirk Q3)
+        data = np.concatenate([np.moveaxis(x.float().numpy(), ch_axis, 0).reshape(x.shape[ch_axis], -1) for x in use], 1)
+        rmn, rmx = oracle.percentile(data, alpha, 0, True)
+    else:
+        data = np.concatenate([x.float().numpy().reshape(-1) for x in use])
+        rmn, rmx = oracle.percentile(data, alpha, per_channel=False)
+    assert same_values(mn.reshape(-1).cpu().numpy(), rmn) and same_values(mx.reshape(-1).cpu().numpy(), rmx)
+
+
+# --------------------------------------------------------------------------------------
+# unstructured mask, fused mask + QDQ
+# --------------------------------------------------------------------------------------
+@pytest.mark.parametrize("ratio", [0.0, 0.3, 0.5, 0.9, 1.0])
+@pytest.mark.parametrize("wname", ["lin", "conv"])
+def test_l1_mask_vs_reference_golden(golden, ratio, wname):
+    from sparsebit_amd.config import sparser_config
+    from sparsebit_amd.sparsers import build_sparser
+
+    x = golden["uni/per-channel-symmetric/8/%s/x" % wname]
+    sp = build_sparser(sparser_config(ratio))
+    m = sp.calc_mask(dev_tensor(x))
+    assert np.array_equal(m.cpu().numpy().astype(np.uint8), golden["mask/%g/%s" % (ratio, wname)])
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("n", [8, 1000, 4097, 300001])
+def test_l1_mask_random_vs_oracle(oracle, dtype, n):
+    from sparsebit_amd.config import sparser_config
+    from sparsebit_amd.sparsers import build_sparser
+
+    g = torch.Generator().manual_seed(n)
+    x = torch.randn(n, generator=g).to(dtype)
+    x[::5] = x[0]  # ties with a repeated magnitude
+    for ratio in (0.1, 0.5, 0.77):
+        sp = build_sparser(sparser_config(ratio))
+        m = sp.calc_mask(x.cuda())
+        rm, rt = oracle.l1_mask(x.float().numpy(), ratio)
+        assert float(sp.calc_threshold(x.cuda())) == float(rt)
+        assert np.array_equal(m.cpu().numpy(), rm)
+        assert m.dtype == torch.bool
+
+
+def test_mask_kat_and_fused_mask_lsq(golden, oracle, ops):
+    from sparsebit_amd.common import Backend
+    from sparsebit_amd.config import quantizer_config, sparser_config
+    from sparsebit_amd.quantizers import build_quantizer
+    from sparsebit_amd.sparsers import build_sparser
+
+    sp = build_sparser(sparser_config(0.5))
+    m = sp.calc_mask(dev_tensor(golden["mask/kat_x"]))
+    assert m.int().cpu().tolist() == [[0, 0, 0, 1], [0, 1, 1, 0]]
+    # config 5's composition: LSQ 4-bit weight quantizer applied to weight * mask
+    x = dev_tensor(golden["maskq/x"])
+    mask = sp.calc_mask(x)
+    assert np.array_equal(mask.cpu().numpy().astype(np.uint8), golden["maskq/mask"])
+    q = build_quantizer(quantizer_config("per-channel-symmetric", 4, quantizer="lsq"))
+    q.set_backend(Backend.VIRTUAL)
+    q.update_observer(x)
+    q.calc_qparams()
+    q.enable_quant()
+    # use the reference's own scale so that the comparison is bit-exact
+    with torch.no_grad():
+        q.scale.copy_(dev_tensor(golden["maskq/scale"]).reshape(q.scale.shape))
+    want = golden["maskq/dq"]
+    assert same_values(q(x * mask).detach().cpu().numpy(), want)  # unfused: mask multiply then quantizer
+    assert same_values(q.forward_masked(x, mask=mask).cpu().numpy(), want)  # fused, mask bytes
+    assert same_values(q.forward_masked(x, thresh=sp.calc_threshold(x)).cpu().numpy(), want)  # fused, threshold
+    y16 = q.forward_masked(x.bfloat16(), mask=mask, out_dtype=torch.bfloat16)
+    assert same_values(y16.float().cpu().numpy(), torch.from_numpy(want).bfloat16().float().numpy())
+
+
+# --------------------------------------------------------------------------------------
+# STE / LSQ backward
+# --------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["bwd/pc4", "bwd/pt8a", "bwd/pc8a_nchw"])
+def test_ste_backward_vs_reference_golden(golden, oracle, ops, name):
+    qmin, qmax, ch_axis = [int(v) for v in golden[name + "/meta"]]
+    x, gy = golden[name + "/x"], golden[name + "/gy"]
+    s, z = golden[name + "/scale"], golden[name + "/zero_point"]
+    gx, gs, gz = ops.fake_quant_backward(dev_tensor(x), dev_tensor(gy), dev_tensor(s), dev_tensor(z), qmin, qmax, ch_axis)
+    assert same_values(gx.cpu().numpy(), golden[name + "/gx"])
+    assert np.allclose(gs.cpu().numpy(), golden[name + "/gs"], rtol=1e-5, atol=1e-5)
+    assert np.allclose(gz.cpu().numpy(), golden[name + "/gzp"], rtol=1e-5, atol=1e-5)
+    ogx, ogs, ogz = oracle.ste_backward(x, gy, s, z, qmin, qmax, ch_axis)
+    assert same_values(gx.cpu().numpy(), ogx)
+    assert np.allclose(gs.cpu().numpy(), ogs, rtol=1e-6, atol=1e-6)
+    assert np.allclose(gz.cpu().numpy(), ogz, rtol=1e-6, atol=1e-6)
+
+
+def test_lsq_training_step_autograd(oracle):
+    """config 5 shape of use: LSQ 4-bit per-channel weight quantizer inside autograd."""
+    from sparsebit_amd.common import Backend
+    from sparsebit_amd.config import quantizer_config
+    from sparsebit_amd.quantizers import build_quantizer
+    import math
+
+    g = torch.Generator().manual_seed(9)
+    w = torch.randn(48, 16, 3, 3, generator=g).cuda().requires_grad_(True)
+    q = build_quantizer(quantizer_config("per-channel-symmetric", 4, quantizer="lsq"))
+    q.set_backend(Backend.VIRTUAL)
+    q.update_observer(w)
+    q.calc_qparams()
+    q.enable_quant()
+    out = q(w)
+    gy = torch.randn(out.shape, generator=g).cuda()
+    out.backward(gy)
+    s = q.scale.detach().abs().reshape(-1).cpu().numpy()
+    gx, gs, gz = oracle.ste_backward(w.detach().cpu().numpy(), gy.cpu().numpy(), s, np.zeros_like(s), -8, 7, 0)
+    assert same_values(w.grad.cpu().numpy(), gx)
+    ratio = 1.0 / math.sqrt(16 * 9 * 7)  # lsq.py:70-71
+    sign = np.sign(q.scale.detach().reshape(-1).cpu().numpy())
+    assert np.allclose(q.scale.grad.reshape(-1).cpu().numpy(), gs * ratio * sign, rtol=1e-5, atol=1e-7)
+
+
+# --------------------------------------------------------------------------------------
+# GPTQ 4-bit mat-vec
+# --------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["g128", "g-1", "rag"])
+def test_gptq_vs_reference_golden(golden, oracle, name):
+    from sparsebit_amd import gptq
+
+    B, M, N, GS = [int(v) for v in golden["gptq/%s/meta" % name]]
+    layer = torch.nn.Linear(M, N).cuda()
+    with torch.no_grad():
+        layer.weight.copy_(dev_tensor(golden["gptq/%s/w" % name]))
+        layer.bias.copy_(dev_tensor(golden["gptq/%s/bias" % name]))
+    qz = gptq.Quantizer()
+    qz.configure(bit=4, perchannel=True, sym=False, mse=False)
+    qz.find_params(layer.weight.data, weight=True, groupsize=GS)
+    assert np.array_equal(qz.scale.reshape(N, -1).cpu().numpy(), golden["gptq/%s/scale" % name])
+    assert np.array_equal(qz.zero.reshape(N, -1).cpu().numpy(), golden["gptq/%s/zero" % name])
+    layer.weight.data = gptq.quantize(layer.weight.data.view(-1, M if GS == -1 else GS), qz.scale.view(-1, 1),
+                                      qz.zero.view(-1, 1), qz.maxq).view(N, M)
+    assert np.array_equal(layer.weight.data.cpu().numpy(), golden["gptq/%s/wq" % name])
+    ql = gptq.QuantLinear(M, N, bit=4, groupsize=GS)
+    ql.pack(layer, qz.scale, qz.zero)
+    assert np.array_equal(ql.qweight.cpu().numpy(), golden["gptq/%s/qweight" % name])
+    y = ql(dev_tensor(golden["gptq/%s/x" % name]))
+    # the reference's own tolerance (test_cuda_kernel.py:45)
+    assert np.allclose(y.cpu().numpy(), golden["gptq/%s/y" % name], rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("B,M,N,GS", [(1, 4096, 4096, 128), (8, 4096, 4096, 128), (32, 1024, 1280, 128), (4, 6661, 1027, -1),
+                                       (2, 4096, 11008, 128), (1, 1024, 256, 256)])
+def test_gptq_random_vs_oracle(oracle, B, M, N, GS):
+    """shapes after test_cuda_kernel.py:48-126 (incl. an irregular M, N and group sizes)"""
+    from sparsebit_amd import gptq
+
+    torch.manual_seed(B * 7 + M)
+    layer = torch.nn.Linear(M, N)
+    x = torch.randn(B, M)
+    w = layer.weight.data.numpy()
+    scale, zero = oracle.gptq_find_params(w, 4, GS)
+    wq = oracle.gptq_quantize(w, scale, zero)
+    qw, zeros_p = oracle.gptq_pack4(wq, scale, zero)
+    ql = gptq.QuantLinear(M, N, bit=4, groupsize=GS)
+    ql.qweight = torch.from_numpy(qw)
+    ql.scales = torch.from_numpy(scale).reshape(ql.scales.shape)
+    ql.zeros = torch.from_numpy(zeros_p).reshape(ql.zeros.shape)
+    ql.bias = layer.bias.detach().clone()
+    ql = ql.cuda()
+    y = ql(x.cuda())
+    want = x.double() @ torch.from_numpy(wq).double().t() + layer.bias.detach().double()
+    assert torch.allclose(y.double().cpu(), want, rtol=1e-5, atol=1e-5)
+    y2 = ql(x.cuda())
+    assert torch.equal(y, y2)  # deterministic: no float atomics
+    if M * N <= 4096 * 1280:
+        ref = oracle.vecquant4matmul(x.numpy(), qw, layer.bias.detach().numpy(), scale, zeros_p, GS)
+        assert np.allclose(y.cpu().numpy(), ref, rtol=1e-5, atol=1e-5)

@@ -1,0 +1,206 @@
+"""CPU tests: host logic, C-ABI surface, registries, no-fallback guarantee, build."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def built():
+    from sparsebit_amd import build
+
+    return build.build(verbose=False)
+
+
+def test_library_exports_every_symbol_of_the_header(built):
+    from sparsebit_amd import lib
+
+    names = lib.header_symbols()
+    assert len(names) >= 25 and "sbq_quant_perchannel_forward" in names
+    assert set(names) == set(lib._SIGNATURES), set(names) ^ set(lib._SIGNATURES)
+    raw = ctypes.CDLL(built)
+    for n in names:
+        getattr(raw, n)  # AttributeError if not exported
+    out = subprocess.run(["nm", "-D", "--defined-only", built], stdout=subprocess.PIPE, text=True).stdout
+    exported = set(re.findall(r" T (sbq_[a-z0-9_]+)", out))
+    assert exported == set(names), "exported C symbols and include/sbq.h differ: %s" % (exported ^ set(names))
+    assert lib.load().sbq_version() == 100
+
+
+def test_status_strings_and_argument_validation_without_gpu(built):
+    """Validation happens before any launch, so it is testable on a GPU-less host."""
+    from sparsebit_amd import lib
+
+    l = lib.load()
+    assert l.sbq_strerror(0) == b"ok"
+    assert b"Invalid dtype" in l.sbq_strerror(1) and b"Tensor is empty" in l.sbq_strerror(2)
+    buf = (ctypes.c_float * 16)()
+    p = ctypes.cast(buf, ctypes.c_void_p)
+    args = dict(x=p, y=p, s=p, z=p)
+    f = l.sbq_quant_perchannel_forward
+    assert f(p, 9, p, 0, None, 0, p, p, 1, 2, 8, -128, 127, 0, None) == 1  # dtype
+    assert f(p, 0, p, 2, None, 0, p, p, 1, 2, 8, -128, 127, 0, None) == 1  # y dtype must be f32 or x's
+    assert f(p, 0, p, 0, None, 0, p, p, 1, 0, 8, -128, 127, 0, None) == 2  # empty
+    assert f(None, 0, p, 0, None, 0, p, p, 1, 2, 8, -128, 127, 0, None) == 3  # null
+    assert f(p, 0, p, 0, None, 1, p, p, 1, 2, 8, -128, 127, 0, None) == 3  # q requested, NULL q
+    assert f(p, 0, p, 0, None, 0, p, p, 1, 2, 8, 127, -128, 0, None) == 4  # qmin > qmax
+    assert f(p, 0, p, 0, p, 1, p, p, 1, 2, 8, -32768, 32767, 0, None) == 4  # int8 storage too narrow
+    assert f(p, 0, p, 0, None, 0, p, p, 1, 2, 8, -128, 127, 7, None) == 4  # rounding mode
+    assert l.sbq_mask_quant_forward(p, 0, p, 0, None, 0, None, None, p, p, 1, 2, 8, -128, 127, 0, None) == 4
+    assert l.sbq_vecquant4matmul(p, p, p, p, p, 1, 128, 4, 64, p, 1 << 20, None) == 4  # group % 128
+    assert l.sbq_percentile_rows(p, 0, 4, 20000, 0.001, p, p, None) == 4  # row too long for the LDS path
+    assert l.sbq_channel_stats(p, 0, 1, 1, 16, p, p, None, p, 0, None) == 5  # workspace too small
+    assert l.sbq_stats_workspace_bytes(1, 4096, 4096) == 4096 * 16
+    assert l.sbq_mse_workspace_bytes(1, 4096, 4096) == 4096 * 80 * 8
+    assert l.sbq_gptq_workspace_bytes(1, 4096, 4096) > 0
+
+
+def test_no_cpu_fallback_in_product_path():
+    """CPU tensors must be refused loudly, and nothing under sparsebit_amd/ may import oracle/."""
+    from sparsebit_amd import lib, ops
+    from sparsebit_amd.config import quantizer_config, sparser_config
+    from sparsebit_amd.quantizers import build_quantizer
+    from sparsebit_amd.sparsers import build_sparser
+
+    with pytest.raises(lib.SbqError, match="no CPU fallback"):
+        ops.fake_quant(torch.randn(4, 8), torch.ones(4), torch.zeros(4), -128, 127)
+    with pytest.raises(lib.SbqError):
+        ops.channel_stats(torch.randn(4, 8))
+    q = build_quantizer(quantizer_config("per-tensor-symmetric", 8))
+    q.enable_quant()
+    q.backend = __import__("sparsebit_amd.common", fromlist=["Backend"]).Backend.VIRTUAL
+    with pytest.raises(lib.SbqError):
+        q(torch.randn(8))
+    if not torch.cuda.is_available():
+        q.update_observer(torch.randn(4, 8))
+        with pytest.raises((lib.SbqError, AssertionError, RuntimeError)):
+            q.calc_qparams()
+        with pytest.raises(lib.SbqError):
+            build_sparser(sparser_config(0.5)).calc_mask(torch.randn(16))
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "sparsebit_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle", src, re.M), f
+                assert "libsbq_oracle" not in src, f
+
+
+def test_missing_library_fails_loudly(tmp_path, monkeypatch):
+    from sparsebit_amd import lib
+
+    monkeypatch.setattr(lib, "_lib", None)
+    monkeypatch.setattr(lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(RuntimeError, match="libsbq.so not found"):
+        lib.load()
+
+
+def test_registries_and_descriptor_match_reference_contract():
+    from sparsebit_amd import observers, quantizers, sparsers
+    from sparsebit_amd.config import quantizer_config
+    from sparsebit_amd.quantizers.quant_descriptor import QuantDescriptor
+
+    assert {"uniform", "lsq"} <= set(quantizers.QUANTIZERS_MAP)
+    assert {"minmax", "mse", "percentile"} <= set(observers.OBSERVERS_MAP)
+    assert "l1norm" in sparsers.SPARSERS_MAP
+    # quant_descriptor.py:28-34: symmetric [-2^(b-1), 2^(b-1)-1], affine [0, 2^b-1]
+    for scheme, bit, lo, hi in (("per-channel-symmetric", 8, -128, 127), ("per-tensor-affine", 8, 0, 255),
+                                ("per-channel-symmetric", 4, -8, 7), ("per-tensor-affine", 4, 0, 15)):
+        d = QuantDescriptor(quantizer_config(scheme, bit))
+        assert d.qrange == (lo, hi) and d.ch_axis == 0 and d.bs_axis is None
+    assert QuantDescriptor(quantizer_config("per-tensor-affine", 8, target="feature", layout="NCHW")).ch_axis == 1
+    assert QuantDescriptor(quantizer_config("per-tensor-affine", 8, target="feature", layout="NLC")).ch_axis == 2
+    d = QuantDescriptor(quantizer_config("per-channel-affine", 4))
+    d.set_symmetric(True)
+    assert d.qrange == (-8, 7) and d.scheme == torch.per_channel_symmetric
+    d.set_bit(8)
+    assert d.qrange == (-128, 127)
+
+    # a later registration overwrites, like the reference's maps
+    @quantizers.register_quantizer
+    class Mine(quantizers.Quantizer):
+        TYPE = "MyQ"
+
+    assert quantizers.QUANTIZERS_MAP["myq"] is Mine
+    del quantizers.QUANTIZERS_MAP["myq"]
+    q = quantizers.build_quantizer(quantizer_config("per-channel-symmetric", 8, quantizer="LSQ"))
+    assert q.TYPE == "LSQ" and sorted(q.state_dict()) == ["observer.max_val", "observer.min_val", "scale", "zero_point"]
+    assert not q.is_enable and q.bit == 8 and q.is_perchannel and q.is_symmetric
+    q.dims = 4
+    assert list(q._broadcast_qparams(torch.arange(5.0)).shape) == [5, 1, 1, 1]
+
+
+def test_export_branch_stays_on_torch_builtins():
+    """enable_export_onnx routes through torch.fake_quantize_* (quant_tensor.py:220-249): runs on CPU."""
+    from sparsebit_amd.common import Backend
+    from sparsebit_amd.config import quantizer_config
+    from sparsebit_amd.quantizers import build_quantizer
+
+    q = build_quantizer(quantizer_config("per-channel-symmetric", 8))
+    q.set_backend(Backend.ONNXRUNTIME)
+    q.dims = 2
+    q.scale = q._broadcast_qparams(torch.tensor([0.1, 0.2, 0.05]))
+    q.zero_point = q._broadcast_qparams(torch.zeros(3))
+    q.enable_quant()
+    q.enable_export_onnx()
+    x = torch.tensor([[0.26, -1.0], [100.0, 0.31], [0.0, -0.024]])
+    y = q(x)
+    want = torch.fake_quantize_per_channel_affine(x, torch.tensor([0.1, 0.2, 0.05]), torch.zeros(3, dtype=torch.int32), 0, -128, 127)
+    assert torch.equal(y, want)
+
+
+def test_plugin_installs_into_reference_when_importable():
+    """Only where /root/reference exists (authoring container): registry + native-module swap."""
+    ref = "/root/reference"
+    if not os.path.isdir(ref):
+        pytest.skip("reference tree not present on this box")
+    code = r'''
+import sys, types, os
+sys.path.insert(0, os.path.join(%r, "tests", "golden"))
+import gen_golden
+gen_golden.install_stubs()
+sys.path.insert(0, %r)
+import sparsebit.quantization.quantizers as rq, sparsebit.quantization.observers as ro
+import sparsebit.quantization.quantizers.quant_tensor as rqt
+sys.path.insert(0, %r)
+import sparsebit_amd.plugin as plugin, sparsebit_amd.fake_quant as fq
+info = plugin.install()
+assert rqt.fake_quant_kernel is fq
+assert rq.QUANTIZERS_MAP["uniform"].__module__.startswith("sparsebit_amd")
+assert ro.OBSERVERS_MAP["percentile"].__module__.startswith("sparsebit_amd")
+from sparsebit.quantization.common import QuantTarget
+cfg = gen_golden.qcfg("per-channel-symmetric", 8)
+q = rq.build_quantizer(cfg)
+assert type(q).__module__ == "sparsebit_amd.quantizers.uniform", type(q)
+for n in ("quant_pertensor_forward","quant_perchannel_forward","quant_pertensor_backward","quant_perchannel_backward"):
+    assert callable(getattr(rqt.fake_quant_kernel, n))
+print("PLUGIN_OK", info)
+''' % (ROOT, ref, ROOT)
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
+    r = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env)
+    assert "PLUGIN_OK" in r.stdout, r.stdout
+
+
+def test_gptq_pack_matches_reference_golden(golden):
+    """QuantLinear.pack is host-side integer shuffling: runs anywhere."""
+    from sparsebit_amd import gptq
+
+    for name in ("g128", "g-1", "rag"):
+        B, M, N, GS = [int(v) for v in golden["gptq/%s/meta" % name]]
+        layer = torch.nn.Linear(M, N)
+        with torch.no_grad():
+            layer.weight.copy_(torch.from_numpy(golden["gptq/%s/wq" % name]))
+            layer.bias.copy_(torch.from_numpy(golden["gptq/%s/bias" % name]))
+        ql = gptq.QuantLinear(M, N, bit=4, groupsize=GS)
+        sh = (N, -1, 1) if GS != -1 and M // GS > 1 else (N, 1)
+        ql.pack(layer, torch.from_numpy(golden["gptq/%s/scale" % name]).reshape(sh),
+                torch.from_numpy(golden["gptq/%s/zero" % name]).reshape(sh))
+        assert np.array_equal(ql.qweight.numpy(), golden["gptq/%s/qweight" % name])
+        assert np.array_equal(ql.zeros.reshape(N, -1).numpy(), golden["gptq/%s/zeros" % name])
+        assert sorted(ql.state_dict()) == ["bias", "qweight", "scales", "zeros"]

@@ -110,8 +110,11 @@ __device__ __forceinline__ void load_pack(const void* base, int64_t i, float (&v
     u32x4 a = ld16<NT>(p), b = ld16<NT>(p + 16);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      v[j] = __builtin_bit_cast(float, a[j]);
-      v[4 + j] = __builtin_bit_cast(float, b[j]);
+      // copy the lane out first: __builtin_bit_cast on an ext-vector ELEMENT lvalue reads
+      // element 0 for every j (clang 22 / ROCm 7.2)
+      const uint32_t aj = a[j], bj = b[j];
+      v[j] = __builtin_bit_cast(float, aj);
+      v[4 + j] = __builtin_bit_cast(float, bj);
     }
   } else {
     const char* p = static_cast<const char*>(base) + i * 2;

@@ -150,7 +150,8 @@ class Quant4Matmul(torch.autograd.Function):
     def forward(ctx, input, qweight, scales, zeros, bias, groupsize=-1):
         x_shape = list(input.shape)
         # y starts as the broadcast bias and is accumulated in place (quant.py:285-289)
-        y = bias.to(input.dtype).expand(x_shape[:-1] + [bias.numel()]).contiguous()
+        # .clone(): for batch 1 an expanded bias is already contiguous and would alias the buffer
+        y = bias.to(input.dtype).expand(x_shape[:-1] + [bias.numel()]).clone(memory_format=torch.contiguous_format)
         ops.vecquant4matmul(input.contiguous(), qweight, y, scales, zeros, 0 if groupsize == -1 else groupsize)
         return y
 

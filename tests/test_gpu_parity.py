@@ -234,7 +234,7 @@ def test_full_size_4096_properties(oracle, ops):
     assert torch.equal(y16, y.bfloat16())
     y2 = ops.fake_quant(y, scale, zp, -128, 127, 0)
     assert torch.equal(y2, y)
-    assert bool((qi.abs().amax(1) >= 127).all())
+    assert bool((qi.int().abs().amax(1) >= 127).all())  # symmetric scale: the extreme lands on 127.5 -> clamps
     # (6) the oracle on a sample of rows, bit for bit
     rows = np.array([0, 1, 17, 255, 1024, 2047, 2048, 3333, 4095])
     ref_dq, ref_q = oracle.qdq(xf[rows], s_ref[rows], z_ref[rows], -128, 127, 0)

@@ -120,6 +120,10 @@ def main():
         assert parity, "timed kernel does not match the oracle"
 
     # ---- timed region ------------------------------------------------------------------------
+    # K direct C-ABI launches on the current stream.  (Replaying the same launches from a
+    # hipGraph was measured 1.1-1.4 us per kernel SLOWER on this stack -- 14.9-15.3 vs
+    # 13.7-13.9 us -- so the plain in-order stream is the fast path, and the host loop keeps
+    # ahead of a ~13 us kernel.)
     for i in range(args.warmup):
         step(i)
     sync_all()

@@ -127,6 +127,45 @@ __device__ __forceinline__ void load_pack(const void* base, int64_t i, float (&v
   }
 }
 
+// Raw (still packed) form of a pack: lets a kernel keep a second tile in flight in a
+// quarter of the registers the unpacked floats would take.
+template <typename T>
+struct RawPack {
+  u32x4 d[T::id == SBQ_F32 ? 2 : 1];
+};
+
+template <typename T, bool NT>
+__device__ __forceinline__ RawPack<T> load_raw(const void* base, int64_t i) {
+  RawPack<T> r;
+  if constexpr (T::id == SBQ_F32) {
+    const char* p = static_cast<const char*>(base) + i * 4;
+    r.d[0] = ld16<NT>(p);
+    r.d[1] = ld16<NT>(p + 16);
+  } else {
+    r.d[0] = ld16<NT>(static_cast<const char*>(base) + i * 2);
+  }
+  return r;
+}
+
+template <typename T>
+__device__ __forceinline__ void unpack_raw(const RawPack<T>& r, float (&v)[kPack]) {
+  if constexpr (T::id == SBQ_F32) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint32_t aj = r.d[0][j], bj = r.d[1][j];  // see load_pack: no bit_cast on a vector lane
+      v[j] = __builtin_bit_cast(float, aj);
+      v[4 + j] = __builtin_bit_cast(float, bj);
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint32_t w = r.d[0][j];
+      v[2 * j] = Elem<T>::from_bits(static_cast<uint16_t>(w & 0xffffu));
+      v[2 * j + 1] = Elem<T>::from_bits(static_cast<uint16_t>(w >> 16));
+    }
+  }
+}
+
 template <typename T, bool NT>
 __device__ __forceinline__ void store_pack(void* base, int64_t i, const float (&v)[kPack]) {
   if constexpr (T::id == SBQ_F32) {
@@ -214,6 +253,44 @@ __device__ __forceinline__ float quant_level(float x, float s, float zp, float q
 
 __device__ __forceinline__ float dequant_level(float q, float s, float zp) {
   return (q - zp) * s;
+}
+
+// ---- exact x/s without the IEEE division sequence ------------------------------------
+// When the divisor is uniform over many elements (one scale per channel row) the
+// 10-instruction v_div_scale/rcp/fma/div_fmas/div_fixup expansion is replaced by
+//     q0 = x * y            with y = RN(1/s), computed ONCE per row by a true division
+//     r0 = fma(-q0, s, x);  q1 = fma(r0, y, q0)      -- q1 is within (1/2 + 2^-23) ulp of x/s
+//     r1 = fma(-q1, s, x);  q2 = fma(r1, y, q1)      -- q2 == RN(x/s)
+// The last step is Markstein's theorem (Muller et al., Handbook of Floating-Point
+// Arithmetic, Thm "Markstein"): if y approximates 1/s with relative error < 2^-24 (true
+// for y = RN(1/s)), q1 is a faithful rounding of x/s and r1 = x - s*q1 is computed exactly
+// (it is, for a faithful q1, as long as nothing underflows), then RN(q1 + r1*y) is the
+// correctly rounded quotient.  q0 alone may be 2 ulp off, hence the first refinement.
+// Range conditions are enforced by the caller: s in [2^-60, 2^60] (else the IEEE path is
+// taken for that row) and x clamped to +-s*2^40, which cannot change a result that is
+// clamped to [qmin, qmax] anyway but keeps every intermediate finite; for |x/s| < 1/4 the
+// residuals may underflow, which cannot move the quotient across 0.5.  NaN inputs are
+// restored by the caller.  tests/test_gpu_parity.py::test_fast_division_equals_ieee
+// compares this against the IEEE path bit for bit on adversarial data.
+__device__ __forceinline__ bool fast_div_ok(float s) {
+  return s >= 0x1p-60f && s <= 0x1p60f;  // false for NaN, subnormal, inf
+}
+
+__device__ __forceinline__ float fast_div(float x, float s, float y) {
+  float q = x * y;
+  float r = __builtin_fmaf(-q, s, x);
+  q = __builtin_fmaf(r, y, q);
+  r = __builtin_fmaf(-q, s, x);
+  return __builtin_fmaf(r, y, q);
+}
+
+// quant_level with the fast division; `bound` = s * 2^40, `y` = 1/s (IEEE)
+__device__ __forceinline__ float quant_level_fast(float x, float s, float y, float bound, float zp,
+                                                  float qlo, float qhi) {
+  const float xc = __builtin_amdgcn_fmed3f(x, -bound, bound);
+  const float v = __builtin_rintf(fast_div(xc, s, y)) + zp;
+  const float c = __builtin_amdgcn_fmed3f(v, qlo, qhi);
+  return (x != x) ? x : c;  // torch.clamp propagates NaN
 }
 
 // observers/base.py:63-79 in fp32, op for op.

@@ -34,73 +34,96 @@ struct OrI { __device__ __forceinline__ int operator()(int a, int b) const { ret
 
 // ---- stage 1: one partial {min, max, sum|x|} per chunk ---------------------------
 // min/max use the NaN-dropping v_min/v_max plus a separate "saw a NaN" flag, which
-// reproduces torch's NaN-propagating result at 1 op per element instead of 5.
-template <typename T, bool VEC>
+// reproduces torch's NaN-propagating result at 1 op per element instead of 5.  The four
+// per-lane accumulators are folded with ONE wave shuffle tree each and a single LDS
+// exchange (one barrier pair per workgroup, not one per statistic).  When a channel is a
+// single chunk (a [C, inner <= 8192] weight) the result is final and written directly:
+// no second kernel.
+struct StatAcc {
+  float mn, mx, as;
+  int nan;
+};
+
+template <typename T, bool VEC, bool FINAL>
 __global__ __launch_bounds__(kBlock) void stats_partial_kernel(const void* __restrict__ x,
                                                                StatPartial* __restrict__ part,
+                                                               float* __restrict__ min_out,
+                                                               float* __restrict__ max_out,
+                                                               double* __restrict__ abssum_out,
                                                                const ChunkGeom g) {
-  __shared__ float s_f[kWavesPerBlock];
-  __shared__ double s_d[kWavesPerBlock];
-  __shared__ int s_i[kWavesPerBlock];
+  __shared__ float s_mn[kWavesPerBlock], s_mx[kWavesPerBlock];
+  __shared__ double s_as[kWavesPerBlock];
+  __shared__ int s_nan[kWavesPerBlock];
   const uint32_t bid = blockIdx.x;
   const ChunkPos cp = chunk_pos(g, bid);
   const int64_t row_base = cp.row_base, begin = cp.begin, end = cp.end;
 
-  float mn = __builtin_inff(), mx = -__builtin_inff(), as = 0.0f;
-  int nan = 0;
+  StatAcc a{__builtin_inff(), -__builtin_inff(), 0.0f, 0};
+  auto visit = [&](float f) {
+    a.mn = __builtin_fminf(a.mn, f);
+    a.mx = __builtin_fmaxf(a.mx, f);
+    a.nan |= (f != f);
+    a.as += __builtin_fabsf(f);
+  };
   if constexpr (VEC) {
     const int64_t vend = begin + ((end - begin) / kPack) * kPack;
-    constexpr int U = 4;
+    constexpr int U = 2;
     for (int64_t base = begin; base < vend; base += static_cast<int64_t>(kBlock) * kPack * U) {
-      float v[U][kPack];
+      RawPack<T> raw[U];
       bool ok[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         int64_t e = base + (static_cast<int64_t>(u) * kBlock + threadIdx.x) * kPack;
         ok[u] = e < vend;
         if (!ok[u]) e = vend - kPack;
-        load_pack<T, true>(x, row_base + e, v[u]);
+        raw[u] = load_raw<T, true>(x, row_base + e);
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         if (!ok[u]) continue;
+        float v[kPack];
+        unpack_raw<T>(raw[u], v);
 #pragma unroll
-        for (int q = 0; q < kPack; ++q) {
-          const float f = v[u][q];
-          mn = __builtin_fminf(mn, f);
-          mx = __builtin_fmaxf(mx, f);
-          nan |= (f != f);
-          as += __builtin_fabsf(f);
-        }
+        for (int q = 0; q < kPack; ++q) visit(v[q]);
       }
     }
     // ragged tail of a per-tensor row (< 8 elements)
-    for (int64_t e = vend + threadIdx.x; e < end; e += kBlock) {
-      const float f = Elem<T>::load1(x, row_base + e);
-      mn = __builtin_fminf(mn, f);
-      mx = __builtin_fmaxf(mx, f);
-      nan |= (f != f);
-      as += __builtin_fabsf(f);
-    }
+    for (int64_t e = vend + threadIdx.x; e < end; e += kBlock) visit(Elem<T>::load1(x, row_base + e));
   } else {
-    for (int64_t e = begin + threadIdx.x; e < end; e += kBlock) {
-      const float f = Elem<T>::load1(x, row_base + e);
-      mn = __builtin_fminf(mn, f);
-      mx = __builtin_fmaxf(mx, f);
-      nan |= (f != f);
-      as += __builtin_fabsf(f);
-    }
+    for (int64_t e = begin + threadIdx.x; e < end; e += kBlock) visit(Elem<T>::load1(x, row_base + e));
   }
-  mn = block_reduce(mn, MinF(), s_f);
-  mx = block_reduce(mx, MaxF(), s_f);
-  nan = block_reduce(nan, OrI(), s_i);
-  const double asd = block_reduce(static_cast<double>(as), Sum(), s_d);
+  const float wmn = wave_reduce(a.mn, MinF());
+  const float wmx = wave_reduce(a.mx, MaxF());
+  const int wnan = wave_reduce(a.nan, OrI());
+  const double was = wave_reduce(static_cast<double>(a.as), Sum());
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wid = threadIdx.x / kWave;
+  if (lane == 0) {
+    s_mn[wid] = wmn;
+    s_mx[wid] = wmx;
+    s_nan[wid] = wnan;
+    s_as[wid] = was;
+  }
+  __syncthreads();
   if (threadIdx.x == 0) {
-    StatPartial p;
-    p.mn = nan ? __builtin_nanf("") : mn;
-    p.mx = nan ? __builtin_nanf("") : mx;
-    p.abssum = asd;
-    part[bid] = p;
+    float mn = s_mn[0], mx = s_mx[0];
+    int nan = s_nan[0];
+    double as = s_as[0];
+#pragma unroll
+    for (int w = 1; w < kWavesPerBlock; ++w) {
+      mn = __builtin_fminf(mn, s_mn[w]);
+      mx = __builtin_fmaxf(mx, s_mx[w]);
+      nan |= s_nan[w];
+      as += s_as[w];
+    }
+    if (nan) mn = mx = __builtin_nanf("");
+    if constexpr (FINAL) {
+      if (min_out) min_out[cp.c] = mn;
+      if (max_out) max_out[cp.c] = mx;
+      if (abssum_out) abssum_out[cp.c] = as;
+    } else {
+      part[bid] = StatPartial{mn, mx, as};
+    }
   }
 }
 
@@ -304,14 +327,17 @@ int sbq_channel_stats(const void* x, int x_dtype, int64_t outer, int64_t C, int6
   StatPartial* part = static_cast<StatPartial*>(workspace);
   const uint32_t grid = g.chunks_per_chan * g.C;
   const bool vec = pack_friendly(x, C, outer, inner);
+  const bool final_ = g.chunks_per_chan == 1;
   int rc = dispatch_dtype(x_dtype, [&](auto tag) {
     using T = decltype(tag);
-    if (vec) stats_partial_kernel<T, true><<<grid, kBlock, 0, st>>>(x, part, g);
-    else stats_partial_kernel<T, false><<<grid, kBlock, 0, st>>>(x, part, g);
+#define SBQ_STATS(V, F) stats_partial_kernel<T, V, F><<<grid, kBlock, 0, st>>>(x, part, min_out, max_out, abssum_out, g)
+    if (vec) { if (final_) SBQ_STATS(true, true); else SBQ_STATS(true, false); }
+    else { if (final_) SBQ_STATS(false, true); else SBQ_STATS(false, false); }
+#undef SBQ_STATS
   });
   if (rc != SBQ_OK) return rc;
   rc = check_launch();
-  if (rc != SBQ_OK) return rc;
+  if (rc != SBQ_OK || final_) return rc;
   stats_finish_kernel<<<g.C, kBlock, 0, st>>>(part, g.chunks_per_chan, min_out, max_out, abssum_out);
   return check_launch();
 }

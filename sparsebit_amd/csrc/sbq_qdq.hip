@@ -14,7 +14,10 @@
 //   * FLAT variant (short rows): packs are numbered across the whole tensor and
 //     the channel is recomputed per pack, keeping every lane busy;
 //   * U independent packs per lane are loaded before any is used (memory-level
-//     parallelism), streamed with non-temporal hints: the data is touched once;
+//     parallelism), streamed with non-temporal hints: the data is touched once, and
+//     the loads of the next tile are issued before the current one is processed;
+//   * x / s is exact but cheap: the row's reciprocal is computed once and each
+//     element pays a multiply and two fma refinements (sbq_common.hpp, fast_div);
 //   * anything not 16-byte friendly (inner % 8 != 0, odd pointers, the exotic
 //     rounding modes) goes through a scalar kernel with identical arithmetic.
 #include "sbq_common.hpp"
@@ -71,20 +74,138 @@ struct QdqPtrs {
   const float* zp;
 };
 
-// development-only arithmetic variants (knob 2), used to locate the bottleneck:
-// MATH_EXACT is the product; the others are NOT parity-correct.
-enum { MATH_EXACT = 0, MATH_RCP = 1, MATH_COPY = 2 };
+// Arithmetic of the pack kernels (knob 2 selects it for A/B measurements on the headline
+// shape; MATH_FAST and MATH_IEEE are both exact, the other two are NOT parity-correct and
+// exist only to locate the bottleneck).
+enum { MATH_FAST = 0, MATH_RCP = 1, MATH_COPY = 2, MATH_IEEE = 3 };
 
-// Pointers are separate __restrict__ kernel parameters (not struct members) so
-// that the compiler may keep the wave-uniform scale / zero_point loads on the
-// scalar unit.  Loads are never predicated: out-of-range lanes re-read the last
-// valid pack (clamped index) and only the stores are masked, which keeps all U
-// loads of a lane in flight together.
+// One tile = U packs per lane.
+template <int U>
+struct Tile {
+  int64_t elem[U];
+  bool ok[U];
+  float s[U], z[U];
+};
+
+// ROWS: the tensor is cut into slabs of kBlock packs (2048 elements) that never straddle a
+// row; a tile is U consecutive slabs, so each of its U loads has a block-uniform channel
+// (scale / zero_point through s_load) and a wave reads 1 KiB of contiguous HBM per load
+// instruction.  FLAT (short rows): packs are numbered across the tensor, channel per lane.
+// Out-of-range lanes point at the last valid pack (loads are never predicated, only stores).
+template <bool FLAT, int U>
+__device__ __forceinline__ void locate(const QdqGeom& g, uint32_t tile, const float* __restrict__ scale,
+                                       const float* __restrict__ zero_point, Tile<U>& t) {
+  if constexpr (!FLAT) {
+    uint32_t sl = tile * U;
+    uint32_t row = sl / g.slabs_per_row;  // scalar unit; once per tile
+    uint32_t col = sl - row * g.slabs_per_row;
+    uint32_t c = row % g.C;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const bool slab_ok = sl < g.n_slabs;
+      const uint32_t pk = col * kBlock + threadIdx.x;
+      t.ok[u] = slab_ok && pk < g.packs_per_row;
+      const uint32_t pkc = pk < g.packs_per_row ? pk : g.packs_per_row - 1;
+      t.elem[u] = static_cast<int64_t>(row) * g.inner + static_cast<int64_t>(pkc) * kPack;
+      t.s[u] = scale[c];
+      t.z[u] = __builtin_rintf(zero_point[c]);
+      // advance to the next slab without dividing; past the end stay on the last one
+      if (sl + 1 < g.n_slabs) {
+        ++sl;
+        if (++col == g.slabs_per_row) {
+          col = 0;
+          ++row;
+          if (++c == g.C) c = 0;
+        }
+      } else {
+        sl = g.n_slabs;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint32_t pk = (tile * U + u) * kBlock + threadIdx.x;
+      t.ok[u] = pk < g.total_packs;
+      const uint32_t pkc = t.ok[u] ? pk : g.total_packs - 1;
+      t.elem[u] = static_cast<int64_t>(pkc) * kPack;
+      uint32_t c = 0;
+      if (g.C != 1) c = (pkc / g.packs_per_row) % g.C;  // per tensor: no division
+      t.s[u] = scale[c];
+      t.z[u] = __builtin_rintf(zero_point[c]);
+    }
+  }
+}
+
+template <typename Tin, int MASK, bool NT, int U>
+__device__ __forceinline__ void issue_loads(const void* __restrict__ x, const uint8_t* __restrict__ mask,
+                                            const Tile<U>& t, RawPack<Tin> (&raw)[U], u32x2 (&mk)[U]) {
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    raw[u] = load_raw<Tin, NT>(x, t.elem[u]);
+    if constexpr (MASK == MASK_BYTES) mk[u] = ld8<NT>(mask + t.elem[u]);
+  }
+}
+
+template <typename Tin, typename Tout, int QT, int MASK, bool FLAT, bool NT, int U, int MATH>
+__device__ __forceinline__ void finish_tile(void* __restrict__ y, void* __restrict__ q, const Tile<U>& t,
+                                            const RawPack<Tin> (&raw)[U], const u32x2 (&mk)[U], float thr,
+                                            float qlo, float qhi) {
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    float v[kPack], lv[kPack], dq[kPack];
+    unpack_raw<Tin>(raw[u], v);
+    const float s = t.s[u], z = t.z[u];
+#pragma unroll
+    for (int j = 0; j < kPack; ++j) {
+      if constexpr (MASK == MASK_BYTES) {
+        const uint32_t byte = (mk[u][j >> 2] >> (8 * (j & 3))) & 0xffu;
+        v[j] = byte ? v[j] : 0.0f;
+      } else if constexpr (MASK == MASK_THRESH) {
+        v[j] = (__builtin_fabsf(v[j]) > thr) ? v[j] : 0.0f;
+      }
+    }
+    // ROWS: `s` is block-uniform, so the choice below is a scalar branch and y = 1/s is one
+    // division per slab instead of one per element.
+    const bool fast = (MATH == MATH_FAST) && !FLAT && fast_div_ok(s);
+    if (fast) {
+      const float yr = 1.0f / s;
+      const float bound = s * 0x1p40f;
+#pragma unroll
+      for (int j = 0; j < kPack; ++j) {
+        lv[j] = quant_level_fast(v[j], s, yr, bound, z, qlo, qhi);
+        dq[j] = dequant_level(lv[j], s, z);
+      }
+    } else if constexpr (MATH == MATH_RCP) {
+      const float yr = 1.0f / s;
+#pragma unroll
+      for (int j = 0; j < kPack; ++j) {
+        lv[j] = __builtin_amdgcn_fmed3f(__builtin_rintf(v[j] * yr) + z, qlo, qhi);
+        dq[j] = dequant_level(lv[j], s, z);
+      }
+    } else if constexpr (MATH == MATH_COPY) {
+#pragma unroll
+      for (int j = 0; j < kPack; ++j) lv[j] = dq[j] = v[j];
+    } else {
+#pragma unroll
+      for (int j = 0; j < kPack; ++j) {
+        lv[j] = quant_level<SBQ_ROUND_HALF_EVEN>(v[j], s, z, qlo, qhi);
+        dq[j] = dequant_level(lv[j], s, z);
+      }
+    }
+    if (t.ok[u]) {
+      store_pack<Tout, NT>(y, t.elem[u], dq);
+      if constexpr (QT != SBQ_Q_NONE) store_q_pack<QT>(q, t.elem[u], lv);
+    }
+  }
+}
+
+// Pointers are separate __restrict__ kernel parameters (not struct members) so that the
+// compiler keeps the block-uniform scale / zero_point loads on the scalar unit.
 //
-// ROWS: the tensor is cut into slabs of kBlock packs (2048 elements) that never
-// straddle a row; a workgroup takes U consecutive slabs per iteration, so each
-// of its U loads has a block-uniform channel (scale/zp via s_load) and a wave
-// reads 1 KiB of contiguous HBM per load instruction.
+// The loop is software pipelined: the (still packed) loads of tile i+1 are in flight while
+// tile i is converted, quantized and stored, so the VALU work (~15 ops per element) hides
+// under HBM latency instead of adding to it -- the kernel is short (one 4096x4096 weight is
+// ~12 us), there is no steady state to amortise a load->compute->store serialisation.
 template <typename Tin, typename Tout, int QT, int MASK, bool FLAT, bool NT, int U, int MATH>
 __global__ __launch_bounds__(kBlock) void qdq_pack_kernel(
     const void* __restrict__ x, void* __restrict__ y, void* __restrict__ q,
@@ -93,90 +214,36 @@ __global__ __launch_bounds__(kBlock) void qdq_pack_kernel(
   float thr = 0.0f;
   if constexpr (MASK == MASK_THRESH) thr = *thresh;
 
-  for (uint32_t tile = blockIdx.x; tile < g.n_tiles; tile += gridDim.x) {
-    int64_t elem[U];
-    bool ok[U];
-    float s[U], z[U];
-    if constexpr (!FLAT) {
-      uint32_t sl = tile * U;
-      uint32_t row = sl / g.slabs_per_row;  // scalar unit; once per tile
-      uint32_t col = sl - row * g.slabs_per_row;
-      uint32_t c = row % g.C;
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const bool slab_ok = sl < g.n_slabs;
-        const uint32_t pk = col * kBlock + threadIdx.x;
-        ok[u] = slab_ok && pk < g.packs_per_row;
-        const uint32_t pkc = pk < g.packs_per_row ? pk : g.packs_per_row - 1;
-        elem[u] = static_cast<int64_t>(row) * g.inner + static_cast<int64_t>(pkc) * kPack;
-        s[u] = scale[c];
-        z[u] = __builtin_rintf(zero_point[c]);
-        // advance to the next slab without dividing; past the end stay on the last one
-        if (sl + 1 < g.n_slabs) {
-          ++sl;
-          if (++col == g.slabs_per_row) {
-            col = 0;
-            ++row;
-            if (++c == g.C) c = 0;
-          }
-        } else {
-          sl = g.n_slabs;
-        }
-      }
-    } else {
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const uint32_t pk = (tile * U + u) * kBlock + threadIdx.x;
-        ok[u] = pk < g.total_packs;
-        const uint32_t pkc = ok[u] ? pk : g.total_packs - 1;
-        elem[u] = static_cast<int64_t>(pkc) * kPack;
-        uint32_t c = 0;
-        if (g.C != 1) c = (pkc / g.packs_per_row) % g.C;  // per tensor: no division
-        s[u] = scale[c];
-        z[u] = __builtin_rintf(zero_point[c]);
-      }
-    }
-
-    float v[U][kPack];
-    u32x2 mk[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      load_pack<Tin, NT>(x, elem[u], v[u]);
-      if constexpr (MASK == MASK_BYTES) mk[u] = ld8<NT>(mask + elem[u]);
-    }
-
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      float lv[kPack], dq[kPack];
-      float rs = 0.0f;
-      if constexpr (MATH == MATH_RCP) rs = 1.0f / s[u];
-#pragma unroll
-      for (int j = 0; j < kPack; ++j) {
-        float xv = v[u][j];
-        if constexpr (MASK == MASK_BYTES) {
-          const uint32_t byte = (mk[u][j >> 2] >> (8 * (j & 3))) & 0xffu;
-          xv = byte ? xv : 0.0f;
-        } else if constexpr (MASK == MASK_THRESH) {
-          xv = (__builtin_fabsf(xv) > thr) ? xv : 0.0f;
-        }
-        if constexpr (MATH == MATH_EXACT) {
-          lv[j] = quant_level<SBQ_ROUND_HALF_EVEN>(xv, s[u], z[u], g.qlo, g.qhi);
-          dq[j] = dequant_level(lv[j], s[u], z[u]);
-        } else if constexpr (MATH == MATH_RCP) {
-          float t = __builtin_rintf(xv * rs) + z[u];
-          lv[j] = __builtin_fminf(__builtin_fmaxf(t, g.qlo), g.qhi);
-          dq[j] = dequant_level(lv[j], s[u], z[u]);
-        } else {
-          lv[j] = xv;
-          dq[j] = xv;
-        }
-      }
-      if (ok[u]) {
-        store_pack<Tout, NT>(y, elem[u], dq);
-        if constexpr (QT != SBQ_Q_NONE) store_q_pack<QT>(q, elem[u], lv);
-      }
-    }
+  uint32_t tile = blockIdx.x;
+  const uint32_t G = gridDim.x;
+  if (tile >= g.n_tiles) return;
+  Tile<U> ta, tb;
+  RawPack<Tin> ra[U], rb[U];
+  u32x2 ma[U], mb[U];
+#define SBQ_FETCH(T, R, M, IDX)                         \
+  locate<FLAT, U>(g, (IDX), scale, zero_point, T);      \
+  issue_loads<Tin, MASK, NT, U>(x, mask, T, R, M)
+#define SBQ_FINISH(T, R, M) finish_tile<Tin, Tout, QT, MASK, FLAT, NT, U, MATH>(y, q, T, R, M, thr, g.qlo, g.qhi)
+  SBQ_FETCH(ta, ra, ma, tile);
+  // Steady state: both prefetches are unconditional, so the compiler's vmcnt bookkeeping
+  // stays exact (a conditional prefetch merges two scoreboard states at the join and makes
+  // every wait drain the prefetched tile too).
+  while (static_cast<uint64_t>(tile) + 2ull * G < g.n_tiles) {
+    SBQ_FETCH(tb, rb, mb, tile + G);
+    SBQ_FINISH(ta, ra, ma);
+    SBQ_FETCH(ta, ra, ma, tile + 2 * G);
+    SBQ_FINISH(tb, rb, mb);
+    tile += 2 * G;
   }
+  if (static_cast<uint64_t>(tile) + G < g.n_tiles) {  // exactly one more tile after this one
+    SBQ_FETCH(tb, rb, mb, tile + G);
+    SBQ_FINISH(ta, ra, ma);
+    SBQ_FINISH(tb, rb, mb);
+  } else {
+    SBQ_FINISH(ta, ra, ma);
+  }
+#undef SBQ_FETCH
+#undef SBQ_FINISH
 }
 
 // Scalar path: any geometry, any alignment, all rounding modes, runtime dtypes.
@@ -232,7 +299,7 @@ __global__ __launch_bounds__(kBlock) void qdq_scalar_kernel(const ScalarArgs a) 
 }
 
 // ---- host dispatch -------------------------------------------------------------------
-constexpr uint32_t kDefaultGridCap = 256 * 8;  // 8 resident workgroups of 256 on each of 256 CUs
+constexpr uint32_t kDefaultGridCap = 256 * 4;  // 4 resident workgroups of 256 on each of 256 CUs
 
 struct QdqCall {
   QdqPtrs p;
@@ -240,7 +307,7 @@ struct QdqCall {
   uint32_t rows;
 };
 
-template <typename Tin, typename Tout, int QT, int MASK, bool FLAT, bool NT, int U, int MATH = MATH_EXACT>
+template <typename Tin, typename Tout, int QT, int MASK, bool FLAT, bool NT, int U, int MATH = MATH_FAST>
 void launch_pack(const QdqCall& c, hipStream_t st) {
   const uint32_t cap = knob(1) > 0 ? static_cast<uint32_t>(knob(1)) : kDefaultGridCap;
   const uint32_t grid = c.g.n_tiles < cap ? c.g.n_tiles : cap;
@@ -248,19 +315,20 @@ void launch_pack(const QdqCall& c, hipStream_t st) {
       c.p.x, c.p.y, c.p.q, c.p.mask, c.p.thresh, c.p.scale, c.p.zp, c.g);
 }
 
-// variant id (knob 0):  bit0-1: log2(U) (0..3) ; bit2: NT off ; -1 auto
+// variant id (knob 0):  bit0-1: log2(U) (0..2) ; bit2: NT off ; -1 auto
 template <typename Tin, typename Tout, int QT, int MASK, bool FLAT>
 void launch_variant(QdqCall c, int variant, hipStream_t st) {
   int lu;
   bool nt = true;
   if (variant >= 0) {
     lu = variant & 3;
+    if (lu > 2) lu = 2;
     nt = !(variant & 4);
   } else {
-    // auto: enough packs in flight per lane to cover HBM latency, but keep >= 2
-    // workgroups per CU busy
+    // auto (measured on the 4096x4096 headline, tools/qdq_sweep.py): two packs per lane per
+    // tile and two tiles in flight, on a grid of 4 workgroups per CU
     const uint32_t units = FLAT ? (c.g.total_packs + kBlock - 1) / kBlock : c.g.n_slabs;
-    lu = units >= 8u * 512u ? 2 : (units >= 4u * 512u ? 1 : 0);
+    lu = units >= 2u * kDefaultGridCap ? 1 : 0;
   }
   const uint32_t U = 1u << lu;
   if (FLAT) c.g.n_tiles = (c.g.total_packs + kBlock * U - 1) / (kBlock * U);
@@ -269,28 +337,29 @@ void launch_variant(QdqCall c, int variant, hipStream_t st) {
   if constexpr (QT == SBQ_Q_NONE && MASK == MASK_NONE && Tin::id == SBQ_BF16 && Tout::id == SBQ_BF16 && !FLAT) {
     // development variants for the headline shape only (A/B measurements)
     const int math = knob(2);
-    if (math == MATH_RCP) {
-      if (U == 4) launch_pack<Tin, Tout, QT, MASK, FLAT, true, 4, MATH_RCP>(c, st);
-      else launch_pack<Tin, Tout, QT, MASK, FLAT, true, 8, MATH_RCP>(c, st);
-      return;
-    }
-    if (math == MATH_COPY) {
-      if (U == 4) launch_pack<Tin, Tout, QT, MASK, FLAT, true, 4, MATH_COPY>(c, st);
-      else launch_pack<Tin, Tout, QT, MASK, FLAT, true, 8, MATH_COPY>(c, st);
+    if (math == MATH_RCP || math == MATH_COPY || math == MATH_IEEE) {
+#define SBQ_LAUNCH_M(UV)                                                                       \
+  do {                                                                                         \
+    if (math == MATH_RCP) launch_pack<Tin, Tout, QT, MASK, FLAT, true, UV, MATH_RCP>(c, st);   \
+    else if (math == MATH_COPY) launch_pack<Tin, Tout, QT, MASK, FLAT, true, UV, MATH_COPY>(c, st); \
+    else launch_pack<Tin, Tout, QT, MASK, FLAT, true, UV, MATH_IEEE>(c, st);                   \
+  } while (0)
+      if (U == 1) SBQ_LAUNCH_M(1);
+      else if (U == 2) SBQ_LAUNCH_M(2);
+      else SBQ_LAUNCH_M(4);
+#undef SBQ_LAUNCH_M
       return;
     }
     if (!nt) {
       if (U == 1) SBQ_LAUNCH(false, 1);
       else if (U == 2) SBQ_LAUNCH(false, 2);
-      else if (U == 4) SBQ_LAUNCH(false, 4);
-      else SBQ_LAUNCH(false, 8);
+      else SBQ_LAUNCH(false, 4);
       return;
     }
   }
   if (U == 1) SBQ_LAUNCH(true, 1);
   else if (U == 2) SBQ_LAUNCH(true, 2);
-  else if (U == 4) SBQ_LAUNCH(true, 4);
-  else SBQ_LAUNCH(true, 8);
+  else SBQ_LAUNCH(true, 4);
 #undef SBQ_LAUNCH
 }
 

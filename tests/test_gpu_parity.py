@@ -177,6 +177,50 @@ def test_qdq_edge_values_and_alignment(oracle, ops):
                 assert np.array_equal(q.cpu().numpy(), ref_q)
 
 
+def test_fast_division_equals_ieee(oracle, ops):
+    """The row kernels replace the IEEE division sequence by reciprocal + two fma refinements
+    (sbq_common.hpp: fast_div).  Compare with the true-division path (taken for a misaligned
+    pointer) bit for bit on data built to sit on rounding boundaries, for awkward and extreme
+    scales, and with the oracle on a sample."""
+    g = torch.Generator().manual_seed(77)
+    C, inner = 512, 4096
+    # scales: random mantissas over many binades, mantissa all-ones, powers of two, range edges
+    s = torch.exp2(torch.randint(-40, 30, (C,), generator=g).float()) * (1 + torch.rand(C, generator=g))
+    s[0], s[1], s[2], s[3] = 2.0 ** -60, 2.0 ** 60, 2.0 ** -61, 2.0 ** 61  # in and just out of the fast range
+    s[4] = torch.tensor(np.float32(np.uint32(0x3FFFFFFF).view(np.float32)).item())  # 1.9999999 (mantissa all ones)
+    s[5], s[6], s[7] = 1.0, 1e-6, 3.0
+    k = torch.randint(-300, 300, (C, inner), generator=g).float() + 0.5  # exact half-integers
+    x = k * s[:, None]
+    # nudge a third of the values by +-1 ulp around the tie, a third fully random
+    ulp = torch.nextafter(x, torch.full_like(x, float("inf"))) - x
+    sel = torch.randint(0, 6, x.shape, generator=g)
+    x = torch.where(sel == 0, x + ulp, torch.where(sel == 1, x - ulp, x))
+    x = torch.where(sel >= 4, torch.randn(x.shape, generator=g) * s[:, None] * 100, x)
+    x[:, 0] = float("inf")
+    x[:, 1] = float("-inf")
+    x[:, 2] = float("nan")
+    x[:, 3] = 3.0e38
+    x[:, 4] = 1e-45
+    x[:, 5] = -0.0
+    z = torch.zeros(C)
+    z[::3] = 7.0
+    for qmin, qmax in ((-128, 127), (0, 255), (-32768, 32767)):
+        for dt in (torch.float32, torch.bfloat16):
+            xd = x.to(dt).cuda()
+            sd, zd = s.cuda(), z.cuda()
+            y_fast, q_fast = ops.fake_quant(xd, sd, zd, qmin, qmax, 0, return_q=torch.int32)
+            pad = torch.empty(xd.numel() + 1, dtype=dt, device="cuda")
+            xm = pad[1:].view(C, inner)  # 2- or 4-byte aligned only -> scalar kernel, true division
+            xm.copy_(xd)
+            y_ieee, q_ieee = ops.fake_quant(xm, sd, zd, qmin, qmax, 0, return_q=torch.int32)
+            assert same_values(y_fast.cpu().numpy(), y_ieee.cpu().numpy()), (qmin, dt)
+            fin = ~torch.isnan(xd.float())
+            assert torch.equal(q_fast[fin], q_ieee[fin])
+            rows = [0, 1, 2, 3, 4, 5, 6, 7, 100, 511]
+            ref_dq, ref_q = oracle.qdq(xd.float().cpu().numpy()[rows], s.numpy()[rows], z.numpy()[rows], qmin, qmax, 0)
+            assert same_values(y_fast[rows].cpu().numpy(), ref_dq)
+
+
 def test_rounding_modes(ops):
     """common.cuh:64-77: half-even (0), half-up floor(v+.5) (1), half-down ceil(v-.5) (2)."""
     x = torch.tensor([0.5, 1.5, 2.5, -0.5, -1.5, -2.5, 0.4, -0.6], device="cuda")

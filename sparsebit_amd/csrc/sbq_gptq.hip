@@ -26,7 +26,6 @@ namespace {
 
 constexpr int kSliceRows = 16;            // qweight rows per K slice
 constexpr int kSliceK = kSliceRows * 8;   // 128 input channels
-constexpr int kBT = 8;                    // batch rows kept in registers at once
 
 struct GptqGeom {
   int64_t in_features, out_features, batch;
@@ -39,7 +38,8 @@ struct GptqGeom {
 };
 
 // COLS = 4: 16-byte loads (out_features % 4 == 0, aligned); COLS = 1: any shape.
-template <int COLS>
+// kBT: batch rows per register tile -- a mat-VEC (batch 1) must not pay 8 FMAs per weight.
+template <int COLS, int kBT>
 __global__ __launch_bounds__(kBlock) void gptq4_partial_kernel(
     const float* __restrict__ x, const int32_t* __restrict__ qw, const float* __restrict__ scales,
     const float* __restrict__ zeros, float* __restrict__ part, const GptqGeom g) {
@@ -197,13 +197,18 @@ int sbq_vecquant4matmul(const float* x, const int32_t* qweight, float* out, cons
   hipStream_t st = as_stream(stream);
   float* part = static_cast<float*>(workspace);
   const bool vec = (out_features % 4 == 0) && aligned16(qweight);
-  if (vec) {
-    dim3 grid(static_cast<uint32_t>(ceil_div(out_features, kWave * 4)), static_cast<uint32_t>(g.kblocks));
-    gptq4_partial_kernel<4><<<grid, kBlock, 0, st>>>(x, qweight, scales, zeros, part, g);
-  } else {
-    dim3 grid(static_cast<uint32_t>(ceil_div(out_features, kWave)), static_cast<uint32_t>(g.kblocks));
-    gptq4_partial_kernel<1><<<grid, kBlock, 0, st>>>(x, qweight, scales, zeros, part, g);
-  }
+  const int bt = batch >= 8 ? 8 : (batch >= 3 ? 4 : (batch == 2 ? 2 : 1));
+#define SBQ_GPTQ(COLS)                                                                              \
+  do {                                                                                              \
+    dim3 grid(static_cast<uint32_t>(ceil_div(out_features, kWave * COLS)), static_cast<uint32_t>(g.kblocks)); \
+    if (bt == 8) gptq4_partial_kernel<COLS, 8><<<grid, kBlock, 0, st>>>(x, qweight, scales, zeros, part, g); \
+    else if (bt == 4) gptq4_partial_kernel<COLS, 4><<<grid, kBlock, 0, st>>>(x, qweight, scales, zeros, part, g); \
+    else if (bt == 2) gptq4_partial_kernel<COLS, 2><<<grid, kBlock, 0, st>>>(x, qweight, scales, zeros, part, g); \
+    else gptq4_partial_kernel<COLS, 1><<<grid, kBlock, 0, st>>>(x, qweight, scales, zeros, part, g);  \
+  } while (0)
+  if (vec) SBQ_GPTQ(4);
+  else SBQ_GPTQ(1);
+#undef SBQ_GPTQ
   int rc = check_launch();
   if (rc != SBQ_OK) return rc;
   const int64_t bn = batch * out_features;

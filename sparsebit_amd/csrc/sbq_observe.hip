@@ -20,7 +20,7 @@
 namespace sbq {
 namespace {
 
-constexpr uint32_t kStatsChunk = kBlock * kPack * 4;  // 8192 elements, 4 packs per lane
+constexpr uint32_t kStatsChunk = kWave * kPack * 8;   // 4096 elements: ONE WAVE, 8 packs per lane
 constexpr uint32_t kMseChunk = kBlock * kPack * 2;    // 4096 elements, 2 packs per lane (registers)
 
 struct StatPartial {
@@ -33,12 +33,13 @@ struct MaxF { __device__ __forceinline__ float operator()(float a, float b) cons
 struct OrI { __device__ __forceinline__ int operator()(int a, int b) const { return a | b; } };
 
 // ---- stage 1: one partial {min, max, sum|x|} per chunk ---------------------------
-// min/max use the NaN-dropping v_min/v_max plus a separate "saw a NaN" flag, which
-// reproduces torch's NaN-propagating result at 1 op per element instead of 5.  The four
-// per-lane accumulators are folded with ONE wave shuffle tree each and a single LDS
-// exchange (one barrier pair per workgroup, not one per statistic).  When a channel is a
-// single chunk (a [C, inner <= 8192] weight) the result is final and written directly:
-// no second kernel.
+// A chunk (<= 4096 elements of one channel row) belongs to ONE WAVE: 8 packs per lane are
+// requested back to back (128 B per lane in flight) and the four accumulators are folded
+// with shuffle trees only -- no LDS, no barrier, nothing shared between the 4 waves of a
+// workgroup.  min/max use the NaN-dropping v_min/v_max plus a separate "saw a NaN" flag,
+// which reproduces torch's NaN-propagating result at 1 op per element instead of 5.  When a
+// channel is a single chunk (a [C, inner <= 4096] weight) the result is final and written
+// directly: no second kernel.
 struct StatAcc {
   float mn, mx, as;
   int nan;
@@ -50,12 +51,11 @@ __global__ __launch_bounds__(kBlock) void stats_partial_kernel(const void* __res
                                                                float* __restrict__ min_out,
                                                                float* __restrict__ max_out,
                                                                double* __restrict__ abssum_out,
-                                                               const ChunkGeom g) {
-  __shared__ float s_mn[kWavesPerBlock], s_mx[kWavesPerBlock];
-  __shared__ double s_as[kWavesPerBlock];
-  __shared__ int s_nan[kWavesPerBlock];
-  const uint32_t bid = blockIdx.x;
-  const ChunkPos cp = chunk_pos(g, bid);
+                                                               const ChunkGeom g, uint32_t n_chunks) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const uint32_t cid = blockIdx.x * kWavesPerBlock + threadIdx.x / kWave;  // wave-uniform
+  if (cid >= n_chunks) return;
+  const ChunkPos cp = chunk_pos(g, cid);
   const int64_t row_base = cp.row_base, begin = cp.begin, end = cp.end;
 
   StatAcc a{__builtin_inff(), -__builtin_inff(), 0.0f, 0};
@@ -67,62 +67,44 @@ __global__ __launch_bounds__(kBlock) void stats_partial_kernel(const void* __res
   };
   if constexpr (VEC) {
     const int64_t vend = begin + ((end - begin) / kPack) * kPack;
-    constexpr int U = 2;
-    for (int64_t base = begin; base < vend; base += static_cast<int64_t>(kBlock) * kPack * U) {
+    constexpr int U = 8;
+    if (vend > begin) {
       RawPack<T> raw[U];
       bool ok[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        int64_t e = base + (static_cast<int64_t>(u) * kBlock + threadIdx.x) * kPack;
+        int64_t e = begin + (static_cast<int64_t>(u) * kWave + lane) * kPack;
         ok[u] = e < vend;
         if (!ok[u]) e = vend - kPack;
         raw[u] = load_raw<T, true>(x, row_base + e);
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        if (!ok[u]) continue;
         float v[kPack];
         unpack_raw<T>(raw[u], v);
+        if (ok[u]) {
 #pragma unroll
-        for (int q = 0; q < kPack; ++q) visit(v[q]);
+          for (int q = 0; q < kPack; ++q) visit(v[q]);
+        }
       }
     }
     // ragged tail of a per-tensor row (< 8 elements)
-    for (int64_t e = vend + threadIdx.x; e < end; e += kBlock) visit(Elem<T>::load1(x, row_base + e));
+    for (int64_t e = vend + lane; e < end; e += kWave) visit(Elem<T>::load1(x, row_base + e));
   } else {
-    for (int64_t e = begin + threadIdx.x; e < end; e += kBlock) visit(Elem<T>::load1(x, row_base + e));
+    for (int64_t e = begin + lane; e < end; e += kWave) visit(Elem<T>::load1(x, row_base + e));
   }
-  const float wmn = wave_reduce(a.mn, MinF());
-  const float wmx = wave_reduce(a.mx, MaxF());
-  const int wnan = wave_reduce(a.nan, OrI());
-  const double was = wave_reduce(static_cast<double>(a.as), Sum());
-  const int lane = threadIdx.x & (kWave - 1);
-  const int wid = threadIdx.x / kWave;
+  float mn = wave_reduce(a.mn, MinF());
+  float mx = wave_reduce(a.mx, MaxF());
+  const int nan = wave_reduce(a.nan, OrI());
+  const double as = wave_reduce(static_cast<double>(a.as), Sum());
   if (lane == 0) {
-    s_mn[wid] = wmn;
-    s_mx[wid] = wmx;
-    s_nan[wid] = wnan;
-    s_as[wid] = was;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    float mn = s_mn[0], mx = s_mx[0];
-    int nan = s_nan[0];
-    double as = s_as[0];
-#pragma unroll
-    for (int w = 1; w < kWavesPerBlock; ++w) {
-      mn = __builtin_fminf(mn, s_mn[w]);
-      mx = __builtin_fmaxf(mx, s_mx[w]);
-      nan |= s_nan[w];
-      as += s_as[w];
-    }
     if (nan) mn = mx = __builtin_nanf("");
     if constexpr (FINAL) {
       if (min_out) min_out[cp.c] = mn;
       if (max_out) max_out[cp.c] = mx;
       if (abssum_out) abssum_out[cp.c] = as;
     } else {
-      part[bid] = StatPartial{mn, mx, as};
+      part[cid] = StatPartial{mn, mx, as};
     }
   }
 }
@@ -191,9 +173,11 @@ __device__ __forceinline__ void mse_candidate(float mn, float mx, int i, float q
 template <typename T, bool VEC>
 __global__ __launch_bounds__(kBlock) void mse_partial_kernel(
     const void* __restrict__ x, const float* __restrict__ min_val, const float* __restrict__ max_val,
-    double* __restrict__ part, const ChunkGeom g, float qrange, float qlo, float qhi, int symmetric) {
+    double* __restrict__ part, double* __restrict__ sse, const ChunkGeom g, float qrange, float qlo,
+    float qhi, int symmetric) {
   __shared__ float s_scale[SBQ_MSE_CANDIDATES];
   __shared__ float s_zp[SBQ_MSE_CANDIDATES];
+  __shared__ float s_rcp[SBQ_MSE_CANDIDATES];  // RN(1/scale) when the exact fast division applies, else 0
   __shared__ float s_acc[SBQ_MSE_CANDIDATES][kWavesPerBlock];
   const uint32_t bid = blockIdx.x;
   const ChunkPos cp = chunk_pos(g, bid);
@@ -205,11 +189,13 @@ __global__ __launch_bounds__(kBlock) void mse_partial_kernel(
     mse_candidate(min_val[c], max_val[c], threadIdx.x, qrange, symmetric != 0, s, z);
     s_scale[threadIdx.x] = s;
     s_zp[threadIdx.x] = z;  // already integral (rint) or 0
+    s_rcp[threadIdx.x] = fast_div_ok(s) ? 1.0f / s : 0.0f;
   }
 
+  // Lanes past the end of the chunk hold x = 0: its QDQ is exactly 0 for every candidate
+  // (zp lies inside [qmin, qmax]), so they add exactly 0 to every sum -- no masking needed.
   constexpr int E = 2 * kPack;  // elements per lane
   float v[E];
-  bool ok[E];
   if constexpr (VEC) {
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
@@ -219,17 +205,13 @@ __global__ __launch_bounds__(kBlock) void mse_partial_kernel(
       float t[kPack];
       load_pack<T, true>(x, row_base + e, t);
 #pragma unroll
-      for (int q = 0; q < kPack; ++q) {
-        v[u * kPack + q] = t[q];
-        ok[u * kPack + q] = in;
-      }
+      for (int q = 0; q < kPack; ++q) v[u * kPack + q] = in ? t[q] : 0.0f;
     }
   } else {
 #pragma unroll
     for (int q = 0; q < E; ++q) {
       const int64_t e = begin + static_cast<int64_t>(q) * kBlock + threadIdx.x;
-      ok[q] = e < end;
-      v[q] = ok[q] ? Elem<T>::load1(x, row_base + e) : 0.0f;
+      v[q] = e < end ? Elem<T>::load1(x, row_base + e) : 0.0f;
     }
   }
   __syncthreads();
@@ -239,13 +221,25 @@ __global__ __launch_bounds__(kBlock) void mse_partial_kernel(
   for (int i = 0; i < SBQ_MSE_CANDIDATES; ++i) {
     const float s = s_scale[i];
     const float z = s_zp[i];
+    const float y = s_rcp[i];
     float acc = 0.0f;
+    if (y != 0.0f) {  // block-uniform: the candidate's scale is shared by the whole chunk
+      const float bound = s * 0x1p40f;
 #pragma unroll
-    for (int q = 0; q < E; ++q) {
-      const float lv = quant_level<SBQ_ROUND_HALF_EVEN>(v[q], s, z, qlo, qhi);
-      const float d = v[q] - dequant_level(lv, s, z);
-      const float sq = d * d;
-      acc += ok[q] ? sq : 0.0f;
+      for (int q = 0; q < E; ++q) {
+        // no NaN restore here: a NaN input poisons the channel's loss either way
+        const float xc = __builtin_amdgcn_fmed3f(v[q], -bound, bound);
+        const float lv = __builtin_amdgcn_fmed3f(__builtin_rintf(fast_div(xc, s, y)) + z, qlo, qhi);
+        const float d = v[q] - dequant_level(lv, s, z);
+        acc += d * d;
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < E; ++q) {
+        const float lv = quant_level<SBQ_ROUND_HALF_EVEN>(v[q], s, z, qlo, qhi);
+        const float d = v[q] - dequant_level(lv, s, z);
+        acc += d * d;
+      }
     }
     acc = wave_reduce(acc, Sum());
     if (lane == 0) s_acc[i][wid] = acc;
@@ -255,24 +249,55 @@ __global__ __launch_bounds__(kBlock) void mse_partial_kernel(
     double t = 0.0;
 #pragma unroll
     for (int w = 0; w < kWavesPerBlock; ++w) t += static_cast<double>(s_acc[threadIdx.x][w]);
-    part[static_cast<size_t>(bid) * SBQ_MSE_CANDIDATES + threadIdx.x] = t;
+    if (g.chunks_per_chan == 1)  // the chunk IS the channel: accumulate in place, no fold kernel
+      sse[static_cast<size_t>(c) * SBQ_MSE_CANDIDATES + threadIdx.x] += t;
+    else
+      part[static_cast<size_t>(bid) * SBQ_MSE_CANDIDATES + threadIdx.x] = t;
   }
 }
 
-// sse[c][i] += sum over the channel's chunks, fixed order.
-__global__ __launch_bounds__(kBlock) void mse_fold_kernel(const double* __restrict__ part,
-                                                          uint32_t chunks_per_chan,
-                                                          double* __restrict__ sse) {
-  __shared__ double s_d[kWavesPerBlock];
-  const uint32_t c = blockIdx.x;
-  const double* p = part + static_cast<size_t>(c) * chunks_per_chan * SBQ_MSE_CANDIDATES;
-  for (int i = 0; i < SBQ_MSE_CANDIDATES; ++i) {
+// Fold the per-chunk tables of a channel in a fixed order, kFoldFan chunks per workgroup
+// and level: in[c][n_in][80] -> out[c][ceil(n_in / kFoldFan)][80]; the last level (one
+// group left) ADDS into sse[c][80] instead.  Thread t owns candidate t % 80 and every third
+// chunk of its group, so consecutive lanes read consecutive doubles.
+constexpr uint32_t kFoldFan = 96;
+
+__global__ __launch_bounds__(kBlock) void mse_fold_kernel(const double* __restrict__ in, uint32_t n_in,
+                                                          double* __restrict__ out, uint32_t n_out,
+                                                          int accumulate) {
+  __shared__ double s_d[3][SBQ_MSE_CANDIDATES];
+  const uint32_t c = blockIdx.y;
+  const uint32_t grp = blockIdx.x;
+  const uint32_t first = grp * kFoldFan;
+  uint32_t last = first + kFoldFan;
+  if (last > n_in) last = n_in;
+  const double* p = in + static_cast<size_t>(c) * n_in * SBQ_MSE_CANDIDATES;
+  const uint32_t i = threadIdx.x % SBQ_MSE_CANDIDATES;
+  const uint32_t lane3 = threadIdx.x / SBQ_MSE_CANDIDATES;  // 0..3; 3 idles (256 = 3*80 + 16)
+  if (lane3 < 3) {
     double t = 0.0;
-    for (uint32_t j = threadIdx.x; j < chunks_per_chan; j += kBlock)
-      t += p[static_cast<size_t>(j) * SBQ_MSE_CANDIDATES + i];
-    t = block_reduce(t, Sum(), s_d);
-    if (threadIdx.x == 0) sse[static_cast<size_t>(c) * SBQ_MSE_CANDIDATES + i] += t;
+    for (uint32_t j = first + lane3; j < last; j += 3) t += p[static_cast<size_t>(j) * SBQ_MSE_CANDIDATES + i];
+    s_d[lane3][i] = t;
   }
+  __syncthreads();
+  if (threadIdx.x < SBQ_MSE_CANDIDATES) {
+    const double t = (s_d[0][i] + s_d[1][i]) + s_d[2][i];
+    double* o = out + (static_cast<size_t>(c) * n_out + grp) * SBQ_MSE_CANDIDATES + i;
+    if (accumulate) *o += t;
+    else *o = t;
+  }
+}
+
+// workspace layout: level-0 tables, then the (geometrically shrinking) fold levels
+size_t mse_workspace_doubles(const ChunkGeom& g) {
+  size_t total = 0;
+  uint32_t n = g.chunks_per_chan;
+  while (true) {
+    total += static_cast<size_t>(n) * g.C * SBQ_MSE_CANDIDATES;
+    if (n <= 1) break;
+    n = (n + kFoldFan - 1) / kFoldFan;
+  }
+  return total;
 }
 
 // mse.py:51-61: keep the first candidate whose fp32 loss is strictly smaller.
@@ -325,12 +350,14 @@ int sbq_channel_stats(const void* x, int x_dtype, int64_t outer, int64_t C, int6
   if (workspace_bytes < need || !aligned16(workspace)) return SBQ_ERR_WORKSPACE;
   hipStream_t st = as_stream(stream);
   StatPartial* part = static_cast<StatPartial*>(workspace);
-  const uint32_t grid = g.chunks_per_chan * g.C;
+  const uint32_t n_chunks = g.chunks_per_chan * g.C;
+  const uint32_t grid = (n_chunks + kWavesPerBlock - 1) / kWavesPerBlock;  // one wave per chunk
   const bool vec = pack_friendly(x, C, outer, inner);
   const bool final_ = g.chunks_per_chan == 1;
   int rc = dispatch_dtype(x_dtype, [&](auto tag) {
     using T = decltype(tag);
-#define SBQ_STATS(V, F) stats_partial_kernel<T, V, F><<<grid, kBlock, 0, st>>>(x, part, min_out, max_out, abssum_out, g)
+#define SBQ_STATS(V, F) \
+  stats_partial_kernel<T, V, F><<<grid, kBlock, 0, st>>>(x, part, min_out, max_out, abssum_out, g, n_chunks)
     if (vec) { if (final_) SBQ_STATS(true, true); else SBQ_STATS(true, false); }
     else { if (final_) SBQ_STATS(false, true); else SBQ_STATS(false, false); }
 #undef SBQ_STATS
@@ -371,7 +398,7 @@ size_t sbq_mse_workspace_bytes(int64_t outer, int64_t C, int64_t inner) {
   using namespace sbq;
   if (!geom_ok(outer, C, inner, kMseChunk)) return 0;
   const ChunkGeom g = make_geom(outer, C, inner, kMseChunk);
-  return static_cast<size_t>(g.chunks_per_chan) * g.C * SBQ_MSE_CANDIDATES * sizeof(double);
+  return mse_workspace_doubles(g) * sizeof(double);
 }
 
 int sbq_mse_accumulate(const void* x, int x_dtype, int64_t outer, int64_t C, int64_t inner,
@@ -386,8 +413,9 @@ int sbq_mse_accumulate(const void* x, int x_dtype, int64_t outer, int64_t C, int
   if (!geom_ok(outer, C, inner, kMseChunk)) return SBQ_ERR_ARG;
   if (reinterpret_cast<uintptr_t>(x) % dtype_size(x_dtype)) return SBQ_ERR_ALIGN;
   const ChunkGeom g = make_geom(outer, C, inner, kMseChunk);
-  const size_t need = static_cast<size_t>(g.chunks_per_chan) * g.C * SBQ_MSE_CANDIDATES * sizeof(double);
+  const size_t need = mse_workspace_doubles(g) * sizeof(double);
   if (workspace_bytes < need || !aligned16(workspace)) return SBQ_ERR_WORKSPACE;
+  if (g.C > 65535) return SBQ_ERR_ARG;  // fold grid.y
   hipStream_t st = as_stream(stream);
   double* part = static_cast<double*>(workspace);
   const uint32_t grid = g.chunks_per_chan * g.C;
@@ -397,15 +425,25 @@ int sbq_mse_accumulate(const void* x, int x_dtype, int64_t outer, int64_t C, int
   int rc = dispatch_dtype(x_dtype, [&](auto tag) {
     using T = decltype(tag);
     if (vec)
-      mse_partial_kernel<T, true><<<grid, kBlock, 0, st>>>(x, min_val, max_val, part, g, qrange, qlo, qhi, symmetric);
+      mse_partial_kernel<T, true><<<grid, kBlock, 0, st>>>(x, min_val, max_val, part, sse, g, qrange, qlo, qhi, symmetric);
     else
-      mse_partial_kernel<T, false><<<grid, kBlock, 0, st>>>(x, min_val, max_val, part, g, qrange, qlo, qhi, symmetric);
+      mse_partial_kernel<T, false><<<grid, kBlock, 0, st>>>(x, min_val, max_val, part, sse, g, qrange, qlo, qhi, symmetric);
   });
   if (rc != SBQ_OK) return rc;
   rc = check_launch();
-  if (rc != SBQ_OK) return rc;
-  mse_fold_kernel<<<g.C, kBlock, 0, st>>>(part, g.chunks_per_chan, sse);
-  return check_launch();
+  if (rc != SBQ_OK || g.chunks_per_chan == 1) return rc;
+  const double* in = part;
+  uint32_t n_in = g.chunks_per_chan;
+  while (true) {
+    const uint32_t n_out = (n_in + kFoldFan - 1) / kFoldFan;
+    const bool last = n_out == 1;
+    double* out = last ? sse : const_cast<double*>(in) + static_cast<size_t>(n_in) * g.C * SBQ_MSE_CANDIDATES;
+    mse_fold_kernel<<<dim3(n_out, g.C), kBlock, 0, st>>>(in, n_in, out, n_out, last ? 1 : 0);
+    rc = check_launch();
+    if (rc != SBQ_OK || last) return rc;
+    in = out;
+    n_in = n_out;
+  }
 }
 
 int sbq_mse_select(const double* sse, double count_per_channel, const float* min_val,

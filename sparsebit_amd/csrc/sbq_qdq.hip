@@ -439,11 +439,11 @@ int qdq_forward(const void* x, int x_dtype, void* y, int y_dtype, void* q, int q
   c.g.qhi = static_cast<float>(qmax);
   c.g.total_packs = static_cast<uint32_t>(total_packs);
   bool flat;
-  if (C == 1) {  // one row of `body` elements
+  if (C == 1) {  // per tensor: one row of `body` elements, cut into slabs like any other row
     c.g.inner = body;
     c.g.packs_per_row = c.g.total_packs;
     c.rows = 1;
-    flat = true;
+    flat = false;
   } else {
     c.g.inner = inner;
     c.g.packs_per_row = static_cast<uint32_t>(inner / kPack);

@@ -58,7 +58,7 @@ def test_status_strings_and_argument_validation_without_gpu(built):
     assert l.sbq_percentile_rows(p, 0, 4, 20000, 0.001, p, p, None) == 4  # row too long for the LDS path
     assert l.sbq_channel_stats(p, 0, 1, 1, 16, p, p, None, p, 0, None) == 5  # workspace too small
     assert l.sbq_stats_workspace_bytes(1, 4096, 4096) == 4096 * 16
-    assert l.sbq_mse_workspace_bytes(1, 4096, 4096) == 4096 * 80 * 8
+    assert l.sbq_mse_workspace_bytes(1, 4096, 4096) == 4096 * 80 * 8  # one chunk per channel: no fold levels
     assert l.sbq_gptq_workspace_bytes(1, 4096, 4096) > 0
 
 

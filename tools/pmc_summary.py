@@ -1,0 +1,76 @@
+"""Turn the two rocprofv3 --pmc passes of tools/rocprof_bench.sh into profiles/ summaries.
+
+usage: python tools/pmc_summary.py <tag>      (reads gpurun_out/<tag>_pmc_{fetch,write}/,
+                                               gpurun_out/<tag>_trace/<tag>_kernel_stats.csv)
+Writes profiles/<tag>_bench_pmc_hbm.csv, profiles/<tag>_bench_kernel_stats.csv and
+profiles/pmc_latest.json (read by bench.py for roofline.traffic).
+
+Corrections, exactly as /opt/skills/guides/MI355X_MICROARCH.md (HBM section) prescribes:
+FETCH_SIZE and WRITE_SIZE are reported in KB (1024 B); on gfx950 FETCH_SIZE tallies each 128-B
+request of a wide coalesced stream as 64 B, so the read side is doubled; WRITE_SIZE is taken as is.
+"""
+import collections
+import csv
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+
+
+def short(name):
+    n = name.replace("void sbq::(anonymous namespace)::", "").replace("sbq::(anonymous namespace)::", "")
+    n = n.replace("sbq::", "")
+    return n.split("(")[0]
+
+
+def main(tag):
+    out = ["kernel,counter,dispatches,avg_reported_KB,min_KB,max_KB"]
+    avg = {}
+    for which in ("fetch", "write"):
+        path = os.path.join(ROOT, "gpurun_out", "%s_pmc_%s" % (tag, which), "%s_counter_collection.csv" % tag)
+        agg = collections.defaultdict(list)
+        for r in csv.DictReader(open(path)):
+            if "sbq" in r["Kernel_Name"]:
+                agg[(short(r["Kernel_Name"]), r["Counter_Name"])].append(float(r["Counter_Value"]))
+        for (k, c), v in sorted(agg.items()):
+            out.append("\"%s\",%s,%d,%.1f,%.1f,%.1f" % (k, c, len(v), sum(v) / len(v), min(v), max(v)))
+            avg[(k, c)] = sum(v) / len(v)
+    head = [
+        "# HBM PMC counters of `python bench.py --no-cpu-baseline --steps 500 --warmup 50` (tag %s)" % tag,
+        "# two separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE); KB as reported.",
+        "# read bytes = 2 x FETCH_SIZE x 1024 (gfx950 correction), written bytes = WRITE_SIZE x 1024",
+    ]
+    os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
+    with open(os.path.join(ROOT, "profiles", "%s_bench_pmc_hbm.csv" % tag), "w") as f:
+        f.write("\n".join(head + out) + "\n")
+    key = [k for (k, c) in avg if k.startswith("qdq_pack_kernel<BF16, BF16, 0, 0")]
+    summary = {"tag": tag}
+    if key:
+        k = key[0]
+        rd = 2 * avg[(k, "FETCH_SIZE")] * 1024
+        wr = avg[(k, "WRITE_SIZE")] * 1024
+        summary.update({
+            "kernel": k,
+            "fetch_size_KB_reported": round(avg[(k, "FETCH_SIZE")], 1),
+            "write_size_KB_reported": round(avg[(k, "WRITE_SIZE")], 1),
+            "read_bytes_corrected": int(rd),
+            "write_bytes": int(wr),
+            "qdq_bf16_bf16_traffic_bytes_per_launch": int(rd + wr),
+            "algorithmic_bytes_per_launch": 4096 * 4096 * 4,
+        })
+    stats = os.path.join(ROOT, "gpurun_out", "%s_trace" % tag, "%s_kernel_stats.csv" % tag)
+    if os.path.exists(stats):
+        shutil.copy(stats, os.path.join(ROOT, "profiles", "%s_bench_kernel_stats.csv" % tag))
+        for r in csv.DictReader(open(stats)):
+            if "qdq_pack_kernel<sbq::BF16, sbq::BF16, 0, 0" in r["Name"]:
+                summary["rocprof_kernel_avg_ns"] = float(r["AverageNs"])
+                summary["rocprof_kernel_calls"] = int(r["Calls"])
+    with open(os.path.join(ROOT, "profiles", "pmc_latest.json"), "w") as f:
+        json.dump(summary, f, indent=1)
+    print(json.dumps(summary, indent=1))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1] if len(sys.argv) > 1 else "r01")

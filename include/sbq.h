@@ -91,6 +91,19 @@ int sbq_quant_perchannel_forward(const void* x, int x_dtype, void* y, int y_dtyp
                                  int64_t outer, int64_t C, int64_t inner,
                                  int qmin, int qmax, int rounding, void* stream);
 
+/* Multi-tensor launch: the same per-channel QDQ over n_items tensors that share dtype,
+ * geometry and integer range (the q/k/v/o projections of a layer, a stack of equal blocks)
+ * in ONE kernel.  A 4096x4096 weight is a ~12 us kernel of which ~2 us are launch ramp, tail
+ * and the stream boundary; batching amortises them (the reference issues one launch per
+ * quantizer per forward, quantizers/base.py:55-64).  `table` is a DEVICE array of
+ * n_items x 4 pointers {x, y, scale, zero_point}; results are identical to n_items calls of
+ * sbq_quant_perchannel_forward.  Needs 16-byte aligned tensors and inner % 8 == 0. */
+#define SBQ_MAX_BATCH 64
+int sbq_quant_perchannel_forward_batched(const void* const* table, int n_items,
+                                         int x_dtype, int y_dtype,
+                                         int64_t outer, int64_t C, int64_t inner,
+                                         int qmin, int qmax, void* stream);
+
 /* Fused unstructured mask + QDQ: y = qdq(keep ? x : 0).
  * keep = mask[i] != 0 when `mask` (1 byte/elem, torch.bool) is given, else
  * keep = |x| > *thresh  (l1norm.py:24-25, strict).  Exactly one of mask/thresh

@@ -246,6 +246,68 @@ __global__ __launch_bounds__(kBlock) void qdq_pack_kernel(
 #undef SBQ_FINISH
 }
 
+// Multi-tensor variant of the ROWS kernel: tile -> (item, tile inside the item); the four
+// pointers of the item come from a device table through scalar loads (block-uniform index).
+// Same helpers, same arithmetic, same two-stage software pipeline.
+template <typename Tin, typename Tout, int U>
+__global__ __launch_bounds__(kBlock) void qdq_batched_kernel(const void* const* __restrict__ table,
+                                                             uint32_t tiles_per_item, uint32_t n_tiles_total,
+                                                             const QdqGeom g) {
+  constexpr int MASK = MASK_NONE;
+  struct Ptrs {
+    const void* x;
+    void* y;
+    const float* scale;
+    const float* zp;
+  };
+  // consecutive tiles of a workgroup mostly stay inside one item: keep its pointers in SGPRs
+  // and go back to the table (a dependent scalar-load chain in front of the data loads) only
+  // when the item changes
+  uint32_t cur_item = 0xffffffffu;
+  Ptrs cur{};
+  auto item_of = [&](uint32_t tile, uint32_t& ltile) -> Ptrs {
+    const uint32_t item = tile / tiles_per_item;
+    ltile = tile - item * tiles_per_item;
+    if (item != cur_item) {
+      const void* const* e = table + static_cast<size_t>(item) * 4;
+      cur = Ptrs{e[0], const_cast<void*>(e[1]), static_cast<const float*>(e[2]), static_cast<const float*>(e[3])};
+      cur_item = item;
+    }
+    return cur;
+  };
+  uint32_t tile = blockIdx.x;
+  const uint32_t G = gridDim.x;
+  if (tile >= n_tiles_total) return;
+  Tile<U> ta, tb;
+  RawPack<Tin> ra[U], rb[U];
+  u32x2 ma[U], mb[U];
+  Ptrs pa, pb;
+  uint32_t lt;
+#define SBQ_FETCH(P, T, R, M, IDX)                     \
+  P = item_of((IDX), lt);                              \
+  locate<false, U>(g, lt, P.scale, P.zp, T);           \
+  issue_loads<Tin, MASK, true, U>(P.x, nullptr, T, R, M)
+#define SBQ_FINISH(P, T, R, M) \
+  finish_tile<Tin, Tout, SBQ_Q_NONE, MASK, false, true, U, MATH_FAST>(P.y, nullptr, T, R, M, 0.0f, g.qlo, g.qhi)
+  SBQ_FETCH(pa, ta, ra, ma, tile);
+  while (static_cast<uint64_t>(tile) + 2ull * G < n_tiles_total) {
+    SBQ_FETCH(pb, tb, rb, mb, tile + G);
+    SBQ_FINISH(pa, ta, ra, ma);
+    SBQ_FETCH(pa, ta, ra, ma, tile + 2 * G);
+    SBQ_FINISH(pb, tb, rb, mb);
+    tile += 2 * G;
+  }
+  if (static_cast<uint64_t>(tile) + G < n_tiles_total) {
+    SBQ_FETCH(pb, tb, rb, mb, tile + G);
+    SBQ_FINISH(pa, ta, ra, ma);
+    SBQ_FINISH(pb, tb, rb, mb);
+  } else {
+    SBQ_FINISH(pa, ta, ra, ma);
+  }
+#undef SBQ_FETCH
+#undef SBQ_FINISH
+}
+
 // Scalar path: any geometry, any alignment, all rounding modes, runtime dtypes.
 struct ScalarArgs {
   const void* x;
@@ -469,10 +531,52 @@ int qdq_forward(const void* x, int x_dtype, void* y, int y_dtype, void* q, int q
   return rc;
 }
 
+int qdq_forward_batched(const void* const* table, int n_items, int x_dtype, int y_dtype, int64_t outer,
+                        int64_t C, int64_t inner, int qmin, int qmax, void* stream) {
+  if (!valid_dtype(x_dtype) || !valid_dtype(y_dtype)) return SBQ_ERR_DTYPE;
+  if (y_dtype != SBQ_F32 && y_dtype != x_dtype) return SBQ_ERR_DTYPE;
+  if (outer < 0 || C < 0 || inner < 0 || n_items < 0) return SBQ_ERR_ARG;
+  if (outer == 0 || C == 0 || inner == 0 || n_items == 0) return SBQ_ERR_EMPTY;
+  if (!table) return SBQ_ERR_NULL;
+  if (n_items > SBQ_MAX_BATCH || qmin > qmax || C > 0x7fffffff) return SBQ_ERR_ARG;
+  if (inner % kPack != 0) return SBQ_ERR_ARG;  // pack kernel only; ragged tensors go one by one
+  const int64_t rows = outer * C;
+  const uint64_t packs = static_cast<uint64_t>(rows) * (inner / kPack);
+  if (rows >= (1ll << 31) || packs * n_items >= (1ull << 31)) return SBQ_ERR_ARG;
+  QdqGeom g{};
+  g.inner = inner;
+  g.C = static_cast<uint32_t>(C);
+  g.packs_per_row = static_cast<uint32_t>(inner / kPack);
+  g.slabs_per_row = (g.packs_per_row + kBlock - 1) / kBlock;
+  g.n_slabs = static_cast<uint32_t>(rows) * g.slabs_per_row;
+  g.total_packs = static_cast<uint32_t>(packs);
+  g.qlo = static_cast<float>(qmin);
+  g.qhi = static_cast<float>(qmax);
+  constexpr uint32_t U = 2;
+  const uint32_t tiles_per_item = (g.n_slabs + U - 1) / U;
+  g.n_tiles = tiles_per_item;
+  const uint32_t total = tiles_per_item * static_cast<uint32_t>(n_items);
+  const uint32_t cap = knob(1) > 0 ? static_cast<uint32_t>(knob(1)) : kDefaultGridCap;
+  const uint32_t grid = total < cap ? total : cap;
+  hipStream_t st = as_stream(stream);
+#define SBQ_B(TI, TO) qdq_batched_kernel<TI, TO, U><<<grid, kBlock, 0, st>>>(table, tiles_per_item, total, g)
+  if (x_dtype == SBQ_F32) SBQ_B(F32, F32);
+  else if (x_dtype == SBQ_F16) { if (y_dtype == SBQ_F32) SBQ_B(F16, F32); else SBQ_B(F16, F16); }
+  else { if (y_dtype == SBQ_F32) SBQ_B(BF16, F32); else SBQ_B(BF16, BF16); }
+#undef SBQ_B
+  return check_launch();
+}
+
 }  // namespace
 }  // namespace sbq
 
 extern "C" {
+
+int sbq_quant_perchannel_forward_batched(const void* const* table, int n_items, int x_dtype, int y_dtype,
+                                         int64_t outer, int64_t C, int64_t inner, int qmin, int qmax,
+                                         void* stream) {
+  return sbq::qdq_forward_batched(table, n_items, x_dtype, y_dtype, outer, C, inner, qmin, qmax, stream);
+}
 
 int sbq_quant_pertensor_forward(const void* x, int x_dtype, void* y, int y_dtype, void* q, int q_type,
                                 const float* scale, const float* zero_point, int64_t numel,

@@ -22,6 +22,7 @@ ROUND_HALF_EVEN, ROUND_HALF_UP, ROUND_HALF_DOWN = 0, 1, 2
 MSE_CANDIDATES = 80
 RADIX_BINS = 2048
 ROWSEL_MAX = 16384
+MAX_BATCH = 64
 
 _DTYPES = {torch.float32: F32, torch.float16: F16, torch.bfloat16: BF16}
 
@@ -47,6 +48,7 @@ _SIGNATURES = {
         c_int,
         [c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_i64, c_i64, c_i64, c_int, c_int, c_int, c_vp],
     ),
+    "sbq_quant_perchannel_forward_batched": (c_int, [c_vp, c_int, c_int, c_int, c_i64, c_i64, c_i64, c_int, c_int, c_vp]),
     "sbq_mask_quant_forward": (
         c_int,
         [c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_int, c_int, c_int, c_vp],

@@ -116,6 +116,50 @@ def fake_quant(x, scale, zero_point, qmin, qmax, ch_axis=0, out_dtype=None, retu
     return (y, q) if return_q is not None else y
 
 
+class BatchedFakeQuant:
+    """Multi-tensor per-channel QDQ: n same-shape tensors, ONE launch (sbq_quant_perchannel_forward_batched).
+
+    Build once per group of weights (the pointer table lives on the device), call every step:
+        bq = BatchedFakeQuant(weights, scales, zero_points, qmin, qmax, ch_axis=0, out_dtype=torch.bfloat16)
+        outs = bq()            # list of dequantized tensors, bit-identical to per-tensor fake_quant
+    The tensors must stay alive and in place (parameters updated in place by an optimizer do)."""
+
+    def __init__(self, xs, scales, zero_points, qmin, qmax, ch_axis=0, out_dtype=None, outs=None):
+        if not (0 < len(xs) <= L.MAX_BATCH) or len(scales) != len(xs) or len(zero_points) != len(xs):
+            raise L.SbqError("BatchedFakeQuant: 1..%d tensors with one scale/zero_point each" % L.MAX_BATCH)
+        self.dev = L.require_device(*xs, *scales, *zero_points)
+        x0 = xs[0]
+        for x in xs:
+            if x.shape != x0.shape or x.dtype != x0.dtype or not x.is_contiguous():
+                raise L.SbqError("BatchedFakeQuant: tensors must share shape/dtype and be contiguous")
+        self.outer, self.C, self.inner = geometry(x0.shape, ch_axis, True)
+        self.xs = list(xs)
+        self.scales = [_f32c(s, self.dev) for s in scales]
+        self.zps = [_f32c(z, self.dev) for z in zero_points]
+        for s_, z_ in zip(self.scales, self.zps):
+            _check_qparams(s_, z_, self.C)
+        out_dtype = out_dtype or torch.float32
+        if out_dtype not in (torch.float32, x0.dtype):
+            raise L.SbqError("out_dtype must be float32 or the input dtype")
+        self.outs = list(outs) if outs is not None else [torch.empty(x.shape, dtype=out_dtype, device=self.dev) for x in xs]
+        self.qmin, self.qmax = int(qmin), int(qmax)
+        rows = [[x.data_ptr(), y.data_ptr(), s_.data_ptr(), z_.data_ptr()]
+                for x, y, s_, z_ in zip(self.xs, self.outs, self.scales, self.zps)]
+        if any(p % 16 for r in rows for p in r[:2]):
+            raise L.SbqError("BatchedFakeQuant: tensors must be 16-byte aligned")
+        self.table = torch.tensor(rows, dtype=torch.int64).to(self.dev)
+        self.x_dt, self.y_dt = L.dtype_id(x0), L.dtype_id(self.outs[0])
+
+    def __call__(self):
+        lib = L.load()
+        with torch.cuda.device(self.dev):
+            rc = lib.sbq_quant_perchannel_forward_batched(L.ptr(self.table), len(self.xs), self.x_dt, self.y_dt,
+                                                          self.outer, self.C, self.inner, self.qmin, self.qmax,
+                                                          L.stream_ptr(self.dev))
+        L.check(rc)
+        return self.outs
+
+
 # ---------------------------------------------------------------------------------
 # STE backward
 # ---------------------------------------------------------------------------------

@@ -221,6 +221,25 @@ def test_fast_division_equals_ieee(oracle, ops):
             assert same_values(y_fast[rows].cpu().numpy(), ref_dq)
 
 
+@pytest.mark.parametrize("dtype,out_dtype", [(torch.bfloat16, torch.bfloat16), (torch.bfloat16, torch.float32),
+                                             (torch.float32, torch.float32), (torch.float16, torch.float16)])
+@pytest.mark.parametrize("shape,ch_axis,n", [((256, 1024), 0, 5), ((96, 2304), 0, 3), ((4, 24, 6, 8), 1, 2), ((8, 8), 0, 64)])
+def test_batched_launch_equals_per_tensor(oracle, ops, dtype, out_dtype, shape, ch_axis, n):
+    """sbq_quant_perchannel_forward_batched == n separate launches == oracle, bit for bit."""
+    g = torch.Generator().manual_seed(n)
+    xs = [(torch.randn(*shape, generator=g) * (i + 1)).to(dtype).cuda() for i in range(n)]
+    C = shape[ch_axis]
+    scales = [(torch.rand(C, generator=g) * 0.05 + 1e-3).cuda() for _ in range(n)]
+    zps = [torch.randint(0, 9, (C,), generator=g).float().cuda() for _ in range(n)]
+    bq = ops.BatchedFakeQuant(xs, scales, zps, 0, 255, ch_axis, out_dtype)
+    outs = bq()
+    for x, s, z, y in zip(xs, scales, zps, outs):
+        one = ops.fake_quant(x, s, z, 0, 255, ch_axis, out_dtype=out_dtype)
+        assert torch.equal(one, y)
+    ref, _ = oracle.qdq(xs[-1].float().cpu().numpy(), scales[-1].cpu().numpy(), zps[-1].cpu().numpy(), 0, 255, ch_axis)
+    assert same_values(outs[-1].float().cpu().numpy(), torch.from_numpy(ref).to(out_dtype).float().numpy())
+
+
 def test_rounding_modes(ops):
     """common.cuh:64-77: half-even (0), half-up floor(v+.5) (1), half-down ceil(v-.5) (2)."""
     x = torch.tensor([0.5, 1.5, 2.5, -0.5, -1.5, -2.5, 0.4, -0.6], device="cuda")

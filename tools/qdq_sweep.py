@@ -19,7 +19,7 @@ def main():
     cols = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
     dev = torch.device("cuda:0")
     lib = L.load(strict=False)
-    nbuf = 12
+    nbuf = 12 if rows * cols <= 4096 * 4096 else 3
     g = torch.Generator().manual_seed(0)
     w = torch.randn(rows, cols, generator=g) * torch.logspace(-2, 1, rows).unsqueeze(1)
     xs = [w.bfloat16().to(dev) for _ in range(nbuf)]

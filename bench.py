@@ -31,6 +31,12 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 BYTES_PER_ELEM = 4  # algorithmic: 2 B read + 2 B written (bf16 -> bf16), SURVEY.md 8(d)
 
 
+def ctypes_stream(s):
+    import ctypes
+
+    return ctypes.c_void_p(s.cuda_stream)
+
+
 def make_weight(seed):
     """randn * logspace(-2, 1) row scales, bf16."""
     g = torch.Generator().manual_seed(seed)
@@ -232,6 +238,27 @@ def main():
     extras["batched_%d_weights_per_launch_us_per_weight" % half] = round(bat_us, 3)
     extras["batched_GBps"] = round(n_elem * BYTES_PER_ELEM / bat_us / 1e3, 1)
     extras["batched_frac_of_peak"] = round(n_elem * BYTES_PER_ELEM / bat_us / 1e3 / HBM_PEAK_GBS, 4)
+
+    # the same single-weight launches issued alternately on two HIP streams (independent
+    # quantizers of different layers may overlap: one kernel's tail hides the next one's ramp)
+    s2 = torch.cuda.Stream(device=dev)
+    st2 = ctypes_stream(s2)
+    s2.wait_stream(stream)
+
+    def step_two_streams(i):
+        j = i % NBUF
+        fwd(xp[j], L.BF16, yp[j], L.BF16, None, L.Q_NONE, sp, zpp, 1, ROWS, COLS, QMIN, QMAX, 0, st2 if i & 1 else st)
+
+    for i in range(20):
+        step_two_streams(i)
+    torch.cuda.synchronize(dev)
+    t_a = time.perf_counter()
+    for i in range(400):
+        step_two_streams(i)
+    torch.cuda.synchronize(dev)
+    two_us = (time.perf_counter() - t_a) * 1e6 / 400
+    extras["two_streams_us_per_weight"] = round(two_us, 3)
+    extras["two_streams_GBps"] = round(n_elem * BYTES_PER_ELEM / two_us / 1e3, 1)
 
     # observer statistic exchange: ONE MAX all-reduce of [max, -min, nan flags] for C = 4096
     mn, mx, _ = ops.channel_stats(xs[0], 0, True)

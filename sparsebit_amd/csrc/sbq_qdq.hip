@@ -92,14 +92,58 @@ struct Tile {
 // (scale / zero_point through s_load) and a wave reads 1 KiB of contiguous HBM per load
 // instruction.  FLAT (short rows): packs are numbered across the tensor, channel per lane.
 // Out-of-range lanes point at the last valid pack (loads are never predicated, only stores).
+// Block-uniform read of a quantization parameter through the scalar unit.  scale/zero_point
+// are never written by these kernels, so they may be read through the constant address
+// space; without this a pointer that itself came from memory (the batched kernel's table)
+// is not provably alias-free and the load degrades to a per-lane VMEM broadcast, doubling
+// the number of vector-memory instructions per tile.
+__device__ __forceinline__ float uniform_load(const float* p, uint32_t i) {
+  typedef const float __attribute__((address_space(4))) * cptr;
+  return reinterpret_cast<cptr>(reinterpret_cast<uintptr_t>(p))[i];
+}
+
+// Position of a ROWS tile's first slab.  Tiles of a workgroup are visited in steps of
+// gridDim.x tiles, so after one division at the start the cursor only adds a precomputed
+// (rows, slabs) stride -- no per-tile integer division on the scalar unit in front of the loads.
+struct RowCursor {
+  uint32_t sl, row, col, c;          // first slab of the current tile
+  uint32_t d_sl, d_row, d_col, d_c;  // stride of one step (gridDim.x tiles)
+};
+
+template <int U>
+__device__ __forceinline__ RowCursor make_cursor(const QdqGeom& g, uint32_t tile, uint32_t step_tiles) {
+  RowCursor k;
+  k.sl = tile * U;
+  k.row = k.sl / g.slabs_per_row;
+  k.col = k.sl - k.row * g.slabs_per_row;
+  k.c = k.row % g.C;
+  k.d_sl = step_tiles * U;
+  k.d_row = k.d_sl / g.slabs_per_row;
+  k.d_col = k.d_sl - k.d_row * g.slabs_per_row;
+  k.d_c = k.d_row % g.C;
+  return k;
+}
+
+__device__ __forceinline__ void advance(const QdqGeom& g, RowCursor& k) {
+  k.sl += k.d_sl;
+  k.col += k.d_col;
+  k.row += k.d_row;
+  k.c += k.d_c;
+  if (k.col >= g.slabs_per_row) {
+    k.col -= g.slabs_per_row;
+    ++k.row;
+    ++k.c;
+  }
+  // c < C and d_c < C before, plus a carry of at most 1: c < 2C, one subtraction suffices
+  if (k.c >= g.C) k.c -= g.C;
+}
+
 template <bool FLAT, int U>
-__device__ __forceinline__ void locate(const QdqGeom& g, uint32_t tile, const float* __restrict__ scale,
+__device__ __forceinline__ void locate(const QdqGeom& g, uint32_t tile, const RowCursor& k,
+                                       const float* __restrict__ scale,
                                        const float* __restrict__ zero_point, Tile<U>& t) {
   if constexpr (!FLAT) {
-    uint32_t sl = tile * U;
-    uint32_t row = sl / g.slabs_per_row;  // scalar unit; once per tile
-    uint32_t col = sl - row * g.slabs_per_row;
-    uint32_t c = row % g.C;
+    uint32_t sl = k.sl, row = k.row, col = k.col, c = k.c;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const bool slab_ok = sl < g.n_slabs;
@@ -107,8 +151,8 @@ __device__ __forceinline__ void locate(const QdqGeom& g, uint32_t tile, const fl
       t.ok[u] = slab_ok && pk < g.packs_per_row;
       const uint32_t pkc = pk < g.packs_per_row ? pk : g.packs_per_row - 1;
       t.elem[u] = static_cast<int64_t>(row) * g.inner + static_cast<int64_t>(pkc) * kPack;
-      t.s[u] = scale[c];
-      t.z[u] = __builtin_rintf(zero_point[c]);
+      t.s[u] = uniform_load(scale, c);
+      t.z[u] = __builtin_rintf(uniform_load(zero_point, c));
       // advance to the next slab without dividing; past the end stay on the last one
       if (sl + 1 < g.n_slabs) {
         ++sl;
@@ -220,9 +264,13 @@ __global__ __launch_bounds__(kBlock) void qdq_pack_kernel(
   Tile<U> ta, tb;
   RawPack<Tin> ra[U], rb[U];
   u32x2 ma[U], mb[U];
-#define SBQ_FETCH(T, R, M, IDX)                         \
-  locate<FLAT, U>(g, (IDX), scale, zero_point, T);      \
-  issue_loads<Tin, MASK, NT, U>(x, mask, T, R, M)
+  RowCursor cur{};
+  if constexpr (!FLAT) cur = make_cursor<U>(g, tile, G);
+  // fetches happen in tile order (tile, tile+G, tile+2G, ...): one cursor, stepped after each
+#define SBQ_FETCH(T, R, M, IDX)                              \
+  locate<FLAT, U>(g, (IDX), cur, scale, zero_point, T);      \
+  issue_loads<Tin, MASK, NT, U>(x, mask, T, R, M);           \
+  if constexpr (!FLAT) advance(g, cur)
 #define SBQ_FINISH(T, R, M) finish_tile<Tin, Tout, QT, MASK, FLAT, NT, U, MATH>(y, q, T, R, M, thr, g.qlo, g.qhi)
   SBQ_FETCH(ta, ra, ma, tile);
   // Steady state: both prefetches are unconditional, so the compiler's vmcnt bookkeeping
@@ -251,8 +299,8 @@ __global__ __launch_bounds__(kBlock) void qdq_pack_kernel(
 // Same helpers, same arithmetic, same two-stage software pipeline.
 template <typename Tin, typename Tout, int U>
 __global__ __launch_bounds__(kBlock) void qdq_batched_kernel(const void* const* __restrict__ table,
-                                                             uint32_t tiles_per_item, uint32_t n_tiles_total,
-                                                             const QdqGeom g) {
+                                                             uint32_t n_items, uint32_t tiles_per_item,
+                                                             uint32_t n_tiles_total, const QdqGeom g) {
   constexpr int MASK = MASK_NONE;
   struct Ptrs {
     const void* x;
@@ -260,33 +308,43 @@ __global__ __launch_bounds__(kBlock) void qdq_batched_kernel(const void* const* 
     const float* scale;
     const float* zp;
   };
-  // consecutive tiles of a workgroup mostly stay inside one item: keep its pointers in SGPRs
-  // and go back to the table (a dependent scalar-load chain in front of the data loads) only
-  // when the item changes
-  uint32_t cur_item = 0xffffffffu;
-  Ptrs cur{};
-  auto item_of = [&](uint32_t tile, uint32_t& ltile) -> Ptrs {
-    const uint32_t item = tile / tiles_per_item;
-    ltile = tile - item * tiles_per_item;
-    if (item != cur_item) {
-      const void* const* e = table + static_cast<size_t>(item) * 4;
-      cur = Ptrs{e[0], const_cast<void*>(e[1]), static_cast<const float*>(e[2]), static_cast<const float*>(e[3])};
-      cur_item = item;
-    }
-    return cur;
-  };
+  // Fetch order is tile, tile+G, tile+2G, ...: (item, tile-in-item) and the row cursor are
+  // stepped, not recomputed; the table (a dependent scalar-load chain in front of the data
+  // loads) is read only when the item changes.
   uint32_t tile = blockIdx.x;
   const uint32_t G = gridDim.x;
   if (tile >= n_tiles_total) return;
+  uint32_t item = tile / tiles_per_item;
+  uint32_t lt = tile - item * tiles_per_item;
+  Ptrs cur{};
+  RowCursor rc{};
+  auto load_item = [&]() {
+    const void* const* e = table + static_cast<size_t>(item) * 4;
+    cur = Ptrs{e[0], const_cast<void*>(e[1]), static_cast<const float*>(e[2]), static_cast<const float*>(e[3])};
+    rc = make_cursor<U>(g, lt, G);
+  };
+  load_item();
+  auto step_item = [&]() {  // move to the tile G further on
+    lt += G;
+    if (lt >= tiles_per_item) {
+      do {
+        lt -= tiles_per_item;
+        ++item;
+      } while (lt >= tiles_per_item);
+      if (item < n_items) load_item();
+    } else {
+      advance(g, rc);
+    }
+  };
   Tile<U> ta, tb;
   RawPack<Tin> ra[U], rb[U];
   u32x2 ma[U], mb[U];
   Ptrs pa, pb;
-  uint32_t lt;
-#define SBQ_FETCH(P, T, R, M, IDX)                     \
-  P = item_of((IDX), lt);                              \
-  locate<false, U>(g, lt, P.scale, P.zp, T);           \
-  issue_loads<Tin, MASK, true, U>(P.x, nullptr, T, R, M)
+#define SBQ_FETCH(P, T, R, M, IDX)                          \
+  P = cur;                                                  \
+  locate<false, U>(g, lt, rc, P.scale, P.zp, T);            \
+  issue_loads<Tin, MASK, true, U>(P.x, nullptr, T, R, M);   \
+  step_item()
 #define SBQ_FINISH(P, T, R, M) \
   finish_tile<Tin, Tout, SBQ_Q_NONE, MASK, false, true, U, MATH_FAST>(P.y, nullptr, T, R, M, 0.0f, g.qlo, g.qhi)
   SBQ_FETCH(pa, ta, ra, ma, tile);
@@ -559,7 +617,8 @@ int qdq_forward_batched(const void* const* table, int n_items, int x_dtype, int 
   const uint32_t cap = knob(1) > 0 ? static_cast<uint32_t>(knob(1)) : kDefaultGridCap;
   const uint32_t grid = total < cap ? total : cap;
   hipStream_t st = as_stream(stream);
-#define SBQ_B(TI, TO) qdq_batched_kernel<TI, TO, U><<<grid, kBlock, 0, st>>>(table, tiles_per_item, total, g)
+#define SBQ_B(TI, TO) \
+  qdq_batched_kernel<TI, TO, U><<<grid, kBlock, 0, st>>>(table, static_cast<uint32_t>(n_items), tiles_per_item, total, g)
   if (x_dtype == SBQ_F32) SBQ_B(F32, F32);
   else if (x_dtype == SBQ_F16) { if (y_dtype == SBQ_F32) SBQ_B(F16, F32); else SBQ_B(F16, F16); }
   else { if (y_dtype == SBQ_F32) SBQ_B(BF16, F32); else SBQ_B(BF16, BF16); }

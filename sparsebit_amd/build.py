@@ -38,6 +38,13 @@ def _hipcc():
     return exe
 
 
+# per-file extras.  sbq_qdq.hip: preload the first 14 kernarg dwords into SGPRs (see the comment
+# on qdq_pack_kernel)
+EXTRA_FLAGS = {
+    "sbq_qdq.hip": ["-mllvm", "-amdgpu-kernarg-preload-count=14"],
+}
+
+
 def sources():
     return sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
 
@@ -61,7 +68,7 @@ def build(force=False, verbose=True):
         obj = os.path.join(OBJ, src[:-4] + ".o")
         objs.append(obj)
         if force or _stale(obj, [os.path.join(CSRC, src)] + headers):
-            jobs.append([hipcc] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj])
+            jobs.append([hipcc] + FLAGS + EXTRA_FLAGS.get(src, []) + ["-c", os.path.join(CSRC, src), "-o", obj])
 
     def run(cmd):
         if verbose:

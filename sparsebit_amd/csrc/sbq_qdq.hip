@@ -250,11 +250,30 @@ __device__ __forceinline__ void finish_tile(void* __restrict__ y, void* __restri
 // tile i is converted, quantized and stored, so the VALU work (~15 ops per element) hides
 // under HBM latency instead of adding to it -- the kernel is short (one 4096x4096 weight is
 // ~12 us), there is no steady state to amortise a load->compute->store serialisation.
+//
+// Parameter order matters: the file is built with -amdgpu-kernarg-preload-count=14, so the
+// first 14 dwords of the kernarg segment (x, the tile geometry, y, scale, zero_point) arrive
+// in SGPRs with the wave instead of through a cold scalar load -- every launch gets a fresh
+// kernarg block, and for a ~12 us kernel one more dependent HBM round trip in front of the
+// first data load is measurable.  The rarely used arguments follow and are loaded normally.
 template <typename Tin, typename Tout, int QT, int MASK, bool FLAT, bool NT, int U, int MATH>
 __global__ __launch_bounds__(kBlock) void qdq_pack_kernel(
-    const void* __restrict__ x, void* __restrict__ y, void* __restrict__ q,
-    const uint8_t* __restrict__ mask, const float* __restrict__ thresh,
-    const float* __restrict__ scale, const float* __restrict__ zero_point, const QdqGeom g) {
+    const void* __restrict__ x, uint32_t n_tiles, uint32_t slabs_per_row, uint32_t packs_per_row,
+    uint32_t n_channels, int64_t inner, void* __restrict__ y, const float* __restrict__ scale,
+    const float* __restrict__ zero_point,
+    // ---- not preloaded ----
+    void* __restrict__ q, const uint8_t* __restrict__ mask, const float* __restrict__ thresh,
+    uint32_t n_slabs, uint32_t total_packs, float qlo, float qhi) {
+  QdqGeom g;
+  g.inner = inner;
+  g.C = n_channels;
+  g.packs_per_row = packs_per_row;
+  g.slabs_per_row = slabs_per_row;
+  g.n_slabs = n_slabs;
+  g.n_tiles = n_tiles;
+  g.total_packs = total_packs;
+  g.qlo = qlo;
+  g.qhi = qhi;
   float thr = 0.0f;
   if constexpr (MASK == MASK_THRESH) thr = *thresh;
 
@@ -432,7 +451,8 @@ void launch_pack(const QdqCall& c, hipStream_t st) {
   const uint32_t cap = knob(1) > 0 ? static_cast<uint32_t>(knob(1)) : kDefaultGridCap;
   const uint32_t grid = c.g.n_tiles < cap ? c.g.n_tiles : cap;
   qdq_pack_kernel<Tin, Tout, QT, MASK, FLAT, NT, U, MATH><<<grid, kBlock, 0, st>>>(
-      c.p.x, c.p.y, c.p.q, c.p.mask, c.p.thresh, c.p.scale, c.p.zp, c.g);
+      c.p.x, c.g.n_tiles, c.g.slabs_per_row, c.g.packs_per_row, c.g.C, c.g.inner, c.p.y, c.p.scale, c.p.zp,
+      c.p.q, c.p.mask, c.p.thresh, c.g.n_slabs, c.g.total_packs, c.g.qlo, c.g.qhi);
 }
 
 // variant id (knob 0):  bit0-1: log2(U) (0..2) ; bit2: NT off ; -1 auto

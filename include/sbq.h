@@ -156,6 +156,31 @@ int sbq_channel_stats(const void* x, int x_dtype,
                       float* min_out, float* max_out, double* abssum_out,
                       void* workspace, size_t workspace_bytes, void* stream);
 
+/* Per-channel moments in one pass (fp64): sum x and sum x^2 -- LSQ+ init (mean / std,
+ * quantizers/lsq_plus.py:33-38) and the ACIQ-Laplace mean (observers/aciq.py:67-72).  With
+ * `center` (fp32 [C]) given, absdev_out receives sum |x - center[c]| instead (the Laplace
+ * scale b, aciq.py:68,71) and sum/sumsq may be NULL.  Outputs are ADDED to (zero them first;
+ * shards and ranks accumulate / all-reduce with SUM).  Workspace: sbq_stats_workspace_bytes. */
+int sbq_channel_moments(const void* x, int x_dtype,
+                        int64_t outer, int64_t C, int64_t inner,
+                        const float* center, double* sum_out, double* sumsq_out, double* absdev_out,
+                        void* workspace, size_t workspace_bytes, void* stream);
+
+/* ACIQ clipping thresholds from the reduced statistics (observers/aciq.py:65-114), fp32 and
+ * correctly rounded like the reference's CPU tensor ops (torch's own GPU division is not):
+ *   gaus    (b == NULL): std = ((max - min) * gaus_const) / sqrt_2logn;  t = alpha * std
+ *   laplace (b != NULL): t = alpha * b
+ *   half_range ? (min_out, max_out) = (0, t) : (-t, t)                                      */
+int sbq_aciq_thresholds(const float* min_val, const float* max_val, const float* b, int64_t C,
+                        float alpha, float gaus_const, float sqrt_2logn, int half_range,
+                        float* min_out, float* max_out, void* stream);
+
+/* Exponential moving average over an ordered run of per-sample (min, max) pairs
+ * (observers/moving_average.py:23-31): state = first sample if !has_state, then
+ * state = ratio * state + (1 - ratio) * sample, in fp32, in order.  state = {min, max}. */
+int sbq_ema_minmax(const float* sample_min, const float* sample_max, int64_t n,
+                   float ratio, float one_minus_ratio, float* state, int has_state, void* stream);
+
 /* scale / zero_point from min / max, observers/base.py:63-79:
  *   symmetric: s = max(max(-min(min,0), max(max,0)) * 2 / (qmax-qmin), 1e-6), zp = 0
  *   affine:    s = max((max(max,0) - min(min,0)) / (qmax-qmin), 1e-6),

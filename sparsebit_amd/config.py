@@ -21,15 +21,16 @@ class Node(dict):
 
 
 def quantizer_config(qscheme, bit, quantizer="uniform", observer="MINMAX", target="weight", layout="NCHW",
-                     alpha=1e-3, disable=False):
+                     alpha=1e-3, disable=False, ema_ratio=0.9, aciq="GAUS", pact_alpha=10):
     """One side (W or A) of a qconfig, already carrying TARGET like QuantOpr.build_quantizer
     sets it (sparsebit/quantization/modules/base.py:36-45)."""
-    obs = Node(TYPE=observer, PERCENTILE=Node(ALPHA=alpha))
+    obs = Node(TYPE=observer, PERCENTILE=Node(ALPHA=alpha), ACIQ=Node(DISTRIBUTION=aciq))
     if target != "weight":
         obs["LAYOUT"] = layout  # activations only: QuantDescriptor keys ch_axis off its presence
+        obs["MOVING_AVERAGE"] = Node(EMA_RATIO=ema_ratio)
     return Node(
         QSCHEME=qscheme,
-        QUANTIZER=Node(TYPE=quantizer, BIT=bit, DISABLE=disable),
+        QUANTIZER=Node(TYPE=quantizer, BIT=bit, DISABLE=disable, PACT=Node(ALPHA_VALUE=pact_alpha)),
         OBSERVER=obs,
         TARGET=(QuantTarget.WEIGHT,) if target == "weight" else (QuantTarget.FEATURE,),
     )

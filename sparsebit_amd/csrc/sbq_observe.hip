@@ -109,6 +109,123 @@ __global__ __launch_bounds__(kBlock) void stats_partial_kernel(const void* __res
   }
 }
 
+// ---- moments: sum x, sum x^2 (fp64) or sum |x - center[c]| -------------------------
+// Same wave-per-chunk structure as the min/max pass.  Accumulation is fp64 per element
+// (the variance formula cancels; fp64 vector rate is ample for a read-once kernel).
+struct MomentPartial {
+  double s1, s2;
+};
+
+template <typename T, bool VEC, bool ABSDEV>
+__global__ __launch_bounds__(kBlock) void moments_partial_kernel(const void* __restrict__ x,
+                                                                 const float* __restrict__ center,
+                                                                 MomentPartial* __restrict__ part,
+                                                                 const ChunkGeom g, uint32_t n_chunks) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const uint32_t cid = blockIdx.x * kWavesPerBlock + threadIdx.x / kWave;
+  if (cid >= n_chunks) return;
+  const ChunkPos cp = chunk_pos(g, cid);
+  const int64_t row_base = cp.row_base, begin = cp.begin, end = cp.end;
+  float m = 0.0f;
+  if constexpr (ABSDEV) m = center[cp.c];
+  double a1 = 0.0, a2 = 0.0;
+  auto visit = [&](float f) {
+    if constexpr (ABSDEV) {
+      a1 += static_cast<double>(__builtin_fabsf(f - m));  // fp32 subtract like torch.abs(data - mean)
+    } else {
+      const double d = static_cast<double>(f);
+      a1 += d;
+      a2 += d * d;
+    }
+  };
+  if constexpr (VEC) {
+    const int64_t vend = begin + ((end - begin) / kPack) * kPack;
+    constexpr int U = 8;
+    if (vend > begin) {
+      RawPack<T> raw[U];
+      bool ok[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        int64_t e = begin + (static_cast<int64_t>(u) * kWave + lane) * kPack;
+        ok[u] = e < vend;
+        if (!ok[u]) e = vend - kPack;
+        raw[u] = load_raw<T, true>(x, row_base + e);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        float v[kPack];
+        unpack_raw<T>(raw[u], v);
+        if (ok[u]) {
+#pragma unroll
+          for (int q = 0; q < kPack; ++q) visit(v[q]);
+        }
+      }
+    }
+    for (int64_t e = vend + lane; e < end; e += kWave) visit(Elem<T>::load1(x, row_base + e));
+  } else {
+    for (int64_t e = begin + lane; e < end; e += kWave) visit(Elem<T>::load1(x, row_base + e));
+  }
+  a1 = wave_reduce(a1, Sum());
+  a2 = wave_reduce(a2, Sum());
+  if (lane == 0) part[cid] = MomentPartial{a1, a2};
+}
+
+__global__ __launch_bounds__(kBlock) void moments_finish_kernel(const MomentPartial* __restrict__ part,
+                                                                uint32_t chunks_per_chan,
+                                                                double* __restrict__ out1,
+                                                                double* __restrict__ out2) {
+  __shared__ double s_d[kWavesPerBlock];
+  const uint32_t c = blockIdx.x;
+  const MomentPartial* p = part + static_cast<size_t>(c) * chunks_per_chan;
+  double a1 = 0.0, a2 = 0.0;
+  for (uint32_t i = threadIdx.x; i < chunks_per_chan; i += kBlock) {
+    a1 += p[i].s1;
+    a2 += p[i].s2;
+  }
+  a1 = block_reduce(a1, Sum(), s_d);
+  a2 = block_reduce(a2, Sum(), s_d);
+  if (threadIdx.x == 0) {
+    if (out1) out1[c] += a1;
+    if (out2) out2[c] += a2;
+  }
+}
+
+__global__ void aciq_kernel(const float* __restrict__ mn, const float* __restrict__ mx,
+                            const float* __restrict__ b, int64_t C, float alpha, float gaus_const,
+                            float sqrt_2logn, int half_range, float* __restrict__ min_out,
+                            float* __restrict__ max_out) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= C) return;
+  float t;
+  if (b) {
+    t = alpha * b[i];
+  } else {
+    const float std = ((mx[i] - mn[i]) * gaus_const) / sqrt_2logn;
+    t = alpha * std;
+  }
+  max_out[i] = t;
+  min_out[i] = half_range ? 0.0f : -t;
+}
+
+// moving_average.py:23-31, one thread: the recurrence is sequential by definition
+__global__ void ema_minmax_kernel(const float* __restrict__ smin, const float* __restrict__ smax, int64_t n,
+                                  float ratio, float one_minus, float* __restrict__ state, int has_state) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  float mn = state[0], mx = state[1];
+  int64_t i = 0;
+  if (!has_state) {
+    mn = smin[0];
+    mx = smax[0];
+    i = 1;
+  }
+  for (; i < n; ++i) {
+    mx = ratio * mx + one_minus * smax[i];
+    mn = ratio * mn + one_minus * smin[i];
+  }
+  state[0] = mn;
+  state[1] = mx;
+}
+
 // ---- stage 2: fold a channel's partials (fixed order => deterministic) ------------
 __global__ __launch_bounds__(kBlock) void stats_finish_kernel(const StatPartial* __restrict__ part,
                                                               uint32_t chunks_per_chan,
@@ -224,12 +341,15 @@ __global__ __launch_bounds__(kBlock) void mse_partial_kernel(
     const float y = s_rcp[i];
     float acc = 0.0f;
     if (y != 0.0f) {  // block-uniform: the candidate's scale is shared by the whole chunk
-      const float bound = s * 0x1p40f;
+      // The level is taken from x * RN(1/s) instead of the correctly rounded x / s: the two can
+      // only differ within ~1e-7 (relative) of a rounding tie, and AT a tie both neighbouring
+      // levels are equally far from x, so the squared error -- the only thing this kernel
+      // produces -- is unchanged to ~1e-7 of one element's term.  (The forward QDQ kernels keep
+      // the exact quotient: there the level itself is the output.)  dq, d and d*d are rounded
+      // separately like the reference's tensor ops.  NaN / inf inputs poison the loss either way.
 #pragma unroll
       for (int q = 0; q < E; ++q) {
-        // no NaN restore here: a NaN input poisons the channel's loss either way
-        const float xc = __builtin_amdgcn_fmed3f(v[q], -bound, bound);
-        const float lv = __builtin_amdgcn_fmed3f(__builtin_rintf(fast_div(xc, s, y)) + z, qlo, qhi);
+        const float lv = __builtin_amdgcn_fmed3f(__builtin_rintf(v[q] * y) + z, qlo, qhi);
         const float d = v[q] - dequant_level(lv, s, z);
         acc += d * d;
       }
@@ -366,6 +486,67 @@ int sbq_channel_stats(const void* x, int x_dtype, int64_t outer, int64_t C, int6
   rc = check_launch();
   if (rc != SBQ_OK || final_) return rc;
   stats_finish_kernel<<<g.C, kBlock, 0, st>>>(part, g.chunks_per_chan, min_out, max_out, abssum_out);
+  return check_launch();
+}
+
+int sbq_channel_moments(const void* x, int x_dtype, int64_t outer, int64_t C, int64_t inner,
+                        const float* center, double* sum_out, double* sumsq_out, double* absdev_out,
+                        void* workspace, size_t workspace_bytes, void* stream) {
+  using namespace sbq;
+  if (!valid_dtype(x_dtype)) return SBQ_ERR_DTYPE;
+  if (outer < 0 || C < 0 || inner < 0) return SBQ_ERR_ARG;
+  if (outer == 0 || C == 0 || inner == 0) return SBQ_ERR_EMPTY;
+  if (!x || !workspace) return SBQ_ERR_NULL;
+  if (center ? !absdev_out : (!sum_out && !sumsq_out)) return SBQ_ERR_NULL;
+  if (!geom_ok(outer, C, inner, kStatsChunk)) return SBQ_ERR_ARG;
+  if (reinterpret_cast<uintptr_t>(x) % dtype_size(x_dtype)) return SBQ_ERR_ALIGN;
+  const ChunkGeom g = make_geom(outer, C, inner, kStatsChunk);
+  static_assert(sizeof(MomentPartial) == sizeof(StatPartial), "shared workspace query");
+  const size_t need = static_cast<size_t>(g.chunks_per_chan) * g.C * sizeof(MomentPartial);
+  if (workspace_bytes < need || !aligned16(workspace)) return SBQ_ERR_WORKSPACE;
+  hipStream_t st = as_stream(stream);
+  MomentPartial* part = static_cast<MomentPartial*>(workspace);
+  const uint32_t n_chunks = g.chunks_per_chan * g.C;
+  const uint32_t grid = (n_chunks + kWavesPerBlock - 1) / kWavesPerBlock;
+  const bool vec = pack_friendly(x, C, outer, inner);
+  int rc = dispatch_dtype(x_dtype, [&](auto tag) {
+    using T = decltype(tag);
+    if (center) {
+      if (vec) moments_partial_kernel<T, true, true><<<grid, kBlock, 0, st>>>(x, center, part, g, n_chunks);
+      else moments_partial_kernel<T, false, true><<<grid, kBlock, 0, st>>>(x, center, part, g, n_chunks);
+    } else {
+      if (vec) moments_partial_kernel<T, true, false><<<grid, kBlock, 0, st>>>(x, center, part, g, n_chunks);
+      else moments_partial_kernel<T, false, false><<<grid, kBlock, 0, st>>>(x, center, part, g, n_chunks);
+    }
+  });
+  if (rc != SBQ_OK) return rc;
+  rc = check_launch();
+  if (rc != SBQ_OK) return rc;
+  moments_finish_kernel<<<g.C, kBlock, 0, st>>>(part, g.chunks_per_chan, center ? absdev_out : sum_out,
+                                                center ? nullptr : sumsq_out);
+  return check_launch();
+}
+
+int sbq_aciq_thresholds(const float* min_val, const float* max_val, const float* b, int64_t C, float alpha,
+                        float gaus_const, float sqrt_2logn, int half_range, float* min_out, float* max_out,
+                        void* stream) {
+  using namespace sbq;
+  if (C < 0) return SBQ_ERR_ARG;
+  if (C == 0) return SBQ_ERR_EMPTY;
+  if (!min_out || !max_out || (!b && (!min_val || !max_val))) return SBQ_ERR_NULL;
+  aciq_kernel<<<static_cast<uint32_t>(ceil_div(C, kBlock)), kBlock, 0, as_stream(stream)>>>(
+      min_val, max_val, b, C, alpha, gaus_const, sqrt_2logn, half_range, min_out, max_out);
+  return check_launch();
+}
+
+int sbq_ema_minmax(const float* sample_min, const float* sample_max, int64_t n, float ratio,
+                   float one_minus_ratio, float* state, int has_state, void* stream) {
+  using namespace sbq;
+  if (n < 0) return SBQ_ERR_ARG;
+  if (n == 0) return SBQ_ERR_EMPTY;
+  if (!sample_min || !sample_max || !state) return SBQ_ERR_NULL;
+  ema_minmax_kernel<<<1, kWave, 0, as_stream(stream)>>>(sample_min, sample_max, n, ratio, one_minus_ratio, state,
+                                                        has_state);
   return check_launch();
 }
 

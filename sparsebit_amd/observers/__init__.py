@@ -8,7 +8,7 @@ def register_observer(observer):
 
 
 from .base import DataCache, Observer  # noqa: E402
-from . import minmax, percentile, mse  # noqa: E402,F401
+from . import minmax, percentile, mse, moving_average, aciq  # noqa: E402,F401
 
 
 def build_observer(config, qdesc):

@@ -215,6 +215,78 @@ def channel_stats(x, ch_axis=0, per_channel=True, want_min=True, want_max=True, 
     return mn, mx, ab
 
 
+def channel_moments(x, ch_axis=0, per_channel=True, sum_out=None, sumsq_out=None):
+    """sum x / sum x^2 per channel, ADDED into fp64 [C] accumulators (created when None)."""
+    dev = L.require_device(x, sum_out, sumsq_out)
+    lib = L.load()
+    x = x.contiguous()
+    outer, C, inner = geometry(x.shape, ch_axis, per_channel)
+    if sum_out is None:
+        sum_out = torch.zeros(C, dtype=torch.float64, device=dev)
+    if sumsq_out is None:
+        sumsq_out = torch.zeros(C, dtype=torch.float64, device=dev)
+    with torch.cuda.device(dev):
+        ws = _workspace(dev, lib.sbq_stats_workspace_bytes(outer, C, inner))
+        rc = lib.sbq_channel_moments(L.ptr(x), L.dtype_id(x), outer, C, inner, None, L.ptr(sum_out), L.ptr(sumsq_out),
+                                     None, L.ptr(ws), ws.numel(), L.stream_ptr(dev))
+    L.check(rc)
+    return sum_out, sumsq_out
+
+
+def channel_absdev(x, center, ch_axis=0, per_channel=True, out=None):
+    """sum |x - center[c]| per channel, ADDED into an fp64 [C] accumulator."""
+    dev = L.require_device(x, center, out)
+    lib = L.load()
+    x = x.contiguous()
+    outer, C, inner = geometry(x.shape, ch_axis, per_channel)
+    center = _f32c(center, dev)
+    if center.numel() != C:
+        raise L.SbqError("center must have C elements")
+    if out is None:
+        out = torch.zeros(C, dtype=torch.float64, device=dev)
+    with torch.cuda.device(dev):
+        ws = _workspace(dev, lib.sbq_stats_workspace_bytes(outer, C, inner))
+        rc = lib.sbq_channel_moments(L.ptr(x), L.dtype_id(x), outer, C, inner, L.ptr(center), None, None, L.ptr(out),
+                                     L.ptr(ws), ws.numel(), L.stream_ptr(dev))
+    L.check(rc)
+    return out
+
+
+def aciq_thresholds(min_val, max_val, b, alpha, gaus_const, sqrt_2logn, half_range):
+    """-> (min, max) clipping thresholds, aciq.py:65-114, correctly rounded fp32 on device."""
+    ref = b if b is not None else min_val
+    dev = L.require_device(min_val, max_val, b)
+    lib = L.load()
+    shape = ref.shape
+    mn = None if min_val is None else _f32c(min_val, dev)
+    mx = None if max_val is None else _f32c(max_val, dev)
+    bb = None if b is None else _f32c(b, dev)
+    n = ref.numel()
+    lo = torch.empty(n, dtype=torch.float32, device=dev)
+    hi = torch.empty(n, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.sbq_aciq_thresholds(L.ptr(mn), L.ptr(mx), L.ptr(bb), n, float(alpha), float(gaus_const), float(sqrt_2logn),
+                                     int(bool(half_range)), L.ptr(lo), L.ptr(hi), L.stream_ptr(dev))
+    L.check(rc)
+    return lo.reshape(shape), hi.reshape(shape)
+
+
+def ema_minmax(sample_min, sample_max, ratio, state, has_state):
+    """state[{min,max}] <- EMA over the samples, in order (moving_average.py:23-31)."""
+    dev = L.require_device(sample_min, sample_max, state)
+    lib = L.load()
+    smin, smax = _f32c(sample_min, dev), _f32c(sample_max, dev)
+    import numpy as np
+
+    r = np.float32(ratio)  # the reference multiplies fp32 tensors by Python floats: both factors round to fp32
+    om = np.float32(1 - ratio)
+    with torch.cuda.device(dev):
+        rc = lib.sbq_ema_minmax(L.ptr(smin), L.ptr(smax), smin.numel(), float(r), float(om), L.ptr(state),
+                                int(bool(has_state)), L.stream_ptr(dev))
+    L.check(rc)
+    return state
+
+
 def qparams_from_minmax(min_val, max_val, qmin, qmax, symmetric):
     """observers/base.py:63-79 on device -> (scale, zero_point), shaped like min_val."""
     dev = L.require_device(min_val, max_val)

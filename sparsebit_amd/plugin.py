@@ -7,8 +7,8 @@ Later registrations overwrite the reference's map entries (quantizers/__init__.p
 observers/__init__.py:4-6, sparse/sparsers/__init__.py:4-6), so after install()
 `QuantModel`, `QuantOpr.build_quantizer`, BN fusion and QDQ-ONNX export run
 unmodified on top of the HIP kernels:
-  * QUANTIZERS_MAP["uniform"], ["lsq"]            -> sparsebit_amd.quantizers
-  * OBSERVERS_MAP["minmax"], ["mse"], ["percentile"] -> sparsebit_amd.observers
+  * QUANTIZERS_MAP["uniform"], ["lsq"], ["lsq+"], ["pact"], ["dorefa"] -> sparsebit_amd.quantizers
+  * OBSERVERS_MAP["minmax"], ["mse"], ["percentile"], ["moving_average"], ["aciq"] -> sparsebit_amd.observers
   * SPARSERS_MAP["l1norm"]                        -> sparsebit_amd.sparsers
   * quant_tensor.fake_quant_kernel                -> sparsebit_amd.fake_quant (for the
     reference quantizers that stay, e.g. PACT / DoReFa / LSQ+, which call STE.apply)
@@ -29,10 +29,10 @@ def install(native_only=False):
     installed = {"fake_quant_kernel": True, "quantizers": [], "observers": [], "sparsers": []}
     if native_only:
         return installed
-    for name in ("uniform", "lsq"):
+    for name in ("uniform", "lsq", "lsq+", "pact", "dorefa"):
         ref_q.QUANTIZERS_MAP[name] = amd_q.QUANTIZERS_MAP[name]
         installed["quantizers"].append(name)
-    for name in ("minmax", "mse", "percentile"):
+    for name in ("minmax", "mse", "percentile", "moving_average", "aciq"):
         ref_o.OBSERVERS_MAP[name] = amd_o.OBSERVERS_MAP[name]
         installed["observers"].append(name)
     try:

@@ -8,7 +8,7 @@ def register_quantizer(quantizer):
 
 
 from .base import Quantizer  # noqa: E402
-from . import uniform, lsq  # noqa: E402,F401
+from . import uniform, lsq, lsq_plus, pact, dorefa  # noqa: E402,F401
 
 
 def build_quantizer(cfg):

@@ -77,13 +77,16 @@ def install_stubs():
     sys.modules["torchvision.ops.stochastic_depth"] = tv_sd
 
 
-def qcfg(qscheme, bit, observer="MINMAX", quantizer="uniform", target_weight=True, layout="NCHW", alpha=1e-3):
+def qcfg(qscheme, bit, observer="MINMAX", quantizer="uniform", target_weight=True, layout="NCHW", alpha=1e-3,
+         ema_ratio=0.9, aciq="GAUS", pact_alpha=10):
     from sparsebit.quantization.common import QuantTarget
 
     c = CfgNode()
     c.QSCHEME = qscheme
-    c.QUANTIZER = CfgNode({"TYPE": quantizer, "DISABLE": False, "BIT": bit})
-    obs = {"TYPE": observer, "PERCENTILE": CfgNode({"ALPHA": alpha})}
+    c.QUANTIZER = CfgNode({"TYPE": quantizer, "DISABLE": False, "BIT": bit, "PACT": CfgNode({"ALPHA_VALUE": pact_alpha})})
+    obs = {"TYPE": observer, "PERCENTILE": CfgNode({"ALPHA": alpha}), "ACIQ": CfgNode({"DISTRIBUTION": aciq})}
+    if not target_weight:
+        obs["MOVING_AVERAGE"] = CfgNode({"EMA_RATIO": ema_ratio})
     if not target_weight:
         obs["LAYOUT"] = layout
     c.OBSERVER = CfgNode(obs)
@@ -299,6 +302,44 @@ def main():
         out["gptq/%s/y" % name] = y.numpy()
         out["gptq/%s/meta" % name] = np.array([B, M, N, GS], dtype=np.int64)
 
+    # ---- widened set: remaining observers / quantizers on the same kernels.
+    # Appended last so that every earlier vector keeps its value. ---------------------------
+    cases2 = []
+
+    def run2(name, x_list, cfg, backend=Backend.VIRTUAL, forward_x=None):
+        n0 = len(cases)
+        q = run_quantizer(name, x_list, cfg, backend)
+        cases.pop()  # keep the original `cases` list (and the tests parametrised on it) unchanged
+        assert len(cases) == n0
+        cases2.append(name)
+        return q
+
+    for scheme in ("per-tensor-symmetric", "per-tensor-affine"):
+        run2("ma/%s/8/nchw" % scheme, a_nchw, qcfg(scheme, 8, "MOVING_AVERAGE", target_weight=False, ema_ratio=0.9))
+        run2("ma/%s/8/nlc" % scheme, a_nlc, qcfg(scheme, 8, "MOVING_AVERAGE", target_weight=False, layout="NLC",
+                                               ema_ratio=0.7))
+    for dist_ in ("GAUS", "LAPLACE"):
+        for scheme in ("per-channel-symmetric", "per-tensor-symmetric", "per-tensor-affine", "per-channel-affine"):
+            for bit in (8, 4):
+                run2("aciq/%s/%s/%d/lin" % (dist_, scheme, bit), [w_lin], qcfg(scheme, bit, "ACIQ", aciq=dist_))
+        for scheme in ("per-tensor-symmetric", "per-tensor-affine"):
+            run2("aciq/%s/%s/8/nchw" % (dist_, scheme), a_nchw, qcfg(scheme, 8, "ACIQ", target_weight=False, aciq=dist_))
+            run2("aciq/%s/%s/8/relu" % (dist_, scheme), a_relu, qcfg(scheme, 8, "ACIQ", target_weight=False, aciq=dist_))
+    for scheme in ("per-tensor-symmetric", "per-tensor-affine"):
+        for bit in (8, 4):
+            run2("pact/%s/%d/nchw" % (scheme, bit), a_nchw, qcfg(scheme, bit, quantizer="pact", target_weight=False,
+                                                             pact_alpha=1.5))
+    run2("pact/per-tensor-affine/4/relu", a_relu, qcfg("per-tensor-affine", 4, quantizer="pact", target_weight=False,
+                                                      pact_alpha=2.0))
+    for scheme in ("per-channel-symmetric", "per-tensor-symmetric", "per-tensor-affine"):
+        run2("dorefa/%s/4/conv" % scheme, [w_conv], qcfg(scheme, 4, quantizer="dorefa"))
+    for bit in (4, 8):
+        run2("lsqp/per-channel-symmetric/%d/conv" % bit, [w_conv], qcfg("per-channel-symmetric", bit, quantizer="lsq+"))
+        run2("lsqp/per-tensor-affine/%d/nchw" % bit, a_nchw, qcfg("per-tensor-affine", bit, quantizer="lsq+",
+                                                                target_weight=False))
+        run2("lsqp/per-tensor-affine/%d/relu" % bit, a_relu, qcfg("per-tensor-affine", bit, quantizer="lsq+",
+                                                                target_weight=False))
+    out["cases2"] = np.array(cases2)
     out["cases"] = np.array(cases)
     np.savez_compressed(OUT, **out)
     print("wrote", OUT, "with", len(out), "arrays,", len(cases), "quantizer cases,",

@@ -582,3 +582,90 @@ def test_gptq_random_vs_oracle(oracle, B, M, N, GS):
     if M * N <= 4096 * 1280:
         ref = oracle.vecquant4matmul(x.numpy(), qw, layer.bias.detach().numpy(), scale, zeros_p, GS)
         assert np.allclose(y.cpu().numpy(), ref, rtol=1e-5, atol=1e-5)
+
+
+# --------------------------------------------------------------------------------------
+# widened set: remaining observers / quantizers on the same kernels
+# --------------------------------------------------------------------------------------
+def _cases2():
+    import os
+
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_golden.npz"))
+    return z["cases2"].tolist()
+
+
+def _cfg2(name):
+    from sparsebit_amd.config import quantizer_config
+
+    parts = name.split("/")
+    kind = parts[0]
+    tail = parts[-1]
+    is_act = tail.startswith(("nchw", "nlc", "relu"))
+    layout = "NLC" if tail.startswith("nlc") else "NCHW"
+    target = "feature" if is_act else "weight"
+    if kind == "ma":
+        return quantizer_config(parts[1], 8, observer="MOVING_AVERAGE", target=target, layout=layout,
+                                ema_ratio=0.7 if layout == "NLC" else 0.9)
+    if kind == "aciq":
+        return quantizer_config(parts[2], int(parts[3]), observer="ACIQ", target=target, layout=layout, aciq=parts[1])
+    if kind == "pact":
+        return quantizer_config(parts[1], int(parts[2]), quantizer="pact", target=target, layout=layout,
+                                pact_alpha=2.0 if tail == "relu" else 1.5)
+    if kind == "dorefa":
+        return quantizer_config(parts[1], 4, quantizer="dorefa")
+    if kind == "lsqp":
+        return quantizer_config(parts[1], int(parts[2]), quantizer="lsq+", target=target, layout=layout)
+    raise KeyError(name)
+
+
+@pytest.mark.parametrize("name", _cases2())
+def test_widened_quantizers_vs_reference_golden(golden, oracle, name):
+    from sparsebit_amd.common import Backend
+    from sparsebit_amd.quantizers import build_quantizer
+
+    kind = name.split("/")[0]
+    qmin, qmax, ch_axis, perch, sym = _meta(golden, name)
+    q = build_quantizer(_cfg2(name))
+    q.set_backend(Backend.VIRTUAL)
+    xs = all_x(golden, name)
+    for x in xs:
+        q.update_observer(dev_tensor(x))
+    scale, zp = q.calc_qparams()
+    assert q.qdesc.qmin == qmin and q.qdesc.qmax == qmax and q.qdesc.is_symmetric == sym
+    s = scale.detach().reshape(-1).cpu().numpy()
+    z = zp.detach().reshape(-1).cpu().numpy()
+    gs, gz = golden[name + "/scale"], golden[name + "/zero_point"]
+    # moving average, ACIQ-gaus and PACT are the reference's fp32 operations in the same order:
+    # exact.  ACIQ-laplace / LSQ+ weights sum in fp64 where torch sums fp32, DoReFa applies the
+    # GPU's tanh: the contract's 1e-6 (tanh: 1e-5) relative on the parameters.
+    exact = kind in ("ma", "pact") or (kind == "aciq" and "GAUS" in name) or (kind == "lsqp" and not perch)
+    if exact:
+        assert np.array_equal(s, gs), (s, gs)
+        assert same_values(z, gz)
+        assert same_values(q.observer.min_val.reshape(-1).cpu().numpy(), golden[name + "/min_val"])
+        assert same_values(q.observer.max_val.reshape(-1).cpu().numpy(), golden[name + "/max_val"])
+    else:
+        tol = 1e-5 if kind == "dorefa" else 1e-6
+        assert rel_err(s, gs) <= tol, rel_err(s, gs)
+        # an affine zero_point is round(-min/scale): a parameter 1 ulp away may land on the
+        # other side of a .5 tie (4-bit laplace: -min/scale is 7.5 by construction)
+        assert np.abs(z - gz).max() <= 1
+    q.enable_quant()
+    x0 = dev_tensor(xs[0])
+    dq = q(x0).detach().cpu().numpy()
+    ref = golden[name + "/dq"]
+    if exact:
+        assert same_values(dq, ref)
+        return
+    if kind != "dorefa":
+        # the forward itself is exact for the parameters this quantizer holds
+        s_fwd, z_fwd = q._qparams_preprocess(x0)
+        own, _ = oracle.qdq(xs[0], s_fwd.detach().reshape(-1).cpu().numpy(), z_fwd.detach().reshape(-1).cpu().numpy(),
+                            qmin, qmax, ch_axis)
+        assert same_values(dq, own)
+    if np.array_equal(z, gz):
+        # same grid up to the parameter tolerance: within one level of the reference everywhere,
+        # identical almost everywhere
+        step = np.broadcast_to(np.abs(gs).reshape([-1 if (perch and i == ch_axis) else 1 for i in range(ref.ndim)]), ref.shape)
+        assert np.all(np.abs(dq - ref) <= step * 1.001 + 1e-12)
+        assert np.mean(np.abs(dq - ref) > step * 1e-3) < 0.02

@@ -1,16 +1,13 @@
-"""Observer registry -- same contract as sparsebit/quantization/observers/__init__.py:1-15."""
-OBSERVERS_MAP = {}
+"""Observer plug-in point: `register_observer`, `OBSERVERS_MAP`, `build_observer(config, qdesc)` --
+the names and behaviour of sparsebit/quantization/observers/__init__.py:1-15."""
+from ..registry import Registry
 
-
-def register_observer(observer):
-    OBSERVERS_MAP[observer.TYPE.lower()] = observer
-    return observer
-
+OBSERVERS_MAP = Registry("observer", "TYPE")
+register_observer = OBSERVERS_MAP.register
 
 from .base import DataCache, Observer  # noqa: E402
 from . import minmax, percentile, mse, moving_average, aciq  # noqa: E402,F401
 
 
 def build_observer(config, qdesc):
-    observer = OBSERVERS_MAP[config.OBSERVER.TYPE.lower()](config, qdesc)
-    return observer
+    return OBSERVERS_MAP.resolve(config.OBSERVER.TYPE)(config, qdesc)

@@ -1,19 +1,15 @@
-"""Quantizer registry -- same contract as sparsebit/quantization/quantizers/__init__.py:1-23."""
-QUANTIZERS_MAP = {}
+"""Quantizer plug-in point: `register_quantizer`, `QUANTIZERS_MAP`, `build_quantizer(cfg)` --
+the names and behaviour of sparsebit/quantization/quantizers/__init__.py:1-23."""
+from ..registry import Registry
 
-
-def register_quantizer(quantizer):
-    QUANTIZERS_MAP[quantizer.TYPE.lower()] = quantizer
-    return quantizer
-
+QUANTIZERS_MAP = Registry("quantizer", "TYPE")
+register_quantizer = QUANTIZERS_MAP.register
 
 from .base import Quantizer  # noqa: E402
 from . import uniform, lsq, lsq_plus, pact, dorefa  # noqa: E402,F401
 
 
 def build_quantizer(cfg):
-    # the reference asserts on the un-lowered name (quantizers/__init__.py:19-21); lower-casing
-    # first accepts exactly a superset of it ("LSQ" and "lsq" both resolve)
-    assert cfg.QUANTIZER.TYPE.lower() in QUANTIZERS_MAP, "no found an implement of {}".format(cfg.QUANTIZER.TYPE)
-    quantizer = QUANTIZERS_MAP[cfg.QUANTIZER.TYPE.lower()](cfg)
-    return quantizer
+    """cfg.QUANTIZER.TYPE picks the class (case-insensitively: a superset of the reference,
+    which asserts on the un-lowered name)."""
+    return QUANTIZERS_MAP.resolve(cfg.QUANTIZER.TYPE)(cfg)

@@ -1,7 +1,14 @@
-"""Quantizer base (mirrors sparsebit/quantization/quantizers/base.py:10-143): same
-attributes (scale / zero_point buffers, observer, qdesc, use_quant, export_onnx,
-fake_fused), same methods and the same state_dict keys."""
-import abc
+"""Quantizer base class.
+
+Keeps the public surface of sparsebit/quantization/quantizers/base.py:10-143 -- attributes
+`scale`, `zero_point` (buffers, or Parameters once a learnable quantizer replaces them),
+`observer`, `qdesc`, `use_quant`, `export_onnx`, `fake_fused`, `backend`, `dims`; methods
+`update_observer`, `calc_qparams`, `calc_qparams_with_minmax`, `forward`, `set_backend`,
+`set_fake_fused`, `enable_quant` / `disable_quant`, `enable_export_onnx` /
+`disable_export_onnx`, `set_bit`, `_broadcast_qparams`, `_qparams_preprocess`, `_forward` --
+so that QuantOpr, BN fusion, CalibrationRunner and checkpoints written by the reference keep
+working.  Subclasses implement `_forward` (and usually reuse quant_tensor.STE).
+"""
 import warnings
 
 import torch
@@ -12,76 +19,89 @@ from .quant_descriptor import QuantDescriptor
 from .quant_tensor import torch_fake_quant
 
 
-class Quantizer(nn.Module, abc.ABC):
+def _default_device():
+    return torch.device("cuda" if torch.cuda.is_available() else "cpu")
+
+
+class Quantizer(nn.Module):
     TYPE = "base"
 
     def __init__(self, config):
-        super(Quantizer, self).__init__()
+        super().__init__()
         self.cfg = config
         self.qdesc = QuantDescriptor(config)
-        self.device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
-        self.register_buffer("scale", torch.tensor([1.0], dtype=torch.float).to(self.device))
-        self.register_buffer("zero_point", torch.tensor([0.0], dtype=torch.float).to(self.device))
+        self.device = _default_device()
+        self._register_identity_qparams()
         self.observer = build_observer(config, self.qdesc)
-        self.use_quant = False
-        self.export_onnx = False
-        self.fake_fused = False
         self.backend = None
-        self.dims = None
-        if self.cfg.QUANTIZER.DISABLE:
+        self.dims = None  # rank of the observed tensor; set by update_observer
+        self.use_quant = self.export_onnx = self.fake_fused = False
+        if config.QUANTIZER.DISABLE:
             self.set_fake_fused()
         if self.qdesc.bit == 0:
             warnings.warn("used bit==0 to disable quantizer is deprecated, please use a flag: QUANTIZER.DISABLE")
 
+    # ---- scale / zero_point state ---------------------------------------------------------
+    def _identity(self):
+        one = torch.ones(1, dtype=torch.float32, device=self.device)
+        return one, torch.zeros_like(one)
+
+    def _register_identity_qparams(self):
+        scale, zero_point = self._identity()
+        self.register_buffer("scale", scale)
+        self.register_buffer("zero_point", zero_point)
+
+    def _broadcast_qparams(self, params):
+        """[C] (or one value) -> the shape that broadcasts against the observed tensor along ch_axis."""
+        shape = [-1 if axis == self.qdesc.ch_axis else 1 for axis in range(self.dims)]
+        return params.reshape(shape)
+
+    def _adopt(self, scale, zero_point):
+        self.scale, self.zero_point = self._broadcast_qparams(scale), self._broadcast_qparams(zero_point)
+        return self.scale, self.zero_point
+
     def calc_qparams(self):
+        """Run the observer over what update_observer cached and keep the result."""
         if self.fake_fused:
             return self.scale, self.zero_point
-        scale, zero_point = self.observer.calc_qparams()
-        self.scale = self._broadcast_qparams(scale)
-        self.zero_point = self._broadcast_qparams(zero_point)
-        return self.scale, self.zero_point
+        return self._adopt(*self.observer.calc_qparams())
 
     def calc_qparams_with_minmax(self, min_val, max_val):
         if self.fake_fused:
             return self.scale, self.zero_point
-        scale, zero_point = self.observer.calc_qparams_with_minmax(min_val, max_val)
-        self.scale = self._broadcast_qparams(scale)
-        self.zero_point = self._broadcast_qparams(zero_point)
-        return self.scale, self.zero_point
+        return self._adopt(*self.observer.calc_qparams_with_minmax(min_val, max_val))
 
-    def _forward(self, x, scale, zero_point):
-        pass
+    def update_observer(self, x):
+        self.dims = x.dim()
+        self.observer.data_cache.update(x.detach())
 
+    # ---- forward ------------------------------------------------------------------------------
     def _qparams_preprocess(self, x):
         return self.scale, self.zero_point
 
+    def _forward(self, x, scale, zero_point):
+        raise NotImplementedError(type(self).__name__)
+
     def forward(self, x):
-        if self.is_enable:
-            scale, zero_point = self._qparams_preprocess(x)
-            if self.export_onnx:
-                x_dq = torch_fake_quant(x, scale, zero_point, self.qdesc)
-            else:
-                x_dq = self._forward(x, scale, zero_point)
-        else:
-            x_dq = x
-        return x_dq
+        if not self.is_enable:
+            return x
+        scale, zero_point = self._qparams_preprocess(x)
+        if self.export_onnx:  # tracing for QDQ-ONNX: torch builtins only, the HIP kernel is never traced
+            return torch_fake_quant(x, scale, zero_point, self.qdesc)
+        return self._forward(x, scale, zero_point)
 
-    def update_observer(self, x):
-        self.dims = len(x.shape)
-        self.observer.data_cache.update(x.detach())
-
+    # ---- switches -----------------------------------------------------------------------------
     def set_backend(self, backend):
-        self.backend = backend
-        self.observer.backend = backend
+        self.backend = self.observer.backend = backend
 
     def set_fake_fused(self):
+        """This quantizer's op was fused into a neighbour: it stays an identity from now on."""
         self.fake_fused = True
         if isinstance(self.scale, nn.Parameter):
-            self.scale.requires_grad_(False)
-            self.zero_point.requires_grad_(False)
+            for p in (self.scale, self.zero_point):
+                p.requires_grad_(False)
         else:
-            self.scale = torch.tensor([1.0], dtype=torch.float).to(self.device)
-            self.zero_point = torch.tensor([0.0], dtype=torch.float).to(self.device)
+            self.scale, self.zero_point = self._identity()
 
     def enable_quant(self):
         self.use_quant = True
@@ -91,45 +111,25 @@ class Quantizer(nn.Module, abc.ABC):
 
     def enable_export_onnx(self):
         self.export_onnx = True
-        self.zero_point = self.zero_point.round()  # round zero point for onnx export
+        self.zero_point = self.zero_point.round()  # ONNX QuantizeLinear wants an integer zero point
 
     def disable_export_onnx(self):
         self.export_onnx = False
 
-    def _broadcast_qparams(self, params):
-        dst_shape = [1] * self.dims
-        dst_shape[self.qdesc.ch_axis] = -1
-        return params.reshape(dst_shape)
-
     def set_bit(self, bit):
         self.qdesc.set_bit(bit)
 
-    @property
-    def is_enable(self):
-        return self.use_quant and (not self.fake_fused)
-
-    @property
-    def bit(self):
-        return self.qdesc.bit
-
-    @property
-    def ch_axis(self):
-        return self.observer.ch_axis
-
-    @property
-    def is_perchannel(self):
-        return self.qdesc.is_perchannel
-
-    @property
-    def is_symmetric(self):
-        return self.qdesc.is_symmetric
+    # ---- read-only views ------------------------------------------------------------------------
+    is_enable = property(lambda self: self.use_quant and not self.fake_fused)
+    bit = property(lambda self: self.qdesc.bit)
+    ch_axis = property(lambda self: self.observer.ch_axis)
+    is_perchannel = property(lambda self: self.qdesc.is_perchannel)
+    is_symmetric = property(lambda self: self.qdesc.is_symmetric)
 
     def __repr__(self):
-        info = "{}, {}, observer={},".format(self.TYPE, self.qdesc, self.observer.TYPE)
-        if not self.is_perchannel:
-            info += " scale={:.4f}, zp={:.4f}".format(self.scale.item(), self.zero_point.item())
+        s, z = self.scale, self.zero_point
+        if self.is_perchannel:
+            qparams = "scale=[{:.4f}, {:.4f}], zp=[{}, {}]".format(s.min(), s.max(), z.min(), z.max())
         else:
-            info += " scale=[{:.4f}, {:.4f}], zp=[{}, {}]".format(
-                self.scale.min(), self.scale.max(), self.zero_point.min(), self.zero_point.max()
-            )
-        return info
+            qparams = "scale={:.4f}, zp={:.4f}".format(s.item(), z.item())
+        return "{}, {}, observer={}, {}".format(self.TYPE, self.qdesc, self.observer.TYPE, qparams)

@@ -1,5 +1,7 @@
-"""DoReFa quantizer (mirrors sparsebit/quantization/quantizers/dorefa.py:8-27): tanh, scale
-to [-1, 1] by the tensor's largest magnitude (one sbq_channel_stats pass), shared STE kernel."""
+"""DoReFa weight quantizer (behaviour of sparsebit/quantization/quantizers/dorefa.py:8-27):
+squash with tanh, rescale to [-1, 1] by the largest magnitude, fake-quantize.  The largest
+magnitude is one sbq_channel_stats reduction; the observer is fed the squashed tensor so that
+calibration sees what the forward pass will quantize."""
 import torch
 
 from . import Quantizer as BaseQuantizer
@@ -8,27 +10,22 @@ from .. import ops
 from .quant_tensor import STE
 
 
-def _absmax(t):
-    mn, mx, _ = ops.channel_stats(t.detach(), 0, False)
-    return torch.maximum(mx, -mn).reshape(())
+def _squash(x):
+    """tanh(x) / max|tanh(x)|; the divisor is a constant of the graph (detached)."""
+    t = x.tanh()
+    lo, hi, _ = ops.channel_stats(t.detach(), 0, False)
+    return t / torch.maximum(hi, -lo).reshape(())
 
 
 @register_quantizer
 class Quantizer(BaseQuantizer):
     TYPE = "DoReFa"
 
-    def __init__(self, config):
-        super(Quantizer, self).__init__(config)
+    def update_observer(self, x):
+        self.dims = x.dim()
+        x = x.detach()
+        self.observer.data_cache.update(_squash(x if x.is_cuda else x.to(self.device)))
 
     def _forward(self, x, scale, zero_point):
-        x_tanhed = x.tanh()
-        x_normed = x_tanhed / _absmax(x_tanhed)  # norm to [-1, +1]
-        scale, zero_point = self.scale, self.zero_point
-        return STE.apply(x_normed, scale, zero_point, self.qdesc, self.backend)
-
-    def update_observer(self, x):
-        self.dims = len(x.shape)
-        if not x.is_cuda:
-            x = x.to(self.device)
-        x_tanhed = x.detach().tanh()
-        self.observer.data_cache.update(x_tanhed / _absmax(x_tanhed))
+        # like the reference, the stored parameters are used, not the preprocessed ones
+        return STE.apply(_squash(x), self.scale, self.zero_point, self.qdesc, self.backend)

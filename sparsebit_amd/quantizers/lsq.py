@@ -91,7 +91,10 @@ class Quantizer(BaseQuantizer):
         return 1.0 / math.sqrt(x.numel() * self.qdesc.qmax)
 
     def _forward(self, x, scale, zero_point):
-        scale = gs_scaling.apply(scale, self._gs_ratio(x))
+        ratio = self._gs_ratio(x)
+        scale = gs_scaling.apply(scale, ratio)
+        if zero_point.requires_grad:  # only LSQ+ learns its zero point (lsq_plus.py:90-92)
+            zero_point = gs_scaling.apply(zero_point, ratio)
         return STE.apply(x, scale, zero_point, self.qdesc, self.backend)
 
     def forward_masked(self, x, mask=None, thresh=None, out_dtype=None):

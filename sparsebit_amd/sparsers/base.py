@@ -1,25 +1,23 @@
-"""Sparser base (mirrors sparsebit/sparse/sparsers/base.py:6-26)."""
-from abc import ABC
-
+"""Common state of a sparser: what to prune (`type`), how (`strategy`), how much (`ratio`).
+Interface of sparsebit/sparse/sparsers/base.py:6-26."""
 from torch import nn
 
 
-class Sparser(nn.Module, ABC):
+class Sparser(nn.Module):
     STRATEGY = "base"
 
     def __init__(self, config, opr=None):
-        super(Sparser, self).__init__()
-        self.config = config
-        self.opr = opr
-        self.type = config.SPARSER.TYPE
-        self.strategy = config.SPARSER.STRATEGY
-        self.ratio = config.SPARSER.RATIO
-
-    def calc_mask(self, x):
-        pass
+        super().__init__()
+        spec = config.SPARSER
+        self.config, self.opr = config, opr
+        self.type, self.strategy, self.ratio = spec.TYPE, spec.STRATEGY, spec.RATIO
 
     def set_ratio(self, ratio):
         self.ratio = ratio
 
+    def calc_mask(self, x):
+        """-> a mask shaped like x (1 keeps, 0 prunes); subclasses implement the strategy."""
+        raise NotImplementedError(type(self).__name__)
+
     def __repr__(self):
-        return "{}, {}, {}".format(self.type, self.strategy, self.ratio)
+        return ", ".join(str(v) for v in (self.type, self.strategy, self.ratio))

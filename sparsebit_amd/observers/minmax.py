@@ -1,17 +1,44 @@
-"""minmax observer (mirrors sparsebit/quantization/observers/minmax.py:14-25)."""
+"""min-max observer (behaviour of sparsebit/quantization/observers/minmax.py:14-25).
+
+Besides the reference's cache-then-reduce protocol it can `consume` batches as they arrive:
+min/max are order independent, so each batch is folded into a running [C] (or scalar)
+statistic on the device and dropped -- calibration then needs no activation storage at all.
+"""
+import torch
+
 from . import Observer as BaseObserver
 from . import register_observer
+from .. import dist as sbq_dist
+from .. import ops
 
 
 @register_observer
 class Observer(BaseObserver):
     TYPE = "minmax"
+    STREAMING = True  # DeviceCalibrator feeds such observers through consume()
 
     def __init__(self, config, qdesc):
-        super(Observer, self).__init__(config, qdesc)
+        super().__init__(config, qdesc)
+        self._running = None  # (min, max) folded so far by consume()
+
+    def consume(self, x):
+        """Fold one batch into the running statistics without caching it."""
+        if not x.is_cuda:
+            x = x.to(self.device, non_blocking=True)
+        lo, hi, _ = ops.channel_stats(x.detach(), self.ch_axis, self.is_perchannel)
+        if self._running is not None:
+            lo = torch.minimum(self._running[0], lo)  # NaN-propagating, like torch.min over the union
+            hi = torch.maximum(self._running[1], hi)
+        self._running = (lo, hi)
 
     def calc_minmax(self):
-        shards = self._shards()
-        self.data_cache.reset()
-        mn, mx = self._minmax_over_shards(shards)
-        return self._store_minmax(mn, mx)
+        running, self._running = self._running, None
+        if len(self.data_cache):
+            shards = self._shards()
+            self.data_cache.reset()
+            for x in shards:
+                lo, hi, _ = ops.channel_stats(x, self.ch_axis, self.is_perchannel)
+                running = (lo, hi) if running is None else (torch.minimum(running[0], lo), torch.maximum(running[1], hi))
+        assert running is not None, "No data cached!"
+        lo, hi = sbq_dist.allreduce_minmax(*running)
+        return self._store_minmax(lo, hi)

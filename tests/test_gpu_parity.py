@@ -669,3 +669,72 @@ def test_widened_quantizers_vs_reference_golden(golden, oracle, name):
         step = np.broadcast_to(np.abs(gs).reshape([-1 if (perch and i == ch_axis) else 1 for i in range(ref.ndim)]), ref.shape)
         assert np.all(np.abs(dq - ref) <= step * 1.001 + 1e-12)
         assert np.mean(np.abs(dq - ref) > step * 1e-3) < 0.02
+
+
+# --------------------------------------------------------------------------------------
+# device-resident calibration driver
+# --------------------------------------------------------------------------------------
+class _QLinear(torch.nn.Module):
+    """Stand-in following the reference's QuantOpr convention (modules/linear.py:30-34)."""
+
+    def __init__(self, lin, wcfg, acfg):
+        from sparsebit_amd.common import Backend
+        from sparsebit_amd.quantizers import build_quantizer
+
+        super().__init__()
+        self.weight, self.bias = lin.weight, lin.bias
+        self.weight_quantizer = build_quantizer(wcfg)
+        self.input_quantizer = build_quantizer(acfg)
+        for q in (self.weight_quantizer, self.input_quantizer):
+            q.set_backend(Backend.VIRTUAL)
+
+    def forward(self, x):
+        return torch.nn.functional.linear(self.input_quantizer(x), self.weight_quantizer(self.weight), self.bias)
+
+
+@pytest.mark.parametrize("aobs", ["MINMAX", "PERCENTILE", "MSE"])
+def test_device_calibrator_matches_oracle(oracle, aobs):
+    from sparsebit_amd.calibration import DeviceCalibrator
+    from sparsebit_amd.config import quantizer_config
+
+    torch.manual_seed(3)
+    wcfg = lambda: quantizer_config("per-channel-symmetric", 8)
+    acfg = lambda: quantizer_config("per-tensor-affine", 8, observer=aobs, target="feature", layout="NLC", alpha=0.01)
+    model = torch.nn.Sequential(_QLinear(torch.nn.Linear(48, 64), wcfg(), acfg()), torch.nn.GELU(),
+                                _QLinear(torch.nn.Linear(64, 32), wcfg(), acfg())).cuda()
+    batches = [torch.randn(3, 17, 48, device="cuda") for _ in range(4)]
+    # what each operator sees in a float forward pass
+    seen = {0: [], 2: []}
+    hooks = [model[i].register_forward_pre_hook(lambda m, a, i=i: seen[i].append(a[0].detach().cpu().numpy())) for i in (0, 2)]
+    with torch.no_grad():
+        for b in batches:
+            model(b)
+    for h in hooks:
+        h.remove()
+    res = DeviceCalibrator(model).calibrate(batches)
+    assert len(res) == 4
+    for i in (0, 2):
+        data = np.concatenate([a.reshape(-1) for a in seen[i]])
+        if aobs == "MINMAX":
+            mn, mx = oracle.minmax(data, 0, False)
+            assert len(model[i].input_quantizer.observer.data_cache) == 0  # streamed, nothing cached
+        elif aobs == "PERCENTILE":
+            mn, mx = oracle.percentile(data, 0.01, per_channel=False)
+        if aobs == "MSE":
+            s, z, _, _ = oracle.mse(data, 0, 255, False, per_channel=False)
+        else:
+            s, z = oracle.qparams_from_minmax(mn, mx, 0, 255, False)
+        iq = model[i].input_quantizer
+        assert np.array_equal(iq.scale.reshape(-1).cpu().numpy(), s) and same_values(iq.zero_point.reshape(-1).cpu().numpy(), z)
+        assert list(iq.scale.shape) == [1, 1, 1]
+        w = model[i].weight.detach().cpu().numpy()
+        ws, wz = oracle.qparams_from_minmax(*oracle.minmax(w, 0, True), -128, 127, True)
+        assert np.array_equal(model[i].weight_quantizer.scale.reshape(-1).cpu().numpy(), ws)
+    # quantized forward afterwards == oracle QDQ chain on the first operator
+    for m in (model[0], model[2]):
+        m.input_quantizer.enable_quant()
+        m.weight_quantizer.enable_quant()
+    x = batches[0]
+    iq, wq = model[0].input_quantizer, model[0].weight_quantizer
+    xq, _ = oracle.qdq(x.cpu().numpy(), iq.scale.reshape(-1).cpu().numpy(), iq.zero_point.reshape(-1).cpu().numpy(), 0, 255, 2)
+    assert same_values(iq(x).cpu().numpy(), xq)

@@ -13,6 +13,17 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _built_library():
+    """libsbq.so normally arrives prebuilt (__graft_entry__.build()); if this checkout has none,
+    build it once -- hipcc is on the CPU container and on the GPU box alike.  No fallback: if the
+    build fails, every test that touches the library fails."""
+    from sparsebit_amd import build as sbq_build
+
+    if not os.path.exists(sbq_build.LIB):
+        sbq_build.build(verbose=False)
+
+
 @pytest.fixture(scope="session")
 def golden():
     """Vectors produced by the real reference (tests/golden/gen_golden.py)."""

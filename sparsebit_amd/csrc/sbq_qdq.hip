@@ -438,7 +438,22 @@ __global__ __launch_bounds__(kBlock) void qdq_scalar_kernel(const ScalarArgs a) 
 }
 
 // ---- host dispatch -------------------------------------------------------------------
-constexpr uint32_t kDefaultGridCap = 256 * 4;  // 4 resident workgroups of 256 on each of 256 CUs
+// Grid policy (tools/qdq_sweep.py on 4096x4096, 11008x4096 and 32768x4096 bf16 weights):
+//  * up to 2048 tiles everything is resident at once (8 workgroups of 256 per CU): one tile each;
+//  * beyond that every workgroup gets at least two tiles, so that the second one's loads are in
+//    flight under the first one's arithmetic, and the grid grows up to 8192 workgroups: only 2048
+//    are resident, the rest are handed out by the dispatcher as workgroups retire, which evens
+//    out the 10-15 % spread in how fast individual CUs get served (a fixed 4-per-CU grid left a
+//    ~1.3 us straggler tail on the headline shape).
+constexpr uint32_t kResidentWorkgroups = 256 * 8;
+constexpr uint32_t kMaxGrid = 8192;
+
+inline uint32_t auto_grid(uint32_t n_tiles) {
+  if (knob(1) > 0) return n_tiles < static_cast<uint32_t>(knob(1)) ? n_tiles : static_cast<uint32_t>(knob(1));
+  if (n_tiles <= kResidentWorkgroups) return n_tiles;
+  const uint32_t half = (n_tiles + 1) / 2;
+  return half < kMaxGrid ? half : kMaxGrid;
+}
 
 struct QdqCall {
   QdqPtrs p;
@@ -448,8 +463,7 @@ struct QdqCall {
 
 template <typename Tin, typename Tout, int QT, int MASK, bool FLAT, bool NT, int U, int MATH = MATH_FAST>
 void launch_pack(const QdqCall& c, hipStream_t st) {
-  const uint32_t cap = knob(1) > 0 ? static_cast<uint32_t>(knob(1)) : kDefaultGridCap;
-  const uint32_t grid = c.g.n_tiles < cap ? c.g.n_tiles : cap;
+  const uint32_t grid = auto_grid(c.g.n_tiles);
   qdq_pack_kernel<Tin, Tout, QT, MASK, FLAT, NT, U, MATH><<<grid, kBlock, 0, st>>>(
       c.p.x, c.g.n_tiles, c.g.slabs_per_row, c.g.packs_per_row, c.g.C, c.g.inner, c.p.y, c.p.scale, c.p.zp,
       c.p.q, c.p.mask, c.p.thresh, c.g.n_slabs, c.g.total_packs, c.g.qlo, c.g.qhi);
@@ -465,10 +479,9 @@ void launch_variant(QdqCall c, int variant, hipStream_t st) {
     if (lu > 2) lu = 2;
     nt = !(variant & 4);
   } else {
-    // auto (measured on the 4096x4096 headline, tools/qdq_sweep.py): two packs per lane per
-    // tile and two tiles in flight, on a grid of 4 workgroups per CU
-    const uint32_t units = FLAT ? (c.g.total_packs + kBlock - 1) / kBlock : c.g.n_slabs;
-    lu = units >= 2u * kDefaultGridCap ? 1 : 0;
+    // auto: one pack per lane per tile; two for very large tensors (>= 64 Mi elements), where the
+    // longer per-workgroup loop amortises the wider tile
+    lu = (!FLAT && c.g.n_slabs >= 32768u) ? 1 : 0;
   }
   const uint32_t U = 1u << lu;
   if (FLAT) c.g.n_tiles = (c.g.total_packs + kBlock * U - 1) / (kBlock * U);
@@ -528,7 +541,7 @@ void launch_scalar(ScalarArgs a, hipStream_t st) {
   const int64_t n = a.end - a.begin;
   if (n <= 0) return;
   int64_t blocks = ceil_div(n, kBlock);
-  if (blocks > static_cast<int64_t>(kDefaultGridCap)) blocks = kDefaultGridCap;
+  if (blocks > static_cast<int64_t>(kMaxGrid)) blocks = kMaxGrid;
   qdq_scalar_kernel<<<static_cast<uint32_t>(blocks), kBlock, 0, st>>>(a);
 }
 
@@ -634,8 +647,7 @@ int qdq_forward_batched(const void* const* table, int n_items, int x_dtype, int 
   const uint32_t tiles_per_item = (g.n_slabs + U - 1) / U;
   g.n_tiles = tiles_per_item;
   const uint32_t total = tiles_per_item * static_cast<uint32_t>(n_items);
-  const uint32_t cap = knob(1) > 0 ? static_cast<uint32_t>(knob(1)) : kDefaultGridCap;
-  const uint32_t grid = total < cap ? total : cap;
+  const uint32_t grid = auto_grid(total);
   hipStream_t st = as_stream(stream);
 #define SBQ_B(TI, TO) \
   qdq_batched_kernel<TI, TO, U><<<grid, kBlock, 0, st>>>(table, static_cast<uint32_t>(n_items), tiles_per_item, total, g)

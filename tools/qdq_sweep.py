@@ -93,17 +93,17 @@ def main():
         assert rc == 0, rc
 
     names = {0: "fast ", 3: "ieee ", 1: "rcp* ", 2: "copy*"}
-    for math in (0, 3, 1, 2):
-        for variant in ((0, 1, 2, 6) if math == 0 else (1, 2)):
-            for cap in ((0, 256, 512, 768, 1024, 4096) if math in (0, 2) else (0, 512, 1024)):
+    for _ in range(3000):
+        run(0)
+    torch.cuda.synchronize()
+    for math in (0, 2):
+        for variant in (0, 1, 2):
+            for cap in (512, 768, 1024, 1280, 1536, 2048, 3072, 4096, 8192):
                 lib.sbq_set_tuning(0, variant)
                 lib.sbq_set_tuning(1, cap)
                 lib.sbq_set_tuning(2, math)
-                cold = min(timeit(run, 240) for _ in range(2))
-                warm = timeit(lambda i: run(0), 240)
-                print("math=%s U=%d nt=%d cap=%5d : cold %.2f us %.2f TB/s | warm %.2f us %.2f TB/s"
-                      % (names[math], 1 << (variant & 3), 0 if variant & 4 else 1, cap, cold, bytes_alg / cold / 1e6,
-                         warm, bytes_alg / warm / 1e6), flush=True)
+                cold = min(timeit(run, 300) for _ in range(3))
+                print("math=%s U=%d cap=%5d : cold %.2f us %.2f TB/s" % (names[math], 1 << (variant & 3), cap, cold, bytes_alg / cold / 1e6), flush=True)
     lib.sbq_set_tuning(2, 0)
     lib.sbq_set_tuning(0, -1)
     lib.sbq_set_tuning(1, 0)

@@ -385,6 +385,58 @@ __global__ __launch_bounds__(kBlock) void qdq_batched_kernel(const void* const* 
 #undef SBQ_FINISH
 }
 
+// Channels-last variant (inner == 1, C % 8 == 0): the NLC activation layout quantized per
+// channel (quant_descriptor.py:36-47, ch_axis = 2).  Consecutive elements are consecutive
+// channels, so a pack needs the 8 scales / zero points of channels c0..c0+7: two 16-byte loads
+// each from vectors that stay in L1/L2.  The divisor differs per element: IEEE division.
+template <typename Tin, typename Tout, int QT>
+__global__ __launch_bounds__(kBlock) void qdq_clast_kernel(const void* __restrict__ x, void* __restrict__ y,
+                                                           void* __restrict__ q, const float* __restrict__ scale,
+                                                           const float* __restrict__ zero_point,
+                                                           uint32_t total_packs, uint32_t C, float qlo, float qhi) {
+  constexpr int U = 2;
+  const uint32_t stride = gridDim.x * kBlock * U;
+  for (uint32_t base = blockIdx.x * kBlock * U; base < total_packs; base += stride) {
+    RawPack<Tin> raw[U];
+    float s[U][kPack], z[U][kPack];
+    uint32_t pk[U];
+    bool ok[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      pk[u] = base + u * kBlock + threadIdx.x;
+      ok[u] = pk[u] < total_packs;
+      if (!ok[u]) pk[u] = total_packs - 1;
+      raw[u] = load_raw<Tin, true>(x, static_cast<int64_t>(pk[u]) * kPack);
+      const uint32_t c0 = static_cast<uint32_t>((static_cast<uint64_t>(pk[u]) * kPack) % C);
+      const u32x4 s0 = ld16<false>(scale + c0), s1 = ld16<false>(scale + c0 + 4);
+      const u32x4 z0 = ld16<false>(zero_point + c0), z1 = ld16<false>(zero_point + c0 + 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const uint32_t a = s0[j], b = s1[j], c = z0[j], d = z1[j];
+        s[u][j] = __builtin_bit_cast(float, a);
+        s[u][4 + j] = __builtin_bit_cast(float, b);
+        z[u][j] = __builtin_rintf(__builtin_bit_cast(float, c));
+        z[u][4 + j] = __builtin_rintf(__builtin_bit_cast(float, d));
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      float v[kPack], lv[kPack], dq[kPack];
+      unpack_raw<Tin>(raw[u], v);
+#pragma unroll
+      for (int j = 0; j < kPack; ++j) {
+        lv[j] = quant_level<SBQ_ROUND_HALF_EVEN>(v[j], s[u][j], z[u][j], qlo, qhi);
+        dq[j] = dequant_level(lv[j], s[u][j], z[u][j]);
+      }
+      if (ok[u]) {
+        const int64_t e = static_cast<int64_t>(pk[u]) * kPack;
+        store_pack<Tout, true>(y, e, dq);
+        if constexpr (QT != SBQ_Q_NONE) store_q_pack<QT>(q, e, lv);
+      }
+    }
+  }
+}
+
 // Scalar path: any geometry, any alignment, all rounding modes, runtime dtypes.
 struct ScalarArgs {
   const void* x;
@@ -574,6 +626,26 @@ int qdq_forward(const void* x, int x_dtype, void* y, int y_dtype, void* q, int q
 
   const bool ptr_ok = aligned16(x) && aligned16(y) && (q_type == SBQ_Q_NONE || aligned16(q)) &&
                       (!mask || (reinterpret_cast<uintptr_t>(mask) & 7u) == 0);
+  // channels-last per-channel (NLC activations): inner == 1, whole packs of channels
+  if (inner == 1 && C > 1 && C % kPack == 0 && rounding == SBQ_ROUND_HALF_EVEN && ptr_ok && !mask && !thresh &&
+      aligned16(scale) && aligned16(zp) && numel / kPack < (1ll << 31)) {
+    const uint32_t packs = static_cast<uint32_t>(numel / kPack);
+    uint32_t grid = (packs + kBlock * 2 - 1) / (kBlock * 2);
+    if (grid > kMaxGrid) grid = kMaxGrid;
+    const float qlo = static_cast<float>(qmin), qhi = static_cast<float>(qmax);
+#define SBQ_CL(TI, TO)                                                                                         \
+  do {                                                                                                         \
+    if (q_type == SBQ_Q_I8) qdq_clast_kernel<TI, TO, SBQ_Q_I8><<<grid, kBlock, 0, st>>>(x, y, q, scale, zp, packs, static_cast<uint32_t>(C), qlo, qhi); \
+    else if (q_type == SBQ_Q_I32) qdq_clast_kernel<TI, TO, SBQ_Q_I32><<<grid, kBlock, 0, st>>>(x, y, q, scale, zp, packs, static_cast<uint32_t>(C), qlo, qhi); \
+    else qdq_clast_kernel<TI, TO, SBQ_Q_NONE><<<grid, kBlock, 0, st>>>(x, y, q, scale, zp, packs, static_cast<uint32_t>(C), qlo, qhi); \
+  } while (0)
+    if (x_dtype == SBQ_F32) SBQ_CL(F32, F32);
+    else if (x_dtype == SBQ_F16) { if (y_dtype == SBQ_F32) SBQ_CL(F16, F32); else SBQ_CL(F16, F16); }
+    else { if (y_dtype == SBQ_F32) SBQ_CL(BF16, F32); else SBQ_CL(BF16, BF16); }
+#undef SBQ_CL
+    return check_launch();
+  }
+
   // The pack kernels need rows made of whole 8-element packs.  A per-tensor
   // call (C == 1) is one long row, so only its last numel % 8 elements are ragged.
   const int64_t body = (C == 1) ? (numel / kPack) * kPack : (inner % kPack == 0 ? numel : 0);

@@ -118,7 +118,9 @@ SHAPES = [
     ((64, 3, 7, 7), 0),  # inner = 147: scalar path
     ((37, 40), 0),  # FLAT path (short rows)
     ((4, 24, 6, 10), 1),  # NCHW activation per channel, outer > 1
-    ((3, 50, 64), 2),  # NLC per channel
+    ((3, 50, 64), 2),  # NLC per channel: channels-last pack kernel
+    ((5, 33, 1536), 2),  # the same, DeiT-like width, ragged pack count per workgroup
+    ((2, 7, 12), 2),  # NLC with C % 8 != 0: scalar path
     ((1, 1), 0),
 ]
 

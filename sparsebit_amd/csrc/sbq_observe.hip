@@ -226,6 +226,58 @@ __global__ void ema_minmax_kernel(const float* __restrict__ smin, const float* _
   state[1] = mx;
 }
 
+// ---- channels-last (inner == 1): [rows, C] reduced over rows, per column -----------------
+// The NLC activation layout observed per channel.  A lane owns 8 adjacent channels (one pack
+// per row), a workgroup 2048 channels, and blockIdx.y strides over the rows; partials land in
+// the same part[c][split] layout, so stats_finish_kernel folds them unchanged.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void stats_clast_kernel(const void* __restrict__ x,
+                                                             StatPartial* __restrict__ part, uint32_t rows,
+                                                             uint32_t C, uint32_t splits) {
+  const uint32_t c0 = (blockIdx.x * kBlock + threadIdx.x) * kPack;
+  if (c0 >= C) return;
+  float mn[kPack], mx[kPack], as[kPack];
+  int nan = 0;  // bit j: channel c0 + j saw a NaN
+#pragma unroll
+  for (int j = 0; j < kPack; ++j) {
+    mn[j] = __builtin_inff();
+    mx[j] = -__builtin_inff();
+    as[j] = 0.0f;
+  }
+  double asd[kPack];
+#pragma unroll
+  for (int j = 0; j < kPack; ++j) asd[j] = 0.0;
+  uint32_t since_flush = 0;
+  for (uint32_t r = blockIdx.y; r < rows; r += splits) {
+    float v[kPack];
+    load_pack<T, true>(x, static_cast<int64_t>(r) * C + c0, v);
+#pragma unroll
+    for (int j = 0; j < kPack; ++j) {
+      mn[j] = __builtin_fminf(mn[j], v[j]);
+      mx[j] = __builtin_fmaxf(mx[j], v[j]);
+      nan |= (v[j] != v[j]) << j;
+      as[j] += __builtin_fabsf(v[j]);
+    }
+    if (++since_flush == 64) {  // bound the fp32 run length like the row kernels do
+#pragma unroll
+      for (int j = 0; j < kPack; ++j) {
+        asd[j] += static_cast<double>(as[j]);
+        as[j] = 0.0f;
+      }
+      since_flush = 0;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < kPack; ++j) {
+    const bool bad = (nan >> j) & 1;
+    StatPartial p;
+    p.mn = bad ? __builtin_nanf("") : mn[j];
+    p.mx = bad ? __builtin_nanf("") : mx[j];
+    p.abssum = asd[j] + static_cast<double>(as[j]);
+    part[static_cast<size_t>(c0 + j) * splits + blockIdx.y] = p;
+  }
+}
+
 // ---- stage 2: fold a channel's partials (fixed order => deterministic) ------------
 __global__ __launch_bounds__(kBlock) void stats_finish_kernel(const StatPartial* __restrict__ part,
                                                               uint32_t chunks_per_chan,
@@ -470,6 +522,25 @@ int sbq_channel_stats(const void* x, int x_dtype, int64_t outer, int64_t C, int6
   if (workspace_bytes < need || !aligned16(workspace)) return SBQ_ERR_WORKSPACE;
   hipStream_t st = as_stream(stream);
   StatPartial* part = static_cast<StatPartial*>(workspace);
+  if (inner == 1 && C % kPack == 0 && outer > 1 && aligned16(x)) {
+    // channels-last: reduce [outer, C] over rows per column; `outer` partials per channel are
+    // provisioned, at most that many row splits are used
+    const uint32_t gx = static_cast<uint32_t>(ceil_div(C / kPack, kBlock));
+    uint32_t splits = 2048u / gx;
+    if (splits < 1) splits = 1;
+    if (splits > static_cast<uint32_t>(outer)) splits = static_cast<uint32_t>(outer);
+    if (splits > 65535u) splits = 65535u;
+    int rc = dispatch_dtype(x_dtype, [&](auto tag) {
+      using T = decltype(tag);
+      stats_clast_kernel<T><<<dim3(gx, splits), kBlock, 0, st>>>(x, part, static_cast<uint32_t>(outer),
+                                                               static_cast<uint32_t>(C), splits);
+    });
+    if (rc != SBQ_OK) return rc;
+    rc = check_launch();
+    if (rc != SBQ_OK) return rc;
+    stats_finish_kernel<<<g.C, kBlock, 0, st>>>(part, splits, min_out, max_out, abssum_out);
+    return check_launch();
+  }
   const uint32_t n_chunks = g.chunks_per_chan * g.C;
   const uint32_t grid = (n_chunks + kWavesPerBlock - 1) / kWavesPerBlock;  // one wave per chunk
   const bool vec = pack_friendly(x, C, outer, inner);

@@ -313,7 +313,8 @@ def test_full_size_4096_properties(oracle, ops):
 # --------------------------------------------------------------------------------------
 # observers on random data vs the oracle
 # --------------------------------------------------------------------------------------
-@pytest.mark.parametrize("shape,ch_axis", SHAPES + [((3, 8192 + 24), 0), ((1, 70001), 0)])
+@pytest.mark.parametrize("shape,ch_axis", SHAPES + [((3, 8192 + 24), 0), ((1, 70001), 0), ((64, 197, 384), 2),
+                                                     ((7, 3000, 8), 2)])
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_channel_stats_vs_oracle(oracle, ops, shape, ch_axis, dtype):
     g = torch.Generator().manual_seed(11)

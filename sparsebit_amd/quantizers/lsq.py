@@ -15,7 +15,7 @@ from . import Quantizer as BaseQuantizer
 from . import register_quantizer
 from .. import dist as sbq_dist
 from .. import ops
-from .quant_tensor import STE, fake_quant_factory
+from .quant_tensor import STE
 
 
 class gs_scaling(torch.autograd.Function):

@@ -9,8 +9,7 @@ reference is the only branch here: CPU tensors are rejected (no fallback).
 import numpy as np
 import torch
 
-from .. import fake_quant as fake_quant_kernel
-from .. import lib as L
+from .. import fake_quant as fake_quant_kernel  # noqa: F401  (the name the reference's module exposes)
 from .. import ops
 from ..common import Backend
 

@@ -741,3 +741,102 @@ def test_device_calibrator_matches_oracle(oracle, aobs):
     iq, wq = model[0].input_quantizer, model[0].weight_quantizer
     xq, _ = oracle.qdq(x.cpu().numpy(), iq.scale.reshape(-1).cpu().numpy(), iq.zero_point.reshape(-1).cpu().numpy(), 0, 255, 2)
     assert same_values(iq(x).cpu().numpy(), xq)
+
+
+# --------------------------------------------------------------------------------------
+# BASELINE.json configs as workload shapes (synthetic tensors; datasets / checkpoints are not
+# available offline): each runs the product API at the config's real tensor sizes and is
+# checked by oracle-on-a-sample plus size-independent properties.
+# --------------------------------------------------------------------------------------
+def _sample_rows_check(oracle, x, scale, zp, qmin, qmax, y, rows):
+    ref, _ = oracle.qdq(x[rows].float().cpu().numpy(), scale.reshape(-1)[rows].cpu().numpy(),
+                        zp.reshape(-1)[rows].cpu().numpy(), qmin, qmax, 0)
+    assert same_values(y[rows].float().cpu().numpy(), ref.reshape(y[rows].shape))
+
+
+def test_config2_resnet50_perchannel_mse_shapes(oracle):
+    """ResNet-50 PTQ per-channel 8w8a, MSE observer: the largest 3x3 conv weight (512x512x3x3)
+    and a per-tensor MSE activation of 32x256x56x56."""
+    from sparsebit_amd.common import Backend
+    from sparsebit_amd.config import quantizer_config
+    from sparsebit_amd.quantizers import build_quantizer
+
+    g = torch.Generator().manual_seed(50)
+    w = (torch.randn(512, 512, 3, 3, generator=g) * 0.05).cuda()
+    q = build_quantizer(quantizer_config("per-channel-symmetric", 8, observer="MSE"))
+    q.set_backend(Backend.VIRTUAL)
+    q.update_observer(w)
+    scale, zp = q.calc_qparams()
+    rows = [0, 1, 77, 255, 511]
+    rs, rz, rbest, _ = oracle.mse(w[rows].cpu().numpy(), -128, 127, True, 0, True)
+    assert np.array_equal(q.observer.best_index.cpu().numpy()[rows], rbest)
+    assert np.array_equal(scale.reshape(-1)[rows].cpu().numpy(), rs)
+    q.enable_quant()
+    y = q(w)
+    _sample_rows_check(oracle, w.reshape(512, -1), scale, zp, -128, 127, y.reshape(512, -1), rows)
+    a = torch.relu(torch.randn(32, 256, 56, 56, generator=g)).cuda()
+    qa = build_quantizer(quantizer_config("per-tensor-affine", 8, observer="MSE", target="feature"))
+    qa.set_backend(Backend.VIRTUAL)
+    for chunk in a.chunk(4):
+        qa.update_observer(chunk)
+    sa, za = qa.calc_qparams()
+    assert 0 <= int(qa.observer.best_index.item()) < 80 and float(sa) > 0
+    qa.enable_quant()
+    ya = qa(a)
+    assert torch.equal(qa(ya), ya)  # idempotent
+    assert int(torch.unique(ya).numel()) <= 256
+
+
+def test_config3_deit_percentile_shapes(oracle):
+    """DeiT-small PTQ, percentile observer: four calibration batches of 64x197x384 tokens per
+    tensor (the shardable radix path) and a 1536x384 weight per channel (row path)."""
+    from sparsebit_amd.config import quantizer_config
+    from sparsebit_amd.observers import build_observer
+    from sparsebit_amd.quantizers.quant_descriptor import QuantDescriptor
+
+    g = torch.Generator().manual_seed(33)
+    xs = [torch.randn(64, 197, 384, generator=g) for _ in range(4)]
+    cfg = quantizer_config("per-tensor-symmetric", 8, observer="PERCENTILE", target="feature", layout="NLC", alpha=1e-3)
+    obs = build_observer(cfg, QuantDescriptor(cfg))
+    for x in xs:
+        obs.data_cache.update(x.cuda())
+    mn, mx = obs.calc_minmax()
+    rmn, rmx = oracle.percentile(np.concatenate([x.numpy().reshape(-1) for x in xs]), 1e-3, per_channel=False)
+    assert float(mn) == float(rmn[0]) and float(mx) == float(rmx[0])
+    w = torch.randn(1536, 384, generator=g)
+    cfgw = quantizer_config("per-channel-symmetric", 8, observer="PERCENTILE", alpha=1e-3)
+    obw = build_observer(cfgw, QuantDescriptor(cfgw))
+    obw.data_cache.update(w.cuda())
+    mn, mx = obw.calc_minmax()
+    rmn, rmx = oracle.percentile(w.numpy(), 1e-3, 0, True)
+    assert np.array_equal(mn.cpu().numpy(), rmn) and np.array_equal(mx.cpu().numpy(), rmx)
+
+
+def test_config5_resnet50_qat_lsq_mask_shapes(oracle):
+    """ResNet-50 QAT 4w4a LSQ + 50 % unstructured mask: fused mask+QDQ forward == mask multiply
+    then quantizer, on the 512x512x3x3 weight; backward through the unfused graph."""
+    from sparsebit_amd.common import Backend
+    from sparsebit_amd.config import quantizer_config, sparser_config
+    from sparsebit_amd.quantizers import build_quantizer
+    from sparsebit_amd.sparsers import build_sparser
+
+    g = torch.Generator().manual_seed(5)
+    w = (torch.randn(512, 512, 3, 3, generator=g) * 0.03).cuda().requires_grad_(True)
+    sp = build_sparser(sparser_config(0.5))
+    mask = sp.calc_mask(w)
+    assert abs(float(mask.float().mean()) - 0.5) < 1e-3
+    rm, rt = oracle.l1_mask(w.detach().cpu().numpy(), 0.5)
+    assert float(sp.calc_threshold(w)) == float(rt) and np.array_equal(mask.cpu().numpy(), rm)
+    q = build_quantizer(quantizer_config("per-channel-symmetric", 4, quantizer="lsq"))
+    q.set_backend(Backend.VIRTUAL)
+    q.update_observer(w)
+    q.calc_qparams()
+    q.enable_quant()
+    unfused = q(w * mask)
+    fused = q.forward_masked(w.detach(), mask=mask)
+    fused_t = q.forward_masked(w.detach(), thresh=sp.calc_threshold(w))
+    assert torch.equal(unfused.detach(), fused) and torch.equal(fused, fused_t)
+    assert int(fused.reshape(512, -1)[3].unique().numel()) <= 16
+    unfused.sum().backward()
+    assert w.grad is not None and q.scale.grad is not None
+    assert bool((w.grad[~mask] == 0).all())  # pruned weights get no gradient through `w * mask`

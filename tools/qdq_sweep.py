@@ -4,7 +4,6 @@ Usage (GPU box):  python tools/qdq_sweep.py [rows cols]
 Prints one line per (variant, grid cap) with HBM-cold (rotating buffers, larger
 than the 256 MiB Infinity Cache) and cache-warm timings.  Not part of the product.
 """
-import ctypes
 import os
 import sys
 

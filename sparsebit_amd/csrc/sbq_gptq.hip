@@ -132,6 +132,150 @@ __global__ __launch_bounds__(kBlock) void gptq4_partial_kernel(
   }
 }
 
+// ---- single-launch "strip" kernel (mat-VEC: batch 1 or 2) --------------------------------
+// For decode-sized batches no cross-workgroup reduction is needed at all: a workgroup owns a
+// 32-column strip of the output for ALL of K.  Its 256 lanes form an 8 (column quads) x 32
+// (K lanes) grid; a K lane takes 16 consecutive qweight rows = 128 input channels = exactly
+// one quantization group, so scale / zero are loaded once per lane, all 16 of its 16-byte
+// weight words are requested back to back (256 B per lane in flight; a wave's load covers
+// full 128-byte lines of 8 rows), and the dequantization factors out of the inner loop:
+//     sum_k (s*nib_k - z) * x_k  =  s * sum_k nib_k*x_k  -  z * sum_k x_k
+// (one convert + one fma per weight instead of two fmas; sum_k x_k is shared by the lane's 4
+// columns).  The activations of a pass (4096 floats per batch row) are staged in LDS with a
+// 4-float skew per K lane so that the broadcast ds_read_b128 of the 8 K lanes of a wave hit
+// different banks.  The 32 K lanes are folded through LDS in a fixed order and the strip is
+// written once: one kernel, deterministic, no atomics, no partial-tile traffic.
+constexpr int kStripCols = 32;
+constexpr int kStripKLanes = kBlock / (kStripCols / 4);       // 32
+constexpr int kStripRowsPerPass = kStripKLanes * kSliceRows;  // 512 qweight rows = 4096 channels
+constexpr int kStripXStride = kSliceK + 4;                    // skewed LDS row of one K lane
+
+template <int kBT>
+__global__ __launch_bounds__(kBlock) void gptq4_strip_kernel(
+    const float* __restrict__ x, const int32_t* __restrict__ qw, const float* __restrict__ scales,
+    const float* __restrict__ zeros, float* __restrict__ out, const GptqGeom g) {
+  __shared__ __attribute__((aligned(16))) float xs[kBT][kStripKLanes * kStripXStride];
+  __shared__ float red[kStripKLanes][kBT][kStripCols + 1];
+  const int cl = threadIdx.x & 7;   // column quad inside the strip
+  const int kl = threadIdx.x >> 3;  // K lane
+  const int64_t col0 = static_cast<int64_t>(blockIdx.x) * kStripCols + cl * 4;
+  // 16-byte loads of x need aligned rows
+  const bool x_vec = (reinterpret_cast<uintptr_t>(x) & 15u) == 0 && (g.in_features & 3) == 0;
+
+  float acc[4][kBT];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int b = 0; b < kBT; ++b) acc[j][b] = 0.0f;
+
+  for (int pass0 = 0; pass0 < g.H; pass0 += kStripRowsPerPass) {
+    const int row0 = pass0 + kl * kSliceRows;
+    const bool live = row0 < g.H;
+    // every global load of the pass is issued before anything waits: this lane's share of the
+    // activations (4 x 16 bytes per batch row, coalesced), its 16 weight words, its scale / zero
+    const int64_t kbase = static_cast<int64_t>(pass0) * 8;
+    f32x4 xg[kBT][4];
+#pragma unroll
+    for (int b = 0; b < kBT; ++b)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int e = (j * kBlock + threadIdx.x) * 4;  // element of the pass, multiple of 4
+        const int64_t k = kbase + e;
+        xg[b][j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        if (b < g.batch) {
+          const float* xr = x + b * g.in_features + k;
+          if (x_vec && k + 4 <= g.in_features) {
+            xg[b][j] = *reinterpret_cast<const f32x4*>(xr);
+          } else {
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+              if (k + n < g.in_features) xg[b][j][n] = xr[n];
+          }
+        }
+      }
+    u32x4 w[kSliceRows];
+#pragma unroll
+    for (int i = 0; i < kSliceRows; ++i) {
+      const int r = row0 + i;
+      w[i] = u32x4{0, 0, 0, 0};
+      if (live && r < g.H) w[i] = ld16<true>(qw + static_cast<int64_t>(r) * g.out_features + col0);
+    }
+    const int64_t k0 = static_cast<int64_t>(row0) * 8;
+    float sc[4] = {0, 0, 0, 0}, zr[4] = {0, 0, 0, 0};
+    if (live) {
+      const int grp = static_cast<int>(k0 / g.group_size);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        sc[j] = scales[(col0 + j) * g.groups + grp];
+        zr[j] = zeros[(col0 + j) * g.groups + grp];
+      }
+    }
+    __syncthreads();  // previous pass done with xs
+#pragma unroll
+    for (int b = 0; b < kBT; ++b)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int e = (j * kBlock + threadIdx.x) * 4;
+        const int lane_k = e / kSliceK, off = e - lane_k * kSliceK;
+        *reinterpret_cast<f32x4*>(&xs[b][lane_k * kStripXStride + off]) = xg[b][j];
+      }
+    __syncthreads();
+    if (live) {
+      float dot[4][kBT], xsum[kBT];
+#pragma unroll
+      for (int b = 0; b < kBT; ++b) {
+        xsum[b] = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dot[j][b] = 0.0f;
+      }
+#pragma unroll
+      for (int i = 0; i < kSliceRows; ++i) {
+        f32x4 xv[kBT][2];
+#pragma unroll
+        for (int b = 0; b < kBT; ++b) {
+          const float* xr = &xs[b][kl * kStripXStride + i * 8];
+          xv[b][0] = *reinterpret_cast<const f32x4*>(xr);
+          xv[b][1] = *reinterpret_cast<const f32x4*>(xr + 4);
+#pragma unroll
+          for (int n = 0; n < 8; ++n) xsum[b] += xv[b][n >> 2][n & 3];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const uint32_t word = w[i][j];
+          const uint32_t even = word & 0x0f0f0f0fu;         // nibbles 0,2,4,6 as bytes
+          const uint32_t odd = (word >> 4) & 0x0f0f0f0fu;   // nibbles 1,3,5,7 as bytes
+#pragma unroll
+          for (int n = 0; n < 8; ++n) {
+            const uint32_t src = (n & 1) ? odd : even;
+            const float nib = static_cast<float>((src >> (8 * (n >> 1))) & 0xffu);  // v_cvt_f32_ubyteN
+#pragma unroll
+            for (int b = 0; b < kBT; ++b) dot[j][b] = __builtin_fmaf(nib, xv[b][n >> 2][n & 3], dot[j][b]);
+          }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int b = 0; b < kBT; ++b) acc[j][b] += __builtin_fmaf(sc[j], dot[j][b], -(zr[j] * xsum[b]));
+    }
+  }
+  // fold the 32 K lanes in ascending order, add to out (pre-filled with the bias)
+#pragma unroll
+  for (int b = 0; b < kBT; ++b)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) red[kl][b][cl * 4 + j] = acc[j][b];
+  __syncthreads();
+  for (int i = threadIdx.x; i < kBT * kStripCols; i += kBlock) {
+    const int b = i / kStripCols, cc = i - b * kStripCols;
+    if (b < g.batch) {
+      float t = 0.0f;
+#pragma unroll
+      for (int q = 0; q < kStripKLanes; ++q) t += red[q][b][cc];
+      out[b * g.out_features + static_cast<int64_t>(blockIdx.x) * kStripCols + cc] += t;
+    }
+  }
+}
+
 // out[b,n] += sum over K blocks, ascending
 __global__ __launch_bounds__(kBlock) void gptq4_fold_kernel(const float* __restrict__ part,
                                                             float* __restrict__ out, int64_t bn,
@@ -198,6 +342,13 @@ int sbq_vecquant4matmul(const float* x, const int32_t* qweight, float* out, cons
   float* part = static_cast<float*>(workspace);
   const bool vec = (out_features % 4 == 0) && aligned16(qweight);
   const int bt = batch >= 8 ? 8 : (batch >= 3 ? 4 : (batch == 2 ? 2 : 1));
+  // single-launch strip kernel: mat-vec sized batches, whole 32-column strips
+  if (vec && out_features % kStripCols == 0 && batch <= 2 && knob(2) != 9) {
+    const uint32_t grid = static_cast<uint32_t>(out_features / kStripCols);
+    if (batch == 2) gptq4_strip_kernel<2><<<grid, kBlock, 0, st>>>(x, qweight, scales, zeros, out, g);
+    else gptq4_strip_kernel<1><<<grid, kBlock, 0, st>>>(x, qweight, scales, zeros, out, g);
+    return check_launch();
+  }
 #define SBQ_GPTQ(COLS)                                                                              \
   do {                                                                                              \
     dim3 grid(static_cast<uint32_t>(ceil_div(out_features, kWave * COLS)), static_cast<uint32_t>(g.kblocks)); \

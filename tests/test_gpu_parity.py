@@ -558,7 +558,8 @@ def test_gptq_vs_reference_golden(golden, oracle, name):
     assert np.allclose(y.cpu().numpy(), golden["gptq/%s/y" % name], rtol=1e-5, atol=1e-5)
 
 
-@pytest.mark.parametrize("B,M,N,GS", [(1, 4096, 4096, 128), (8, 4096, 4096, 128), (32, 1024, 1280, 128), (4, 6661, 1027, -1),
+@pytest.mark.parametrize("B,M,N,GS", [(1, 4096, 4096, 128), (2, 4096, 4096, 128), (1, 11008, 4096, 128), (2, 1000, 96, -1),
+                                       (8, 4096, 4096, 128), (32, 1024, 1280, 128), (4, 6661, 1027, -1),
                                        (2, 4096, 11008, 128), (1, 1024, 256, 256)])
 def test_gptq_random_vs_oracle(oracle, B, M, N, GS):
     """shapes after test_cuda_kernel.py:48-126 (incl. an irregular M, N and group sizes)"""

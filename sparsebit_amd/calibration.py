@@ -111,6 +111,16 @@ class DeviceCalibrator:
 
         if sharded:
             with sbq_dist.sharded_calibration():
+                # every streaming min-max observer of the model in ONE collective
+                obs = [
+                    m.input_quantizer.observer
+                    for _, m in self.oprs
+                    if _live(getattr(m, "input_quantizer", None))
+                    and getattr(m.input_quantizer.observer, "pending", lambda: None)() is not None
+                ]
+                if obs:
+                    for o, (lo, hi) in zip(obs, sbq_dist.allreduce_minmax_many([o.pending() for o in obs])):
+                        o.resolve(lo, hi)
                 finish()
         else:
             finish()

@@ -256,7 +256,7 @@ __device__ __forceinline__ void finish_tile(void* __restrict__ y, void* __restri
 // in SGPRs with the wave instead of through a cold scalar load -- every launch gets a fresh
 // kernarg block, and for a ~12 us kernel one more dependent HBM round trip in front of the
 // first data load is measurable.  The rarely used arguments follow and are loaded normally.
-template <typename Tin, typename Tout, int QT, int MASK, bool FLAT, bool NT, int U, int MATH>
+template <typename Tin, typename Tout, int QT, int MASK, bool FLAT, bool NT, int U, int MATH, bool NTS = NT>
 __global__ __launch_bounds__(kBlock) void qdq_pack_kernel(
     const void* __restrict__ x, uint32_t n_tiles, uint32_t slabs_per_row, uint32_t packs_per_row,
     uint32_t n_channels, int64_t inner, void* __restrict__ y, const float* __restrict__ scale,
@@ -290,7 +290,7 @@ __global__ __launch_bounds__(kBlock) void qdq_pack_kernel(
   locate<FLAT, U>(g, (IDX), cur, scale, zero_point, T);      \
   issue_loads<Tin, MASK, NT, U>(x, mask, T, R, M);           \
   if constexpr (!FLAT) advance(g, cur)
-#define SBQ_FINISH(T, R, M) finish_tile<Tin, Tout, QT, MASK, FLAT, NT, U, MATH>(y, q, T, R, M, thr, g.qlo, g.qhi)
+#define SBQ_FINISH(T, R, M) finish_tile<Tin, Tout, QT, MASK, FLAT, NTS, U, MATH>(y, q, T, R, M, thr, g.qlo, g.qhi)
   SBQ_FETCH(ta, ra, ma, tile);
   // Steady state: both prefetches are unconditional, so the compiler's vmcnt bookkeeping
   // stays exact (a conditional prefetch merges two scoreboard states at the join and makes
@@ -513,10 +513,10 @@ struct QdqCall {
   uint32_t rows;
 };
 
-template <typename Tin, typename Tout, int QT, int MASK, bool FLAT, bool NT, int U, int MATH = MATH_FAST>
+template <typename Tin, typename Tout, int QT, int MASK, bool FLAT, bool NT, int U, int MATH = MATH_FAST, bool NTS = NT>
 void launch_pack(const QdqCall& c, hipStream_t st) {
   const uint32_t grid = auto_grid(c.g.n_tiles);
-  qdq_pack_kernel<Tin, Tout, QT, MASK, FLAT, NT, U, MATH><<<grid, kBlock, 0, st>>>(
+  qdq_pack_kernel<Tin, Tout, QT, MASK, FLAT, NT, U, MATH, NTS><<<grid, kBlock, 0, st>>>(
       c.p.x, c.g.n_tiles, c.g.slabs_per_row, c.g.packs_per_row, c.g.C, c.g.inner, c.p.y, c.p.scale, c.p.zp,
       c.p.q, c.p.mask, c.p.thresh, c.g.n_slabs, c.g.total_packs, c.g.qlo, c.g.qhi);
 }
@@ -553,6 +553,11 @@ void launch_variant(QdqCall c, int variant, hipStream_t st) {
       else if (U == 2) SBQ_LAUNCH_M(2);
       else SBQ_LAUNCH_M(4);
 #undef SBQ_LAUNCH_M
+      return;
+    }
+    if (variant >= 0 && (variant & 8)) {  // mixed cache policy: bit3 set -> loads nt, stores cached;
+      if (variant & 4) launch_pack<Tin, Tout, QT, MASK, FLAT, false, 1, MATH_FAST, true>(c, st);  // + bit2 -> loads cached, stores nt
+      else launch_pack<Tin, Tout, QT, MASK, FLAT, true, 1, MATH_FAST, false>(c, st);
       return;
     }
     if (!nt) {

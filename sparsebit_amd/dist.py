@@ -73,6 +73,23 @@ def allreduce_minmax(min_val, max_val):
     return mn.reshape(min_val.shape).to(min_val.dtype), mx.reshape(max_val.shape).to(max_val.dtype)
 
 
+def allreduce_minmax_many(pairs):
+    """[(min, max), ...] of many observers combined with ONE collective (one flat buffer):
+    the messages are latency bound, so a model's worth of min-max observers costs one
+    all-reduce instead of one per quantizer.  Returns the reduced pairs, shapes preserved."""
+    if not active() or not pairs:
+        return list(pairs)
+    sizes = [p[0].numel() for p in pairs]
+    mn = torch.cat([p[0].reshape(-1).float() for p in pairs])
+    mx = torch.cat([p[1].reshape(-1).float() for p in pairs])
+    mn, mx = allreduce_minmax(mn, mx)
+    out, o = [], 0
+    for (a, b), n in zip(pairs, sizes):
+        out.append((mn[o:o + n].reshape(a.shape).to(a.dtype), mx[o:o + n].reshape(b.shape).to(b.dtype)))
+        o += n
+    return out
+
+
 def allreduce_sum_(t):
     """In-place SUM over ranks (fp64 / int64 tables: exact or order-insensitive enough)."""
     if active():

@@ -31,7 +31,20 @@ class Observer(BaseObserver):
             hi = torch.maximum(self._running[1], hi)
         self._running = (lo, hi)
 
+    def pending(self):
+        """The locally folded (min, max), or None -- lets a calibration driver all-reduce the
+        statistics of many observers in one collective (dist.allreduce_minmax_many) and hand
+        the result back through `resolve`."""
+        return self._running
+
+    def resolve(self, lo, hi):
+        """Install globally reduced statistics: calc_minmax will then skip its own exchange."""
+        self._running = (lo, hi)
+        self._resolved = True
+
     def calc_minmax(self):
+        resolved = getattr(self, "_resolved", False)
+        self._resolved = False
         running, self._running = self._running, None
         if len(self.data_cache):
             shards = self._shards()
@@ -40,5 +53,5 @@ class Observer(BaseObserver):
                 lo, hi, _ = ops.channel_stats(x, self.ch_axis, self.is_perchannel)
                 running = (lo, hi) if running is None else (torch.minimum(running[0], lo), torch.maximum(running[1], hi))
         assert running is not None, "No data cached!"
-        lo, hi = sbq_dist.allreduce_minmax(*running)
+        lo, hi = running if resolved else sbq_dist.allreduce_minmax(*running)
         return self._store_minmax(lo, hi)

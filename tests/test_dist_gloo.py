@@ -100,6 +100,18 @@ def _worker(rank, world, port, tmp):
             mn, mx = sd.allreduce_minmax(mn, mx)
             rmn, rmx = O.minmax(everything, 1, perch)
             ok["minmax%d" % perch] = np.array_equal(mn.numpy(), rmn) and np.array_equal(mx.numpy(), rmx)
+        # many observers, one collective
+        pairs = []
+        for k, perch in enumerate((False, True, False)):
+            loc = [O.minmax(x.numpy() * (k + 1), 1, perch) for x in mine]
+            pairs.append((torch.from_numpy(np.min([l[0] for l in loc], 0)), torch.from_numpy(np.max([l[1] for l in loc], 0))))
+        red = sd.allreduce_minmax_many(pairs)
+        good = True
+        for k, perch in enumerate((False, True, False)):
+            rmn, rmx = O.minmax(everything * (k + 1), 1, perch)
+            good &= np.array_equal(red[k][0].numpy(), rmn) and np.array_equal(red[k][1].numpy(), rmx)
+            good &= red[k][0].shape == pairs[k][0].shape
+        ok["minmax_many"] = bool(good)
         # NaN on one rank must reach every rank
         v = torch.tensor([float("nan") if rank == 1 else 0.5, 1.0])
         mn, mx = sd.allreduce_minmax(v.clone(), v.clone())
@@ -162,7 +174,7 @@ def test_sharded_statistics_equal_single_process(tmp_path):
         ok = torch.load(os.path.join(str(tmp_path), "rank%d.pt" % r))
         bad = [k for k, v in ok.items() if not v]
         assert not bad, (r, bad)
-        assert len(ok) >= 11
+        assert len(ok) >= 12
 
 
 def test_numpy_select_backend_is_the_protocol(oracle):

@@ -717,6 +717,10 @@ def test_device_calibrator_matches_oracle(oracle, aobs):
         h.remove()
     res = DeviceCalibrator(model).calibrate(batches)
     assert len(res) == 4
+    # sharded=True in a single process: same protocol, collectives are no-ops -> same result
+    res2 = DeviceCalibrator(model).calibrate(batches, sharded=True)
+    for k in res:
+        assert torch.equal(res[k][0], res2[k][0]) and torch.equal(res[k][1], res2[k][1])
     for i in (0, 2):
         data = np.concatenate([a.reshape(-1) for a in seen[i]])
         if aobs == "MINMAX":

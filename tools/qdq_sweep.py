@@ -95,14 +95,14 @@ def main():
     for _ in range(3000):
         run(0)
     torch.cuda.synchronize()
-    for math in (0, 2):
-        for variant in (0, 1, 2):
-            for cap in (512, 768, 1024, 1280, 1536, 2048, 3072, 4096, 8192):
-                lib.sbq_set_tuning(0, variant)
-                lib.sbq_set_tuning(1, cap)
-                lib.sbq_set_tuning(2, math)
-                cold = min(timeit(run, 300) for _ in range(3))
-                print("math=%s U=%d cap=%5d : cold %.2f us %.2f TB/s" % (names[math], 1 << (variant & 3), cap, cold, bytes_alg / cold / 1e6), flush=True)
+    lib.sbq_set_tuning(2, 0)
+    for rep in range(2):
+        for variant, label in ((0, "loads nt , stores nt "), (8, "loads nt , stores wb "), (12, "loads wb , stores nt "), (4, "loads wb , stores wb ")):
+            lib.sbq_set_tuning(0, variant)
+            lib.sbq_set_tuning(1, 0)
+            cold = min(timeit(run, 300) for _ in range(3))
+            warm = min(timeit(lambda i: run(0), 300) for _ in range(2))
+            print("%s : cold %.2f us %.2f TB/s | warm %.2f us" % (label, cold, bytes_alg / cold / 1e6, warm), flush=True)
     lib.sbq_set_tuning(2, 0)
     lib.sbq_set_tuning(0, -1)
     lib.sbq_set_tuning(1, 0)

@@ -8,10 +8,10 @@
 //       order statistic, then `abs(w) > thresh`).
 //
 // Two selection engines, both exact and atomics-free in their results:
-//   * rows: a [C, inner] weight whose row fits in LDS (<= 16384 keys = 64 KiB).
-//     One workgroup per row loads the row ONCE (16-byte loads), converts it to
-//     order-preserving uint32 keys in LDS and finds both k-th keys by a 32-step
-//     MSB-first bisection; each step is one LDS sweep + one block-wide count.
+//   * rows: a [C, inner] weight with inner <= 16384.  One workgroup per row loads the
+//     row ONCE (16-byte loads) into registers as order-preserving uint32 keys and
+//     finds both k-th keys by 8 bisection steps on the top byte + three 8-bit radix
+//     passes over LDS histograms.
 //   * radix: any size / geometry / sharding.  Three passes (11+11+10 key bits);
 //     per pass one HBM sweep builds a 2048-bin histogram per (channel, selector)
 //     in LDS with integer atomics (order independent => deterministic), flushed
@@ -27,72 +27,141 @@ struct SumU { __device__ __forceinline__ uint32_t operator()(uint32_t a, uint32_
 // ---------------------------------------------------------------------------------
 // rows engine
 // ---------------------------------------------------------------------------------
-template <typename T, bool VEC>
+// One workgroup per row.  The row is read ONCE into registers as order-preserving uint32
+// keys (K keys per lane, 256*K >= inner) and both ranks are found by a hybrid select: 8
+// bisection steps for the low-entropy top byte, then three 8-bit radix passes (256-bin LDS
+// histogram per selector, a block scan with one bin per lane, the lane whose bin holds the
+// rank publishes the digit).
+struct RowSel {
+  uint32_t prefix, k;
+};
+
+// inclusive scan of one value per lane over the 256 lanes of the workgroup
+__device__ __forceinline__ uint32_t block_scan_incl(uint32_t v, uint32_t* wave_tot) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wid = threadIdx.x / kWave;
+#pragma unroll
+  for (int d = 1; d < kWave; d <<= 1) {
+    const uint32_t up = __shfl_up(v, d, kWave);
+    if (lane >= d) v += up;
+  }
+  if (lane == kWave - 1) wave_tot[wid] = v;
+  __syncthreads();
+  uint32_t off = 0;
+#pragma unroll
+  for (int w = 0; w < kWavesPerBlock; ++w)
+    if (w < wid) off += wave_tot[w];
+  return v + off;
+}
+
+template <typename T, int K>
 __global__ __launch_bounds__(kBlock) void percentile_rows_kernel(const void* __restrict__ x,
                                                                  uint32_t inner, double alpha,
                                                                  float* __restrict__ min_out,
                                                                  float* __restrict__ max_out) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  uint32_t* keys = reinterpret_cast<uint32_t*>(smem);        // [inner]
-  uint32_t* red = keys + ((inner + 3u) & ~3u);                // [2][kWavesPerBlock]
+  __shared__ uint32_t hist[2][256];
+  __shared__ uint32_t wave_tot[2][kWavesPerBlock];
+  __shared__ uint32_t red[kWavesPerBlock];
+  __shared__ RowSel pick[2];
   const uint32_t row = blockIdx.x;
   const int64_t base = static_cast<int64_t>(row) * inner;
 
+  // element e = k * 256 + tid (coalesced scalar loads: K is small and the row is read once;
+  // rows that are whole packs use 16-byte loads: 8 keys per load)
+  uint32_t keys[K];
+  bool valid[K];
   uint32_t neg = 0, pos = 0;
-  if constexpr (VEC) {
-    for (uint32_t p = threadIdx.x; p < inner / kPack; p += kBlock) {
+  const bool packs = (inner % kPack == 0) && (reinterpret_cast<uintptr_t>(x) & 15u) == 0 && (K % kPack == 0);
+  if (packs) {
+#pragma unroll
+    for (int p = 0; p < K / kPack; ++p) {
+      const uint32_t e = (p * kBlock + threadIdx.x) * kPack;
+      const bool in = e < inner;
       float v[kPack];
-      load_pack<T, true>(x, base + static_cast<int64_t>(p) * kPack, v);
+      load_pack<T, true>(x, base + (in ? e : 0), v);
 #pragma unroll
       for (int j = 0; j < kPack; ++j) {
-        neg += v[j] < 0.0f;
-        pos += v[j] >= 0.0f;
+        valid[p * kPack + j] = in;
         keys[p * kPack + j] = float_key(v[j], false);
+        neg += in && v[j] < 0.0f;
+        pos += in && v[j] >= 0.0f;
       }
     }
   } else {
-    for (uint32_t e = threadIdx.x; e < inner; e += kBlock) {
-      const float f = Elem<T>::load1(x, base + e);
-      neg += f < 0.0f;
-      pos += f >= 0.0f;
-      keys[e] = float_key(f, false);
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const uint32_t e = k * kBlock + threadIdx.x;
+      valid[k] = e < inner;
+      const float f = valid[k] ? Elem<T>::load1(x, base + e) : 0.0f;
+      keys[k] = float_key(f, false);
+      neg += valid[k] && f < 0.0f;
+      pos += valid[k] && f >= 0.0f;
     }
   }
   neg = block_reduce(neg, SumU(), red);
-  pos = block_reduce(pos, SumU(), red);  // block_reduce syncs: keys[] are visible after this
+  pos = block_reduce(pos, SumU(), red);
 
   // percentile.py:36-43 (1-indexed k-th smallest; Python round == rint on a double)
   const double rp = __builtin_rint(static_cast<double>(pos) * alpha);
   const double rn = __builtin_rint(static_cast<double>(neg) * alpha);
   int64_t k_max = static_cast<int64_t>(inner) - static_cast<int64_t>(rp > 0.0 ? rp : 0.0);
   int64_t k_min = static_cast<int64_t>(rn > 1.0 ? rn : 1.0);
-  // torch.kthvalue raises for k outside [1, n]; clamp instead of faulting
-  if (k_max < 1) k_max = 1;
+  if (k_max < 1) k_max = 1;  // torch.kthvalue raises outside [1, n]; clamp instead of faulting
   if (k_min > inner) k_min = inner;
+  RowSel sel[2] = {{0u, static_cast<uint32_t>(k_min)}, {0u, static_cast<uint32_t>(k_max)}};
 
-  // MSB-first bisection for two ranks at once.  Invariant: `pre` holds the decided
-  // high bits of the answer; `k` is the rank inside the bucket of keys sharing them.
-  uint32_t pre0 = 0, pre1 = 0;
-  uint32_t k0 = static_cast<uint32_t>(k_min), k1 = static_cast<uint32_t>(k_max);
-  for (int bit = 31; bit >= 0; --bit) {
-    const uint32_t hi_mask = bit == 31 ? 0u : ~((2u << bit) - 1u);  // bits above `bit`
+  // Top 8 bits (sign + most of the exponent) by bisection: the values of a row share a handful
+  // of exponents, so a histogram on this digit would serialise thousands of LDS atomics on a few
+  // bins.  Each step counts, for both ranks at once, the keys of the current bucket whose bit is
+  // 0 (two 16-bit counts packed into one block reduction; a row has at most 16384 keys).
+  for (int bit = 31; bit >= 24; --bit) {
+    const uint32_t hi_mask = bit == 31 ? 0u : ~((2u << bit) - 1u);
     const uint32_t b = 1u << bit;
-    uint32_t c0 = 0, c1 = 0;  // keys in the bucket whose `bit` is 0
-    for (uint32_t e = threadIdx.x; e < inner; e += kBlock) {
-      const uint32_t kk = keys[e];
-      c0 += ((kk & hi_mask) == pre0) & !(kk & b);
-      c1 += ((kk & hi_mask) == pre1) & !(kk & b);
+    uint32_t c0 = 0, c1 = 0;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const uint32_t kk = keys[k];
+      const bool zero_bit = valid[k] && !(kk & b);
+      c0 += zero_bit && (kk & hi_mask) == sel[0].prefix;
+      c1 += zero_bit && (kk & hi_mask) == sel[1].prefix;
     }
-    // pack the two counts (each <= 16384) into one reduction
     const uint32_t packed = block_reduce(c0 | (c1 << 16), SumU(), red);
     c0 = packed & 0xffffu;
     c1 = packed >> 16;
-    if (k0 > c0) { k0 -= c0; pre0 |= b; }
-    if (k1 > c1) { k1 -= c1; pre1 |= b; }
+    if (sel[0].k > c0) { sel[0].k -= c0; sel[0].prefix |= b; }
+    if (sel[1].k > c1) { sel[1].k -= c1; sel[1].prefix |= b; }
+  }
+  // Lower 24 bits: three 8-bit radix passes.  Only keys inside the chosen bucket take part and
+  // mantissa digits spread over the 256 bins, so the LDS atomics rarely collide.
+  for (int pass = 1; pass < 4; ++pass) {
+    const int shift = 24 - 8 * pass;
+    hist[0][threadIdx.x] = 0;
+    hist[1][threadIdx.x] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      if (!valid[k]) continue;
+      const uint32_t d = (keys[k] >> shift) & 0xffu;
+      const uint32_t hi = keys[k] >> (shift + 8);
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+        if (hi == (sel[s2].prefix >> (shift + 8))) atomicAdd(&hist[s2][d], 1u);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      const uint32_t c = hist[s2][threadIdx.x];
+      const uint32_t cum = block_scan_incl(c, wave_tot[s2]);
+      if (cum >= sel[s2].k && cum - c < sel[s2].k)  // exactly one lane: its bin holds the rank
+        pick[s2] = RowSel{sel[s2].prefix | (static_cast<uint32_t>(threadIdx.x) << shift), sel[s2].k - (cum - c)};
+    }
+    __syncthreads();
+    sel[0] = pick[0];
+    sel[1] = pick[1];
   }
   if (threadIdx.x == 0) {
-    min_out[row] = neg > 0 ? key_float(pre0) : 0.0f;
-    max_out[row] = pos > 0 ? key_float(pre1) : 0.0f;
+    min_out[row] = neg > 0 ? key_float(sel[0].prefix) : 0.0f;
+    max_out[row] = pos > 0 ? key_float(sel[1].prefix) : 0.0f;
   }
 }
 
@@ -288,17 +357,16 @@ int sbq_percentile_rows(const void* x, int x_dtype, int64_t C, int64_t inner, do
   if (inner > SBQ_ROWSEL_MAX || C >= (1ll << 31)) return SBQ_ERR_ARG;
   if (!(alpha >= 0.0 && alpha <= 1.0)) return SBQ_ERR_ARG;
   if (reinterpret_cast<uintptr_t>(x) % dtype_size(x_dtype)) return SBQ_ERR_ALIGN;
-  const bool vec = aligned16(x) && inner % kPack == 0;
-  const size_t lds = ((static_cast<size_t>(inner) + 3) & ~size_t(3)) * 4 + 2 * kWavesPerBlock * 4 + 16;
   hipStream_t st = as_stream(stream);
+  const uint32_t n = static_cast<uint32_t>(inner);
   int rc = dispatch_dtype(x_dtype, [&](auto tag) {
     using T = decltype(tag);
-    if (vec)
-      percentile_rows_kernel<T, true><<<static_cast<uint32_t>(C), kBlock, lds, st>>>(
-          x, static_cast<uint32_t>(inner), alpha, min_out, max_out);
-    else
-      percentile_rows_kernel<T, false><<<static_cast<uint32_t>(C), kBlock, lds, st>>>(
-          x, static_cast<uint32_t>(inner), alpha, min_out, max_out);
+#define SBQ_ROWS(KK) percentile_rows_kernel<T, KK><<<static_cast<uint32_t>(C), kBlock, 0, st>>>(x, n, alpha, min_out, max_out)
+    if (n <= 8u * kBlock) SBQ_ROWS(8);
+    else if (n <= 16u * kBlock) SBQ_ROWS(16);
+    else if (n <= 32u * kBlock) SBQ_ROWS(32);
+    else SBQ_ROWS(64);
+#undef SBQ_ROWS
   });
   if (rc != SBQ_OK) return rc;
   return check_launch();

@@ -267,10 +267,10 @@ __device__ __forceinline__ float dequant_level(float q, float s, float zp) {
 // (it is, for a faithful q1, as long as nothing underflows), then RN(q1 + r1*y) is the
 // correctly rounded quotient.  q0 alone may be 2 ulp off, hence the first refinement.
 // Range conditions are enforced by the caller: s in [2^-60, 2^60] (else the IEEE path is
-// taken for that row) and x clamped to +-s*2^40, which cannot change a result that is
-// clamped to [qmin, qmax] anyway but keeps every intermediate finite; for |x/s| < 1/4 the
-// residuals may underflow, which cannot move the quotient across 0.5.  NaN inputs are
-// restored by the caller.  tests/test_gpu_parity.py::test_fast_division_equals_ieee
+// taken for that row) and |x| < s*2^40 (NaN, inf or larger magnitudes send the whole wave's
+// pack through the IEEE path -- a wave-wide vote on one compare per element -- or, in
+// quant_level_fast, are clamped / restored per element); for |x/s| < 1/4 the residuals may
+// underflow, which cannot move the quotient across 0.5.  tests/test_gpu_parity.py::test_fast_division_equals_ieee
 // compares this against the IEEE path bit for bit on adversarial data.
 __device__ __forceinline__ bool fast_div_ok(float s) {
   return s >= 0x1p-60f && s <= 0x1p60f;  // false for NaN, subnormal, inf

@@ -214,10 +214,25 @@ __device__ __forceinline__ void finish_tile(void* __restrict__ y, void* __restri
     if (fast) {
       const float yr = 1.0f / s;
       const float bound = s * 0x1p40f;
+      // NaN, +-inf and |x| >= s * 2^40 leave the range in which the fma refinement is exact.
+      // One compare per element feeds a wave-wide vote; a wave that holds any such value
+      // (never, on real weights) redoes the pack with IEEE division instead of every element
+      // paying a clamp and a NaN restore.
+      bool odd = false;
 #pragma unroll
-      for (int j = 0; j < kPack; ++j) {
-        lv[j] = quant_level_fast(v[j], s, yr, bound, z, qlo, qhi);
-        dq[j] = dequant_level(lv[j], s, z);
+      for (int j = 0; j < kPack; ++j) odd |= !(__builtin_fabsf(v[j]) < bound);
+      if (__builtin_amdgcn_ballot_w64(odd) == 0) {
+#pragma unroll
+        for (int j = 0; j < kPack; ++j) {
+          lv[j] = __builtin_amdgcn_fmed3f(__builtin_rintf(fast_div(v[j], s, yr)) + z, qlo, qhi);
+          dq[j] = dequant_level(lv[j], s, z);
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < kPack; ++j) {
+          lv[j] = quant_level<SBQ_ROUND_HALF_EVEN>(v[j], s, z, qlo, qhi);
+          dq[j] = dequant_level(lv[j], s, z);
+        }
       }
     } else if constexpr (MATH == MATH_RCP) {
       const float yr = 1.0f / s;

@@ -39,8 +39,12 @@ __global__ __launch_bounds__(kBlock) void ste_backward_kernel(
   const float zp = __builtin_rintf(zero_point[cp.c]);
   float gs = 0.0f, gz = 0.0f;
 
-  auto one = [&](float xv, float gyv) -> float {
-    const float t = xv / s;
+  // the chunk's scale is block-uniform: exact quotient by reciprocal + two fma refinements
+  // (sbq_common.hpp: fast_div) whenever the scale and the element are in its range
+  const bool fast_s = fast_div_ok(s) && rounding == SBQ_ROUND_HALF_EVEN;
+  const float yr = fast_s ? 1.0f / s : 0.0f;
+  const float bound = s * 0x1p40f;
+  auto one_t = [&](float t, float gyv) -> float {  // t = x / s, correctly rounded
     float r;
     if (rounding == SBQ_ROUND_HALF_EVEN) r = __builtin_rintf(t);
     else if (rounding == SBQ_ROUND_HALF_UP) r = __builtin_floorf(t + 0.5f);
@@ -55,6 +59,7 @@ __global__ __launch_bounds__(kBlock) void ste_backward_kernel(
     gz += inside ? 0.0f : (-s * gyv);
     return inside ? gyv : 0.0f;
   };
+  auto one = [&](float xv, float gyv) -> float { return one_t(xv / s, gyv); };
 
   if constexpr (VEC) {
     const int64_t vend = cp.begin + ((cp.end - cp.begin) / kPack) * kPack;
@@ -63,8 +68,18 @@ __global__ __launch_bounds__(kBlock) void ste_backward_kernel(
       float xv[kPack], gv[kPack], o[kPack];
       load_pack<T, true>(x, cp.row_base + e, xv);
       load_pack<T, true>(gy, cp.row_base + e, gv);
+      // same wave-wide vote as the forward kernel: NaN / inf / huge inputs send the pack
+      // through IEEE division, everything else through the exact fma refinement
+      bool odd = false;
 #pragma unroll
-      for (int q = 0; q < kPack; ++q) o[q] = one(xv[q], gv[q]);
+      for (int q = 0; q < kPack; ++q) odd |= !(__builtin_fabsf(xv[q]) < bound);
+      if (fast_s && __builtin_amdgcn_ballot_w64(odd) == 0) {
+#pragma unroll
+        for (int q = 0; q < kPack; ++q) o[q] = one_t(fast_div(xv[q], s, yr), gv[q]);
+      } else {
+#pragma unroll
+        for (int q = 0; q < kPack; ++q) o[q] = one(xv[q], gv[q]);
+      }
       store_pack<Tg, true>(gx, cp.row_base + e, o);
     }
     for (int64_t e = vend + threadIdx.x; e < cp.end; e += kBlock) {

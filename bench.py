@@ -57,14 +57,21 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
     assert torch.cuda.is_available(), "bench.py measures the HIP path: it needs an MI355X"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # SBQ_BENCH_DEBUG_SINGLE_GPU=1: rehearse the N > 1 control flow on a one-GPU box (every rank on
+    # cuda:0, gloo instead of RCCL).  Never set by the driver; numbers from such a run mean nothing.
+    debug_one_gpu = os.environ.get("SBQ_BENCH_DEBUG_SINGLE_GPU") == "1"
+    dev_index = 0 if debug_one_gpu else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
 
     import torch.distributed as dist
 
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
+        if debug_one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
 
     from sparsebit_amd import dist as sbq_dist
     from sparsebit_amd import lib as L

@@ -189,6 +189,13 @@ int sbq_qparams_from_minmax(const float* min_val, const float* max_val, int64_t 
                             int qmin, int qmax, int symmetric,
                             float* scale_out, float* zero_point_out, void* stream);
 
+/* Wire format of the cross-GPU min/max exchange: ONE MAX all-reduce over
+ * buf[4C] = { max or -inf if NaN, -min or -inf if NaN, isnan(max), isnan(min) }.
+ * pack builds it from a rank's local statistics, unpack restores (min, max) with the NaNs
+ * (torch.min/max propagate NaN locally; a MAX collective's NaN behaviour is backend defined). */
+int sbq_minmax_pack(const float* min_val, const float* max_val, int64_t C, float* buf, void* stream);
+int sbq_minmax_unpack(const float* buf, int64_t C, float* min_out, float* max_out, void* stream);
+
 /* LSQ init: scale[c] = 2 * (abssum[c] / count) / sqrt(qmax)   (lsq.py:44-47) */
 int sbq_lsq_init_scale(const double* abssum, int64_t C, double count, int qmax,
                        float* scale_out, void* stream);

@@ -207,6 +207,27 @@ __global__ void aciq_kernel(const float* __restrict__ mn, const float* __restric
   min_out[i] = half_range ? 0.0f : -t;
 }
 
+__global__ void minmax_pack_kernel(const float* __restrict__ mn, const float* __restrict__ mx, int64_t C,
+                                   float* __restrict__ buf) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= C) return;
+  const float a = mx[i], b = mn[i];
+  const bool na = a != a, nb = b != b;
+  buf[i] = na ? -__builtin_inff() : a;
+  buf[C + i] = nb ? -__builtin_inff() : -b;
+  buf[2 * C + i] = na ? 1.0f : 0.0f;
+  buf[3 * C + i] = nb ? 1.0f : 0.0f;
+}
+
+__global__ void minmax_unpack_kernel(const float* __restrict__ buf, int64_t C, float* __restrict__ mn,
+                                     float* __restrict__ mx) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= C) return;
+  const float nan = __builtin_nanf("");
+  mx[i] = buf[2 * C + i] > 0.0f ? nan : buf[i];
+  mn[i] = buf[3 * C + i] > 0.0f ? nan : -buf[C + i];
+}
+
 // moving_average.py:23-31, one thread: the recurrence is sequential by definition
 __global__ void ema_minmax_kernel(const float* __restrict__ smin, const float* __restrict__ smax, int64_t n,
                                   float ratio, float one_minus, float* __restrict__ state, int has_state) {
@@ -607,6 +628,24 @@ int sbq_aciq_thresholds(const float* min_val, const float* max_val, const float*
   if (!min_out || !max_out || (!b && (!min_val || !max_val))) return SBQ_ERR_NULL;
   aciq_kernel<<<static_cast<uint32_t>(ceil_div(C, kBlock)), kBlock, 0, as_stream(stream)>>>(
       min_val, max_val, b, C, alpha, gaus_const, sqrt_2logn, half_range, min_out, max_out);
+  return check_launch();
+}
+
+int sbq_minmax_pack(const float* min_val, const float* max_val, int64_t C, float* buf, void* stream) {
+  using namespace sbq;
+  if (C < 0) return SBQ_ERR_ARG;
+  if (C == 0) return SBQ_ERR_EMPTY;
+  if (!min_val || !max_val || !buf) return SBQ_ERR_NULL;
+  minmax_pack_kernel<<<static_cast<uint32_t>(ceil_div(C, kBlock)), kBlock, 0, as_stream(stream)>>>(min_val, max_val, C, buf);
+  return check_launch();
+}
+
+int sbq_minmax_unpack(const float* buf, int64_t C, float* min_out, float* max_out, void* stream) {
+  using namespace sbq;
+  if (C < 0) return SBQ_ERR_ARG;
+  if (C == 0) return SBQ_ERR_EMPTY;
+  if (!buf || !min_out || !max_out) return SBQ_ERR_NULL;
+  minmax_unpack_kernel<<<static_cast<uint32_t>(ceil_div(C, kBlock)), kBlock, 0, as_stream(stream)>>>(buf, C, min_out, max_out);
   return check_launch();
 }
 

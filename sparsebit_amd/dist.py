@@ -61,6 +61,15 @@ def allreduce_minmax(min_val, max_val):
     behaviour is backend defined."""
     if not active():
         return min_val, max_val
+    if min_val.is_cuda:
+        # device statistics: one pack kernel, one collective, one unpack kernel
+        from . import ops
+
+        buf = ops.minmax_pack(min_val, max_val)
+        dist.all_reduce(buf, op=dist.ReduceOp.MAX, group=_group)
+        mn, mx = ops.minmax_unpack(buf, min_val.shape)
+        return mn.to(min_val.dtype), mx.to(max_val.dtype)
+    # host tensors (the gloo tests): the same wire format with torch ops
     n = min_val.numel()
     mx = max_val.reshape(-1).float()
     mn = min_val.reshape(-1).float()

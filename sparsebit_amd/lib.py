@@ -66,6 +66,8 @@ _SIGNATURES = {
     "sbq_channel_stats": (c_int, [c_vp, c_int, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "sbq_channel_moments": (c_int, [c_vp, c_int, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "sbq_aciq_thresholds": (c_int, [c_vp, c_vp, c_vp, c_i64, ctypes.c_float, ctypes.c_float, ctypes.c_float, c_int, c_vp, c_vp, c_vp]),
+    "sbq_minmax_pack": (c_int, [c_vp, c_vp, c_i64, c_vp, c_vp]),
+    "sbq_minmax_unpack": (c_int, [c_vp, c_i64, c_vp, c_vp, c_vp]),
     "sbq_ema_minmax": (c_int, [c_vp, c_vp, c_i64, ctypes.c_float, ctypes.c_float, c_vp, c_int, c_vp]),
     "sbq_qparams_from_minmax": (c_int, [c_vp, c_vp, c_i64, c_int, c_int, c_int, c_vp, c_vp, c_vp]),
     "sbq_lsq_init_scale": (c_int, [c_vp, c_i64, c_dbl, c_int, c_vp, c_vp]),

@@ -271,6 +271,30 @@ def aciq_thresholds(min_val, max_val, b, alpha, gaus_const, sqrt_2logn, half_ran
     return lo.reshape(shape), hi.reshape(shape)
 
 
+def minmax_pack(min_val, max_val):
+    """-> fp32 [4C] wire buffer of the min/max exchange (include/sbq.h: sbq_minmax_pack)."""
+    dev = L.require_device(min_val, max_val)
+    lib = L.load()
+    mn, mx = _f32c(min_val, dev), _f32c(max_val, dev)
+    buf = torch.empty(4 * mn.numel(), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.sbq_minmax_pack(L.ptr(mn), L.ptr(mx), mn.numel(), L.ptr(buf), L.stream_ptr(dev))
+    L.check(rc)
+    return buf
+
+
+def minmax_unpack(buf, shape):
+    dev = L.require_device(buf)
+    lib = L.load()
+    C = buf.numel() // 4
+    mn = torch.empty(C, dtype=torch.float32, device=dev)
+    mx = torch.empty(C, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.sbq_minmax_unpack(L.ptr(buf), C, L.ptr(mn), L.ptr(mx), L.stream_ptr(dev))
+    L.check(rc)
+    return mn.reshape(shape), mx.reshape(shape)
+
+
 def ema_minmax(sample_min, sample_max, ratio, state, has_state):
     """state[{min,max}] <- EMA over the samples, in order (moving_average.py:23-31)."""
     dev = L.require_device(sample_min, sample_max, state)

@@ -845,3 +845,15 @@ def test_config5_resnet50_qat_lsq_mask_shapes(oracle):
     unfused.sum().backward()
     assert w.grad is not None and q.scale.grad is not None
     assert bool((w.grad[~mask] == 0).all())  # pruned weights get no gradient through `w * mask`
+
+
+def test_minmax_wire_format_kernels(ops):
+    """pack -> (MAX over ranks) -> unpack keeps values and NaNs; two simulated ranks."""
+    a_mn = torch.tensor([-1.0, float("nan"), 0.5, -3.0], device="cuda")
+    a_mx = torch.tensor([2.0, 1.0, float("nan"), 4.0], device="cuda")
+    b_mn = torch.tensor([-2.0, 0.0, 0.25, float("-inf")], device="cuda")
+    b_mx = torch.tensor([1.0, 5.0, 7.0, float("inf")], device="cuda")
+    buf = torch.maximum(ops.minmax_pack(a_mn, a_mx), ops.minmax_pack(b_mn, b_mx))
+    mn, mx = ops.minmax_unpack(buf, a_mn.shape)
+    assert same_values(mn.cpu().numpy(), np.array([-2.0, np.nan, 0.25, -np.inf], np.float32))
+    assert same_values(mx.cpu().numpy(), np.array([2.0, 5.0, np.nan, np.inf], np.float32))

@@ -17,8 +17,8 @@
  *     LSQ's init (sparsebit/quantization/quantizers/lsq.py:32-51) and the
  *     unstructured L1 masker (sparsebit/sparse/sparsers/l1norm.py:14-26),
  *     which have no native form in the reference.
- *   - pybind module `cuda_kernel` vecquant4matmul / vecgroupquant4matmul
- *     (large_language_models/llama/quantization/cuda/cuda_kernel.cpp:6-23).
+ *   - pybind module `cuda_kernel` vecquant{4,3,2}matmul / vecgroupquant{4,3,2}matmul
+ *     (large_language_models/llama/quantization/cuda/cuda_kernel.cpp:6-62).
  *
  * Tensor geometry.  A contiguous tensor quantized along `ch_axis` is described
  * as [outer, C, inner]: C = shape[ch_axis], inner = prod(shape[ch_axis+1:]),
@@ -268,16 +268,37 @@ int sbq_mask_from_threshold(const void* x, int x_dtype, int64_t numel,
                             const float* thresh, uint8_t* mask_out, void* stream);
 
 /* ------------------------------------------------------------------ *
- * 5. GPTQ 4-bit grouped mat-vec (config 4)
- *    out[b,n] += sum_k (scales[n,g(k)] * nib(k,n) - zeros[n,g(k)]) * x[b,k]
- *    replaces vecquant4matmul_cuda (cuda_kernel_4bit.cu:36-180).
- *    qweight int32 [in/8, out] (8 input-channel nibbles per word, low first;
- *    quant.py:187-260), scales/zeros fp32 [out, groups], x fp32 [batch, in],
- *    out fp32 [batch, out] pre-filled with the bias (quant.py:285-289) and
- *    accumulated in place.  group_size 0 == one group (cuda_kernel.cpp:10-16).
+ * 5. GPTQ 4- / 3- / 2-bit grouped mat-vec (config 4)
+ *    out[b,n] += sum_k (scales[n,g(k)] * lvl(k,n) - zeros[n,g(k)]) * x[b,k]
+ *    replaces vecquant{4,3,2}matmul_cuda and their vecgroupquant* twins
+ *    (cuda_kernel.cpp:6-62; cuda_kernel_4bit.cu:36-180, cuda_kernel_3bit.cu:29-196,
+ *    cuda_kernel_2bit.cu:29-150).
+ *    qweight int32 [rows, out]: each column is a little-endian bit stream over the
+ *    rows with `bits` bits per input channel, as written by QuantLinear.pack
+ *    (quant.py:187-260) -- rows = ceil(in/8) (4-bit), ceil(in/16) (2-bit),
+ *    3*ceil(in/32) (3-bit: 32 levels per 3 words).  scales/zeros fp32 [out, groups],
+ *    x fp32 [batch, in], out fp32 [batch, out] pre-filled with the bias
+ *    (quant.py:285-289) and accumulated in place.  group_size 0 == one group
+ *    (cuda_kernel.cpp:10-16); otherwise a multiple of 128 (4-, 3-bit) or 64 (2-bit).
+ *    Deterministic: no float atomics, fixed summation order.
  * ------------------------------------------------------------------ */
+/* Workspace contract: its first SBQ_GPTQ_COUNTER_BYTES bytes are arrival counters of the
+ * single-launch K-split fold; they must be ZERO before the first call (allocate with
+ * hipMemset once), every call leaves them zero, and a workspace must not be shared by calls
+ * that can run concurrently (different streams). */
+#define SBQ_GPTQ_COUNTER_BYTES 262144
 size_t sbq_gptq_workspace_bytes(int64_t batch, int64_t in_features, int64_t out_features);
 int sbq_vecquant4matmul(const float* x, const int32_t* qweight, float* out,
+                        const float* scales, const float* zeros,
+                        int64_t batch, int64_t in_features, int64_t out_features,
+                        int64_t group_size,
+                        void* workspace, size_t workspace_bytes, void* stream);
+int sbq_vecquant3matmul(const float* x, const int32_t* qweight, float* out,
+                        const float* scales, const float* zeros,
+                        int64_t batch, int64_t in_features, int64_t out_features,
+                        int64_t group_size,
+                        void* workspace, size_t workspace_bytes, void* stream);
+int sbq_vecquant2matmul(const float* x, const int32_t* qweight, float* out,
                         const float* scales, const float* zeros,
                         int64_t batch, int64_t in_features, int64_t out_features,
                         int64_t group_size,

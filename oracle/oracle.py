@@ -49,8 +49,9 @@ def _load():
         lib.orc_l1_mask.restype = ctypes.c_float
         lib.orc_ste_backward.argtypes = [_f32p, _f32p, _i64, _i64, _i64, _f32p, _f32p, _int, _int, _f32p, _f32p, _f32p]
         lib.orc_vecquant4matmul.argtypes = [_f32p, _i32p, _f32p, _f32p, _f32p, _i64, _i64, _i64, _i64]
+        lib.orc_vecquantmatmul.argtypes = [ctypes.c_int, _f32p, _i32p, _f32p, _f32p, _f32p, _i64, _i64, _i64, _i64]
         for f in ("orc_qdq", "orc_mask_qdq", "orc_qparams_from_minmax", "orc_minmax", "orc_lsq_init_scale",
-                  "orc_mse", "orc_percentile", "orc_ste_backward", "orc_vecquant4matmul"):
+                  "orc_mse", "orc_percentile", "orc_ste_backward", "orc_vecquant4matmul", "orc_vecquantmatmul"):
             getattr(lib, f).restype = None
         _lib = lib
     return _lib
@@ -182,6 +183,11 @@ def ste_backward(x, gy, scale, zero_point, qmin, qmax, ch_axis=0):
 
 def vecquant4matmul(x, qweight, bias, scales, zeros, group_size):
     """y = bias + dequant(qweight) @ x ; x [B, in], qweight int32 [ceil(in/8), out]."""
+    return vecquantmatmul(x, qweight, bias, scales, zeros, group_size, 4)
+
+
+def vecquantmatmul(x, qweight, bias, scales, zeros, group_size, bits):
+    """y = bias + dequant(qweight) @ x for 4 / 3 / 2-bit packed weights; x [B, in], qweight int32 [rows, out]."""
     x = _f32(x)
     B, in_f = x.shape
     qw = np.ascontiguousarray(qweight, dtype=np.int32)
@@ -189,8 +195,8 @@ def vecquant4matmul(x, qweight, bias, scales, zeros, group_size):
     sc = _f32(scales).reshape(out_f, -1)
     zr = _f32(zeros).reshape(out_f, -1)
     out = np.ascontiguousarray(np.broadcast_to(_f32(bias), (B, out_f))).copy()
-    _load().orc_vecquant4matmul(_p(x, _f32p), _p(qw, _i32p), _p(out, _f32p), _p(sc, _f32p), _p(zr, _f32p),
-                                B, in_f, out_f, 0 if group_size in (-1, 0) else group_size)
+    _load().orc_vecquantmatmul(int(bits), _p(x, _f32p), _p(qw, _i32p), _p(out, _f32p), _p(sc, _f32p), _p(zr, _f32p),
+                               B, in_f, out_f, 0 if group_size in (-1, 0) else group_size)
     return out
 
 
@@ -226,6 +232,34 @@ def gptq_quantize(w, scale, zero, bit=4):
     z = zero[:, :, None].astype(np.float32)
     q = np.clip(np.rint(wg / s) + z, 0, maxq).astype(np.float32)
     return (s * (q - z)).reshape(out_f, in_f).astype(np.float32)
+
+
+def gptq_rows(in_f, bits):
+    """qweight rows for in_f input channels (QuantLinear.__init__, quant.py:171-183)."""
+    par = 3 if bits == 3 else 1
+    return -(-(in_f * bits) // (32 * par)) * par
+
+
+def gptq_pack(w_q, scale, zero, bits):
+    """QuantLinear.pack (quant.py:187-260) for 4 / 3 / 2 bits, restated as what its loop builds:
+    zeros' = zero*scale; intweight = round((w + zeros')/scale); every output column is one
+    little-endian bit stream over the rows, `bits` bits per input channel (for 3 bits the
+    reference's two split levels per 32 are the ones that straddle a word of that stream).
+    -> qweight int32 [rows, out], zeros' [out, groups]"""
+    out_f, in_f = w_q.shape
+    groups = scale.shape[1]
+    zeros_p = (zero * scale).astype(np.float32)
+    wg = _f32(w_q).reshape(out_f, groups, -1)
+    iw = np.rint((wg + zeros_p[:, :, None]) / scale[:, :, None]).astype(np.int64).reshape(out_f, in_f)
+    iw = iw.T.astype(np.uint64) & np.uint64(2 ** bits - 1)  # [in, out]
+    qw = np.zeros((gptq_rows(in_f, bits), out_f), dtype=np.uint64)
+    for j in range(in_f):
+        bit = bits * j
+        idx, sh = bit >> 5, bit & 31
+        qw[idx] |= (iw[j] << np.uint64(sh)) & np.uint64(0xFFFFFFFF)
+        if sh + bits > 32:
+            qw[idx + 1] |= iw[j] >> np.uint64(32 - sh)
+    return qw.astype(np.uint32).astype(np.int32), zeros_p
 
 
 def gptq_pack4(w_q, scale, zero):

@@ -295,28 +295,46 @@ ORC_API void orc_ste_backward(const float* x, const float* gy, int64_t outer, in
  * (large_language_models/llama/quantization/utils/quant.py:281-307,
  *  cuda/cuda_kernel_4bit.cu:88-180):
  *   out[b,n] += sum_k (scales[n,g]*nib(k,n) - zeros[n,g]) * x[b,k],  g = k / group_size
- * qweight int32 [ceil(in/8), out], 8 input-channel nibbles per word, low first
- * (QuantLinear.pack, quant.py:224-229); scales/zeros [out, groups]; `out`
- * pre-filled with the bias.  The reference accumulates fp32 with atomics in an
+ * qweight int32 [rows, out] (4-bit: 8 input-channel nibbles per word, low first,
+ * QuantLinear.pack, quant.py:224-229; 2- and 3-bit: see orc_stream_level);
+ * scales/zeros [out, groups]; `out` pre-filled with the bias.  The reference accumulates fp32 with atomics in an
  * unspecified order (its own test tolerance is 1e-5); the oracle accumulates in
  * fp64.
  * ------------------------------------------------------------------------ */
-ORC_API void orc_vecquant4matmul(const float* x, const int32_t* qweight, float* out, const float* scales,
-                                 const float* zeros, int64_t batch, int64_t in_features,
-                                 int64_t out_features, int64_t group_size) {
+/* level k of column n: bits [bits*k, bits*k + bits) of the column's little-endian bit stream
+ * over the qweight rows.  For 4 and 2 bits that is (word >> bits*(k % per_word)) & mask
+ * (cuda_kernel_4bit.cu:133-156, cuda_kernel_2bit.cu:139-143); for 3 bits it is the layout
+ * QuantLinear.pack builds with its two split levels per 32 (quant.py:230-257), which
+ * cuda_kernel_3bit.cu:126-189 unpicks word by word. */
+static uint32_t orc_stream_level(const int32_t* qweight, int64_t out_features, int64_t n, int bits, int64_t k) {
+  const int64_t bit = (int64_t)bits * k, idx = bit >> 5;
+  const int sh = (int)(bit & 31);
+  uint32_t v = (uint32_t)qweight[idx * out_features + n] >> sh;
+  if (sh + bits > 32) v |= (uint32_t)qweight[(idx + 1) * out_features + n] << (32 - sh);
+  return v & ((1u << bits) - 1u);
+}
+
+ORC_API void orc_vecquantmatmul(int bits, const float* x, const int32_t* qweight, float* out, const float* scales,
+                                const float* zeros, int64_t batch, int64_t in_features,
+                                int64_t out_features, int64_t group_size) {
   if (group_size == 0) group_size = in_features;
   const int64_t groups = (in_features + group_size - 1) / group_size;
   for (int64_t b = 0; b < batch; ++b) {
     for (int64_t n = 0; n < out_features; ++n) {
       double acc = 0.0;
       for (int64_t k = 0; k < in_features; ++k) {
-        const uint32_t word = (uint32_t)qweight[(k / 8) * out_features + n];
-        const float nib = (float)((word >> (4 * (k % 8))) & 0xfu);
+        const float lvl = (float)orc_stream_level(qweight, out_features, n, bits, k);
         const int64_t g = k / group_size;
-        const float w = scales[n * groups + g] * nib - zeros[n * groups + g];
+        const float w = scales[n * groups + g] * lvl - zeros[n * groups + g];
         acc += (double)w * (double)x[b * in_features + k];
       }
       out[b * out_features + n] = (float)((double)out[b * out_features + n] + acc);
     }
   }
+}
+
+ORC_API void orc_vecquant4matmul(const float* x, const int32_t* qweight, float* out, const float* scales,
+                                 const float* zeros, int64_t batch, int64_t in_features,
+                                 int64_t out_features, int64_t group_size) {
+  orc_vecquantmatmul(4, x, qweight, out, scales, zeros, batch, in_features, out_features, group_size);
 }

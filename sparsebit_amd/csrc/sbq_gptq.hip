@@ -1,11 +1,15 @@
-// sbq_gptq.hip -- GPTQ 4-bit (grouped) weight mat-vec for gfx950.
+// sbq_gptq.hip -- GPTQ 4- / 3- / 2-bit (grouped) weight mat-vec for gfx950.
 //
-// Replaces VecQuant4MatMulKernel / vecquant4matmul_cuda
-// (large_language_models/llama/quantization/cuda/cuda_kernel_4bit.cu:36-180):
-//   out[b,n] += sum_k (scales[n,g(k)] * nib(k,n) - zeros[n,g(k)]) * x[b,k]
-// with qweight int32 [ceil(in/8), out] holding 8 consecutive input-channel
-// nibbles per word, low nibble first (QuantLinear.pack, utils/quant.py:187-260),
-// scales / zeros fp32 [out, groups] and `out` pre-filled with the bias.
+// Replaces VecQuant{4,3,2}MatMulKernel / vecquant{4,3,2}matmul_cuda
+// (large_language_models/llama/quantization/cuda/cuda_kernel_4bit.cu:36-180,
+//  cuda_kernel_3bit.cu:29-196, cuda_kernel_2bit.cu:29-150):
+//   out[b,n] += sum_k (scales[n,g(k)] * lvl(k,n) - zeros[n,g(k)]) * x[b,k]
+// with qweight int32 [rows, out], scales / zeros fp32 [out, groups] and `out`
+// pre-filled with the bias.  QuantLinear.pack (utils/quant.py:187-260) lays a column's
+// levels out as ONE little-endian bit stream over its rows, BITS bits per input channel:
+// 8 nibbles per word (4-bit), 16 crumbs per word (2-bit), and for 3-bit 32 levels per three
+// words -- its "<< 30 / >> 2 & 1" and "<< 31 / >> 1 & 3" split cases are exactly the two
+// levels of a 96-bit stream that straddle a word boundary.  lvl(k) = bits [BITS*k, BITS*k+BITS).
 //
 // The op is a weight stream (8.4 MB for 4096x4096, ~3.5 flop/byte): HBM/latency
 // bound, no MFMA.  Design:
@@ -24,8 +28,18 @@
 namespace sbq {
 namespace {
 
-constexpr int kSliceRows = 16;            // qweight rows per K slice
-constexpr int kSliceK = kSliceRows * 8;   // 128 input channels
+constexpr int kSliceK = 128;  // input channels per K slice (64 only for 2-bit with 64-channel groups)
+
+// level k of a column whose stream words are w[0..]: all indices are compile-time constants
+// at every call site (fully unrolled), so this is a v_bfe_u32 (plus one v_alignbit for the two
+// straddling 3-bit levels of every 32)
+template <int BITS, typename W>
+__device__ __forceinline__ uint32_t stream_level(const W& w, int k) {
+  const int bit = BITS * k, idx = bit >> 5, sh = bit & 31;
+  uint32_t v = w(idx) >> sh;
+  if (sh + BITS > 32) v |= w(idx + 1) << (32 - sh);
+  return v & ((1u << BITS) - 1u);
+}
 
 struct GptqGeom {
   int64_t in_features, out_features, batch;
@@ -39,11 +53,19 @@ struct GptqGeom {
 
 // COLS = 4: 16-byte loads (out_features % 4 == 0, aligned); COLS = 1: any shape.
 // kBT: batch rows per register tile -- a mat-VEC (batch 1) must not pay 8 FMAs per weight.
-template <int COLS, int kBT>
-__global__ __launch_bounds__(kBlock) void gptq4_partial_kernel(
+// A slice of SK channels is SK*BITS/32 stream words; a wave owns whole "units" of the slice
+// (a unit = the fewest words holding whole levels: 1 word, or 3 for 3-bit).
+template <int BITS, int SK, int COLS, int kBT>
+__global__ __launch_bounds__(kBlock) void gptq_partial_kernel(
     const float* __restrict__ x, const int32_t* __restrict__ qw, const float* __restrict__ scales,
     const float* __restrict__ zeros, float* __restrict__ part, const GptqGeom g) {
-  __shared__ __attribute__((aligned(16))) float xs[kBT][kSliceK];
+  constexpr int kUnitRows = BITS == 3 ? 3 : 1;
+  constexpr int kUnitCh = 32 * kUnitRows / BITS;   // 8 / 32 / 16 channels
+  constexpr int kUnits = SK / kUnitCh;             // per slice
+  constexpr int kUPW = kUnits / kWavesPerBlock;    // units per wave
+  constexpr int kSliceRows = SK * BITS / 32;
+  static_assert(kUnits % kWavesPerBlock == 0 && kUPW >= 1, "slice must split evenly over the waves");
+  __shared__ __attribute__((aligned(16))) float xs[kBT][SK];
   __shared__ float red[kWavesPerBlock][kBT][kWave * COLS];
   const int lane = threadIdx.x & (kWave - 1);
   const int wid = threadIdx.x / kWave;
@@ -60,23 +82,25 @@ __global__ __launch_bounds__(kBlock) void gptq4_partial_kernel(
 
     for (int sl = kb * g.slices_per_block; sl < (kb + 1) * g.slices_per_block && sl < g.slices; ++sl) {
       const int row0 = sl * kSliceRows;
-      const int64_t k0 = static_cast<int64_t>(row0) * 8;
-      // this wave's rows of the slice: row0 + wid, +4, +8, +12 -- request them all first
-      uint32_t w[kSliceRows / kWavesPerBlock][COLS];
+      const int64_t k0 = static_cast<int64_t>(sl) * SK;
+      // this wave's units of the slice: wid, wid + 4, ... -- request all their words first
+      uint32_t w[kUPW][kUnitRows][COLS];
 #pragma unroll
-      for (int i = 0; i < kSliceRows / kWavesPerBlock; ++i) {
-        const int r = row0 + wid + i * kWavesPerBlock;
-        const bool ok = col_ok && r < g.H;
-        if constexpr (COLS == 4) {
-          u32x4 t = {0, 0, 0, 0};
-          if (ok) t = ld16<true>(qw + static_cast<int64_t>(r) * g.out_features + col0);
+      for (int i = 0; i < kUPW; ++i)
 #pragma unroll
-          for (int j = 0; j < 4; ++j) w[i][j] = t[j];
-        } else {
-          w[i][0] = ok ? static_cast<uint32_t>(__builtin_nontemporal_load(qw + static_cast<int64_t>(r) * g.out_features + col0)) : 0u;
+        for (int rr = 0; rr < kUnitRows; ++rr) {
+          const int r = row0 + (wid + i * kWavesPerBlock) * kUnitRows + rr;
+          const bool ok = col_ok && r < g.H;
+          if constexpr (COLS == 4) {
+            u32x4 t = {0, 0, 0, 0};
+            if (ok) t = ld16<true>(qw + static_cast<int64_t>(r) * g.out_features + col0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) w[i][rr][j] = t[j];
+          } else {
+            w[i][rr][0] = ok ? static_cast<uint32_t>(__builtin_nontemporal_load(qw + static_cast<int64_t>(r) * g.out_features + col0)) : 0u;
+          }
         }
-      }
-      // quantization group of this slice (group_size % 128 == 0, so it is unique)
+      // quantization group of this slice (group_size % SK == 0, so it is unique)
       const int grp = static_cast<int>(k0 / g.group_size);
       float sc[COLS], zr[COLS];
 #pragma unroll
@@ -87,17 +111,17 @@ __global__ __launch_bounds__(kBlock) void gptq4_partial_kernel(
       }
       // activations of the slice -> LDS (zero beyond in_features / batch)
       __syncthreads();
-      for (int i = threadIdx.x; i < kBT * kSliceK; i += kBlock) {
-        const int b = i / kSliceK, kk = i - b * kSliceK;
+      for (int i = threadIdx.x; i < kBT * SK; i += kBlock) {
+        const int b = i / SK, kk = i - b * SK;
         const int64_t k = k0 + kk;
         xs[b][kk] = (b0 + b < g.batch && k < g.in_features) ? x[(b0 + b) * g.in_features + k] : 0.0f;
       }
       __syncthreads();
 #pragma unroll
-      for (int i = 0; i < kSliceRows / kWavesPerBlock; ++i) {
-        const int kk0 = (wid + i * kWavesPerBlock) * 8;
+      for (int i = 0; i < kUPW; ++i) {
+        const int kk0 = (wid + i * kWavesPerBlock) * kUnitCh;
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int h = 0; h < kUnitCh / 4; ++h) {
           f32x4 xv[kBT];
 #pragma unroll
           for (int b = 0; b < kBT; ++b) xv[b] = *reinterpret_cast<const f32x4*>(&xs[b][kk0 + 4 * h]);
@@ -105,8 +129,9 @@ __global__ __launch_bounds__(kBlock) void gptq4_partial_kernel(
           for (int j = 0; j < COLS; ++j) {
 #pragma unroll
             for (int n = 0; n < 4; ++n) {
-              const float nib = static_cast<float>((w[i][j] >> (4 * (4 * h + n))) & 0xfu);
-              const float wt = __builtin_fmaf(sc[j], nib, -zr[j]);
+              const float lvl = static_cast<float>(
+                  stream_level<BITS>([&](int idx) { return w[i][idx][j]; }, 4 * h + n));
+              const float wt = __builtin_fmaf(sc[j], lvl, -zr[j]);
 #pragma unroll
               for (int b = 0; b < kBT; ++b) acc[j][b] = __builtin_fmaf(wt, xv[b][n], acc[j][b]);
             }
@@ -133,32 +158,65 @@ __global__ __launch_bounds__(kBlock) void gptq4_partial_kernel(
 }
 
 // ---- single-launch "strip" kernel (mat-VEC: batch 1 or 2) --------------------------------
-// For decode-sized batches no cross-workgroup reduction is needed at all: a workgroup owns a
-// 32-column strip of the output for ALL of K.  Its 256 lanes form an 8 (column quads) x 32
-// (K lanes) grid; a K lane takes 16 consecutive qweight rows = 128 input channels = exactly
-// one quantization group, so scale / zero are loaded once per lane, all 16 of its 16-byte
-// weight words are requested back to back (256 B per lane in flight; a wave's load covers
-// full 128-byte lines of 8 rows), and the dequantization factors out of the inner loop:
-//     sum_k (s*nib_k - z) * x_k  =  s * sum_k nib_k*x_k  -  z * sum_k x_k
+// A workgroup owns a 32-column strip of the output for a block of K.  Its lanes form an
+// 8 (column quads) x KL (K lanes) grid; a K lane takes CH = 128 or 64 consecutive input channels
+// (CH*BITS/32 qweight rows) inside one quantization group, so scale / zero are loaded once per lane, all
+// of its 16-byte weight words are requested back to back (up to 256 B per lane in flight; a
+// wave's load covers full 128-byte lines of 8 rows), and the dequantization factors out of the
+// inner loop:
+//     sum_k (s*lvl_k - z) * x_k  =  s * sum_k lvl_k*x_k  -  z * sum_k x_k
 // (one convert + one fma per weight instead of two fmas; sum_k x_k is shared by the lane's 4
-// columns).  The activations of a pass (4096 floats per batch row) are staged in LDS with a
+// columns).  The activations of a pass (KL*128 floats per batch row) are staged in LDS with a
 // 4-float skew per K lane so that the broadcast ds_read_b128 of the 8 K lanes of a wave hit
-// different banks.  The 32 K lanes are folded through LDS in a fixed order and the strip is
-// written once: one kernel, deterministic, no atomics, no partial-tile traffic.
+// different banks.
+// A mat-vec is a latency problem before it is a bandwidth problem (9.4 MB for 4096x4096 is
+// 1.2 us of HBM time): what matters is that the WHOLE weight matrix is in flight at once on
+// all 256 CUs.  So CH and the K split S = gridDim.y are chosen per shape to put a few workgroups
+// on every CU, each of which issues every one of its loads before it waits for any.
+// Cross-workgroup fold without atomics on floats and without a second launch: every workgroup
+// writes its 32-column partial, then bumps the strip's arrival counter; whichever workgroup
+// arrives last adds the S partials IN INDEX ORDER (so the sum does not depend on who was last)
+// and resets the counter.  One kernel, deterministic, nobody ever waits on another workgroup.
 constexpr int kStripCols = 32;
-constexpr int kStripKLanes = kBlock / (kStripCols / 4);       // 32
-constexpr int kStripRowsPerPass = kStripKLanes * kSliceRows;  // 512 qweight rows = 4096 channels
-constexpr int kStripXStride = kSliceK + 4;                    // skewed LDS row of one K lane
+constexpr int kStripMaxSplit = 16;          // upper bound of the K split S
+constexpr size_t kCounterBytes = SBQ_GPTQ_COUNTER_BYTES;  // fixed region at the head of the workspace
+constexpr int64_t kMaxStrips = static_cast<int64_t>(kCounterBytes / sizeof(uint32_t));
 
-template <int kBT>
-__global__ __launch_bounds__(kBlock) void gptq4_strip_kernel(
+// level k (0..127) of column j of a K lane's words as a float.  4- and 2-bit levels never
+// straddle a word: mask them into byte lanes first so that the convert is v_cvt_f32_ubyteN
+// (the masks are shared by all levels of a word after unrolling).
+template <int BITS, int ROWS>
+__device__ __forceinline__ float strip_level(const u32x4 (&w)[ROWS], int j, int k) {
+  if constexpr (BITS == 4) {
+    const uint32_t word = w[k >> 3][j];
+    const uint32_t src = (k & 1) ? (word >> 4) & 0x0f0f0f0fu : word & 0x0f0f0f0fu;
+    return static_cast<float>((src >> (8 * ((k & 7) >> 1))) & 0xffu);
+  } else if constexpr (BITS == 2) {
+    const uint32_t word = w[k >> 4][j];
+    const uint32_t src = (word >> (2 * (k & 3))) & 0x03030303u;  // crumbs s, s+4, s+8, s+12
+    return static_cast<float>((src >> (8 * ((k & 15) >> 2))) & 0xffu);
+  } else {
+    return static_cast<float>(stream_level<BITS>([&](int idx) { return w[idx][j]; }, k));
+  }
+}
+
+template <int BITS, int kBT, int KL, int CH>
+__global__ __launch_bounds__(8 * KL) void gptq_strip_kernel(
     const float* __restrict__ x, const int32_t* __restrict__ qw, const float* __restrict__ scales,
-    const float* __restrict__ zeros, float* __restrict__ out, const GptqGeom g) {
-  __shared__ __attribute__((aligned(16))) float xs[kBT][kStripKLanes * kStripXStride];
-  __shared__ float red[kStripKLanes][kBT][kStripCols + 1];
+    const float* __restrict__ zeros, float* __restrict__ out, float* __restrict__ part,
+    uint32_t* __restrict__ arrivals, const GptqGeom g) {
+  constexpr int kThreads = 8 * KL;
+  constexpr int kRows = CH * BITS / 32;       // qweight rows of one K lane: 16 / 12 / 8 for CH = 128
+  constexpr int kRowsPerPass = KL * kRows;    // = KL * CH input channels
+  constexpr int kXLoads = (KL * CH) / (kThreads * 4);  // 16-byte x loads per thread per pass
+  constexpr int kXStride = CH + 4;            // skewed LDS row of one K lane
+  __shared__ __attribute__((aligned(16))) float xs[kBT][KL * kXStride];
+  __shared__ float red[KL][kBT][kStripCols + 1];
+  __shared__ uint32_t s_prev;
   const int cl = threadIdx.x & 7;   // column quad inside the strip
   const int kl = threadIdx.x >> 3;  // K lane
   const int64_t col0 = static_cast<int64_t>(blockIdx.x) * kStripCols + cl * 4;
+  const int split = gridDim.y;
   // 16-byte loads of x need aligned rows
   const bool x_vec = (reinterpret_cast<uintptr_t>(x) & 15u) == 0 && (g.in_features & 3) == 0;
 
@@ -168,18 +226,20 @@ __global__ __launch_bounds__(kBlock) void gptq4_strip_kernel(
 #pragma unroll
     for (int b = 0; b < kBT; ++b) acc[j][b] = 0.0f;
 
-  for (int pass0 = 0; pass0 < g.H; pass0 += kStripRowsPerPass) {
-    const int row0 = pass0 + kl * kSliceRows;
+  // passes y, y + S, y + 2S, ... of the K dimension
+  for (int64_t pass0 = static_cast<int64_t>(blockIdx.y) * kRowsPerPass; pass0 < g.H;
+       pass0 += static_cast<int64_t>(split) * kRowsPerPass) {
+    const int64_t row0 = pass0 + kl * kRows;
     const bool live = row0 < g.H;
     // every global load of the pass is issued before anything waits: this lane's share of the
-    // activations (4 x 16 bytes per batch row, coalesced), its 16 weight words, its scale / zero
-    const int64_t kbase = static_cast<int64_t>(pass0) * 8;
-    f32x4 xg[kBT][4];
+    // activations (4 x 16 bytes per batch row, coalesced), its weight words, its scale / zero
+    const int64_t kbase = (pass0 / kRows) * CH;
+    f32x4 xg[kBT][kXLoads];
 #pragma unroll
     for (int b = 0; b < kBT; ++b)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int e = (j * kBlock + threadIdx.x) * 4;  // element of the pass, multiple of 4
+      for (int j = 0; j < kXLoads; ++j) {
+        const int e = (j * kThreads + threadIdx.x) * 4;  // element of the pass, multiple of 4
         const int64_t k = kbase + e;
         xg[b][j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
         if (b < g.batch) {
@@ -193,14 +253,14 @@ __global__ __launch_bounds__(kBlock) void gptq4_strip_kernel(
           }
         }
       }
-    u32x4 w[kSliceRows];
+    u32x4 w[kRows];
 #pragma unroll
-    for (int i = 0; i < kSliceRows; ++i) {
-      const int r = row0 + i;
+    for (int i = 0; i < kRows; ++i) {
+      const int64_t r = row0 + i;
       w[i] = u32x4{0, 0, 0, 0};
-      if (live && r < g.H) w[i] = ld16<true>(qw + static_cast<int64_t>(r) * g.out_features + col0);
+      if (live && r < g.H) w[i] = ld16<true>(qw + r * g.out_features + col0);
     }
-    const int64_t k0 = static_cast<int64_t>(row0) * 8;
+    const int64_t k0 = kbase + static_cast<int64_t>(kl) * CH;
     float sc[4] = {0, 0, 0, 0}, zr[4] = {0, 0, 0, 0};
     if (live) {
       const int grp = static_cast<int>(k0 / g.group_size);
@@ -214,10 +274,10 @@ __global__ __launch_bounds__(kBlock) void gptq4_strip_kernel(
 #pragma unroll
     for (int b = 0; b < kBT; ++b)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int e = (j * kBlock + threadIdx.x) * 4;
-        const int lane_k = e / kSliceK, off = e - lane_k * kSliceK;
-        *reinterpret_cast<f32x4*>(&xs[b][lane_k * kStripXStride + off]) = xg[b][j];
+      for (int j = 0; j < kXLoads; ++j) {
+        const int e = (j * kThreads + threadIdx.x) * 4;
+        const int lane_k = e / CH, off = e - lane_k * CH;
+        *reinterpret_cast<f32x4*>(&xs[b][lane_k * kXStride + off]) = xg[b][j];
       }
     __syncthreads();
     if (live) {
@@ -229,11 +289,11 @@ __global__ __launch_bounds__(kBlock) void gptq4_strip_kernel(
         for (int j = 0; j < 4; ++j) dot[j][b] = 0.0f;
       }
 #pragma unroll
-      for (int i = 0; i < kSliceRows; ++i) {
+      for (int i = 0; i < CH / 8; ++i) {  // 8 channels at a time
         f32x4 xv[kBT][2];
 #pragma unroll
         for (int b = 0; b < kBT; ++b) {
-          const float* xr = &xs[b][kl * kStripXStride + i * 8];
+          const float* xr = &xs[b][kl * kXStride + i * 8];
           xv[b][0] = *reinterpret_cast<const f32x4*>(xr);
           xv[b][1] = *reinterpret_cast<const f32x4*>(xr + 4);
 #pragma unroll
@@ -241,15 +301,11 @@ __global__ __launch_bounds__(kBlock) void gptq4_strip_kernel(
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const uint32_t word = w[i][j];
-          const uint32_t even = word & 0x0f0f0f0fu;         // nibbles 0,2,4,6 as bytes
-          const uint32_t odd = (word >> 4) & 0x0f0f0f0fu;   // nibbles 1,3,5,7 as bytes
 #pragma unroll
           for (int n = 0; n < 8; ++n) {
-            const uint32_t src = (n & 1) ? odd : even;
-            const float nib = static_cast<float>((src >> (8 * (n >> 1))) & 0xffu);  // v_cvt_f32_ubyteN
+            const float lvl = strip_level<BITS, kRows>(w, j, i * 8 + n);
 #pragma unroll
-            for (int b = 0; b < kBT; ++b) dot[j][b] = __builtin_fmaf(nib, xv[b][n >> 2][n & 3], dot[j][b]);
+            for (int b = 0; b < kBT; ++b) dot[j][b] = __builtin_fmaf(lvl, xv[b][n >> 2][n & 3], dot[j][b]);
           }
         }
       }
@@ -259,25 +315,55 @@ __global__ __launch_bounds__(kBlock) void gptq4_strip_kernel(
         for (int b = 0; b < kBT; ++b) acc[j][b] += __builtin_fmaf(sc[j], dot[j][b], -(zr[j] * xsum[b]));
     }
   }
-  // fold the 32 K lanes in ascending order, add to out (pre-filled with the bias)
+  // fold the K lanes in ascending order
 #pragma unroll
   for (int b = 0; b < kBT; ++b)
 #pragma unroll
     for (int j = 0; j < 4; ++j) red[kl][b][cl * 4 + j] = acc[j][b];
   __syncthreads();
-  for (int i = threadIdx.x; i < kBT * kStripCols; i += kBlock) {
-    const int b = i / kStripCols, cc = i - b * kStripCols;
-    if (b < g.batch) {
-      float t = 0.0f;
+  const bool owner = threadIdx.x < kBT * kStripCols;  // one thread per (batch row, column)
+  const int ob = threadIdx.x / kStripCols, occ = threadIdx.x - ob * kStripCols;
+  const int64_t ocol = static_cast<int64_t>(blockIdx.x) * kStripCols + occ;
+  float t = 0.0f;
+  if (owner) {
 #pragma unroll
-      for (int q = 0; q < kStripKLanes; ++q) t += red[q][b][cc];
-      out[b * g.out_features + static_cast<int64_t>(blockIdx.x) * kStripCols + cc] += t;
-    }
+    for (int q = 0; q < KL; ++q) t += red[q][ob][occ];
   }
+  if (split == 1) {  // this workgroup saw all of K: add to out (pre-filled with the bias)
+    if (owner && ob < g.batch) out[ob * g.out_features + ocol] += t;
+    return;
+  }
+  // publish the partial, count the arrival; the last one folds all S partials in index order.
+  // No agent-scope fence anywhere: on gfx950 such a fence writes back / invalidates the whole
+  // per-XCD L2 (measured: +15..35 us per launch with ~1000 workgroups doing it).  Instead every
+  // access of the protocol individually goes to the device-coherent level -- agent-scope atomic
+  // store / load / add carry sc1 and bypass the non-coherent L2 -- and the only ordering needed
+  // is "my partial stores are acknowledged before my arrival is counted": s_waitcnt vmcnt(0)
+  // (a workgroup-scope release fence) + the barrier.  The fold's loads depend on the counter
+  // value through LDS and the barrier, so they are issued after the add has returned.
+  if (owner && ob < g.batch)
+    __hip_atomic_store(&part[(static_cast<int64_t>(blockIdx.y) * g.batch + ob) * g.out_features + ocol], t,
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_s_waitcnt(0);  // belt and braces: all counters drained
+  __syncthreads();
+  if (threadIdx.x == 0)
+    s_prev = __hip_atomic_fetch_add(&arrivals[blockIdx.x], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  if (s_prev != static_cast<uint32_t>(split - 1)) return;
+  if (owner && ob < g.batch) {
+    float total = 0.0f;
+    for (int sidx = 0; sidx < split; ++sidx)
+      total += __hip_atomic_load(&part[(static_cast<int64_t>(sidx) * g.batch + ob) * g.out_features + ocol],
+                                 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    out[ob * g.out_features + ocol] += total;
+  }
+  if (threadIdx.x == 0)  // leave the counter as we found it: the workspace stays reusable
+    __hip_atomic_store(&arrivals[blockIdx.x], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // out[b,n] += sum over K blocks, ascending
-__global__ __launch_bounds__(kBlock) void gptq4_fold_kernel(const float* __restrict__ part,
+__global__ __launch_bounds__(kBlock) void gptq_fold_kernel(const float* __restrict__ part,
                                                             float* __restrict__ out, int64_t bn,
                                                             int kblocks) {
   const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
@@ -287,7 +373,13 @@ __global__ __launch_bounds__(kBlock) void gptq4_fold_kernel(const float* __restr
   out[i] += t;
 }
 
-bool gptq_geom(int64_t batch, int64_t in_f, int64_t out_f, int64_t group_size, GptqGeom& g) {
+// rows of qweight for `in_f` input channels (QuantLinear.__init__, quant.py:171-183)
+int64_t gptq_rows(int bits, int64_t in_f) {
+  return bits == 3 ? ceil_div(in_f, 32) * 3 : ceil_div(in_f * bits, 32);
+}
+
+bool gptq_geom(int bits, int slice_k, int64_t batch, int64_t in_f, int64_t out_f, int64_t group_size,
+               GptqGeom& g) {
   if (batch <= 0 || in_f <= 0 || out_f <= 0) return false;
   if (in_f >= (1ll << 31) || out_f >= (1ll << 31)) return false;
   if (group_size == 0) group_size = in_f;
@@ -295,10 +387,10 @@ bool gptq_geom(int64_t batch, int64_t in_f, int64_t out_f, int64_t group_size, G
   g.in_features = in_f;
   g.out_features = out_f;
   g.batch = batch;
-  g.H = static_cast<int32_t>(ceil_div(in_f, 8));
+  g.H = static_cast<int32_t>(gptq_rows(bits, in_f));
   g.group_size = static_cast<int32_t>(group_size);
   g.groups = static_cast<int32_t>(ceil_div(in_f, group_size));
-  g.slices = static_cast<int32_t>(ceil_div(g.H, kSliceRows));
+  g.slices = static_cast<int32_t>(ceil_div(in_f, slice_k));
   // enough workgroups to fill 256 CUs a few times over, but not more K blocks than
   // that needs: each K block costs batch*out floats of partial traffic
   const int64_t colblocks = ceil_div(out_f, kWave * 4);
@@ -310,6 +402,97 @@ bool gptq_geom(int64_t batch, int64_t in_f, int64_t out_f, int64_t group_size, G
   return true;
 }
 
+// upper bound of kblocks over every bit width / slice size (the workspace query does not
+// take the bit width)
+int64_t gptq_max_kblocks(int64_t in_f, int64_t out_f) {
+  const int64_t colblocks = ceil_div(out_f, kWave * 4);
+  int64_t want = ceil_div(1024, colblocks);
+  const int64_t slices = ceil_div(in_f, 64);
+  if (want > slices) want = slices;
+  return want < 1 ? 1 : want;
+}
+
+template <int BITS, int SK>
+int gptq_launch_partial(const float* x, const int32_t* qweight, float* out, const float* scales,
+                        const float* zeros, float* part, const GptqGeom& g, bool vec, hipStream_t st) {
+  const int64_t batch = g.batch;
+  const int bt = batch >= 8 ? 8 : (batch >= 3 ? 4 : (batch == 2 ? 2 : 1));
+#define SBQ_GPTQ(COLS)                                                                              \
+  do {                                                                                              \
+    dim3 grid(static_cast<uint32_t>(ceil_div(g.out_features, kWave * COLS)), static_cast<uint32_t>(g.kblocks)); \
+    if (bt == 8) gptq_partial_kernel<BITS, SK, COLS, 8><<<grid, kBlock, 0, st>>>(x, qweight, scales, zeros, part, g); \
+    else if (bt == 4) gptq_partial_kernel<BITS, SK, COLS, 4><<<grid, kBlock, 0, st>>>(x, qweight, scales, zeros, part, g); \
+    else if (bt == 2) gptq_partial_kernel<BITS, SK, COLS, 2><<<grid, kBlock, 0, st>>>(x, qweight, scales, zeros, part, g); \
+    else gptq_partial_kernel<BITS, SK, COLS, 1><<<grid, kBlock, 0, st>>>(x, qweight, scales, zeros, part, g);  \
+  } while (0)
+  if (vec) SBQ_GPTQ(4);
+  else SBQ_GPTQ(1);
+#undef SBQ_GPTQ
+  int rc = check_launch();
+  if (rc != SBQ_OK) return rc;
+  const int64_t bn = batch * g.out_features;
+  gptq_fold_kernel<<<static_cast<uint32_t>(ceil_div(bn, kBlock)), kBlock, 0, st>>>(part, out, bn, g.kblocks);
+  return check_launch();
+}
+
+template <int BITS>
+int gptq_matmul(const float* x, const int32_t* qweight, float* out, const float* scales,
+                const float* zeros, int64_t batch, int64_t in_features, int64_t out_features,
+                int64_t group_size, void* workspace, size_t workspace_bytes, void* stream) {
+  if (batch < 0 || in_features < 0 || out_features < 0) return SBQ_ERR_ARG;
+  if (batch == 0 || in_features == 0 || out_features == 0) return SBQ_ERR_EMPTY;
+  if (!x || !qweight || !out || !scales || !zeros || !workspace) return SBQ_ERR_NULL;
+  // cuda_kernel_4bit.cu:58-61, cuda_kernel_3bit.cu:56-59: group size must be a multiple of 128
+  // (0 = one group); cuda_kernel_2bit.cu:56-59: of 64
+  constexpr int kMinGroup = BITS == 2 ? 64 : 128;
+  if (group_size != 0 && group_size % kMinGroup != 0) return SBQ_ERR_ARG;
+  const bool half_slices = group_size % kSliceK != 0;  // 2-bit with 64-channel group granularity
+  GptqGeom g;
+  if (!gptq_geom(BITS, half_slices ? 64 : kSliceK, batch, in_features, out_features, group_size, g))
+    return SBQ_ERR_ARG;
+  const int64_t tiles = g.kblocks > kStripMaxSplit ? g.kblocks : kStripMaxSplit;
+  const size_t need = kCounterBytes + static_cast<size_t>(tiles) * batch * out_features * sizeof(float);
+  if (workspace_bytes < need || !aligned16(workspace)) return SBQ_ERR_WORKSPACE;
+  if ((reinterpret_cast<uintptr_t>(x) & 3u) || (reinterpret_cast<uintptr_t>(qweight) & 3u) ||
+      (reinterpret_cast<uintptr_t>(out) & 3u))
+    return SBQ_ERR_ALIGN;
+  hipStream_t st = as_stream(stream);
+  // workspace = [arrival counters (fixed size, zero between calls) | partial tiles]
+  uint32_t* arrivals = static_cast<uint32_t*>(workspace);
+  float* part = reinterpret_cast<float*>(static_cast<char*>(workspace) + kCounterBytes);
+  const bool vec = (out_features % 4 == 0) && aligned16(qweight);
+  // single-launch strip kernel: mat-vec sized batches, whole 32-column strips
+  const int64_t strips = out_features / kStripCols;
+  if (vec && out_features % kStripCols == 0 && batch <= 2 && !half_slices && strips <= kMaxStrips &&
+      knob(2) != 9) {
+    // 256-thread workgroups (32 K lanes) measured best throughout.  A K lane takes a whole
+    // 128-channel group when that alone fills the chip; otherwise half a group, which doubles
+    // the workgroup count and halves each one's serial decode (decode shapes: 4096x4096 is 128
+    // strips on 256 CUs).  The K split S then covers the K lanes a single pass does not.
+    int ch = strips * ceil_div(in_features, 32 * kSliceK) >= 1024 ? kSliceK : kSliceK / 2;
+    if (knob(2) == 1) ch = kSliceK;      // dev overrides
+    if (knob(2) == 2) ch = kSliceK / 2;
+    int64_t split = ceil_div(in_features, 32 * ch);
+    if (split > kStripMaxSplit) split = kStripMaxSplit;
+    const dim3 grid(static_cast<uint32_t>(strips), static_cast<uint32_t>(split));
+#define SBQ_STRIP(CH)                                                                                      \
+  do {                                                                                                     \
+    if (batch == 2)                                                                                        \
+      gptq_strip_kernel<BITS, 2, 32, CH><<<grid, 256, 0, st>>>(x, qweight, scales, zeros, out, part, arrivals, g); \
+    else                                                                                                   \
+      gptq_strip_kernel<BITS, 1, 32, CH><<<grid, 256, 0, st>>>(x, qweight, scales, zeros, out, part, arrivals, g); \
+  } while (0)
+    if (ch == kSliceK) SBQ_STRIP(128);
+    else SBQ_STRIP(64);
+#undef SBQ_STRIP
+    return check_launch();
+  }
+  if constexpr (BITS == 2) {
+    if (half_slices) return gptq_launch_partial<2, 64>(x, qweight, out, scales, zeros, part, g, vec, st);
+  }
+  return gptq_launch_partial<BITS, kSliceK>(x, qweight, out, scales, zeros, part, g, vec, st);
+}
+
 }  // namespace
 }  // namespace sbq
 
@@ -317,54 +500,32 @@ extern "C" {
 
 size_t sbq_gptq_workspace_bytes(int64_t batch, int64_t in_features, int64_t out_features) {
   using namespace sbq;
-  GptqGeom g;
-  if (!gptq_geom(batch, in_features, out_features, 0, g)) return 0;
-  return static_cast<size_t>(g.kblocks) * batch * out_features * sizeof(float);
+  if (batch <= 0 || in_features <= 0 || out_features <= 0) return 0;
+  if (in_features >= (1ll << 31) || out_features >= (1ll << 31)) return 0;
+  int64_t tiles = gptq_max_kblocks(in_features, out_features);
+  if (tiles < kStripMaxSplit) tiles = kStripMaxSplit;
+  return kCounterBytes + static_cast<size_t>(tiles) * batch * out_features * sizeof(float);
 }
 
 int sbq_vecquant4matmul(const float* x, const int32_t* qweight, float* out, const float* scales,
                         const float* zeros, int64_t batch, int64_t in_features, int64_t out_features,
                         int64_t group_size, void* workspace, size_t workspace_bytes, void* stream) {
-  using namespace sbq;
-  if (batch < 0 || in_features < 0 || out_features < 0) return SBQ_ERR_ARG;
-  if (batch == 0 || in_features == 0 || out_features == 0) return SBQ_ERR_EMPTY;
-  if (!x || !qweight || !out || !scales || !zeros || !workspace) return SBQ_ERR_NULL;
-  // cuda_kernel_4bit.cu:58-61: group size must be a multiple of 128 (0 = one group)
-  if (group_size != 0 && group_size % 128 != 0) return SBQ_ERR_ARG;
-  GptqGeom g;
-  if (!gptq_geom(batch, in_features, out_features, group_size, g)) return SBQ_ERR_ARG;
-  const size_t need = static_cast<size_t>(g.kblocks) * batch * out_features * sizeof(float);
-  if (workspace_bytes < need || !aligned16(workspace)) return SBQ_ERR_WORKSPACE;
-  if ((reinterpret_cast<uintptr_t>(x) & 3u) || (reinterpret_cast<uintptr_t>(qweight) & 3u) ||
-      (reinterpret_cast<uintptr_t>(out) & 3u))
-    return SBQ_ERR_ALIGN;
-  hipStream_t st = as_stream(stream);
-  float* part = static_cast<float*>(workspace);
-  const bool vec = (out_features % 4 == 0) && aligned16(qweight);
-  const int bt = batch >= 8 ? 8 : (batch >= 3 ? 4 : (batch == 2 ? 2 : 1));
-  // single-launch strip kernel: mat-vec sized batches, whole 32-column strips
-  if (vec && out_features % kStripCols == 0 && batch <= 2 && knob(2) != 9) {
-    const uint32_t grid = static_cast<uint32_t>(out_features / kStripCols);
-    if (batch == 2) gptq4_strip_kernel<2><<<grid, kBlock, 0, st>>>(x, qweight, scales, zeros, out, g);
-    else gptq4_strip_kernel<1><<<grid, kBlock, 0, st>>>(x, qweight, scales, zeros, out, g);
-    return check_launch();
-  }
-#define SBQ_GPTQ(COLS)                                                                              \
-  do {                                                                                              \
-    dim3 grid(static_cast<uint32_t>(ceil_div(out_features, kWave * COLS)), static_cast<uint32_t>(g.kblocks)); \
-    if (bt == 8) gptq4_partial_kernel<COLS, 8><<<grid, kBlock, 0, st>>>(x, qweight, scales, zeros, part, g); \
-    else if (bt == 4) gptq4_partial_kernel<COLS, 4><<<grid, kBlock, 0, st>>>(x, qweight, scales, zeros, part, g); \
-    else if (bt == 2) gptq4_partial_kernel<COLS, 2><<<grid, kBlock, 0, st>>>(x, qweight, scales, zeros, part, g); \
-    else gptq4_partial_kernel<COLS, 1><<<grid, kBlock, 0, st>>>(x, qweight, scales, zeros, part, g);  \
-  } while (0)
-  if (vec) SBQ_GPTQ(4);
-  else SBQ_GPTQ(1);
-#undef SBQ_GPTQ
-  int rc = check_launch();
-  if (rc != SBQ_OK) return rc;
-  const int64_t bn = batch * out_features;
-  gptq4_fold_kernel<<<static_cast<uint32_t>(ceil_div(bn, kBlock)), kBlock, 0, st>>>(part, out, bn, g.kblocks);
-  return check_launch();
+  return sbq::gptq_matmul<4>(x, qweight, out, scales, zeros, batch, in_features, out_features, group_size,
+                             workspace, workspace_bytes, stream);
+}
+
+int sbq_vecquant3matmul(const float* x, const int32_t* qweight, float* out, const float* scales,
+                        const float* zeros, int64_t batch, int64_t in_features, int64_t out_features,
+                        int64_t group_size, void* workspace, size_t workspace_bytes, void* stream) {
+  return sbq::gptq_matmul<3>(x, qweight, out, scales, zeros, batch, in_features, out_features, group_size,
+                             workspace, workspace_bytes, stream);
+}
+
+int sbq_vecquant2matmul(const float* x, const int32_t* qweight, float* out, const float* scales,
+                        const float* zeros, int64_t batch, int64_t in_features, int64_t out_features,
+                        int64_t group_size, void* workspace, size_t workspace_bytes, void* stream) {
+  return sbq::gptq_matmul<2>(x, qweight, out, scales, zeros, batch, in_features, out_features, group_size,
+                             workspace, workspace_bytes, stream);
 }
 
 }  // extern "C"

@@ -1,11 +1,11 @@
-"""GPTQ 4-bit weight path (config 4): host-side mirror of
+"""GPTQ 4- / 3- / 2-bit weight path (config 4): host-side mirror of
 large_language_models/llama/quantization/utils/quant.py.
 
   quantize()                     quant.py:8-10
   Quantizer.find_params()        quant.py:43-132   (weight=True, perchannel, asymmetric,
                                                      mse=False -- what convert.py/test use)
   QuantLinear.pack / forward     quant.py:187-278
-  Quant4Matmul                   quant.py:281-307  -> sbq_vecquant4matmul
+  Quant{4,3,2}Matmul             quant.py:281-403  -> sbq_vecquant{4,3,2}matmul
 
 find_params / quantize are a handful of tiny elementwise+rowwise torch ops on the
 weight's own device (grouped min/max is served by sbq_channel_stats with
@@ -90,15 +90,23 @@ class Quantizer(nn.Module):
         return torch.all(self.scale != 0)
 
 
+MIN_GROUP = {4: 128, 3: 128, 2: 64}  # quant.py:153
+
+
+def packed_rows(infeatures, bit):
+    """rows of qweight: 3-bit levels come 32 to three words (quant.py:171-183)"""
+    par = 3 if bit == 3 else 1
+    return ceiling_div(infeatures * bit, 32 * par) * par
+
+
 class QuantLinear(nn.Module):
-    """4-bit packed linear layer; same buffers / state_dict layout as the reference's."""
+    """2/3/4-bit packed linear layer; same buffers / state_dict layout as the reference's."""
 
     def __init__(self, infeatures, outfeatures, bit=4, groupsize=-1):
         super().__init__()
-        if bit != 4:
-            raise NotImplementedError("only the 4-bit mat-vec is on the MI355X hot path (2/3-bit: SURVEY.md 2)")
+        assert bit in (2, 3, 4), "only support 2/3/4 bit now"
         if groupsize != -1:
-            assert groupsize % 128 == 0
+            assert groupsize % MIN_GROUP[bit] == 0
             assert infeatures % groupsize == 0
             groups = infeatures // groupsize
         else:
@@ -112,11 +120,14 @@ class QuantLinear(nn.Module):
         self.register_buffer("zeros", torch.zeros(shape))
         self.register_buffer("scales", torch.zeros(shape))
         self.register_buffer("bias", torch.zeros(outfeatures))
-        self.register_buffer("qweight", torch.zeros((ceiling_div(infeatures * 4, 32), outfeatures), dtype=torch.int))
+        self.register_buffer("qweight", torch.zeros((packed_rows(infeatures, bit), outfeatures), dtype=torch.int))
 
     def pack(self, linear, scales, zeros):
-        """quant.py:187-229 for bit == 4: zeros' = zero*scale; intweight = round((w + zeros')/scale);
-        8 consecutive input channels per int32, low nibble first."""
+        """quant.py:187-260: zeros' = zero*scale; intweight = round((w + zeros')/scale); then every
+        output column becomes one little-endian bit stream over the rows of qweight, `bit` bits per
+        input channel (8 nibbles or 16 crumbs per int32; for 3 bits, 32 levels per three int32 with
+        the reference's two split levels being the ones that straddle a word).  Done with a handful
+        of tensor ops on the weight's own device instead of the reference's numpy row loop."""
         dev = linear.weight.device
         scales = scales.to(dev)
         zeros = zeros.to(dev)
@@ -128,33 +139,97 @@ class QuantLinear(nn.Module):
             weight = weight.view(self.outfeatures, self.groups, -1)
         intweight = torch.round((weight + self.zeros) / self.scales).to(torch.int64)
         intweight = intweight.reshape(self.outfeatures, self.infeatures).t().contiguous()  # [in, out]
+        bit = self.bit
         H = self.qweight.shape[0]
-        pad = H * 8 - self.infeatures
-        if pad:
-            intweight = torch.cat([intweight, intweight.new_zeros(pad, self.outfeatures)], 0)
-        nib = (intweight & 0xF).reshape(H, 8, self.outfeatures)
-        shifts = (4 * torch.arange(8, device=dev, dtype=torch.int64)).reshape(1, 8, 1)
-        words = (nib << shifts).sum(1)  # disjoint bit fields: sum == or
+        level = intweight & (2 ** bit - 1)
+        start = bit * torch.arange(self.infeatures, device=dev, dtype=torch.int64)  # stream position
+        row, shift = start >> 5, start & 31
+        lo = (level << shift.unsqueeze(1)) & 0xFFFFFFFF
+        words = torch.zeros((H + 1, self.outfeatures), dtype=torch.int64, device=dev)
+        words.index_add_(0, row, lo)  # disjoint bit fields: sum == or
+        spill = shift + bit > 32
+        if bool(spill.any()):
+            hi = level[spill] >> (32 - shift[spill]).unsqueeze(1)
+            words.index_add_(0, row[spill] + 1, hi)
+        words = words[:H]
         words = torch.where(words >= 2 ** 31, words - 2 ** 32, words)  # two's complement int32
         self.qweight = words.to(torch.int32).contiguous()
 
     def forward(self, x):
         # fp32 inside like the reference (quant.py:262-278), result back in x.dtype
-        y = Quant4Matmul.apply(x.float(), self.qweight, self.scales.float(), self.zeros.float(), self.bias.float(),
-                               self.groupsize)
+        fn = {2: Quant2Matmul, 3: Quant3Matmul, 4: Quant4Matmul}[self.bit]
+        y = fn.apply(x.float(), self.qweight, self.scales.float(), self.zeros.float(), self.bias.float(), self.groupsize)
         return y.to(x.dtype)
+
+
+def _quant_matmul(bits, input, qweight, scales, zeros, bias, groupsize):
+    x_shape = list(input.shape)
+    # y starts as the broadcast bias and is accumulated in place (quant.py:285-289)
+    # .clone(): for batch 1 an expanded bias is already contiguous and would alias the buffer
+    y = bias.to(input.dtype).expand(x_shape[:-1] + [bias.numel()]).clone(memory_format=torch.contiguous_format)
+    ops.vecquantmatmul(bits, input.contiguous(), qweight, y, scales, zeros, 0 if groupsize == -1 else groupsize)
+    return y
 
 
 class Quant4Matmul(torch.autograd.Function):
     @staticmethod
     def forward(ctx, input, qweight, scales, zeros, bias, groupsize=-1):
-        x_shape = list(input.shape)
-        # y starts as the broadcast bias and is accumulated in place (quant.py:285-289)
-        # .clone(): for batch 1 an expanded bias is already contiguous and would alias the buffer
-        y = bias.to(input.dtype).expand(x_shape[:-1] + [bias.numel()]).clone(memory_format=torch.contiguous_format)
-        ops.vecquant4matmul(input.contiguous(), qweight, y, scales, zeros, 0 if groupsize == -1 else groupsize)
-        return y
+        return _quant_matmul(4, input, qweight, scales, zeros, bias, groupsize)
 
     @staticmethod
     def backward(ctx, grad):
         raise NotImplementedError("inference-only kernel (the reference's backward lives in alpaca-qlora)")
+
+
+class Quant3Matmul(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, input, qweight, scales, zeros, bias, groupsize=-1):
+        return _quant_matmul(3, input, qweight, scales, zeros, bias, groupsize)
+
+    @staticmethod
+    def backward(ctx, grad):
+        raise NotImplementedError("inference-only kernel")
+
+
+class Quant2Matmul(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, input, qweight, scales, zeros, bias, groupsize=-1):
+        return _quant_matmul(2, input, qweight, scales, zeros, bias, groupsize)
+
+    @staticmethod
+    def backward(ctx, grad):
+        raise NotImplementedError("inference-only kernel")
+
+
+class _KernelModule:
+    """Stand-in for the reference's pybind module `cuda_kernel` (cuda/cuda_kernel.cpp:65-73): the six
+    entry points with the reference's argument order, accumulating into `out` in place.  Assigning
+    `utils.quant.cuda_kernel = sparsebit_amd.gptq.cuda_kernel` makes the reference's own
+    Quant{2,3,4}Matmul run on these kernels."""
+
+    @staticmethod
+    def _run(bits, inp1, inp2, out, scales, zeros, group_size):
+        if inp1.dim() < 2:
+            raise RuntimeError("input1 must be with dimension > 2")
+        ops.vecquantmatmul(bits, inp1.contiguous(), inp2, out, scales, zeros, group_size)
+
+    def vecquant4matmul(self, inp1, inp2, out, scales, zeros):
+        self._run(4, inp1, inp2, out, scales, zeros, 0)
+
+    def vecgroupquant4matmul(self, inp1, inp2, out, scales, zeros, group_size):
+        self._run(4, inp1, inp2, out, scales, zeros, group_size)
+
+    def vecquant3matmul(self, inp1, inp2, out, scales, zeros):
+        self._run(3, inp1, inp2, out, scales, zeros, 0)
+
+    def vecgroupquant3matmul(self, inp1, inp2, out, scales, zeros, group_size):
+        self._run(3, inp1, inp2, out, scales, zeros, group_size)
+
+    def vecquant2matmul(self, inp1, inp2, out, scales, zeros):
+        self._run(2, inp1, inp2, out, scales, zeros, 0)
+
+    def vecgroupquant2matmul(self, inp1, inp2, out, scales, zeros, group_size):
+        self._run(2, inp1, inp2, out, scales, zeros, group_size)
+
+
+cuda_kernel = _KernelModule()

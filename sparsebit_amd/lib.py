@@ -85,6 +85,8 @@ _SIGNATURES = {
     "sbq_mask_from_threshold": (c_int, [c_vp, c_int, c_i64, c_vp, c_vp, c_vp]),
     "sbq_gptq_workspace_bytes": (c_sz, [c_i64, c_i64, c_i64]),
     "sbq_vecquant4matmul": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_vp, c_sz, c_vp]),
+    "sbq_vecquant3matmul": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_vp, c_sz, c_vp]),
+    "sbq_vecquant2matmul": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_vp, c_sz, c_vp]),
 }
 
 _lib = None

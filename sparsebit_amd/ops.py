@@ -40,6 +40,21 @@ def _workspace(device, nbytes):
     return buf
 
 
+_gptq_workspaces = {}
+
+
+def _gptq_workspace(device, nbytes):
+    """The mat-vec's workspace starts with arrival counters that must be zero before the first call
+    and are left zero by every call (include/sbq.h): it gets its own zero-initialised buffer per
+    (device, stream) instead of sharing the general scratch, which other kernels scribble on."""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    buf = _gptq_workspaces.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.zeros(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _gptq_workspaces[key] = buf
+    return buf
+
+
 def _f32c(t, device):
     if t.dtype != torch.float32:
         t = t.float()
@@ -472,26 +487,43 @@ def mask_from_threshold(x, thresh):
 
 
 # ---------------------------------------------------------------------------------
-# GPTQ 4-bit mat-vec
+# GPTQ 4- / 3- / 2-bit mat-vec
 # ---------------------------------------------------------------------------------
-def vecquant4matmul(x, qweight, out, scales, zeros, group_size=0):
-    """out[b,n] += sum_k (scales[n,g]*nib - zeros[n,g]) * x[b,k], in place (cuda_kernel.cpp:6-23)."""
+def vecquantmatmul(bits, x, qweight, out, scales, zeros, group_size=0):
+    """out[b,n] += sum_k (scales[n,g]*lvl - zeros[n,g]) * x[b,k], in place (cuda_kernel.cpp:6-62).
+    group_size 0 is the reference's un-grouped vecquant{bits}matmul, anything else its vecgroupquant twin."""
     dev = L.require_device(x, qweight, out, scales, zeros)
     lib = L.load()
+    if bits not in (2, 3, 4):
+        raise L.SbqError("vecquantmatmul: only support 2/3/4 bit now")
     if x.dtype != torch.float32 or out.dtype != torch.float32 or qweight.dtype != torch.int32:
-        raise L.SbqError("vecquant4matmul: x/out must be float32 and qweight int32")
+        raise L.SbqError("vecquantmatmul: x/out must be float32 and qweight int32")
     if not (x.is_contiguous() and out.is_contiguous() and qweight.is_contiguous()):
-        raise L.SbqError("vecquant4matmul: tensors must be contiguous")
+        raise L.SbqError("vecquantmatmul: tensors must be contiguous")
+    if qweight.dim() != 2:
+        raise L.SbqError("input2 must be with dimension == 2")
     in_f = x.shape[-1]
     batch = x.numel() // in_f
     out_f = qweight.shape[1]
-    if out.shape[-1] != out_f:
+    rows = (in_f + 31) // 32 * 3 if bits == 3 else (in_f * bits + 31) // 32
+    if qweight.shape[0] != rows:
+        raise L.SbqError("qweight has %d rows, %d-bit packing of %d input channels needs %d"
+                         % (qweight.shape[0], bits, in_f, rows))
+    if out.shape[-1] != out_f or out.numel() != batch * out_f:
         raise L.SbqError("output channel must be the same with input2 out_channel")
     scales = _f32c(scales, dev)
     zeros = _f32c(zeros, dev)
+    groups = 1 if not group_size else (in_f + group_size - 1) // group_size
+    if scales.numel() != out_f * groups or zeros.numel() != out_f * groups:
+        raise L.SbqError("scales / zeros must hold out_features x groups values")
+    fn = {4: lib.sbq_vecquant4matmul, 3: lib.sbq_vecquant3matmul, 2: lib.sbq_vecquant2matmul}[bits]
     with torch.cuda.device(dev):
-        ws = _workspace(dev, lib.sbq_gptq_workspace_bytes(batch, in_f, out_f))
-        rc = lib.sbq_vecquant4matmul(L.ptr(x), L.ptr(qweight), L.ptr(out), L.ptr(scales), L.ptr(zeros), batch, in_f, out_f,
-                                     int(group_size), L.ptr(ws), ws.numel(), L.stream_ptr(dev))
+        ws = _gptq_workspace(dev, lib.sbq_gptq_workspace_bytes(batch, in_f, out_f))
+        rc = fn(L.ptr(x), L.ptr(qweight), L.ptr(out), L.ptr(scales), L.ptr(zeros), batch, in_f, out_f,
+                int(group_size), L.ptr(ws), ws.numel(), L.stream_ptr(dev))
     L.check(rc)
     return out
+
+
+def vecquant4matmul(x, qweight, out, scales, zeros, group_size=0):
+    return vecquantmatmul(4, x, qweight, out, scales, zeros, group_size)

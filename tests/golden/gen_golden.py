@@ -339,6 +339,39 @@ def main():
                                                                 target_weight=False))
         run2("lsqp/per-tensor-affine/%d/relu" % bit, a_relu, qcfg("per-tensor-affine", bit, quantizer="lsq+",
                                                                 target_weight=False))
+    # ---- GPTQ 3- and 2-bit, same recipe as the 4-bit block above.
+    # Appended after everything else: no earlier vector changes. -------------------------------
+    g23 = torch.Generator().manual_seed(23)
+    gptq23 = {"b3/g128": (3, 3, 256, 72, 128), "b3/g-1": (3, 2, 136, 40, -1), "b3/rag": (3, 5, 384, 33, 128),
+              "b3/strip": (3, 1, 512, 64, 256),
+              "b2/g64": (2, 3, 256, 72, 64), "b2/g-1": (2, 2, 136, 40, -1), "b2/rag": (2, 5, 384, 33, 128),
+              "b2/strip": (2, 2, 512, 64, 128)}
+    for name, (bit, B, M, N, GS) in gptq23.items():
+        torch.manual_seed(11)
+        layer = torch.nn.Linear(M, N)
+        vec = torch.randn(B, M, generator=g23)
+        qz = rq.Quantizer()
+        qz.configure(bit=bit, perchannel=True, sym=False, mse=False)
+        qz.find_params(layer.weight.data, weight=True, groupsize=GS)
+        w_orig = layer.weight.data.clone()
+        layer.weight.data = rq.quantize(layer.weight.data.view(-1, M if GS == -1 else GS), qz.scale.view(-1, 1),
+                                        qz.zero.view(-1, 1), qz.maxq).view(N, M)
+        ql = rq.QuantLinear(M, N, bit=bit, groupsize=GS)
+        ql.pack(layer, qz.scale, qz.zero)
+        with torch.no_grad():
+            y = layer(vec)
+        out["gptq/%s/w" % name] = w_orig.numpy()
+        out["gptq/%s/wq" % name] = layer.weight.data.numpy()
+        out["gptq/%s/x" % name] = vec.numpy()
+        out["gptq/%s/scale" % name] = qz.scale.numpy().reshape(N, -1)
+        out["gptq/%s/zero" % name] = qz.zero.numpy().reshape(N, -1)
+        out["gptq/%s/qweight" % name] = ql.qweight.numpy()
+        out["gptq/%s/scales" % name] = ql.scales.numpy().reshape(N, -1)
+        out["gptq/%s/zeros" % name] = ql.zeros.numpy().reshape(N, -1)
+        out["gptq/%s/bias" % name] = ql.bias.detach().numpy()
+        out["gptq/%s/y" % name] = y.numpy()
+        out["gptq/%s/meta" % name] = np.array([B, M, N, GS, bit], dtype=np.int64)
+    out["gptq23"] = np.array(sorted(gptq23))
     out["cases2"] = np.array(cases2)
     out["cases"] = np.array(cases)
     np.savez_compressed(OUT, **out)

@@ -588,6 +588,100 @@ def test_gptq_random_vs_oracle(oracle, B, M, N, GS):
         assert np.allclose(y.cpu().numpy(), ref, rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("name", ["b3/g128", "b3/g-1", "b3/rag", "b3/strip", "b2/g64", "b2/g-1", "b2/rag", "b2/strip"])
+def test_gptq_low_bit_vs_reference_golden(golden, oracle, name):
+    from sparsebit_amd import gptq
+
+    B, M, N, GS, bit = [int(v) for v in golden["gptq/%s/meta" % name]]
+    layer = torch.nn.Linear(M, N).cuda()
+    with torch.no_grad():
+        layer.weight.copy_(dev_tensor(golden["gptq/%s/w" % name]))
+        layer.bias.copy_(dev_tensor(golden["gptq/%s/bias" % name]))
+    qz = gptq.Quantizer()
+    qz.configure(bit=bit, perchannel=True, sym=False, mse=False)
+    qz.find_params(layer.weight.data, weight=True, groupsize=GS)
+    assert np.array_equal(qz.scale.reshape(N, -1).cpu().numpy(), golden["gptq/%s/scale" % name])
+    assert np.array_equal(qz.zero.reshape(N, -1).cpu().numpy(), golden["gptq/%s/zero" % name])
+    layer.weight.data = gptq.quantize(layer.weight.data.view(-1, M if GS == -1 else GS), qz.scale.view(-1, 1),
+                                      qz.zero.view(-1, 1), qz.maxq).view(N, M)
+    assert np.array_equal(layer.weight.data.cpu().numpy(), golden["gptq/%s/wq" % name])
+    ql = gptq.QuantLinear(M, N, bit=bit, groupsize=GS)
+    ql.pack(layer, qz.scale, qz.zero)
+    assert np.array_equal(ql.qweight.cpu().numpy(), golden["gptq/%s/qweight" % name])
+    y = ql(dev_tensor(golden["gptq/%s/x" % name]))
+    assert np.allclose(y.cpu().numpy(), golden["gptq/%s/y" % name], rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("bit", [3, 2])
+@pytest.mark.parametrize("B,M,N,GS", [(1, 4096, 4096, 128), (2, 4096, 4096, 128), (1, 11008, 4096, 128), (2, 1000, 96, -1),
+                                       (8, 4096, 4096, 128), (32, 1024, 1280, 128), (4, 6661, 1027, -1),
+                                       (1, 1024, 256, 256), (3, 1024, 256, 64), (1, 1024, 256, 64)])
+def test_gptq_low_bit_random_vs_oracle(oracle, bit, B, M, N, GS):
+    from sparsebit_amd import gptq
+
+    if bit == 3 and GS == 64:
+        pytest.skip("3-bit groups are multiples of 128 (cuda_kernel_3bit.cu:56-59)")
+    torch.manual_seed(B * 7 + M + bit)
+    layer = torch.nn.Linear(M, N)
+    x = torch.randn(B, M)
+    w = layer.weight.data.numpy()
+    scale, zero = oracle.gptq_find_params(w, bit, GS)
+    wq = oracle.gptq_quantize(w, scale, zero, bit)
+    qw, zeros_p = oracle.gptq_pack(wq, scale, zero, bit)
+    ql = gptq.QuantLinear(M, N, bit=bit, groupsize=GS)
+    ql.qweight = torch.from_numpy(qw)
+    ql.scales = torch.from_numpy(scale).reshape(ql.scales.shape)
+    ql.zeros = torch.from_numpy(zeros_p).reshape(ql.zeros.shape)
+    ql.bias = layer.bias.detach().clone()
+    ql = ql.cuda()
+    # device-side pack of the same quantized weight gives the same words
+    lay_q = torch.nn.Linear(M, N).cuda()
+    with torch.no_grad():
+        lay_q.weight.copy_(torch.from_numpy(wq))
+    ql2 = gptq.QuantLinear(M, N, bit=bit, groupsize=GS).cuda()
+    ql2.pack(lay_q, torch.from_numpy(scale).reshape(ql.scales.shape).cuda(), torch.from_numpy(zero).reshape(ql.scales.shape).cuda())
+    assert torch.equal(ql2.qweight, ql.qweight)
+    y = ql(x.cuda())
+    want = x.double() @ torch.from_numpy(wq).double().t() + layer.bias.detach().double()
+    assert torch.allclose(y.double().cpu(), want, rtol=1e-5, atol=2e-5)
+    assert torch.equal(y, ql(x.cuda()))  # deterministic
+    if M * N <= 4096 * 1280:
+        ref = oracle.vecquantmatmul(x.numpy(), qw, layer.bias.detach().numpy(), scale, zeros_p, GS, bit)
+        assert np.allclose(y.cpu().numpy(), ref, rtol=1e-5, atol=1e-5)
+
+
+def test_gptq_kernel_module_entry_points(golden):
+    """the six names of the reference's pybind module, reference argument order, in-place accumulate"""
+    from sparsebit_amd import gptq
+
+    for name, bit in (("g128", 4), ("b3/g128", 3), ("b2/g64", 2), ("g-1", 4), ("b3/g-1", 3), ("b2/g-1", 2)):
+        meta = [int(v) for v in golden["gptq/%s/meta" % name]]
+        B, M, N, GS = meta[:4]
+        x = dev_tensor(golden["gptq/%s/x" % name])
+        qw = torch.from_numpy(golden["gptq/%s/qweight" % name]).cuda()
+        sc = dev_tensor(golden["gptq/%s/scales" % name])
+        zr = dev_tensor(golden["gptq/%s/zeros" % name])
+        y = dev_tensor(golden["gptq/%s/bias" % name]).repeat(B, 1).contiguous()
+        if GS == -1:
+            getattr(gptq.cuda_kernel, "vecquant%dmatmul" % bit)(x, qw, y, sc, zr)
+        else:
+            getattr(gptq.cuda_kernel, "vecgroupquant%dmatmul" % bit)(x, qw, y, sc, zr, GS)
+        assert np.allclose(y.cpu().numpy(), golden["gptq/%s/y" % name], rtol=1e-5, atol=1e-5)
+
+
+def test_gptq_rejects_wrong_packing():
+    from sparsebit_amd import ops
+    from sparsebit_amd.lib import SbqError
+
+    x = torch.zeros(1, 256, device="cuda")
+    out = torch.zeros(1, 32, device="cuda")
+    sc = torch.ones(32, 1, device="cuda")
+    with pytest.raises(SbqError):  # 4-bit sized buffer handed to the 3-bit kernel
+        ops.vecquantmatmul(3, x, torch.zeros(32, 32, dtype=torch.int32, device="cuda"), out, sc, sc, 0)
+    with pytest.raises(SbqError):
+        ops.vecquantmatmul(5, x, torch.zeros(32, 32, dtype=torch.int32, device="cuda"), out, sc, sc, 0)
+
+
 # --------------------------------------------------------------------------------------
 # widened set (SURVEY.md 8f rank 3): remaining observers / quantizers on the same kernels
 # --------------------------------------------------------------------------------------

@@ -55,6 +55,8 @@ def test_status_strings_and_argument_validation_without_gpu(built):
     assert f(p, 0, p, 0, None, 0, p, p, 1, 2, 8, -128, 127, 7, None) == 4  # rounding mode
     assert l.sbq_mask_quant_forward(p, 0, p, 0, None, 0, None, None, p, p, 1, 2, 8, -128, 127, 0, None) == 4
     assert l.sbq_vecquant4matmul(p, p, p, p, p, 1, 128, 4, 64, p, 1 << 20, None) == 4  # group % 128
+    assert l.sbq_vecquant3matmul(p, p, p, p, p, 1, 128, 4, 64, p, 1 << 20, None) == 4
+    assert l.sbq_vecquant2matmul(p, p, p, p, p, 1, 128, 4, 32, p, 1 << 20, None) == 4  # group % 64
     assert l.sbq_percentile_rows(p, 0, 4, 20000, 0.001, p, p, None) == 4  # row too long for the LDS path
     assert l.sbq_channel_stats(p, 0, 1, 1, 16, p, p, None, p, 0, None) == 5  # workspace too small
     assert l.sbq_stats_workspace_bytes(1, 4096, 4096) == 4096 * 16
@@ -191,13 +193,15 @@ def test_gptq_pack_matches_reference_golden(golden):
     """QuantLinear.pack is host-side integer shuffling: runs anywhere."""
     from sparsebit_amd import gptq
 
-    for name in ("g128", "g-1", "rag"):
-        B, M, N, GS = [int(v) for v in golden["gptq/%s/meta" % name]]
+    for name in ["g128", "g-1", "rag"] + golden["gptq23"].tolist():
+        meta = [int(v) for v in golden["gptq/%s/meta" % name]]
+        B, M, N, GS = meta[:4]
+        bit = meta[4] if len(meta) > 4 else 4
         layer = torch.nn.Linear(M, N)
         with torch.no_grad():
             layer.weight.copy_(torch.from_numpy(golden["gptq/%s/wq" % name]))
             layer.bias.copy_(torch.from_numpy(golden["gptq/%s/bias" % name]))
-        ql = gptq.QuantLinear(M, N, bit=4, groupsize=GS)
+        ql = gptq.QuantLinear(M, N, bit=bit, groupsize=GS)
         sh = (N, -1, 1) if GS != -1 and M // GS > 1 else (N, 1)
         ql.pack(layer, torch.from_numpy(golden["gptq/%s/scale" % name]).reshape(sh),
                 torch.from_numpy(golden["gptq/%s/zero" % name]).reshape(sh))

@@ -163,3 +163,30 @@ def test_gptq_matches_reference(golden, oracle, name):
                                golden["gptq/%s/scales" % name], zeros_p, GS)
     # the reference's own tolerance (test_cuda_kernel.py:45)
     assert np.allclose(y, golden["gptq/%s/y" % name], rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("name", ["b3/g128", "b3/g-1", "b3/rag", "b3/strip", "b2/g64", "b2/g-1", "b2/rag", "b2/strip"])
+def test_gptq_low_bit_matches_reference(golden, oracle, name):
+    """3- and 2-bit find_params / quantize / pack / mat-vec against the reference's own outputs."""
+    B, M, N, GS, bit = [int(v) for v in golden["gptq/%s/meta" % name]]
+    w = golden["gptq/%s/w" % name]
+    scale, zero = oracle.gptq_find_params(w, bit, GS)
+    assert np.array_equal(scale, golden["gptq/%s/scale" % name])
+    assert np.array_equal(zero, golden["gptq/%s/zero" % name])
+    wq = oracle.gptq_quantize(w, scale, zero, bit)
+    assert np.array_equal(wq, golden["gptq/%s/wq" % name])
+    qw, zeros_p = oracle.gptq_pack(wq, scale, zero, bit)
+    assert qw.shape == golden["gptq/%s/qweight" % name].shape
+    assert np.array_equal(qw, golden["gptq/%s/qweight" % name])
+    assert np.array_equal(zeros_p, golden["gptq/%s/zeros" % name])
+    y = oracle.vecquantmatmul(golden["gptq/%s/x" % name], qw, golden["gptq/%s/bias" % name],
+                              golden["gptq/%s/scales" % name], zeros_p, GS, bit)
+    assert np.allclose(y, golden["gptq/%s/y" % name], rtol=1e-5, atol=1e-5)
+
+
+def test_gptq_pack_generic_equals_pack4(golden, oracle):
+    for name in ("g128", "g-1", "rag"):
+        wq, scale, zero = (golden["gptq/%s/%s" % (name, k)] for k in ("wq", "scale", "zero"))
+        a, za = oracle.gptq_pack4(wq, scale, zero)
+        b, zb = oracle.gptq_pack(wq, scale, zero, 4)
+        assert np.array_equal(a, b) and np.array_equal(za, zb)

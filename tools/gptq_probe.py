@@ -13,18 +13,24 @@ def timed(fn, iters=200, warm=20):
     for i in range(iters): fn(i)
     b.record(); torch.cuda.synchronize()
     return a.elapsed_time(b) * 1e3 / iters
-for (M, N) in ((4096, 4096), (4096, 11008), (11008, 4096)):
-    for gs in (128, 0):
+for bits in (4, 3, 2):
+  fn = {4: lib.sbq_vecquant4matmul, 3: lib.sbq_vecquant3matmul, 2: lib.sbq_vecquant2matmul}[bits]
+  for (M, N) in ((4096, 4096), (4096, 11008), (11008, 4096), (8192, 8192), (8192, 28672)):
+    for B in (1, 2):
+        gs = 128
         groups = M // gs if gs else 1
-        qw = torch.randint(-2**31, 2**31 - 1, (M // 8, N), dtype=torch.int32, device=dev)
+        rows = M // 32 * 3 if bits == 3 else M * bits // 32
+        qw = torch.randint(-2**31, 2**31 - 1, (rows, N), dtype=torch.int32, device=dev)
         sc = torch.rand(N * groups, device=dev) * 0.01; zr = torch.rand(N * groups, device=dev) * 0.1
-        x = torch.randn(1, M, device=dev); y = torch.zeros(1, N, device=dev)
-        ws = torch.empty(max(lib.sbq_gptq_workspace_bytes(1, M, N), 16), dtype=torch.uint8, device=dev)
+        x = torch.randn(B, M, device=dev); y = torch.zeros(B, N, device=dev)
+        ws = torch.zeros(max(lib.sbq_gptq_workspace_bytes(B, M, N), 16), dtype=torch.uint8, device=dev)
         st = L.stream_ptr(dev)
         def run(i):
-            lib.sbq_vecquant4matmul(L.ptr(x), L.ptr(qw), L.ptr(y), L.ptr(sc), L.ptr(zr), 1, M, N, gs, L.ptr(ws), ws.numel(), st)
-        for force_old in (0, 9):
-            lib.sbq_set_tuning(2, force_old)
+            fn(L.ptr(x), L.ptr(qw), L.ptr(y), L.ptr(sc), L.ptr(zr), B, M, N, gs, L.ptr(ws), ws.numel(), st)
+        for mode in ((0, 1, 2) if B <= 2 else (0,)):
+            lib.sbq_set_tuning(2, mode)
             t = timed(run)
-            print("in=%5d out=%5d group=%3d %s: %.2f us  (%.2f TB/s on %.1f MB)" % (M, N, gs, "k-split+fold" if force_old else "strip       ", t, (M * N / 2 + 2 * N * groups * 4) / t / 1e6, (M * N / 2 + 2 * N * groups * 4) / 1e6), flush=True)
+            nbytes = rows * N * 4 + 2 * N * groups * 4
+            label = {0: "auto", 1: "strip CH128", 2: "strip CH64", 9: "k-split+fold"}[mode] if B <= 2 else "k-split+fold"
+            print("%d-bit B=%d in=%5d out=%5d group=%3d %-12s: %.2f us  (%.2f TB/s on %.1f MB)" % (bits, B, M, N, gs, label, t, nbytes / t / 1e6, nbytes / 1e6), flush=True)
 lib.sbq_set_tuning(2, 0)

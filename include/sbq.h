@@ -41,7 +41,7 @@ extern "C" {
 /* element types of data tensors */
 enum { SBQ_F32 = 0, SBQ_F16 = 1, SBQ_BF16 = 2 };
 /* type of the optional integer output of the forward QDQ */
-enum { SBQ_Q_NONE = 0, SBQ_Q_I8 = 1, SBQ_Q_I32 = 2 };
+enum { SBQ_Q_NONE = 0, SBQ_Q_I8 = 1, SBQ_Q_I32 = 2, SBQ_Q_I4 = 3 };
 /* rounding of x/scale: common.cuh:13-15,64-77 (Python always passes 0) */
 enum { SBQ_ROUND_HALF_EVEN = 0, SBQ_ROUND_HALF_UP = 1, SBQ_ROUND_HALF_DOWN = 2 };
 
@@ -76,7 +76,11 @@ const char* sbq_last_hip_error(void);
  *    x        data, dtype x_dtype, outer*C*inner elements
  *    y        dequantized output, y_dtype == SBQ_F32 or == x_dtype (RNE cast)
  *    q        optional integer tensor (NULL with SBQ_Q_NONE); SBQ_Q_I8 stores
- *             the low 8 bits (needs qmax - qmin <= 255), SBQ_Q_I32 an int32
+ *             the low 8 bits (needs qmax - qmin <= 255), SBQ_Q_I32 an int32,
+ *             SBQ_Q_I4 two levels per byte (element i in the low nibble of byte
+ *             i/2 for even i, two's complement when qmin < 0; needs
+ *             qmax - qmin <= 15, rows of whole 8-element packs, 16-byte aligned
+ *             pointers, half-even rounding and no fused mask -- else SBQ_ERR_ARG)
  *    scale, zero_point   fp32, C elements (1 for per tensor)
  * ------------------------------------------------------------------ */
 int sbq_quant_pertensor_forward(const void* x, int x_dtype, void* y, int y_dtype,

@@ -50,6 +50,13 @@ __device__ __forceinline__ void store_q_pack(void* q, int64_t i, const float (&l
     char* p = static_cast<char*>(q) + i * 4;
     st16<true>(p, a);
     st16<true>(p + 16, b);
+  } else if constexpr (QT == SBQ_Q_I4) {
+    // eight levels -> one dword: element i in the low nibble of byte i/2 (two's complement for a
+    // signed range).  i is a multiple of 8, so a wave writes 256 contiguous bytes.
+    uint32_t acc = 0;
+#pragma unroll
+    for (int j = 0; j < kPack; ++j) acc |= (static_cast<uint32_t>(static_cast<int>(lv[j])) & 0xfu) << (4 * j);
+    __builtin_nontemporal_store(acc, reinterpret_cast<uint32_t*>(static_cast<char*>(q) + (i >> 1)));
   }
 }
 
@@ -605,6 +612,7 @@ void launch_mask(const QdqCall& c, bool flat, hipStream_t st) {
 template <typename Tin, typename Tout>
 void launch_q(const QdqCall& c, int q_type, bool flat, hipStream_t st) {
   if (q_type == SBQ_Q_I8) launch_mask<Tin, Tout, SBQ_Q_I8>(c, flat, st);
+  else if (q_type == SBQ_Q_I4) launch_geom<Tin, Tout, SBQ_Q_I4, MASK_NONE>(c, flat, st);  // no mask variants
   else if (q_type == SBQ_Q_I32) launch_mask<Tin, Tout, SBQ_Q_I32>(c, flat, st);
   else launch_mask<Tin, Tout, SBQ_Q_NONE>(c, flat, st);
 }
@@ -623,13 +631,18 @@ int qdq_forward(const void* x, int x_dtype, void* y, int y_dtype, void* q, int q
                 void* stream) {
   if (!valid_dtype(x_dtype) || !valid_dtype(y_dtype)) return SBQ_ERR_DTYPE;
   if (y_dtype != SBQ_F32 && y_dtype != x_dtype) return SBQ_ERR_DTYPE;
-  if (q_type != SBQ_Q_NONE && q_type != SBQ_Q_I8 && q_type != SBQ_Q_I32) return SBQ_ERR_DTYPE;
+  if (q_type != SBQ_Q_NONE && q_type != SBQ_Q_I8 && q_type != SBQ_Q_I32 && q_type != SBQ_Q_I4) return SBQ_ERR_DTYPE;
   if (outer < 0 || C < 0 || inner < 0) return SBQ_ERR_ARG;
   if (outer == 0 || C == 0 || inner == 0) return SBQ_ERR_EMPTY;
   if (!x || !y || !scale || !zp) return SBQ_ERR_NULL;
   if (q_type != SBQ_Q_NONE && !q) return SBQ_ERR_NULL;
   if (qmin > qmax) return SBQ_ERR_ARG;
   if (q_type == SBQ_Q_I8 && static_cast<int64_t>(qmax) - qmin > 255) return SBQ_ERR_ARG;
+  // packed int4: 16 levels, whole 8-element packs only (two elements share a byte: no scalar
+  // path), the even-rounding pack kernels, no fused mask
+  if (q_type == SBQ_Q_I4 && (static_cast<int64_t>(qmax) - qmin > 15 || mask || thresh ||
+                             rounding != SBQ_ROUND_HALF_EVEN))
+    return SBQ_ERR_ARG;
   if (rounding < 0 || rounding > 2) return SBQ_ERR_ARG;
   if (mask && thresh) return SBQ_ERR_ARG;
   if (C > 0x7fffffff) return SBQ_ERR_ARG;
@@ -657,6 +670,7 @@ int qdq_forward(const void* x, int x_dtype, void* y, int y_dtype, void* q, int q
   do {                                                                                                         \
     if (q_type == SBQ_Q_I8) qdq_clast_kernel<TI, TO, SBQ_Q_I8><<<grid, kBlock, 0, st>>>(x, y, q, scale, zp, packs, static_cast<uint32_t>(C), qlo, qhi); \
     else if (q_type == SBQ_Q_I32) qdq_clast_kernel<TI, TO, SBQ_Q_I32><<<grid, kBlock, 0, st>>>(x, y, q, scale, zp, packs, static_cast<uint32_t>(C), qlo, qhi); \
+    else if (q_type == SBQ_Q_I4) qdq_clast_kernel<TI, TO, SBQ_Q_I4><<<grid, kBlock, 0, st>>>(x, y, q, scale, zp, packs, static_cast<uint32_t>(C), qlo, qhi); \
     else qdq_clast_kernel<TI, TO, SBQ_Q_NONE><<<grid, kBlock, 0, st>>>(x, y, q, scale, zp, packs, static_cast<uint32_t>(C), qlo, qhi); \
   } while (0)
     if (x_dtype == SBQ_F32) SBQ_CL(F32, F32);
@@ -670,9 +684,11 @@ int qdq_forward(const void* x, int x_dtype, void* y, int y_dtype, void* q, int q
   // call (C == 1) is one long row, so only its last numel % 8 elements are ragged.
   const int64_t body = (C == 1) ? (numel / kPack) * kPack : (inner % kPack == 0 ? numel : 0);
   const uint64_t total_packs = static_cast<uint64_t>(body / kPack);
+  if (q_type == SBQ_Q_I4 && body != numel) return SBQ_ERR_ARG;  // no ragged tail in packed int4
   // 32-bit pack / tile arithmetic in the kernels: < 2^31 packs (16 Gi elements)
   if (rounding != SBQ_ROUND_HALF_EVEN || !ptr_ok || body == 0 || total_packs >= (1ull << 31) ||
       rows >= (1ll << 31)) {
+    if (q_type == SBQ_Q_I4) return ptr_ok ? SBQ_ERR_ARG : SBQ_ERR_ALIGN;
     launch_scalar(sa, st);
     return check_launch();
   }

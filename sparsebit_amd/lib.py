@@ -17,7 +17,7 @@ HEADER_PATH = os.path.join(_HERE, "..", "include", "sbq.h")
 
 # include/sbq.h enums
 F32, F16, BF16 = 0, 1, 2
-Q_NONE, Q_I8, Q_I32 = 0, 1, 2
+Q_NONE, Q_I8, Q_I32, Q_I4 = 0, 1, 2, 3
 ROUND_HALF_EVEN, ROUND_HALF_UP, ROUND_HALF_DOWN = 0, 1, 2
 MSE_CANDIDATES = 80
 RADIX_BINS = 2048

@@ -75,7 +75,8 @@ def fake_quant(x, scale, zero_point, qmin, qmax, ch_axis=0, out_dtype=None, retu
 
     scale.numel() > 1 selects per-channel along ch_axis.  out_dtype: torch.float32
     (the reference's output type) or x.dtype.  return_q: None | torch.int8 | torch.uint8 |
-    torch.int32 -> also return the integer tensor.  mask (torch.bool/uint8) or thresh
+    torch.int32 -> also return the integer tensor; "int4" -> a flat uint8 tensor of x.numel()/2
+    bytes holding two levels per byte (export.unpack_int4 undoes it).  mask (torch.bool/uint8) or thresh
     (0-d fp32 tensor) fuse the unstructured-sparsity multiply in front of the QDQ.
     """
     dev = L.require_device(x, scale, zero_point, mask, thresh)
@@ -97,9 +98,16 @@ def fake_quant(x, scale, zero_point, qmin, qmax, ch_axis=0, out_dtype=None, retu
             q_type = L.Q_I8
         elif return_q == torch.int32:
             q_type = L.Q_I32
+        elif return_q == "int4":
+            q_type = L.Q_I4
         else:
-            raise L.SbqError("return_q must be int8, uint8 or int32")
-        q = torch.empty(x.shape, dtype=return_q, device=dev)
+            raise L.SbqError("return_q must be int8, uint8, int32 or 'int4'")
+        if q_type == L.Q_I4:
+            if x.numel() % 2:
+                raise L.SbqError("packed int4 needs an even number of elements")
+            q = torch.empty(x.numel() // 2, dtype=torch.uint8, device=dev)  # flat: byte i holds elements 2i, 2i+1
+        else:
+            q = torch.empty(x.shape, dtype=return_q, device=dev)
     if x.numel() == 0:
         L.check(2)
     with torch.cuda.device(dev):

@@ -372,6 +372,21 @@ def main():
         out["gptq/%s/y" % name] = y.numpy()
         out["gptq/%s/meta" % name] = np.array([B, M, N, GS, bit], dtype=np.int64)
     out["gptq23"] = np.array(sorted(gptq23))
+
+    # ---- pack32 -> pack8 checkpoint conversion: run the reference's script on a tiny checkpoint
+    import tempfile
+
+    qlora = os.path.join(REF, "large_language_models/alpaca-qlora")
+    sys.path.insert(0, qlora)
+    conv = importlib.import_module("convert_pack32topack8")
+    with tempfile.TemporaryDirectory() as td:
+        src, dst = os.path.join(td, "a.pth"), os.path.join(td, "b.pth")
+        qw32 = torch.from_numpy(out["gptq/g128/qweight"]).clone()
+        torch.save({"model": {"layers.0.qweight": qw32, "layers.0.scales": torch.ones(3)}}, src)
+        conv.main(types.SimpleNamespace(checkpoint=src, output=dst))
+        got = torch.load(dst)["model"]
+    out["pack8/qweight32"] = qw32.numpy()
+    out["pack8/qweight8"] = got["layers.0.qweight"].numpy()
     out["cases2"] = np.array(cases2)
     out["cases"] = np.array(cases)
     np.savez_compressed(OUT, **out)

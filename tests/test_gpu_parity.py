@@ -683,6 +683,94 @@ def test_gptq_rejects_wrong_packing():
 
 
 # --------------------------------------------------------------------------------------
+# real quantized storage
+# --------------------------------------------------------------------------------------
+EXPORT_CASES = [c for c in QUANT_CASES if c.split("/")[0] in ("uni", "act", "pct", "mse") and "/16/" not in c]
+
+
+@pytest.mark.parametrize("name", EXPORT_CASES)
+def test_qdq_export_matches_reference_fake_quant(golden, oracle, name):
+    """QuantizeLinear constants from the kernel: DequantizeLinear(q) == the reference's fake-quant
+    output bit for bit, q == round(x/s)+zp saturated (ONNX QuantizeLinear), containers as in
+    torch_fake_quant (int8 / uint8)."""
+    from sparsebit_amd import export
+    from sparsebit_amd.quantizers import build_quantizer
+
+    cfg, backend = case_config(name)
+    qmin, qmax, ch_axis, perch, sym = _meta(golden, name)
+    if qmax - qmin > 255:
+        pytest.skip("wider than the 8-bit QDQ container")
+    q = build_quantizer(cfg)
+    q.set_backend(backend)
+    xs = all_x(golden, name)
+    for x in xs:
+        q.update_observer(dev_tensor(x))
+    q.calc_qparams()
+    x0 = dev_tensor(xs[0])
+    dq, rec = export.quantize_linear(q, x0)
+    assert same_values(dq.cpu().numpy(), golden[name + "/dq"])
+    assert same_values(rec.dequantize().cpu().numpy(), golden[name + "/dq"])
+    want_dtype = torch.int8 if qmin < 0 else torch.uint8
+    assert rec.q.dtype == want_dtype and rec.zero_point.dtype == want_dtype and rec.scale.dtype == torch.float32
+    assert rec.bits == q.bit and rec.axis == (ch_axis if perch else None)
+    _, ref_q = oracle.qdq(xs[0], golden[name + "/scale"], golden[name + "/zero_point"], qmin, qmax, ch_axis)
+    assert np.array_equal(rec.levels().cpu().numpy().astype(np.int32), ref_q)
+    assert int(rec.levels().min()) >= qmin and int(rec.levels().max()) <= qmax
+    back = export.QDQTensor.from_state_dict({k: v.cpu() for k, v in rec.state_dict("w.").items()}, "w.")
+    assert same_values(back.dequantize().numpy(), golden[name + "/dq"])
+    if qmax - qmin <= 15 and xs[0].shape[-1] % 8 == 0 and not (perch and ch_axis == xs[0].ndim - 1):
+        dq4, rec4 = export.quantize_linear(q, x0, pack_int4=True)
+        assert rec4.packed and rec4.q.dtype == torch.uint8 and rec4.q.numel() * 2 == x0.numel()
+        assert torch.equal(rec4.levels(), rec.levels())
+        assert torch.equal(rec4.q, export.pack_int4(rec.levels()))
+        assert same_values(rec4.dequantize().cpu().numpy(), golden[name + "/dq"])
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape,ch_axis,lo,hi", [((4096, 4096), 0, -8, 7), ((512, 512, 3, 3), 0, 0, 15),
+                                                 ((64, 197, 384), 2, -8, 7), ((3, 1000, 64), None, 0, 15),
+                                                 ((33, 72), 0, -2, 1)])
+def test_packed_int4_output_equals_packed_levels(ops, dtype, shape, ch_axis, lo, hi):
+    """SBQ_Q_I4 straight from the kernel == pack_int4 of the int8 levels, all layouts the pack kernels cover"""
+    from sparsebit_amd import export
+
+    g = torch.Generator().manual_seed(5)
+    x = (torch.randn(shape, generator=g) * 3).to(dtype).cuda()
+    C = 1 if ch_axis is None else shape[ch_axis]
+    scale = (torch.rand(C, generator=g) * 0.5 + 0.25).cuda()
+    zp = torch.full((C,), 0.0 if lo < 0 else 7.0).cuda()
+    ax = 0 if ch_axis is None else ch_axis
+    y8, q8 = ops.fake_quant(x, scale, zp, lo, hi, ax, return_q=torch.int8 if lo < 0 else torch.uint8)
+    y4, q4 = ops.fake_quant(x, scale, zp, lo, hi, ax, return_q="int4")
+    assert torch.equal(y4, y8)
+    assert q4.dtype == torch.uint8 and q4.numel() * 2 == x.numel()
+    assert torch.equal(q4, export.pack_int4(q8))
+    assert torch.equal(export.unpack_int4(q4, lo < 0).reshape(shape), q8)
+
+
+def test_packed_int4_rejects_what_it_cannot_pack(ops):
+    from sparsebit_amd.lib import SbqError
+
+    s, z = torch.ones(1, device="cuda"), torch.zeros(1, device="cuda")
+    with pytest.raises(SbqError):  # 8-bit range
+        ops.fake_quant(torch.randn(64, 64, device="cuda"), s, z, -128, 127, 0, return_q="int4")
+    with pytest.raises(SbqError):  # ragged tail: two elements share a byte, no scalar path
+        ops.fake_quant(torch.randn(10, 10, device="cuda"), s, z, -8, 7, 0, return_q="int4")
+    with pytest.raises(SbqError):  # fused mask variants are not instantiated for int4 output
+        ops.fake_quant(torch.randn(64, 64, device="cuda"), s, z, -8, 7, 0, return_q="int4",
+                       mask=torch.ones(64, 64, dtype=torch.bool, device="cuda"))
+
+
+def test_pack8_checkpoint_layout_on_device(golden):
+    from sparsebit_amd import export
+
+    q32 = torch.from_numpy(golden["pack8/qweight32"]).cuda()
+    q8 = export.pack32_to_pack8(q32)
+    assert np.array_equal(q8.cpu().numpy(), golden["pack8/qweight8"])
+    assert torch.equal(export.pack8_to_pack32(q8), q32)
+
+
+# --------------------------------------------------------------------------------------
 # widened set (SURVEY.md 8f rank 3): remaining observers / quantizers on the same kernels
 # --------------------------------------------------------------------------------------
 def _cases2():

@@ -208,3 +208,31 @@ def test_gptq_pack_matches_reference_golden(golden):
         assert np.array_equal(ql.qweight.numpy(), golden["gptq/%s/qweight" % name])
         assert np.array_equal(ql.zeros.reshape(N, -1).numpy(), golden["gptq/%s/zeros" % name])
         assert sorted(ql.state_dict()) == ["bias", "qweight", "scales", "zeros"]
+
+
+def test_pack32_to_pack8_matches_reference_script(golden):
+    """convert_pack32topack8.py run on a tiny checkpoint (gen_golden.py) vs export.pack32_to_pack8"""
+    from sparsebit_amd import export
+
+    q32 = torch.from_numpy(golden["pack8/qweight32"])
+    q8 = export.pack32_to_pack8(q32)
+    assert q8.dtype == torch.int8
+    assert np.array_equal(q8.numpy(), golden["pack8/qweight8"])
+    assert torch.equal(export.pack8_to_pack32(q8), q32)
+    sd = export.convert_checkpoint_pack32_to_pack8({"l.qweight": q32, "l.scales": torch.ones(2)})
+    assert sd["l.qweight"].dtype == torch.int8 and sd["l.scales"].dtype == torch.float32
+    with pytest.raises(TypeError):
+        export.pack32_to_pack8(q32.to(torch.int64))
+
+
+def test_int4_pack_roundtrip():
+    from sparsebit_amd import export
+
+    g = torch.Generator().manual_seed(0)
+    lv = torch.randint(-8, 8, (6, 10), generator=g, dtype=torch.int8)
+    p = export.pack_int4(lv)
+    assert p.dtype == torch.uint8 and p.numel() == 30
+    assert torch.equal(export.unpack_int4(p, True).reshape(6, 10), lv)
+    lu = torch.randint(0, 16, (4, 8), generator=g, dtype=torch.uint8)
+    assert torch.equal(export.unpack_int4(export.pack_int4(lu), False).reshape(4, 8), lu)
+    assert int(export.pack_int4(torch.tensor([1, -1], dtype=torch.int8))[0]) == 0xF1  # element 0 low nibble

@@ -310,6 +310,42 @@ def test_full_size_4096_properties(oracle, ops):
     assert same_values(y.cpu().numpy(), ref_all)
 
 
+@pytest.mark.parametrize("shape", [(11008, 4096), (16384, 4096), (9000, 8200), (3, 4096 * 4096 + 8)])
+def test_large_grid_paths(oracle, ops, shape):
+    """grids beyond one resident wave: several tiles per workgroup (software-pipelined loop), the
+    two-tiles-per-iteration variant (>= 32768 slabs), ragged last slabs, very long rows.  Checked by
+    (1) dq == q * scale, (2) the oracle on sampled rows incl. the first / last tiles, (3) every
+    forced launch variant producing the same bits as the automatic one."""
+    from sparsebit_amd import lib as L
+
+    g = torch.Generator().manual_seed(shape[0])
+    C, inner = shape
+    x = (torch.randn(C, 1, generator=g) * torch.randn(1, 4099, generator=g)).repeat(1, inner // 4099 + 1)[:, :inner]
+    x = (x * torch.logspace(-1, 1, C).unsqueeze(1)).bfloat16().cuda().contiguous()
+    mn, mx, _ = ops.channel_stats(x, 0, True)
+    scale, zp = ops.qparams_from_minmax(mn, mx, -128, 127, True)
+    y, qi = ops.fake_quant(x, scale, zp, -128, 127, 0, return_q=torch.int8)
+    assert torch.equal(y, qi.float() * scale.reshape(-1, 1))
+    rows = sorted({0, 1, C // 2, C - 2, C - 1})
+    xr = x[rows].float().cpu().numpy()
+    ref_dq, ref_q = oracle.qdq(xr, scale[rows].cpu().numpy(), zp[rows].cpu().numpy(), -128, 127, 0)
+    assert same_values(y[rows].cpu().numpy(), ref_dq)
+    assert np.array_equal(qi[rows].cpu().numpy().astype(np.int32), ref_q)
+    y16 = ops.fake_quant(x, scale, zp, -128, 127, 0, out_dtype=torch.bfloat16)
+    assert torch.equal(y16, y.bfloat16())
+    try:
+        for variant in (0, 1, 2, 4, 5):  # U = 1 / 2 / 4, cached instead of nontemporal
+            L.set_tuning(0, variant)
+            assert torch.equal(ops.fake_quant(x, scale, zp, -128, 127, 0, out_dtype=torch.bfloat16), y16), variant
+        L.set_tuning(0, -1)
+        for cap in (256, 1000):  # many tiles per workgroup
+            L.set_tuning(1, cap)
+            assert torch.equal(ops.fake_quant(x, scale, zp, -128, 127, 0, out_dtype=torch.bfloat16), y16), cap
+    finally:
+        L.set_tuning(0, -1)
+        L.set_tuning(1, 0)
+
+
 # --------------------------------------------------------------------------------------
 # observers on random data vs the oracle
 # --------------------------------------------------------------------------------------

@@ -246,6 +246,37 @@ def main():
     extras["batched_GBps"] = round(n_elem * BYTES_PER_ELEM / bat_us / 1e3, 1)
     extras["batched_frac_of_peak"] = round(n_elem * BYTES_PER_ELEM / bat_us / 1e3 / HBM_PEAK_GBS, 4)
 
+    # model-wide launch: every conv / fc weight of a ResNet-50 (BASELINE configs 1, 2, 5; synthetic
+    # fp32 masters, 4-bit per channel) one launch per layer vs ONE grid for all of them
+    rshapes = []
+    inp = 64
+    for width, blocks in ((64, 3), (128, 4), (256, 6), (512, 3)):
+        for b in range(blocks):
+            rshapes += [(width, inp, 1, 1), (width, width, 3, 3), (width * 4, width, 1, 1)]
+            if b == 0:
+                rshapes.append((width * 4, inp, 1, 1))
+            inp = width * 4
+    rshapes.append((1000, 2048))
+    gw = torch.Generator().manual_seed(5)
+    rentries = []
+    for shp in rshapes:
+        w_ = torch.randn(shp, generator=gw).to(dev)
+        mn_, mx_, _ = ops.channel_stats(w_, 0, True)
+        s_, z_ = ops.qparams_from_minmax(mn_, mx_, -8, 7, True)
+        rentries.append((w_, s_, z_, -8, 7))
+    gq = ops.GroupFakeQuant(rentries)
+    r_elem = sum(e[0].numel() for e in rentries)
+    grp_us = timed(lambda i: gq(), 60)
+
+    def per_layer(i):
+        for (w_, s_, z_, lo, hi) in rentries:
+            ops.fake_quant(w_, s_, z_, lo, hi, 0)
+
+    lay_us = timed(per_layer, 10)
+    extras["resnet50_%d_weights_one_launch_us" % len(rentries)] = round(grp_us, 2)
+    extras["resnet50_weights_one_launch_GBps"] = round(r_elem * 8 / grp_us / 1e3, 1)
+    extras["resnet50_weights_launch_per_layer_us"] = round(lay_us, 1)
+
     # the same single-weight launches issued alternately on two HIP streams (independent
     # quantizers of different layers may overlap: one kernel's tail hides the next one's ramp)
     s2 = torch.cuda.Stream(device=dev)

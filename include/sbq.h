@@ -108,6 +108,43 @@ int sbq_quant_perchannel_forward_batched(const void* const* table, int n_items,
                                          int64_t outer, int64_t C, int64_t inner,
                                          int qmin, int qmax, void* stream);
 
+/* Model-wide launch: the weights of a whole model -- any mix of [C, inner] shapes, per channel
+ * (C > 1) or per tensor (C == 1), each with its own integer range and optionally its own
+ * sparsity mask -- quantized by ONE grid.  The reference launches one kernel per layer per
+ * forward (modules/conv.py:30-36 -> quantizers/base.py:55-64); for CNN / ViT weights every one
+ * of those is pure launch latency.
+ *   1. describe the tensors with sbq_group_item (host array);
+ *   2. sbq_group_table_build(items, n, NULL, 0, &n_tiles, &bytes) sizes the table, a second call
+ *      fills a HOST buffer of `bytes`; copy it to device memory (16-byte aligned) once;
+ *   3. sbq_quant_group_forward(device_table, n, n_tiles, ...) as often as needed: pointers are
+ *      captured, so tensors must stay where they are (in-place optimizer updates do).
+ * Results are identical to per-tensor sbq_quant_per{channel,tensor}_forward / sbq_mask_quant_forward
+ * calls.  Constraints per item: contiguous, channel axis 0, inner % 8 == 0, 16-byte aligned x / y,
+ * fewer than 2^24 packs (134 M elements); a group is either all masked (1 byte per element) or
+ * mask-free, and shares x / y dtypes.  SBQ_GROUP_LSQ applies LSQ's pre-ops to the item inside
+ * the kernel (lsq.py:61-62: scale = |scale|, zero_point = clamp(zero_point, qmin, qmax)). */
+#define SBQ_GROUP_LSQ 1u
+/* the item's `y` is a byte offset (multiple of 16) from the y_base handed to the launch: the
+ * outputs of a step live in ONE freshly allocated buffer while the table stays constant */
+#define SBQ_GROUP_Y_OFFSET 2u
+typedef struct {
+  const void* x;
+  void* y;
+  const float* scale;      /* C values */
+  const float* zero_point; /* C values */
+  const uint8_t* mask;     /* NULL, or C*inner bytes */
+  int64_t C, inner;
+  int32_t qmin, qmax;
+  uint32_t flags;
+  uint32_t reserved;
+} sbq_group_item;
+int sbq_group_table_build(const sbq_group_item* items, int n_items,
+                          void* host_table, size_t host_table_bytes,
+                          uint32_t* n_tiles_out, size_t* bytes_needed_out);
+int sbq_quant_group_forward(const void* device_table, int n_items, uint32_t n_tiles,
+                            int x_dtype, int y_dtype, int has_mask,
+                            void* y_base /* NULL: items hold absolute y pointers */, void* stream);
+
 /* Fused unstructured mask + QDQ: y = qdq(keep ? x : 0).
  * keep = mask[i] != 0 when `mask` (1 byte/elem, torch.bool) is given, else
  * keep = |x| > *thresh  (l1norm.py:24-25, strict).  Exactly one of mask/thresh

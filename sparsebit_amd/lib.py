@@ -24,7 +24,27 @@ RADIX_BINS = 2048
 ROWSEL_MAX = 16384
 MAX_BATCH = 64
 
+GROUP_LSQ, GROUP_Y_OFFSET = 1, 2
+
 _DTYPES = {torch.float32: F32, torch.float16: F16, torch.bfloat16: BF16}
+
+
+class GroupItem(ctypes.Structure):
+    """sbq_group_item of include/sbq.h"""
+
+    _fields_ = [
+        ("x", ctypes.c_void_p),
+        ("y", ctypes.c_void_p),
+        ("scale", ctypes.c_void_p),
+        ("zero_point", ctypes.c_void_p),
+        ("mask", ctypes.c_void_p),
+        ("C", ctypes.c_int64),
+        ("inner", ctypes.c_int64),
+        ("qmin", ctypes.c_int32),
+        ("qmax", ctypes.c_int32),
+        ("flags", ctypes.c_uint32),
+        ("reserved", ctypes.c_uint32),
+    ]
 
 c_i64, c_int, c_vp, c_sz, c_dbl = (
     ctypes.c_int64,
@@ -49,6 +69,8 @@ _SIGNATURES = {
         [c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_i64, c_i64, c_i64, c_int, c_int, c_int, c_vp],
     ),
     "sbq_quant_perchannel_forward_batched": (c_int, [c_vp, c_int, c_int, c_int, c_i64, c_i64, c_i64, c_int, c_int, c_vp]),
+    "sbq_group_table_build": (c_int, [c_vp, c_int, c_vp, c_sz, c_vp, c_vp]),
+    "sbq_quant_group_forward": (c_int, [c_vp, c_int, ctypes.c_uint32, c_int, c_int, c_int, c_vp, c_vp]),
     "sbq_mask_quant_forward": (
         c_int,
         [c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_int, c_int, c_int, c_vp],

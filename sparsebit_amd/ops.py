@@ -6,6 +6,8 @@ path (lib.require_device raises).  Outputs are allocated here with torch because
 the C ABI is caller-allocates (the reference's native layer allocated with
 at::empty_like, fake_quant_tensor.cu:80,211).
 """
+import ctypes
+
 import torch
 
 from . import lib as L
@@ -53,6 +55,9 @@ def _gptq_workspace(device, nbytes):
         buf = torch.zeros(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
         _gptq_workspaces[key] = buf
     return buf
+
+
+_DTYPE_IDS = {torch.float32: L.F32, torch.float16: L.F16, torch.bfloat16: L.BF16}
 
 
 def _f32c(t, device):
@@ -181,6 +186,115 @@ class BatchedFakeQuant:
                                                           L.stream_ptr(self.dev))
         L.check(rc)
         return self.outs
+
+
+class GroupFakeQuant:
+    """Model-wide QDQ: tensors of ANY mix of shapes / integer ranges, ONE launch
+    (sbq_group_table_build + sbq_quant_group_forward).
+
+        gq = GroupFakeQuant([(w, scale, zero_point, qmin, qmax), ...], out_dtype=torch.float32,
+                            masks=None | [mask, ...], lsq=False | [bool, ...])
+        outs = gq()      # list of dequantized tensors, bit-identical to per-tensor fake_quant
+
+    Each tensor is quantized along axis 0 when its scale has more than one element, per tensor
+    otherwise.  Build once (the descriptor table lives on the device), call every step; tensors,
+    scales and masks must stay alive and in place.  `GroupFakeQuant.supports(w)` tells which
+    tensors qualify (contiguous, whole 8-element packs per row, 16-byte aligned); the others
+    keep going through fake_quant one by one."""
+
+    @staticmethod
+    def supports(x, per_channel=True):
+        if not (x.is_cuda and x.is_contiguous() and x.dim() >= 1 and x.numel() > 0) or x.data_ptr() % 16:
+            return False
+        inner = x.numel() // x.shape[0] if per_channel else x.numel()
+        return inner % 8 == 0 and x.numel() < (1 << 27)
+
+    def __init__(self, entries, out_dtype=None, masks=None, lsq=False, outs=None, fresh_outputs=False):
+        n = len(entries)
+        if n == 0:
+            raise L.SbqError("GroupFakeQuant: no tensors")
+        xs = [e[0] for e in entries]
+        self.dev = L.require_device(*xs, *[e[1] for e in entries], *[e[2] for e in entries],
+                                    *(masks if masks is not None else []))
+        x0 = xs[0]
+        out_dtype = out_dtype or torch.float32
+        if out_dtype not in (torch.float32, x0.dtype):
+            raise L.SbqError("out_dtype must be float32 or the input dtype")
+        if masks is not None and len(masks) != n:
+            raise L.SbqError("GroupFakeQuant: one mask per tensor (or none at all)")
+        lsq = list(lsq) if isinstance(lsq, (list, tuple)) else [bool(lsq)] * n
+        self.xs, self.scales, self.zps, self.masks = [], [], [], []
+        # fresh_outputs: every call returns views of ONE newly allocated buffer (what an autograd
+        # Function must hand out); the table then holds offsets instead of pointers
+        self.fresh = bool(fresh_outputs)
+        self.out_dtype = out_dtype
+        esz = torch.empty(0, dtype=out_dtype).element_size()
+        self.offsets, total = [], 0
+        for x in xs:
+            self.offsets.append(total)
+            total += (x.numel() * esz + 255) // 256 * 256
+        self.flat_bytes = total
+        if self.fresh:
+            self.outs = None
+        else:
+            self.outs = list(outs) if outs is not None else [torch.empty(x.shape, dtype=out_dtype, device=self.dev) for x in xs]
+        items = (L.GroupItem * n)()
+        for i, (x, scale, zp, qmin, qmax) in enumerate(entries):
+            if x.dtype != x0.dtype or not x.is_contiguous():
+                raise L.SbqError("GroupFakeQuant: tensors must share a dtype and be contiguous")
+            per_channel = scale.numel() > 1
+            C = x.shape[0] if per_channel else 1
+            scale, zp = _f32c(scale, self.dev), _f32c(zp, self.dev)
+            _check_qparams(scale, zp, C)
+            m = None
+            if masks is not None:
+                m = masks[i]
+                if m.shape != x.shape or m.dtype not in (torch.bool, torch.uint8) or not m.is_contiguous():
+                    raise L.SbqError("mask must be a contiguous bool / uint8 tensor with the shape of x")
+                m = m.view(torch.uint8) if m.dtype == torch.bool else m
+            self.xs.append(x), self.scales.append(scale), self.zps.append(zp), self.masks.append(m)
+            it = items[i]
+            it.x, it.scale, it.zero_point = x.data_ptr(), scale.data_ptr(), zp.data_ptr()
+            it.flags = L.GROUP_LSQ if lsq[i] else 0
+            if self.fresh:
+                it.y = self.offsets[i] or None
+                it.flags |= L.GROUP_Y_OFFSET
+            else:
+                y = self.outs[i]
+                if y.shape != x.shape or y.dtype != out_dtype or not y.is_contiguous():
+                    raise L.SbqError("GroupFakeQuant: outputs must match the inputs' shapes and be contiguous")
+                it.y = y.data_ptr()
+            it.mask = m.data_ptr() if m is not None else None
+            it.C, it.inner = C, x.numel() // C
+            it.qmin, it.qmax = int(qmin), int(qmax)
+        lib = L.load()
+        n_tiles, need = ctypes.c_uint32(0), ctypes.c_size_t(0)
+        L.check(lib.sbq_group_table_build(items, n, None, 0, ctypes.byref(n_tiles), ctypes.byref(need)))
+        host = torch.empty(need.value, dtype=torch.uint8)
+        L.check(lib.sbq_group_table_build(items, n, host.data_ptr(), need.value, ctypes.byref(n_tiles), None))
+        self.table = host.to(self.dev)
+        self.n, self.n_tiles = n, n_tiles.value
+        self.x_dt, self.y_dt = L.dtype_id(x0), _DTYPE_IDS[out_dtype]
+        self.has_mask = int(masks is not None)
+        self.shapes = [x.shape for x in xs]
+
+    def pointers(self):
+        """what the device table captured -- compare to notice tensors that were re-allocated"""
+        return [t.data_ptr() for t in self.xs + self.scales + self.zps + [m for m in self.masks if m is not None]]
+
+    def __call__(self):
+        lib = L.load()
+        with torch.cuda.device(self.dev):
+            flat = None
+            if self.fresh:
+                flat = torch.empty(self.flat_bytes, dtype=torch.uint8, device=self.dev)
+            rc = lib.sbq_quant_group_forward(L.ptr(self.table), self.n, self.n_tiles, self.x_dt, self.y_dt,
+                                             self.has_mask, L.ptr(flat), L.stream_ptr(self.dev))
+        L.check(rc)
+        if not self.fresh:
+            return self.outs
+        esz = torch.empty(0, dtype=self.out_dtype).element_size()
+        return [flat[o:o + sh.numel() * esz].view(self.out_dtype).view(sh) for o, sh in zip(self.offsets, self.shapes)]
 
 
 # ---------------------------------------------------------------------------------

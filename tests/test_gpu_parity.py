@@ -310,6 +310,136 @@ def test_full_size_4096_properties(oracle, ops):
     assert same_values(y.cpu().numpy(), ref_all)
 
 
+GROUP_SHAPES = [(64, 64, 3, 3), (8, 8), (512, 4608), (1000, 512), (3, 8), (256, 64, 1, 1), (96, 2304), (1, 16), (33, 1096)]
+
+
+@pytest.mark.parametrize("dtype,out_dtype", [(torch.float32, torch.float32), (torch.bfloat16, torch.bfloat16),
+                                              (torch.bfloat16, torch.float32), (torch.float16, torch.float16)])
+@pytest.mark.parametrize("masked", [False, True])
+def test_group_launch_equals_per_tensor(oracle, ops, dtype, out_dtype, masked):
+    """ONE launch over tensors of mixed shapes, integer ranges and granularity == fake_quant one by one
+    (which the other tests pin to the oracle); plus the oracle directly on two of the items."""
+    g = torch.Generator().manual_seed(17)
+    entries, masks, want = [], [], []
+    for i, shape in enumerate(GROUP_SHAPES):
+        x = (torch.randn(shape, generator=g) * (0.5 + i)).to(dtype).cuda()
+        per_channel = i % 3 != 2
+        qmin, qmax = [(-8, 7), (-128, 127), (0, 255), (0, 15)][i % 4]
+        C = shape[0] if per_channel else 1
+        scale = (torch.rand(C, generator=g) * 0.1 + 0.01).cuda() * (0.5 + i)
+        zp = torch.zeros(C).cuda() if qmin < 0 else torch.randint(0, qmax, (C,), generator=g).float().cuda()
+        m = (torch.rand(shape, generator=g) > 0.4).cuda() if masked else None
+        entries.append((x, scale, zp, qmin, qmax))
+        masks.append(m)
+        want.append(ops.fake_quant(x, scale, zp, qmin, qmax, 0, out_dtype=out_dtype, mask=m))
+    gq = ops.GroupFakeQuant(entries, out_dtype=out_dtype, masks=masks if masked else None)
+    assert gq.n_tiles == sum(-(-(x.numel() // 8) // 256) for x, *_ in entries)
+    for rep in range(2):  # the table is reusable
+        outs = gq()
+        for i, (y, w) in enumerate(zip(outs, want)):
+            assert y.dtype == out_dtype and torch.equal(y, w), (i, GROUP_SHAPES[i])
+    for i in (2, 3):
+        x, scale, zp, qmin, qmax = entries[i]
+        xf = x.float()
+        if masked:
+            xf = xf * masks[i]
+        ref, _ = oracle.qdq(xf.cpu().numpy(), scale.cpu().numpy(), zp.cpu().numpy(), qmin, qmax, 0)
+        assert same_values(outs[i].float().cpu().numpy(), torch.from_numpy(ref).to(out_dtype).float().numpy())
+
+
+def test_group_launch_lsq_preops_and_inplace_updates(ops):
+    """SBQ_GROUP_LSQ = |scale| and clamp(zero_point) inside the kernel (lsq.py:61-62); the table holds
+    pointers, so in-place updates of weights / scales are seen by the next call"""
+    g = torch.Generator().manual_seed(3)
+    ws = [torch.randn(s, generator=g).cuda() for s in ((32, 16, 3, 3), (64, 256), (10, 64))]
+    scales = [(torch.randn(w.shape[0], generator=g) * 0.05).cuda() for w in ws]  # LSQ steps may go negative
+    zps = [torch.full((w.shape[0],), 20.0).cuda() for w in ws]  # beyond qmax: clamped to 7
+    gq = ops.GroupFakeQuant([(w, s, z, -8, 7) for w, s, z in zip(ws, scales, zps)], lsq=True)
+    for step in range(2):
+        outs = gq()
+        for w, s, z, y in zip(ws, scales, zps, outs):
+            assert torch.equal(y, ops.fake_quant(w, s.abs(), z.clamp(-8, 7), -8, 7, 0))
+        for w, s in zip(ws, scales):  # "optimizer step", in place
+            w.mul_(0.9)
+            s.add_(0.01)
+
+
+@pytest.mark.parametrize("masked", [False, True])
+def test_weight_quant_group_forward_and_gradients(masked):
+    """WeightQuantGroup == the quantizers called one by one: values, weight gradients and LSQ step-size
+    gradients bit for bit, incl. tensors that fall back (7x7 conv, a disabled quantizer, LSQ+)."""
+    from sparsebit_amd.common import Backend
+    from sparsebit_amd.config import quantizer_config
+    from sparsebit_amd.group import WeightQuantGroup
+    from sparsebit_amd.quantizers import build_quantizer
+
+    torch.manual_seed(0)
+    specs = [((64, 3, 7, 7), "lsq", 8), ((64, 64, 3, 3), "lsq", 4), ((256, 64, 1, 1), "lsq", 4), ((128, 64, 3, 3), "uniform", 8),
+             ((10, 256), "lsq", 8), ((32, 64, 1, 1), "lsq+", 4), ((48, 32, 3, 3), "lsq", 4)]
+    triples = []
+    for k, (shape, kind, bit) in enumerate(specs):
+        w = torch.nn.Parameter(torch.randn(shape, device="cuda") * 0.1)
+        q = build_quantizer(quantizer_config("per-channel-symmetric", bit, quantizer=kind))
+        q.set_backend(Backend.VIRTUAL)
+        q.update_observer(w.detach())
+        q.calc_qparams()
+        if k != 6:
+            q.enable_quant()  # the last one stays disabled: identity
+        if kind == "lsq" and k == 2:
+            with torch.no_grad():
+                q.scale[::2] *= -1  # learned step sizes may change sign: |scale| is what quantizes
+        m = (torch.rand(shape, device="cuda") > 0.5) if masked else None
+        triples.append((q, w, m))
+    group = WeightQuantGroup(triples)
+    assert len(group.members) == 4 and sorted(group.rest_idx) == [0, 5, 6]
+    gys = [torch.randn(s, device="cuda") for s, _, _ in specs]
+
+    def run(fn):
+        for q, w, _ in triples:
+            w.grad = None
+            if isinstance(q.scale, torch.nn.Parameter):
+                q.scale.grad = None
+        outs = fn()
+        loss = sum((y * gy).sum() for y, gy in zip(outs, gys))
+        loss.backward()
+        return ([y.detach().clone() for y in outs], [w.grad.clone() for _, w, _ in triples],
+                [q.scale.grad.clone() if isinstance(q.scale, torch.nn.Parameter) and q.scale.grad is not None else None
+                 for q, _, _ in triples])
+
+    ref = run(lambda: [q(w if m is None else w * m) for q, w, m in triples])
+    got = run(group)
+    for k in range(len(specs)):
+        assert torch.equal(got[0][k], ref[0][k]), ("value", k)
+        assert torch.equal(got[1][k], ref[1][k]), ("weight grad", k)
+        assert (got[2][k] is None) == (ref[2][k] is None)
+        if ref[2][k] is not None:
+            assert torch.equal(got[2][k], ref[2][k]), ("scale grad", k)
+    with torch.no_grad():
+        for y, r in zip(group(), ref[0]):
+            assert torch.equal(y, r)
+        # re-calibration replaces the scale tensors: the group notices and rebuilds its table
+        q1, w1, m1 = triples[3]
+        q1.update_observer(w1.detach() * 2)
+        q1.calc_qparams()
+        want = q1(w1 if m1 is None else w1 * m1)
+        assert torch.equal(group()[3], want)
+
+
+def test_group_launch_rejects_unsupported(ops):
+    from sparsebit_amd.lib import SbqError
+
+    s1, z1 = torch.ones(1, device="cuda"), torch.zeros(1, device="cuda")
+    with pytest.raises(SbqError):  # 147 elements per row: no whole packs (first ResNet conv) -> one by one
+        ops.GroupFakeQuant([(torch.randn(64, 3, 7, 7, device="cuda"), torch.ones(64, device="cuda"),
+                             torch.zeros(64, device="cuda"), -128, 127)])
+    assert not ops.GroupFakeQuant.supports(torch.randn(64, 3, 7, 7, device="cuda"))
+    assert ops.GroupFakeQuant.supports(torch.randn(64, 64, 3, 3, device="cuda"))
+    with pytest.raises(SbqError):  # CPU tensor: no fallback
+        ops.GroupFakeQuant([(torch.randn(8, 8), s1, z1, -8, 7)])
+    with pytest.raises(SbqError):
+        ops.GroupFakeQuant([])
+
+
 @pytest.mark.parametrize("shape", [(11008, 4096), (16384, 4096), (9000, 8200), (3, 4096 * 4096 + 8)])
 def test_large_grid_paths(oracle, ops, shape):
     """grids beyond one resident wave: several tiles per workgroup (software-pipelined loop), the

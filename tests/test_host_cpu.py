@@ -236,3 +236,43 @@ def test_int4_pack_roundtrip():
     lu = torch.randint(0, 16, (4, 8), generator=g, dtype=torch.uint8)
     assert torch.equal(export.unpack_int4(export.pack_int4(lu), False).reshape(4, 8), lu)
     assert int(export.pack_int4(torch.tensor([1, -1], dtype=torch.int8))[0]) == 0xF1  # element 0 low nibble
+
+
+def test_group_table_build_is_host_side_and_validates():
+    """sbq_group_table_build never touches the GPU: sizes, layout and error codes on the CPU"""
+    import ctypes
+
+    from sparsebit_amd import lib as L
+
+    l = L.load()
+
+    def item(C, inner, x=0x1000, y=0x2000, mask=None, qmin=-8, qmax=7):
+        it = L.GroupItem()
+        it.x, it.y, it.scale, it.zero_point, it.mask = x, y, 0x3000, 0x4000, mask
+        it.C, it.inner, it.qmin, it.qmax, it.flags = C, inner, qmin, qmax, 0
+        return it
+
+    def build(items, buf=None):
+        arr = (L.GroupItem * len(items))(*items)
+        nt, need = ctypes.c_uint32(0), ctypes.c_size_t(0)
+        rc = l.sbq_group_table_build(arr, len(items), buf.ctypes.data if buf is not None else None,
+                                     buf.nbytes if buf is not None else 0, ctypes.byref(nt), ctypes.byref(need))
+        return rc, nt.value, need.value
+
+    items = [item(64, 576), item(1, 4096), item(3, 8)]  # 4608 + 512 + 3 packs -> 18 + 2 + 1 tiles
+    rc, nt, need = build(items)
+    assert rc == 0 and nt == 21 and need == 64 + 3 * 80 + 21 * 4
+    buf = np.zeros(need, dtype=np.uint8)
+    rc, nt2, _ = build(items, buf)
+    assert rc == 0 and nt2 == 21
+    words = buf.view(np.uint32)
+    assert words[0] == 3 and words[1] == 21
+    tile_item = words[(64 + 240) // 4:]
+    assert tile_item.tolist() == [0] * 18 + [1] * 2 + [2]
+    assert build(items, np.zeros(need - 4, dtype=np.uint8))[0] == 5  # SBQ_ERR_WORKSPACE
+    assert build([item(8, 12)])[0] == 4  # inner % 8
+    assert build([item(8, 16, x=0x1004)])[0] == 7  # SBQ_ERR_ALIGN
+    assert build([item(8, 16), item(8, 16, mask=0x5000)])[0] == 4  # all masked or none
+    assert build([item(8, 16, qmin=3, qmax=1)])[0] == 4
+    assert build([item(0, 16)])[0] == 2  # empty
+    assert build([item(1 << 20, 1 << 10)])[0] == 4  # >= 2^24 packs

@@ -145,6 +145,40 @@ int sbq_quant_group_forward(const void* device_table, int n_items, uint32_t n_ti
                             int x_dtype, int y_dtype, int has_mask,
                             void* y_base /* NULL: items hold absolute y pointers */, void* stream);
 
+/* Model-wide STE backward: gx of every grouped weight (and the LSQ step-size gradient of those
+ * that want one) in two launches -- replaces quant_per{tensor,channel}_backward per layer
+ * (fake_quant_tensor.cu:97-132,227-270) and the gs_scaling / abs autograd nodes of
+ * lsq.py:13-21,61-76.  gx = mask * STE'(mask * x); gs[c] = sum_row gy * dq/ds, then for
+ * SBQ_GROUP_LSQ items gs *= gs_ratio * sign(scale).  Outputs live in caller-provided flat
+ * buffers (gx_base: bytes, gs_base: floats) at the item's offsets, so a step allocates two
+ * tensors whatever the number of layers.  `gy` is a HOST array of n_items device pointers
+ * (contiguous, 16-byte aligned, dtype == x dtype): they change every step and travel as kernel
+ * arguments, SBQ_GROUP_BWD_CHUNK items per launch.  Same per-item constraints as the forward. */
+#define SBQ_GROUP_BWD_CHUNK 128
+typedef struct {
+  const void* x;
+  const float* scale;
+  const float* zero_point;
+  const uint8_t* mask; /* NULL or C*inner bytes; all-or-none inside a group */
+  uint64_t gx_offset;  /* bytes from gx_base, multiple of 16 */
+  uint64_t gs_offset;  /* floats from gs_base (C values written) */
+  int64_t C, inner;
+  int32_t qmin, qmax;
+  uint32_t flags;      /* SBQ_GROUP_LSQ */
+  int32_t want_gs;
+  float gs_ratio;      /* LSQ: 1/sqrt(inner * qmax) (lsq.py:68-71) */
+  uint32_t reserved;
+} sbq_group_bwd_item;
+int sbq_group_bwd_table_build(const sbq_group_bwd_item* items, int n_items,
+                              void* host_table, size_t host_table_bytes,
+                              uint32_t* n_wgs_out, uint32_t* n_rows_out,
+                              size_t* bytes_needed_out, size_t* workspace_bytes_out);
+/* device_table: the built table copied to the GPU; host_table: the same bytes, still on the host */
+int sbq_quant_group_backward(const void* device_table, const void* host_table, int n_items,
+                             int x_dtype, int gx_dtype, int has_mask,
+                             const void* const* gy, void* gx_base, float* gs_base,
+                             void* workspace, size_t workspace_bytes, void* stream);
+
 /* Fused unstructured mask + QDQ: y = qdq(keep ? x : 0).
  * keep = mask[i] != 0 when `mask` (1 byte/elem, torch.bool) is given, else
  * keep = |x| > *thresh  (l1norm.py:24-25, strict).  Exactly one of mask/thresh

@@ -31,8 +31,8 @@ def _kind(q):
 
 
 class _GroupSTE(torch.autograd.Function):
-    """forward: the grouped launch; backward: the per-tensor STE kernels (sbq_quant_*_backward),
-    LSQ's |scale| and gradient scaling applied as in lsq.py:13-21,61-76."""
+    """forward: the grouped launch; backward: the grouped STE backward (two launches), LSQ's |scale|
+    and gradient scaling applied inside the kernels as in lsq.py:13-21,61-76."""
 
     @staticmethod
     def forward(ctx, group, *tensors):
@@ -46,30 +46,14 @@ class _GroupSTE(torch.autograd.Function):
     def backward(ctx, *gouts):
         group = ctx.group
         n = len(group.members)
-        weights, scales = ctx.saved_tensors[:n], ctx.saved_tensors[n:]
-        gws, gss = [], []
-        for i, (q, _, mask) in enumerate(group.members):
-            gy = gouts[i]
-            need_w, need_s = ctx.needs_input_grad[1 + i], ctx.needs_input_grad[1 + n + i]
-            if gy is None or not (need_w or need_s):
-                gws.append(None), gss.append(None)
-                continue
-            w, s = weights[i], scales[i]
-            lsq = group.kinds[i] == "lsq"
-            x = w if mask is None else w * mask
-            s_eff = s.detach().abs() if lsq else s.detach()
-            zp = q.zero_point.detach().float()
-            qmin, qmax = q.qdesc.qrange
-            if lsq:
-                zp = zp.clamp(qmin, qmax)
-            gx, gs, _ = ops.fake_quant_backward(x.detach(), gy, s_eff, zp, qmin, qmax, 0, need_s, False, gx_dtype=w.dtype)
-            if mask is not None:
-                gx = gx * mask
-            if gs is not None:
-                gs = gs.reshape(s.shape)
-                if lsq:
-                    gs = gs * q._gs_ratio(w) * torch.sign(s.detach())
-            gws.append(gx if need_w else None), gss.append(gs if need_s else None)
+        need_w = ctx.needs_input_grad[1:1 + n]
+        need_s = ctx.needs_input_grad[1 + n:1 + 2 * n]
+        if all(g is not None for g in gouts):
+            gws, gss = group._backward(list(gouts))  # two launches for the whole model
+        else:
+            gws, gss = group._backward_one_by_one(ctx.saved_tensors, gouts)
+        gws = [g if k else None for g, k in zip(gws, need_w)]
+        gss = [g if k else None for g, k in zip(gss, need_s)]
         return (None, *gws, *gss)
 
 
@@ -126,6 +110,63 @@ class WeightQuantGroup:
             for k, y in zip(half["idx"], half["gq"]()):
                 outs[k] = y
         return outs
+
+    # ---- backward -----------------------------------------------------------------------------
+    def _build_backward(self, half):
+        entries, masks, lsq, want, ratios = [], [], [], [], []
+        for k in half["idx"]:
+            q, w, m = self.members[k]
+            qmin, qmax = q.qdesc.qrange
+            entries.append((w.detach(), q.scale.detach(), q.zero_point.detach().float(), qmin, qmax))
+            masks.append(m)
+            is_lsq = self.kinds[k] == "lsq"
+            lsq.append(is_lsq)
+            want.append(bool(q.scale.requires_grad))
+            ratios.append(q._gs_ratio(w) if is_lsq else 1.0)
+        half["gb"] = ops.GroupFakeQuantBackward(entries, masks=masks if masks[0] is not None else None, lsq=lsq,
+                                                want_gs=want, gs_ratios=ratios)
+        half["bptrs"] = self._live_pointers(half) + [int(v) for v in want]
+
+    def _backward(self, gys):
+        gws, gss = [None] * len(self.members), [None] * len(self.members)
+        for half in self._halves:
+            want = [int(self.members[k][0].scale.requires_grad) for k in half["idx"]]
+            if half.get("gb") is None or half["bptrs"] != self._live_pointers(half) + want:
+                self._build_backward(half)
+            gx, gs = half["gb"]([gys[k] for k in half["idx"]])
+            for j, k in enumerate(half["idx"]):
+                gws[k] = gx[j]
+                gss[k] = None if gs[j] is None else gs[j].reshape(self.members[k][0].scale.shape)
+        return gws, gss
+
+    def _backward_one_by_one(self, saved, gouts):
+        """a layer whose output took no part in the loss hands in None: per-tensor kernels then"""
+        n = len(self.members)
+        weights, scales = saved[:n], saved[n:]
+        gws, gss = [], []
+        for i, (q, _, mask) in enumerate(self.members):
+            gy = gouts[i]
+            if gy is None:
+                gws.append(None), gss.append(None)
+                continue
+            w, s = weights[i], scales[i]
+            lsq = self.kinds[i] == "lsq"
+            x = w if mask is None else w * mask
+            s_eff = s.detach().abs() if lsq else s.detach()
+            zp = q.zero_point.detach().float()
+            qmin, qmax = q.qdesc.qrange
+            if lsq:
+                zp = zp.clamp(qmin, qmax)
+            need_s = bool(s.requires_grad)
+            gx, gs, _ = ops.fake_quant_backward(x.detach(), gy, s_eff, zp, qmin, qmax, 0, need_s, False, gx_dtype=w.dtype)
+            if mask is not None:
+                gx = gx * mask
+            if gs is not None:
+                gs = gs.reshape(s.shape)
+                if lsq:
+                    gs = gs * q._gs_ratio(w) * torch.sign(s.detach())
+            gws.append(gx), gss.append(gs)
+        return gws, gss
 
     # ---- forward ------------------------------------------------------------------------------
     def __call__(self):

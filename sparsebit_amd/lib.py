@@ -25,6 +25,7 @@ ROWSEL_MAX = 16384
 MAX_BATCH = 64
 
 GROUP_LSQ, GROUP_Y_OFFSET = 1, 2
+GROUP_BWD_CHUNK = 128
 
 _DTYPES = {torch.float32: F32, torch.float16: F16, torch.bfloat16: BF16}
 
@@ -55,6 +56,27 @@ c_i64, c_int, c_vp, c_sz, c_dbl = (
 )
 
 # name -> (restype, argtypes); mirrors include/sbq.h declaration by declaration
+class GroupBwdItem(ctypes.Structure):
+    """sbq_group_bwd_item of include/sbq.h"""
+
+    _fields_ = [
+        ("x", ctypes.c_void_p),
+        ("scale", ctypes.c_void_p),
+        ("zero_point", ctypes.c_void_p),
+        ("mask", ctypes.c_void_p),
+        ("gx_offset", ctypes.c_uint64),
+        ("gs_offset", ctypes.c_uint64),
+        ("C", ctypes.c_int64),
+        ("inner", ctypes.c_int64),
+        ("qmin", ctypes.c_int32),
+        ("qmax", ctypes.c_int32),
+        ("flags", ctypes.c_uint32),
+        ("want_gs", ctypes.c_int32),
+        ("gs_ratio", ctypes.c_float),
+        ("reserved", ctypes.c_uint32),
+    ]
+
+
 _SIGNATURES = {
     "sbq_version": (c_int, []),
     "sbq_strerror": (ctypes.c_char_p, [c_int]),
@@ -71,6 +93,8 @@ _SIGNATURES = {
     "sbq_quant_perchannel_forward_batched": (c_int, [c_vp, c_int, c_int, c_int, c_i64, c_i64, c_i64, c_int, c_int, c_vp]),
     "sbq_group_table_build": (c_int, [c_vp, c_int, c_vp, c_sz, c_vp, c_vp]),
     "sbq_quant_group_forward": (c_int, [c_vp, c_int, ctypes.c_uint32, c_int, c_int, c_int, c_vp, c_vp]),
+    "sbq_group_bwd_table_build": (c_int, [c_vp, c_int, c_vp, c_sz, c_vp, c_vp, c_vp, c_vp]),
+    "sbq_quant_group_backward": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "sbq_mask_quant_forward": (
         c_int,
         [c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_int, c_int, c_int, c_vp],

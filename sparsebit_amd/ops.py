@@ -230,10 +230,11 @@ class GroupFakeQuant:
         self.out_dtype = out_dtype
         esz = torch.empty(0, dtype=out_dtype).element_size()
         self.offsets, total = [], 0
-        for x in xs:
+        for x in xs:  # rows are whole 8-element packs: every tensor's byte size is a multiple of 16
             self.offsets.append(total)
-            total += (x.numel() * esz + 255) // 256 * 256
-        self.flat_bytes = total
+            total += x.numel() * esz
+        self.flat_elems = total // esz
+        self.numels = [x.numel() for x in xs]
         if self.fresh:
             self.outs = None
         else:
@@ -287,14 +288,113 @@ class GroupFakeQuant:
         with torch.cuda.device(self.dev):
             flat = None
             if self.fresh:
-                flat = torch.empty(self.flat_bytes, dtype=torch.uint8, device=self.dev)
+                flat = torch.empty(self.flat_elems, dtype=self.out_dtype, device=self.dev)
             rc = lib.sbq_quant_group_forward(L.ptr(self.table), self.n, self.n_tiles, self.x_dt, self.y_dt,
                                              self.has_mask, L.ptr(flat), L.stream_ptr(self.dev))
         L.check(rc)
         if not self.fresh:
             return self.outs
-        esz = torch.empty(0, dtype=self.out_dtype).element_size()
-        return [flat[o:o + sh.numel() * esz].view(self.out_dtype).view(sh) for o, sh in zip(self.offsets, self.shapes)]
+        return [t.view(sh) for t, sh in zip(flat.split_with_sizes(self.numels), self.shapes)]
+
+
+class GroupFakeQuantBackward:
+    """STE backward of a whole group in two launches (sbq_quant_group_backward).
+
+        gb = GroupFakeQuantBackward([(w, scale, zero_point, qmin, qmax), ...], masks=None | [...],
+                                    lsq=[bool, ...], want_gs=[bool, ...], gs_ratios=[float, ...])
+        gxs, gss = gb(gys)     # lists; gss[i] is None where want_gs[i] is False
+
+    gx_i = mask_i * STE'(mask_i * w_i) * gy_i;  gs_i per channel (flat fp32 [C]), for LSQ items already
+    multiplied by gs_ratio and sign(scale).  Outputs are views of two buffers allocated per call."""
+
+    def __init__(self, entries, masks=None, lsq=False, want_gs=False, gs_ratios=None, gx_dtype=None):
+        n = len(entries)
+        if n == 0:
+            raise L.SbqError("GroupFakeQuantBackward: no tensors")
+        xs = [e[0] for e in entries]
+        self.dev = L.require_device(*xs, *[e[1] for e in entries], *[e[2] for e in entries],
+                                    *(masks if masks is not None else []))
+        x0 = xs[0]
+        self.gx_dtype = gx_dtype or x0.dtype
+        if self.gx_dtype not in (torch.float32, x0.dtype):
+            raise L.SbqError("gx_dtype must be float32 or the input dtype")
+        lsq = list(lsq) if isinstance(lsq, (list, tuple)) else [bool(lsq)] * n
+        want_gs = list(want_gs) if isinstance(want_gs, (list, tuple)) else [bool(want_gs)] * n
+        gs_ratios = list(gs_ratios) if gs_ratios is not None else [1.0] * n
+        esz = torch.empty(0, dtype=self.gx_dtype).element_size()
+        self.xs, self.scales, self.zps, self.masks = [], [], [], []
+        self.gx_off, self.gs_off, self.shapes, self.Cs = [], [], [x.shape for x in xs], []
+        gx_total = gs_total = 0
+        items = (L.GroupBwdItem * n)()
+        for i, (x, scale, zp, qmin, qmax) in enumerate(entries):
+            if x.dtype != x0.dtype or not x.is_contiguous():
+                raise L.SbqError("GroupFakeQuantBackward: tensors must share a dtype and be contiguous")
+            per_channel = scale.numel() > 1
+            C = x.shape[0] if per_channel else 1
+            scale, zp = _f32c(scale, self.dev), _f32c(zp, self.dev)
+            _check_qparams(scale, zp, C)
+            m = None
+            if masks is not None:
+                m = masks[i]
+                if m.shape != x.shape or m.dtype not in (torch.bool, torch.uint8) or not m.is_contiguous():
+                    raise L.SbqError("mask must be a contiguous bool / uint8 tensor with the shape of x")
+                m = m.view(torch.uint8) if m.dtype == torch.bool else m
+            self.xs.append(x), self.scales.append(scale), self.zps.append(zp), self.masks.append(m), self.Cs.append(C)
+            self.gx_off.append(gx_total)
+            gx_total += x.numel() * esz
+            self.gs_off.append(gs_total if want_gs[i] else None)
+            if want_gs[i]:
+                gs_total += C
+            it = items[i]
+            it.x, it.scale, it.zero_point = x.data_ptr(), scale.data_ptr(), zp.data_ptr()
+            it.mask = m.data_ptr() if m is not None else None
+            it.gx_offset, it.gs_offset = self.gx_off[i], self.gs_off[i] or 0
+            it.C, it.inner = C, x.numel() // C
+            it.qmin, it.qmax = int(qmin), int(qmax)
+            it.flags = L.GROUP_LSQ if lsq[i] else 0
+            it.want_gs = int(want_gs[i])
+            it.gs_ratio = float(gs_ratios[i])
+        self.gx_elems, self.gs_floats = gx_total // esz, gs_total
+        self.numels = [x.numel() for x in xs]
+        self.gs_sizes = [C for C, o in zip(self.Cs, self.gs_off) if o is not None]
+        lib = L.load()
+        need, wsb = ctypes.c_size_t(0), ctypes.c_size_t(0)
+        L.check(lib.sbq_group_bwd_table_build(items, n, None, 0, None, None, ctypes.byref(need), ctypes.byref(wsb)))
+        self.host_table = torch.empty(need.value, dtype=torch.uint8)
+        L.check(lib.sbq_group_bwd_table_build(items, n, self.host_table.data_ptr(), need.value, None, None, None, None))
+        self.table = self.host_table.to(self.dev)
+        self.workspace = torch.empty(max(wsb.value, 16), dtype=torch.uint8, device=self.dev)
+        self.n = n
+        self.x_dt, self.gx_dt = L.dtype_id(x0), _DTYPE_IDS[self.gx_dtype]
+        self.has_mask = int(masks is not None)
+        self.x_dtype = x0.dtype
+
+    def __call__(self, gys):
+        if len(gys) != self.n:
+            raise L.SbqError("one output gradient per tensor")
+        keep = []
+        ptrs = (ctypes.c_void_p * self.n)()
+        for i, gy in enumerate(gys):
+            if gy.shape != self.shapes[i]:
+                raise L.SbqError("gradient %d has the wrong shape" % i)
+            if gy.dtype != self.x_dtype or not gy.is_contiguous() or gy.data_ptr() % 16:
+                gy = gy.to(self.x_dtype).contiguous()
+                if gy.data_ptr() % 16:
+                    gy = gy.clone()
+            keep.append(gy)
+            ptrs[i] = gy.data_ptr()
+        lib = L.load()
+        with torch.cuda.device(self.dev):
+            gx_flat = torch.empty(self.gx_elems, dtype=self.gx_dtype, device=self.dev)
+            gs_flat = torch.empty(max(self.gs_floats, 1), dtype=torch.float32, device=self.dev)
+            rc = lib.sbq_quant_group_backward(L.ptr(self.table), self.host_table.data_ptr(), self.n, self.x_dt, self.gx_dt,
+                                              self.has_mask, ptrs, L.ptr(gx_flat), L.ptr(gs_flat), L.ptr(self.workspace),
+                                              self.workspace.numel(), L.stream_ptr(self.dev))
+        L.check(rc)
+        gxs = [t.view(sh) for t, sh in zip(gx_flat.split_with_sizes(self.numels), self.shapes)]
+        parts = iter(gs_flat[:self.gs_floats].split_with_sizes(self.gs_sizes)) if self.gs_sizes else iter(())
+        gss = [None if o is None else next(parts) for o in self.gs_off]
+        return gxs, gss
 
 
 # ---------------------------------------------------------------------------------

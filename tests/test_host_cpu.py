@@ -276,3 +276,42 @@ def test_group_table_build_is_host_side_and_validates():
     assert build([item(8, 16, qmin=3, qmax=1)])[0] == 4
     assert build([item(0, 16)])[0] == 2  # empty
     assert build([item(1 << 20, 1 << 10)])[0] == 4  # >= 2^24 packs
+
+
+def test_group_backward_table_build_on_host():
+    import ctypes
+
+    from sparsebit_amd import lib as L
+
+    l = L.load()
+
+    def item(C, inner, want_gs=1, mask=None, gx_off=0):
+        it = L.GroupBwdItem()
+        it.x, it.scale, it.zero_point, it.mask = 0x1000, 0x3000, 0x4000, mask
+        it.gx_offset, it.gs_offset, it.C, it.inner = gx_off, 0, C, inner
+        it.qmin, it.qmax, it.flags, it.want_gs, it.gs_ratio = -8, 7, L.GROUP_LSQ, want_gs, 0.5
+        return it
+
+    def build(items, buf=None):
+        arr = (L.GroupBwdItem * len(items))(*items)
+        wgs, rows, need, wsb = ctypes.c_uint32(0), ctypes.c_uint32(0), ctypes.c_size_t(0), ctypes.c_size_t(0)
+        rc = l.sbq_group_bwd_table_build(arr, len(items), buf.ctypes.data if buf is not None else None,
+                                         buf.nbytes if buf is not None else 0, ctypes.byref(wgs), ctypes.byref(rows),
+                                         ctypes.byref(need), ctypes.byref(wsb))
+        return rc, wgs.value, rows.value, need.value, wsb.value
+
+    # 64 rows x 576 elements: 72 packs -> 2 segments per row -> 128 segments -> 32 workgroups;
+    # 3 rows x 8 elements: 1 segment per row -> 3 segments -> 1 (padded) workgroup
+    rc, wgs, rows, need, wsb = build([item(64, 576), item(3, 8)])
+    assert (rc, wgs, rows) == (0, 33, 67)
+    assert need == 64 + 2 * 96 + 33 * 4 and wsb >= 131 * 8
+    buf = np.zeros(need, dtype=np.uint8)
+    assert build([item(64, 576), item(3, 8)], buf)[0] == 0
+    words = buf.view(np.uint32)
+    assert words[:3].tolist() == [2, 33, 67]
+    assert words[(64 + 192) // 4:].tolist() == [0] * 32 + [1]
+    assert build([item(8, 12)])[0] == 4  # rows of whole packs only
+    assert build([item(8, 16, gx_off=8)])[0] == 7  # gx offsets are multiples of 16
+    assert build([item(8, 16), item(8, 16, mask=0x5000)])[0] == 4
+    p = ctypes.c_void_p(0x1000)
+    assert l.sbq_quant_group_backward(None, None, 1, 0, 0, 0, None, None, None, None, 0, None) == 3

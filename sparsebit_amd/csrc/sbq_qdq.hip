@@ -81,10 +81,11 @@ struct QdqPtrs {
   const float* zp;
 };
 
-// Arithmetic of the pack kernels (knob 2 selects it for A/B measurements on the headline
-// shape; MATH_FAST and MATH_IEEE are both exact, the other two are NOT parity-correct and
-// exist only to locate the bottleneck).
-enum { MATH_FAST = 0, MATH_RCP = 1, MATH_COPY = 2, MATH_IEEE = 3 };
+// Arithmetic of the pack kernels: both are exact.  MATH_IEEE (knob 2 == 3, headline shape only)
+// is kept for A/B measurements of what the reciprocal + fma refinement buys; the two
+// non-parity probes used to locate the bottleneck (reciprocal multiply, plain copy; numbers
+// in DESIGN.md 7) are gone from the product library.
+enum { MATH_FAST = 0, MATH_IEEE = 3 };
 
 // One tile = U packs per lane.
 template <int U>
@@ -241,16 +242,6 @@ __device__ __forceinline__ void finish_tile(void* __restrict__ y, void* __restri
           dq[j] = dequant_level(lv[j], s, z);
         }
       }
-    } else if constexpr (MATH == MATH_RCP) {
-      const float yr = 1.0f / s;
-#pragma unroll
-      for (int j = 0; j < kPack; ++j) {
-        lv[j] = __builtin_amdgcn_fmed3f(__builtin_rintf(v[j] * yr) + z, qlo, qhi);
-        dq[j] = dequant_level(lv[j], s, z);
-      }
-    } else if constexpr (MATH == MATH_COPY) {
-#pragma unroll
-      for (int j = 0; j < kPack; ++j) lv[j] = dq[j] = v[j];
     } else {
 #pragma unroll
       for (int j = 0; j < kPack; ++j) {
@@ -564,13 +555,8 @@ void launch_variant(QdqCall c, int variant, hipStream_t st) {
   if constexpr (QT == SBQ_Q_NONE && MASK == MASK_NONE && Tin::id == SBQ_BF16 && Tout::id == SBQ_BF16 && !FLAT) {
     // development variants for the headline shape only (A/B measurements)
     const int math = knob(2);
-    if (math == MATH_RCP || math == MATH_COPY || math == MATH_IEEE) {
-#define SBQ_LAUNCH_M(UV)                                                                       \
-  do {                                                                                         \
-    if (math == MATH_RCP) launch_pack<Tin, Tout, QT, MASK, FLAT, true, UV, MATH_RCP>(c, st);   \
-    else if (math == MATH_COPY) launch_pack<Tin, Tout, QT, MASK, FLAT, true, UV, MATH_COPY>(c, st); \
-    else launch_pack<Tin, Tout, QT, MASK, FLAT, true, UV, MATH_IEEE>(c, st);                   \
-  } while (0)
+    if (math == MATH_IEEE) {
+#define SBQ_LAUNCH_M(UV) launch_pack<Tin, Tout, QT, MASK, FLAT, true, UV, MATH_IEEE>(c, st)
       if (U == 1) SBQ_LAUNCH_M(1);
       else if (U == 2) SBQ_LAUNCH_M(2);
       else SBQ_LAUNCH_M(4);

@@ -110,11 +110,20 @@ def main():
         if rc:
             L.check(rc)
 
+    flag = torch.zeros(1, device=dev)
+
     def sync_all():
-        torch.cuda.synchronize(dev)
+        """barrier + synchronize.  Over RCCL the barrier is what dist.barrier() is underneath -- a
+        one-element all-reduce, which cannot complete before every rank has enqueued it -- issued
+        stream-ordered behind the launches, so the closing bracket costs one tiny collective and one
+        host wait instead of two host round trips."""
         if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize(dev)
+            if debug_one_gpu:
+                torch.cuda.synchronize(dev)
+                dist.barrier()
+            else:
+                dist.all_reduce(flag)
+        torch.cuda.synchronize(dev)
 
     # ---- parity gate inside the benchmark (rank 0): the timed kernel == oracle --------------
     parity = None

@@ -74,7 +74,8 @@ const char* sbq_last_hip_error(void);
  *    half-to-even, everything in fp32).
  *
  *    x        data, dtype x_dtype, outer*C*inner elements
- *    y        dequantized output, y_dtype == SBQ_F32 or == x_dtype (RNE cast)
+ *    y        dequantized output, y_dtype == SBQ_F32 or == x_dtype (RNE cast); may be NULL
+ *             together with an integer output: quantize only (QuantizeLinear)
  *    q        optional integer tensor (NULL with SBQ_Q_NONE); SBQ_Q_I8 stores
  *             the low 8 bits (needs qmax - qmin <= 255), SBQ_Q_I32 an int32,
  *             SBQ_Q_I4 two levels per byte (element i in the low nibble of byte
@@ -94,6 +95,14 @@ int sbq_quant_perchannel_forward(const void* x, int x_dtype, void* y, int y_dtyp
                                  const float* scale, const float* zero_point,
                                  int64_t outer, int64_t C, int64_t inner,
                                  int qmin, int qmax, int rounding, void* stream);
+
+/* DequantizeLinear of stored levels: y = (q - round(zp)) * s in fp32, cast to y_dtype.
+ * q_type SBQ_Q_I8 (q_signed: int8, else uint8), SBQ_Q_I4 (two per byte as written by the
+ * forward, q_signed: two's complement nibbles) or SBQ_Q_I32.  Bit-identical to the dequantized
+ * output of sbq_quant_*_forward for the same levels (quant_tensor.py:184). */
+int sbq_dequantize_linear(const void* q, int q_type, int q_signed, void* y, int y_dtype,
+                          const float* scale, const float* zero_point,
+                          int64_t outer, int64_t C, int64_t inner, void* stream);
 
 /* Multi-tensor launch: the same per-channel QDQ over n_items tensors that share dtype,
  * geometry and integer range (the q/k/v/o projections of a layer, a stack of equal blocks)

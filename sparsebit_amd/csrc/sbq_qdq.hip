@@ -250,8 +250,12 @@ __device__ __forceinline__ void finish_tile(void* __restrict__ y, void* __restri
       }
     }
     if (t.ok[u]) {
-      store_pack<Tout, NT>(y, t.elem[u], dq);
-      if constexpr (QT != SBQ_Q_NONE) store_q_pack<QT>(q, t.elem[u], lv);
+      if constexpr (QT != SBQ_Q_NONE) {
+        if (y) store_pack<Tout, NT>(y, t.elem[u], dq);  // y == nullptr: quantize only (block-uniform)
+        store_q_pack<QT>(q, t.elem[u], lv);
+      } else {
+        store_pack<Tout, NT>(y, t.elem[u], dq);
+      }
     }
   }
 }
@@ -443,7 +447,7 @@ __global__ __launch_bounds__(kBlock) void qdq_clast_kernel(const void* __restric
       }
       if (ok[u]) {
         const int64_t e = static_cast<int64_t>(pk[u]) * kPack;
-        store_pack<Tout, true>(y, e, dq);
+        if (QT == SBQ_Q_NONE || y) store_pack<Tout, true>(y, e, dq);
         if constexpr (QT != SBQ_Q_NONE) store_q_pack<QT>(q, e, lv);
       }
     }
@@ -496,7 +500,7 @@ __global__ __launch_bounds__(kBlock) void qdq_scalar_kernel(const ScalarArgs a) 
       lv = quant_level<SBQ_ROUND_HALF_UP>(xv, s, z, a.qlo, a.qhi);
     else
       lv = quant_level<SBQ_ROUND_HALF_DOWN>(xv, s, z, a.qlo, a.qhi);
-    store_any(a.y, a.y_dtype, i, dequant_level(lv, s, z));
+    if (a.y) store_any(a.y, a.y_dtype, i, dequant_level(lv, s, z));
     if (a.q_type == SBQ_Q_I8) static_cast<int8_t*>(a.q)[i] = static_cast<int8_t>(static_cast<int>(lv));
     else if (a.q_type == SBQ_Q_I32) static_cast<int32_t*>(a.q)[i] = static_cast<int>(lv);
   }
@@ -620,8 +624,9 @@ int qdq_forward(const void* x, int x_dtype, void* y, int y_dtype, void* q, int q
   if (q_type != SBQ_Q_NONE && q_type != SBQ_Q_I8 && q_type != SBQ_Q_I32 && q_type != SBQ_Q_I4) return SBQ_ERR_DTYPE;
   if (outer < 0 || C < 0 || inner < 0) return SBQ_ERR_ARG;
   if (outer == 0 || C == 0 || inner == 0) return SBQ_ERR_EMPTY;
-  if (!x || !y || !scale || !zp) return SBQ_ERR_NULL;
+  if (!x || !scale || !zp) return SBQ_ERR_NULL;
   if (q_type != SBQ_Q_NONE && !q) return SBQ_ERR_NULL;
+  if (!y && q_type == SBQ_Q_NONE) return SBQ_ERR_NULL;  // y may be NULL only in quantize-only mode
   if (qmin > qmax) return SBQ_ERR_ARG;
   if (q_type == SBQ_Q_I8 && static_cast<int64_t>(qmax) - qmin > 255) return SBQ_ERR_ARG;
   // packed int4: 16 levels, whole 8-element packs only (two elements share a byte: no scalar

@@ -38,14 +38,15 @@ class QDQTensor:
             return self.q
         return unpack_int4(self.q, self.signed).reshape(self.shape)
 
-    def dequantize(self):
-        """DequantizeLinear: (q - zero_point) * scale in fp32"""
-        q = self.levels().to(torch.float32)
-        if self.axis is None:
-            return (q - self.zero_point.to(torch.float32)) * self.scale
-        view = [1] * len(self.shape)
-        view[self.axis] = -1
-        return (q - self.zero_point.to(torch.float32).reshape(view)) * self.scale.reshape(view)
+    def dequantize(self, out_dtype=None):
+        """DequantizeLinear on the GPU (sbq_dequantize_linear): (q - zero_point) * scale, fp32 unless out_dtype"""
+        return ops.dequantize_linear(self.q, self.scale, self.zero_point.to(torch.float32), shape=self.shape,
+                                     ch_axis=0 if self.axis is None else self.axis, signed=self.signed,
+                                     packed_int4=self.packed, out_dtype=out_dtype)
+
+    def to(self, device):
+        return QDQTensor(self.q.to(device), self.scale.to(device), self.zero_point.to(device), self.axis, self.bits,
+                         self.shape, self.signed, self.packed)
 
     def state_dict(self, prefix=""):
         return {prefix + "q": self.q, prefix + "scale": self.scale, prefix + "zero_point": self.zero_point,
@@ -61,8 +62,9 @@ class QDQTensor:
 
 
 @torch.no_grad()
-def quantize_linear(quantizer, x, pack_int4=False):
-    """Materialise `x` with a calibrated quantizer -> (fake-quant result, QDQTensor).
+def quantize_linear(quantizer, x, pack_int4=False, dequantized=True):
+    """Materialise `x` with a calibrated quantizer -> (fake-quant result, QDQTensor); with
+    dequantized=False the kernel writes the levels only and the first element is None.
 
     The integer container follows `torch_fake_quant` (quant_tensor.py:226-231): int8 for signed
     ranges, uint8 for unsigned, whatever the bit width; with pack_int4 a <= 4-bit tensor is stored
@@ -77,7 +79,11 @@ def quantize_linear(quantizer, x, pack_int4=False):
     scale, zero_point = quantizer._qparams_preprocess(x)
     per_channel = scale.numel() > 1
     packed = bool(pack_int4) and hi - lo <= 15
-    dq, q = ops.fake_quant(x, scale, zero_point, lo, hi, qdesc.ch_axis, return_q="int4" if packed else int_dtype)
+    want = "int4" if packed else int_dtype
+    if dequantized:
+        dq, q = ops.fake_quant(x, scale, zero_point, lo, hi, qdesc.ch_axis, return_q=want)
+    else:
+        dq, q = None, ops.quantize_only(x, scale, zero_point, lo, hi, qdesc.ch_axis, return_q=want)
     rec = QDQTensor(q, scale.detach().reshape(-1).float() if per_channel else scale.detach().reshape(()).float(),
                     (zero_point.detach().round().reshape(-1) if per_channel else zero_point.detach().round().reshape(())).to(int_dtype),
                     qdesc.ch_axis if per_channel else None, qdesc.bit, x.shape, signed, packed)

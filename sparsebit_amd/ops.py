@@ -144,6 +144,73 @@ def fake_quant(x, scale, zero_point, qmin, qmax, ch_axis=0, out_dtype=None, retu
     return (y, q) if return_q is not None else y
 
 
+def quantize_only(x, scale, zero_point, qmin, qmax, ch_axis=0, return_q=torch.int8):
+    """QuantizeLinear alone: the integer levels without the dequantized tensor (half the writes).
+    return_q as in fake_quant (torch.int8 | torch.uint8 | torch.int32 | "int4")."""
+    dev = L.require_device(x, scale, zero_point)
+    lib = L.load()
+    x = x.contiguous()
+    per_channel = scale.numel() > 1
+    outer, C, inner = geometry(x.shape, ch_axis, per_channel)
+    scale = _f32c(scale, dev)
+    zero_point = _f32c(zero_point, dev)
+    _check_qparams(scale, zero_point, C)
+    if return_q in (torch.int8, torch.uint8):
+        q_type, q = L.Q_I8, torch.empty(x.shape, dtype=return_q, device=dev)
+    elif return_q == torch.int32:
+        q_type, q = L.Q_I32, torch.empty(x.shape, dtype=torch.int32, device=dev)
+    elif return_q == "int4":
+        if x.numel() % 2:
+            raise L.SbqError("packed int4 needs an even number of elements")
+        q_type, q = L.Q_I4, torch.empty(x.numel() // 2, dtype=torch.uint8, device=dev)
+    else:
+        raise L.SbqError("return_q must be int8, uint8, int32 or 'int4'")
+    if x.numel() == 0:
+        L.check(2)
+    with torch.cuda.device(dev):
+        rc = lib.sbq_quant_perchannel_forward(L.ptr(x), L.dtype_id(x), None, L.dtype_id(x), L.ptr(q), q_type,
+                                              L.ptr(scale), L.ptr(zero_point), outer, C, inner, int(qmin), int(qmax),
+                                              L.ROUND_HALF_EVEN, L.stream_ptr(dev))
+    L.check(rc)
+    return q
+
+
+def dequantize_linear(q, scale, zero_point, shape=None, ch_axis=0, signed=True, packed_int4=False, out_dtype=None):
+    """DequantizeLinear: (q - round(zp)) * scale -> out_dtype (default fp32).  q: int8 / uint8 / int32 levels
+    in the tensor's shape, or the flat packed-int4 bytes (then `shape` is required)."""
+    dev = L.require_device(q, scale, zero_point)
+    lib = L.load()
+    q = q.contiguous()
+    if packed_int4:
+        if shape is None or q.dtype != torch.uint8:
+            raise L.SbqError("packed int4 levels are uint8 bytes and need the tensor's shape")
+        shape = torch.Size(shape)
+        if q.numel() * 2 != shape.numel():
+            raise L.SbqError("packed int4: %d bytes cannot hold %d elements" % (q.numel(), shape.numel()))
+        q_type = L.Q_I4
+    else:
+        shape = q.shape
+        if q.dtype in (torch.int8, torch.uint8):
+            q_type, signed = L.Q_I8, q.dtype == torch.int8
+        elif q.dtype == torch.int32:
+            q_type = L.Q_I32
+        else:
+            raise L.SbqError("levels must be int8, uint8 or int32")
+    per_channel = scale.numel() > 1
+    outer, C, inner = geometry(shape, ch_axis, per_channel)
+    scale = _f32c(scale, dev)
+    zero_point = _f32c(zero_point, dev)
+    _check_qparams(scale, zero_point, C)
+    y = torch.empty(shape, dtype=out_dtype or torch.float32, device=dev)
+    if y.numel() == 0:
+        L.check(2)
+    with torch.cuda.device(dev):
+        rc = lib.sbq_dequantize_linear(L.ptr(q), q_type, int(bool(signed)), L.ptr(y), L.dtype_id(y), L.ptr(scale),
+                                       L.ptr(zero_point), outer, C, inner, L.stream_ptr(dev))
+    L.check(rc)
+    return y
+
+
 class BatchedFakeQuant:
     """Multi-tensor per-channel QDQ: n same-shape tensors, ONE launch (sbq_quant_perchannel_forward_batched).
 

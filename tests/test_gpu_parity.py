@@ -934,8 +934,11 @@ def test_qdq_export_matches_reference_fake_quant(golden, oracle, name):
     _, ref_q = oracle.qdq(xs[0], golden[name + "/scale"], golden[name + "/zero_point"], qmin, qmax, ch_axis)
     assert np.array_equal(rec.levels().cpu().numpy().astype(np.int32), ref_q)
     assert int(rec.levels().min()) >= qmin and int(rec.levels().max()) <= qmax
-    back = export.QDQTensor.from_state_dict({k: v.cpu() for k, v in rec.state_dict("w.").items()}, "w.")
-    assert same_values(back.dequantize().numpy(), golden[name + "/dq"])
+    back = export.QDQTensor.from_state_dict({k: v.cpu() for k, v in rec.state_dict("w.").items()}, "w.").to("cuda")
+    assert same_values(back.dequantize().cpu().numpy(), golden[name + "/dq"])
+    none_dq, rec_q = export.quantize_linear(q, x0, dequantized=False)  # QuantizeLinear alone: same levels
+    assert none_dq is None and torch.equal(rec_q.q, rec.q)
+    assert torch.equal(rec.dequantize(torch.bfloat16), dq.bfloat16())
     if qmax - qmin <= 15 and xs[0].shape[-1] % 8 == 0 and not (perch and ch_axis == xs[0].ndim - 1):
         dq4, rec4 = export.quantize_linear(q, x0, pack_int4=True)
         assert rec4.packed and rec4.q.dtype == torch.uint8 and rec4.q.numel() * 2 == x0.numel()
@@ -964,6 +967,36 @@ def test_packed_int4_output_equals_packed_levels(ops, dtype, shape, ch_axis, lo,
     assert q4.dtype == torch.uint8 and q4.numel() * 2 == x.numel()
     assert torch.equal(q4, export.pack_int4(q8))
     assert torch.equal(export.unpack_int4(q4, lo < 0).reshape(shape), q8)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape,ch_axis", SHAPES + [((4096, 4096), 0)])
+def test_quantize_only_and_dequantize_kernel(ops, dtype, shape, ch_axis):
+    """quantize-only (y == NULL) gives the fake-quant launch's levels; sbq_dequantize_linear of them gives its
+    dequantized tensor bit for bit -- int8, uint8, int32 and packed int4, every geometry path"""
+    from sparsebit_amd import export
+
+    g = torch.Generator().manual_seed(sum(shape))
+    x = (torch.randn(shape, generator=g) * 2).to(dtype).cuda()
+    for per_channel in (True, False):
+        C = shape[ch_axis] if per_channel else 1
+        scale = (torch.rand(C, generator=g) * 0.2 + 0.05).cuda()
+        for lo, hi, zpv, rq in ((-128, 127, 0.0, torch.int8), (0, 255, 101.0, torch.uint8), (-8, 7, 0.0, torch.int32),
+                                (-8, 7, 0.0, "int4"), (0, 15, 9.0, "int4")):
+            zp = torch.full((C,), zpv).cuda()
+            inner = int(np.prod(shape[ch_axis + 1:])) if per_channel else x.numel()
+            if rq == "int4" and (inner % 8 or (per_channel and ch_axis == len(shape) - 1 and shape[-1] % 8)):
+                continue  # packed int4 is emitted by the pack kernels only
+            y, q = ops.fake_quant(x, scale, zp, lo, hi, ch_axis, return_q=rq)
+            q2 = ops.quantize_only(x, scale, zp, lo, hi, ch_axis, return_q=rq)
+            assert torch.equal(q2, q), (per_channel, lo, hi)
+            packed = rq == "int4"
+            back = ops.dequantize_linear(q, scale, zp, shape=shape if packed else None, ch_axis=ch_axis,
+                                         signed=lo < 0, packed_int4=packed)
+            assert torch.equal(back, y), (per_channel, lo, hi, rq)
+            back16 = ops.dequantize_linear(q, scale, zp, shape=shape if packed else None, ch_axis=ch_axis,
+                                           signed=lo < 0, packed_int4=packed, out_dtype=torch.bfloat16)
+            assert torch.equal(back16, y.bfloat16())
 
 
 def test_packed_int4_rejects_what_it_cannot_pack(ops):

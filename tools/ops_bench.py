@@ -38,6 +38,30 @@ rep("qdq bf16->bf16 per-tensor", timed(lambda i: ops.fake_quant(xs[i % NB], scal
 rep("qdq bf16->fp32 per-channel", timed(lambda i: ops.fake_quant(xs[i % NB], scale, zp, -128, 127, 0)), n * 6)
 xf = [x.float() for x in xs[:4]]
 rep("qdq fp32->fp32 per-channel", timed(lambda i: ops.fake_quant(xf[i % 4], scale, zp, -128, 127, 0)), n * 8)
+s4q, z4q = ops.qparams_from_minmax(mn, mx, -8, 7, True)
+rep("qdq bf16->bf16 + int8 levels", timed(lambda i: ops.fake_quant(xs[i % NB], scale, zp, -128, 127, 0, out_dtype=torch.bfloat16, return_q=torch.int8)), n * 5)
+rep("qdq bf16->bf16 + packed int4", timed(lambda i: ops.fake_quant(xs[i % NB], s4q, z4q, -8, 7, 0, out_dtype=torch.bfloat16, return_q="int4")), n * 4.5)
+rep("quantize only bf16->int8", timed(lambda i: ops.quantize_only(xs[i % NB], scale, zp, -128, 127, 0, torch.int8)), n * 3)
+rep("quantize only bf16->packed int4", timed(lambda i: ops.quantize_only(xs[i % NB], s4q, z4q, -8, 7, 0, "int4")), n * 2.5)
+q8s = [ops.quantize_only(x, scale, zp, -128, 127, 0, torch.int8) for x in xs]
+q4s = [ops.quantize_only(x, s4q, z4q, -8, 7, 0, "int4") for x in xs]
+rep("dequantize int8->bf16", timed(lambda i: ops.dequantize_linear(q8s[i % NB], scale, zp, out_dtype=torch.bfloat16)), n * 3)
+rep("dequantize packed int4->bf16", timed(lambda i: ops.dequantize_linear(q4s[i % NB], s4q, z4q, shape=(R, C), packed_int4=True, out_dtype=torch.bfloat16)), n * 2.5)
+rep("dequantize int8->fp32", timed(lambda i: ops.dequantize_linear(q8s[i % NB], scale, zp)), n * 5)
+# the same through the C ABI directly (ops.* costs ~15 us of Python per call: host-bound above)
+lib = L.load(); st = L.stream_ptr(dev)
+xp = [L.ptr(x) for x in xs]; sp_, zp_, s4p, z4p = L.ptr(scale), L.ptr(zp), L.ptr(s4q), L.ptr(z4q)
+q8p = [L.ptr(t) for t in q8s]; q4p = [L.ptr(t) for t in q4s]
+y16 = [torch.empty(R, C, dtype=torch.bfloat16, device=dev) for _ in range(NB)]; y16p = [L.ptr(t) for t in y16]
+fw = lib.sbq_quant_perchannel_forward; dqf = lib.sbq_dequantize_linear
+rep("[C ABI] qdq bf16->bf16", timed(lambda i: fw(xp[i % NB], L.BF16, y16p[i % NB], L.BF16, None, L.Q_NONE, sp_, zp_, 1, R, C, -128, 127, 0, st), 300, 50), n * 4)
+rep("[C ABI] qdq bf16->bf16 + int8", timed(lambda i: fw(xp[i % NB], L.BF16, y16p[i % NB], L.BF16, q8p[i % NB], L.Q_I8, sp_, zp_, 1, R, C, -128, 127, 0, st), 300, 50), n * 5)
+rep("[C ABI] qdq bf16->bf16 + int4", timed(lambda i: fw(xp[i % NB], L.BF16, y16p[i % NB], L.BF16, q4p[i % NB], L.Q_I4, s4p, z4p, 1, R, C, -8, 7, 0, st), 300, 50), n * 4.5)
+rep("[C ABI] quantize only bf16->int8", timed(lambda i: fw(xp[i % NB], L.BF16, None, L.BF16, q8p[i % NB], L.Q_I8, sp_, zp_, 1, R, C, -128, 127, 0, st), 300, 50), n * 3)
+rep("[C ABI] quantize only bf16->int4", timed(lambda i: fw(xp[i % NB], L.BF16, None, L.BF16, q4p[i % NB], L.Q_I4, s4p, z4p, 1, R, C, -8, 7, 0, st), 300, 50), n * 2.5)
+rep("[C ABI] dequantize int8->bf16", timed(lambda i: dqf(q8p[i % NB], L.Q_I8, 1, y16p[i % NB], L.BF16, sp_, zp_, 1, R, C, st), 300, 50), n * 3)
+rep("[C ABI] dequantize int4->bf16", timed(lambda i: dqf(q4p[i % NB], L.Q_I4, 1, y16p[i % NB], L.BF16, s4p, z4p, 1, R, C, st), 300, 50), n * 2.5)
+del q8s, q4s, y16
 rep("minmax stats per-channel", timed(lambda i: ops.channel_stats(xs[i % NB], 0, True)), n * 2)
 rep("minmax stats per-tensor", timed(lambda i: ops.channel_stats(xs[i % NB], 0, False)), n * 2)
 

@@ -342,6 +342,15 @@ int sbq_radix_advance(const int64_t* hist, int64_t C, int pass, int n_sel,
 int sbq_radix_finish(const int64_t* state, int64_t C, int n_sel, int use_abs,
                      float* values_out /* [C][n_sel] */, void* stream);
 
+/* The percentile observer's two ranks per channel, straight from the pass-0 histogram
+ * (after any cross-rank SUM): neg / pos counts are sums over its lower / upper half, then
+ * k_min = max(round(neg*alpha), 1), k_max = n - max(round(pos*alpha), 0) with Python's
+ * half-to-even round on the fp64 product (percentile.py:27-43).  Writes state
+ * [C][2][2] = {prefix 0, rank} for selectors {min, max} and counts_out [2][C] = {neg, pos};
+ * no host round trip, no separate sign-count pass.  hist must come from use_abs == 0. */
+int sbq_percentile_ranks(const int64_t* hist, int64_t C, int n_sel /* 2 */, double alpha,
+                         int64_t* state, int64_t* counts_out, void* stream);
+
 /* counts per channel: neg = count(x < 0), pos = count(x >= 0) (int64 [C] each,
  * ADDED into the outputs) -- percentile.py:27-28 */
 int sbq_sign_counts(const void* x, int x_dtype, int64_t outer, int64_t C, int64_t inner,

@@ -262,6 +262,45 @@ __global__ __launch_bounds__(kBlock) void radix_advance_kernel(const int64_t* __
   }
 }
 
+// percentile.py:27-43 from the FIRST histogram: with the order-preserving key (−0 folded onto
+// +0, every NaN on the last key) bins [0, 1024) are exactly the elements < 0, bins [1024, 2047)
+// those >= 0 and bin 2047 the NaNs -- so the sign counts the reference takes with two extra
+// passes over the data are sums over a histogram that is needed anyway.  Ranks as the
+// reference computes them: Python's round() (half to even) of the fp64 product count * alpha.
+__global__ __launch_bounds__(kBlock) void percentile_ranks_kernel(const int64_t* __restrict__ hist, int n_sel,
+                                                                  double alpha, int64_t* __restrict__ state,
+                                                                  int64_t* __restrict__ counts, int64_t C) {
+  __shared__ int64_t red[kWavesPerBlock];
+  const size_t c = blockIdx.x;
+  const int64_t* h = hist + c * n_sel * SBQ_RADIX_BINS;  // selector 0 (both are identical in pass 0)
+  constexpr int kPer = SBQ_RADIX_BINS / kBlock;
+  int64_t neg = 0, pos = 0, nan = 0;
+#pragma unroll
+  for (int i = 0; i < kPer; ++i) {
+    const int b = threadIdx.x * kPer + i;
+    const int64_t v = h[b];
+    if (b < SBQ_RADIX_BINS / 2) neg += v;
+    else if (b < SBQ_RADIX_BINS - 1) pos += v;
+    else nan += v;
+  }
+  neg = block_reduce(neg, Sum(), red);
+  pos = block_reduce(pos, Sum(), red);
+  nan = block_reduce(nan, Sum(), red);
+  if (threadIdx.x == 0) {
+    const int64_t n = neg + pos + nan;
+    int64_t k_max = n - static_cast<int64_t>(__builtin_fmax(__builtin_rint(static_cast<double>(pos) * alpha), 0.0));
+    int64_t k_min = static_cast<int64_t>(__builtin_fmax(__builtin_rint(static_cast<double>(neg) * alpha), 1.0));
+    k_min = k_min < 1 ? 1 : (k_min > n ? n : k_min);
+    k_max = k_max < 1 ? 1 : (k_max > n ? n : k_max);
+    state[(c * n_sel + 0) * 2] = 0;
+    state[(c * n_sel + 0) * 2 + 1] = k_min;
+    state[(c * n_sel + 1) * 2] = 0;
+    state[(c * n_sel + 1) * 2 + 1] = k_max;
+    counts[c] = neg;
+    counts[C + c] = pos;
+  }
+}
+
 __global__ void radix_finish_kernel(const int64_t* __restrict__ state, int64_t n, float* __restrict__ out) {
   const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -418,6 +457,18 @@ int sbq_radix_finish(const int64_t* state, int64_t C, int n_sel, int use_abs, fl
   const int64_t n = C * n_sel;
   radix_finish_kernel<<<static_cast<uint32_t>(ceil_div(n, kBlock)), kBlock, 0, as_stream(stream)>>>(
       state, n, values_out);
+  return check_launch();
+}
+
+int sbq_percentile_ranks(const int64_t* hist, int64_t C, int n_sel, double alpha, int64_t* state,
+                         int64_t* counts_out, void* stream) {
+  using namespace sbq;
+  if (C < 0) return SBQ_ERR_ARG;
+  if (C == 0) return SBQ_ERR_EMPTY;
+  if (!hist || !state || !counts_out) return SBQ_ERR_NULL;
+  if (n_sel != 2 || C >= (1ll << 31) || !(alpha >= 0.0 && alpha <= 1.0)) return SBQ_ERR_ARG;
+  percentile_ranks_kernel<<<static_cast<uint32_t>(C), kBlock, 0, as_stream(stream)>>>(hist, n_sel, alpha, state,
+                                                                                      counts_out, C);
   return check_launch();
 }
 

@@ -39,23 +39,10 @@ class Observer(BaseObserver):
         dev = shards[0].device
         perch = self.is_perchannel
         C = shards[0].shape[self.ch_axis] if perch else 1
-        neg = torch.zeros(C, dtype=torch.int64, device=dev)
-        pos = torch.zeros(C, dtype=torch.int64, device=dev)
-        n_local = 0
-        for x in shards:
-            ops.sign_counts(x, neg, pos, self.ch_axis, perch)
-            n_local += x.numel() // C
-        counts = torch.stack([neg, pos])
-        sbq_dist.allreduce_sum_(counts)
-        n = sbq_dist.allreduce_count(n_local)
-        neg_l, pos_l = counts[0].tolist(), counts[1].tolist()
-        # percentile.py:36-43 -- Python's round (half to even) on pos*alpha / neg*alpha
-        ranks = []
-        for c in range(C):
-            k_max = n - max(round(pos_l[c] * self.alpha), 0)
-            k_min = max(round(neg_l[c] * self.alpha), 1)
-            ranks.append([min(max(k_min, 1), n), min(max(k_max, 1), n)])
-        vals = select.kth_values(shards, ranks, ops.HipSelectBackend(), False, self.ch_axis, perch, dev)
+        # percentile.py:27-43: the counts of negative / non-negative elements and the two ranks come out of
+        # the first radix histogram on the device (select.kth_values), three reads of the data in total
+        vals, counts = select.kth_values(shards, None, ops.HipSelectBackend(), False, self.ch_axis, perch, dev,
+                                         percentile_alpha=self.alpha, n_channels=C)
         zero = torch.zeros(C, dtype=torch.float32, device=dev)
         mn = torch.where(counts[0] > 0, vals[:, 0], zero)
         mx = torch.where(counts[1] > 0, vals[:, 1], zero)

@@ -752,6 +752,19 @@ class HipSelectBackend:
     def new_hist(self, C, n_sel, device):
         return torch.zeros((C, n_sel, L.RADIX_BINS), dtype=torch.int64, device=device)
 
+    def zero_state(self, C, n_sel, device):
+        return torch.zeros((C, n_sel, 2), dtype=torch.int64, device=device)
+
+    def percentile_ranks(self, hist, state, alpha, C):
+        """ranks of the percentile observer from the (all-reduced) pass-0 histogram -> counts [2][C]"""
+        dev = L.require_device(hist, state)
+        counts = torch.empty((2, C), dtype=torch.int64, device=dev)
+        with torch.cuda.device(dev):
+            rc = L.load().sbq_percentile_ranks(L.ptr(hist), C, 2, float(alpha), L.ptr(state), L.ptr(counts),
+                                               L.stream_ptr(dev))
+        L.check(rc)
+        return counts
+
     def histogram(self, x, state, hist, pass_, n_sel, use_abs, ch_axis, per_channel):
         radix_histogram(x, state, hist, pass_, n_sel, use_abs, ch_axis, per_channel)
 

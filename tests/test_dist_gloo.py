@@ -41,6 +41,21 @@ class NumpySelectBackend:
     def new_hist(self, C, n_sel, device):
         return torch.zeros((C, n_sel, self.BINS), dtype=torch.int64)
 
+    def zero_state(self, C, n_sel, device):
+        return torch.zeros((C, n_sel, 2), dtype=torch.int64)
+
+    def percentile_ranks(self, hist, state, alpha, C):
+        """sbq_percentile_ranks: counts and ranks from the pass-0 histogram (percentile.py:27-43)"""
+        h = hist[:, 0].numpy()
+        neg, pos, nan = h[:, :1024].sum(1), h[:, 1024:2047].sum(1), h[:, 2047]
+        n = neg + pos + nan
+        for c in range(C):
+            k_min = max(round(int(neg[c]) * alpha), 1)
+            k_max = int(n[c]) - max(round(int(pos[c]) * alpha), 0)
+            state[c, 0, 0], state[c, 0, 1] = 0, min(max(k_min, 1), int(n[c]))
+            state[c, 1, 0], state[c, 1, 1] = 0, min(max(k_max, 1), int(n[c]))
+        return torch.from_numpy(np.stack([neg, pos]).astype(np.int64))
+
     def histogram(self, x, state, hist, p, n_sel, use_abs, ch_axis, per_channel):
         x = x.numpy()
         rows = np.moveaxis(x, ch_axis, 0).reshape(x.shape[ch_axis], -1) if per_channel else x.reshape(1, -1)
@@ -150,6 +165,10 @@ def _worker(rank, world, port, tmp):
             rows = np.moveaxis(everything, 1, 0).reshape(6, -1) if perch else everything.reshape(1, -1)
             rmn_p, rmx_p = O.percentile(rows, alpha, 0, True)
             ok["pct%d" % perch] = np.array_equal(vals[:, 0].numpy(), rmn_p) and np.array_equal(vals[:, 1].numpy(), rmx_p)
+            # the observer's own route: ranks derived from the all-reduced first histogram, no count pass
+            vals2, cnt2 = select.kth_values(mine, None, NumpySelectBackend(), False, 1, perch, torch.device("cpu"),
+                                            percentile_alpha=alpha, n_channels=C)
+            ok["pct_dev_ranks%d" % perch] = (torch.equal(vals2, vals) and torch.equal(cnt2, cnt))
         # ---- mask threshold of a row-sharded weight: k-th |w| over the union ----
         w = torch.randn(64, 33, generator=g)
         shard = w[rank::world].contiguous()

@@ -646,6 +646,32 @@ def test_percentile_radix_path_vs_oracle(oracle, case, alpha):
 # --------------------------------------------------------------------------------------
 # unstructured mask, fused mask + QDQ
 # --------------------------------------------------------------------------------------
+def test_percentile_ranks_from_first_histogram(ops):
+    """sbq_percentile_ranks: neg / pos counts (with -0.0 counted as >= 0 and NaN as neither, like
+    percentile.py:27-28) and Python-rounded ranks, all from the pass-0 histogram"""
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(5, 3001, generator=g)
+    x[0, :7] = -0.0
+    x[1, 5:9] = float("nan")
+    x[2] = x[2].abs()  # no negatives
+    x[3] = -x[3].abs() - 1  # no non-negatives
+    x[4, ::2] = 0.0
+    xd = x.cuda()
+    be = ops.HipSelectBackend()
+    for alpha in (1e-3, 0.0125, 0.5):
+        state = be.zero_state(5, 2, xd.device)
+        hist = be.new_hist(5, 2, xd.device)
+        be.histogram(xd, state, hist, 0, 2, False, 0, True)
+        counts = be.percentile_ranks(hist, state, alpha, 5).cpu()
+        neg, pos = (x < 0).sum(1), (x >= 0).sum(1)
+        assert torch.equal(counts[0], neg) and torch.equal(counts[1], pos)
+        n = x.shape[1]
+        for c in range(5):
+            k_min = min(max(max(round(int(neg[c]) * alpha), 1), 1), n)
+            k_max = min(max(n - max(round(int(pos[c]) * alpha), 0), 1), n)
+            assert state[c, 0].tolist() == [0, k_min] and state[c, 1].tolist() == [0, k_max], (alpha, c)
+
+
 @pytest.mark.parametrize("ratio", [0.0, 0.3, 0.5, 0.9, 1.0])
 @pytest.mark.parametrize("wname", ["lin", "conv"])
 def test_l1_mask_vs_reference_golden(golden, ratio, wname):

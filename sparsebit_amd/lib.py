@@ -220,8 +220,33 @@ def ptr(t):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def stream_ptr(device=None):
+    """hipStream_t of torch's current stream on `device` (the raw-handle accessor is ~10x cheaper than
+    building a torch.cuda.Stream object; the quantizer calls are host-bound on small tensors)"""
+    if _raw_stream is not None and device is not None and device.index is not None:
+        return ctypes.c_void_p(_raw_stream(device.index))
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+class _NoGuard:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NO_GUARD = _NoGuard()
+
+
+def device_guard(device):
+    """`with device_guard(dev):` == torch.cuda.device(dev), free when dev is already current"""
+    if device.index is None or torch.cuda.current_device() == device.index:
+        return _NO_GUARD
+    return torch.cuda.device(device)
 
 
 def set_tuning(knob, value):

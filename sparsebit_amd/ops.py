@@ -115,7 +115,7 @@ def fake_quant(x, scale, zero_point, qmin, qmax, ch_axis=0, out_dtype=None, retu
             q = torch.empty(x.shape, dtype=return_q, device=dev)
     if x.numel() == 0:
         L.check(2)
-    with torch.cuda.device(dev):
+    with L.device_guard(dev):
         st = L.stream_ptr(dev)
         if mask is None and thresh is None:
             if per_channel:
@@ -167,7 +167,7 @@ def quantize_only(x, scale, zero_point, qmin, qmax, ch_axis=0, return_q=torch.in
         raise L.SbqError("return_q must be int8, uint8, int32 or 'int4'")
     if x.numel() == 0:
         L.check(2)
-    with torch.cuda.device(dev):
+    with L.device_guard(dev):
         rc = lib.sbq_quant_perchannel_forward(L.ptr(x), L.dtype_id(x), None, L.dtype_id(x), L.ptr(q), q_type,
                                               L.ptr(scale), L.ptr(zero_point), outer, C, inner, int(qmin), int(qmax),
                                               L.ROUND_HALF_EVEN, L.stream_ptr(dev))
@@ -204,7 +204,7 @@ def dequantize_linear(q, scale, zero_point, shape=None, ch_axis=0, signed=True, 
     y = torch.empty(shape, dtype=out_dtype or torch.float32, device=dev)
     if y.numel() == 0:
         L.check(2)
-    with torch.cuda.device(dev):
+    with L.device_guard(dev):
         rc = lib.sbq_dequantize_linear(L.ptr(q), q_type, int(bool(signed)), L.ptr(y), L.dtype_id(y), L.ptr(scale),
                                        L.ptr(zero_point), outer, C, inner, L.stream_ptr(dev))
     L.check(rc)
@@ -247,7 +247,7 @@ class BatchedFakeQuant:
 
     def __call__(self):
         lib = L.load()
-        with torch.cuda.device(self.dev):
+        with L.device_guard(self.dev):
             rc = lib.sbq_quant_perchannel_forward_batched(L.ptr(self.table), len(self.xs), self.x_dt, self.y_dt,
                                                           self.outer, self.C, self.inner, self.qmin, self.qmax,
                                                           L.stream_ptr(self.dev))
@@ -352,7 +352,7 @@ class GroupFakeQuant:
 
     def __call__(self):
         lib = L.load()
-        with torch.cuda.device(self.dev):
+        with L.device_guard(self.dev):
             flat = None
             if self.fresh:
                 flat = torch.empty(self.flat_elems, dtype=self.out_dtype, device=self.dev)
@@ -451,7 +451,7 @@ class GroupFakeQuantBackward:
             keep.append(gy)
             ptrs[i] = gy.data_ptr()
         lib = L.load()
-        with torch.cuda.device(self.dev):
+        with L.device_guard(self.dev):
             gx_flat = torch.empty(self.gx_elems, dtype=self.gx_dtype, device=self.dev)
             gs_flat = torch.empty(max(self.gs_floats, 1), dtype=torch.float32, device=self.dev)
             rc = lib.sbq_quant_group_backward(L.ptr(self.table), self.host_table.data_ptr(), self.n, self.x_dt, self.gx_dt,
@@ -486,7 +486,7 @@ def fake_quant_backward(x, gy, scale, zero_point, qmin, qmax, ch_axis=0, need_gs
     gzp = torch.empty(C, dtype=torch.float32, device=dev) if need_gzp else None
     if x.numel() == 0:
         L.check(2)
-    with torch.cuda.device(dev):
+    with L.device_guard(dev):
         nbytes = lib.sbq_backward_workspace_bytes(outer, C, inner)
         ws = _workspace(dev, nbytes)
         rc = lib.sbq_quant_perchannel_backward(L.ptr(x), L.ptr(gy), L.dtype_id(x), L.ptr(gx), L.dtype_id(gx),
@@ -511,7 +511,7 @@ def channel_stats(x, ch_axis=0, per_channel=True, want_min=True, want_max=True, 
     ab = torch.empty(C, dtype=torch.float64, device=dev) if want_abssum else None
     if x.numel() == 0:
         L.check(2)
-    with torch.cuda.device(dev):
+    with L.device_guard(dev):
         ws = _workspace(dev, lib.sbq_stats_workspace_bytes(outer, C, inner))
         rc = lib.sbq_channel_stats(L.ptr(x), L.dtype_id(x), outer, C, inner, L.ptr(mn), L.ptr(mx), L.ptr(ab),
                                    L.ptr(ws), ws.numel(), L.stream_ptr(dev))
@@ -529,7 +529,7 @@ def channel_moments(x, ch_axis=0, per_channel=True, sum_out=None, sumsq_out=None
         sum_out = torch.zeros(C, dtype=torch.float64, device=dev)
     if sumsq_out is None:
         sumsq_out = torch.zeros(C, dtype=torch.float64, device=dev)
-    with torch.cuda.device(dev):
+    with L.device_guard(dev):
         ws = _workspace(dev, lib.sbq_stats_workspace_bytes(outer, C, inner))
         rc = lib.sbq_channel_moments(L.ptr(x), L.dtype_id(x), outer, C, inner, None, L.ptr(sum_out), L.ptr(sumsq_out),
                                      None, L.ptr(ws), ws.numel(), L.stream_ptr(dev))
@@ -548,7 +548,7 @@ def channel_absdev(x, center, ch_axis=0, per_channel=True, out=None):
         raise L.SbqError("center must have C elements")
     if out is None:
         out = torch.zeros(C, dtype=torch.float64, device=dev)
-    with torch.cuda.device(dev):
+    with L.device_guard(dev):
         ws = _workspace(dev, lib.sbq_stats_workspace_bytes(outer, C, inner))
         rc = lib.sbq_channel_moments(L.ptr(x), L.dtype_id(x), outer, C, inner, L.ptr(center), None, None, L.ptr(out),
                                      L.ptr(ws), ws.numel(), L.stream_ptr(dev))
@@ -568,7 +568,7 @@ def aciq_thresholds(min_val, max_val, b, alpha, gaus_const, sqrt_2logn, half_ran
     n = ref.numel()
     lo = torch.empty(n, dtype=torch.float32, device=dev)
     hi = torch.empty(n, dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with L.device_guard(dev):
         rc = lib.sbq_aciq_thresholds(L.ptr(mn), L.ptr(mx), L.ptr(bb), n, float(alpha), float(gaus_const), float(sqrt_2logn),
                                      int(bool(half_range)), L.ptr(lo), L.ptr(hi), L.stream_ptr(dev))
     L.check(rc)
@@ -581,7 +581,7 @@ def minmax_pack(min_val, max_val):
     lib = L.load()
     mn, mx = _f32c(min_val, dev), _f32c(max_val, dev)
     buf = torch.empty(4 * mn.numel(), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with L.device_guard(dev):
         rc = lib.sbq_minmax_pack(L.ptr(mn), L.ptr(mx), mn.numel(), L.ptr(buf), L.stream_ptr(dev))
     L.check(rc)
     return buf
@@ -593,7 +593,7 @@ def minmax_unpack(buf, shape):
     C = buf.numel() // 4
     mn = torch.empty(C, dtype=torch.float32, device=dev)
     mx = torch.empty(C, dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with L.device_guard(dev):
         rc = lib.sbq_minmax_unpack(L.ptr(buf), C, L.ptr(mn), L.ptr(mx), L.stream_ptr(dev))
     L.check(rc)
     return mn.reshape(shape), mx.reshape(shape)
@@ -608,7 +608,7 @@ def ema_minmax(sample_min, sample_max, ratio, state, has_state):
 
     r = np.float32(ratio)  # the reference multiplies fp32 tensors by Python floats: both factors round to fp32
     om = np.float32(1 - ratio)
-    with torch.cuda.device(dev):
+    with L.device_guard(dev):
         rc = lib.sbq_ema_minmax(L.ptr(smin), L.ptr(smax), smin.numel(), float(r), float(om), L.ptr(state),
                                 int(bool(has_state)), L.stream_ptr(dev))
     L.check(rc)
@@ -624,7 +624,7 @@ def qparams_from_minmax(min_val, max_val, qmin, qmax, symmetric):
     mx = _f32c(max_val, dev)
     scale = torch.empty_like(mn)
     zp = torch.empty_like(mn)
-    with torch.cuda.device(dev):
+    with L.device_guard(dev):
         rc = lib.sbq_qparams_from_minmax(L.ptr(mn), L.ptr(mx), mn.numel(), int(qmin), int(qmax), int(bool(symmetric)),
                                          L.ptr(scale), L.ptr(zp), L.stream_ptr(dev))
     L.check(rc)
@@ -638,7 +638,7 @@ def lsq_init_scale(abssum, count, qmax):
     if ab.dtype != torch.float64:
         ab = ab.double()
     scale = torch.empty(ab.numel(), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with L.device_guard(dev):
         rc = lib.sbq_lsq_init_scale(L.ptr(ab), ab.numel(), float(count), int(qmax), L.ptr(scale), L.stream_ptr(dev))
     L.check(rc)
     return scale
@@ -656,7 +656,7 @@ def mse_accumulate(x, min_val, max_val, qmin, qmax, symmetric, sse, ch_axis=0, p
         raise L.SbqError("sse must be a contiguous float64 [C, 80] tensor")
     if mn.numel() != C or mx.numel() != C:
         raise L.SbqError("min/max must have C elements")
-    with torch.cuda.device(dev):
+    with L.device_guard(dev):
         ws = _workspace(dev, lib.sbq_mse_workspace_bytes(outer, C, inner))
         rc = lib.sbq_mse_accumulate(L.ptr(x), L.dtype_id(x), outer, C, inner, L.ptr(mn), L.ptr(mx), int(qmin), int(qmax),
                                     int(bool(symmetric)), L.ptr(sse), L.ptr(ws), ws.numel(), L.stream_ptr(dev))
@@ -674,7 +674,7 @@ def mse_select(sse, count_per_channel, min_val, max_val, qmin, qmax, symmetric):
     scale = torch.empty(C, dtype=torch.float32, device=dev)
     zp = torch.empty(C, dtype=torch.float32, device=dev)
     best = torch.empty(C, dtype=torch.int32, device=dev)
-    with torch.cuda.device(dev):
+    with L.device_guard(dev):
         rc = lib.sbq_mse_select(L.ptr(sse), float(count_per_channel), L.ptr(mn), L.ptr(mx), C, int(qmin), int(qmax),
                                 int(bool(symmetric)), L.ptr(scale), L.ptr(zp), L.ptr(best), L.stream_ptr(dev))
     L.check(rc)
@@ -692,7 +692,7 @@ def percentile_rows(x2d, alpha):
     C, inner = x2d.shape
     mn = torch.empty(C, dtype=torch.float32, device=dev)
     mx = torch.empty(C, dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with L.device_guard(dev):
         rc = lib.sbq_percentile_rows(L.ptr(x2d), L.dtype_id(x2d), C, inner, float(alpha), L.ptr(mn), L.ptr(mx),
                                      L.stream_ptr(dev))
     L.check(rc)
@@ -705,7 +705,7 @@ def sign_counts(x, neg, pos, ch_axis=0, per_channel=True):
     lib = L.load()
     x = x.contiguous()
     outer, C, inner = geometry(x.shape, ch_axis, per_channel)
-    with torch.cuda.device(dev):
+    with L.device_guard(dev):
         rc = lib.sbq_sign_counts(L.ptr(x), L.dtype_id(x), outer, C, inner, L.ptr(neg), L.ptr(pos), L.stream_ptr(dev))
     L.check(rc)
 
@@ -715,7 +715,7 @@ def radix_histogram(x, state, hist, pass_, n_sel, use_abs, ch_axis=0, per_channe
     lib = L.load()
     x = x.contiguous()
     outer, C, inner = geometry(x.shape, ch_axis, per_channel)
-    with torch.cuda.device(dev):
+    with L.device_guard(dev):
         rc = lib.sbq_radix_histogram(L.ptr(x), L.dtype_id(x), outer, C, inner, int(bool(use_abs)), int(pass_), int(n_sel),
                                      L.ptr(state), L.ptr(hist), L.stream_ptr(dev))
     L.check(rc)
@@ -724,7 +724,7 @@ def radix_histogram(x, state, hist, pass_, n_sel, use_abs, ch_axis=0, per_channe
 def radix_advance(hist, state, pass_, n_sel, C):
     dev = L.require_device(hist, state)
     lib = L.load()
-    with torch.cuda.device(dev):
+    with L.device_guard(dev):
         rc = lib.sbq_radix_advance(L.ptr(hist), int(C), int(pass_), int(n_sel), L.ptr(state), L.stream_ptr(dev))
     L.check(rc)
 
@@ -733,7 +733,7 @@ def radix_finish(state, n_sel, C, use_abs):
     dev = L.require_device(state)
     lib = L.load()
     out = torch.empty((C, n_sel), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with L.device_guard(dev):
         rc = lib.sbq_radix_finish(L.ptr(state), int(C), int(n_sel), int(bool(use_abs)), L.ptr(out), L.stream_ptr(dev))
     L.check(rc)
     return out
@@ -759,7 +759,7 @@ class HipSelectBackend:
         """ranks of the percentile observer from the (all-reduced) pass-0 histogram -> counts [2][C]"""
         dev = L.require_device(hist, state)
         counts = torch.empty((2, C), dtype=torch.int64, device=dev)
-        with torch.cuda.device(dev):
+        with L.device_guard(dev):
             rc = L.load().sbq_percentile_ranks(L.ptr(hist), C, 2, float(alpha), L.ptr(state), L.ptr(counts),
                                                L.stream_ptr(dev))
         L.check(rc)
@@ -782,7 +782,7 @@ def mask_from_threshold(x, thresh):
     x = x.contiguous()
     thresh = _f32c(thresh, dev)
     mask = torch.empty(x.shape, dtype=torch.uint8, device=dev)
-    with torch.cuda.device(dev):
+    with L.device_guard(dev):
         rc = lib.sbq_mask_from_threshold(L.ptr(x), L.dtype_id(x), x.numel(), L.ptr(thresh), L.ptr(mask), L.stream_ptr(dev))
     L.check(rc)
     return mask.view(torch.bool)
@@ -819,7 +819,7 @@ def vecquantmatmul(bits, x, qweight, out, scales, zeros, group_size=0):
     if scales.numel() != out_f * groups or zeros.numel() != out_f * groups:
         raise L.SbqError("scales / zeros must hold out_features x groups values")
     fn = {4: lib.sbq_vecquant4matmul, 3: lib.sbq_vecquant3matmul, 2: lib.sbq_vecquant2matmul}[bits]
-    with torch.cuda.device(dev):
+    with L.device_guard(dev):
         ws = _gptq_workspace(dev, lib.sbq_gptq_workspace_bytes(batch, in_f, out_f))
         rc = fn(L.ptr(x), L.ptr(qweight), L.ptr(out), L.ptr(scales), L.ptr(zeros), batch, in_f, out_f,
                 int(group_size), L.ptr(ws), ws.numel(), L.stream_ptr(dev))

@@ -393,6 +393,7 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "frac_of_measured_copy_ceiling": round(achieved / 6290.0, 4),  # MI355X_MICROARCH.md: float4 copy 6.29 TB/s
                 "traffic": traffic,
                 "kernel": "sbq::qdq_pack_kernel<BF16,BF16,...>",
                 "kernel_avg_us": round(kern_us, 3),

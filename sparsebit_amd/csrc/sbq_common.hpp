@@ -19,6 +19,7 @@ constexpr int kWavesPerBlock = kBlock / kWave;
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // Element tags.  Storage is raw bits; conversion is explicit so that the
 // arithmetic is always IEEE fp32 exactly like the reference's CPU path.

@@ -200,7 +200,12 @@ __device__ __forceinline__ float strip_level(const u32x4 (&w)[ROWS], int j, int 
   }
 }
 
-template <int BITS, int kBT, int KL, int CH>
+// DEC8 (4-bit only): a nibble sitting alone in a byte IS the OCP e4m3 encoding of n * 2^-9
+// (subnormals m * 2^-9 for n < 8, then (8 + m) * 2^-9), so v_cvt_pk_f32_fp8 turns two levels into two
+// exact floats per instruction and its result pair feeds v_pk_fma_f32 directly; the 2^9 is folded back
+// into the scale (a power of two: the products are the same reals).  The activations are staged in LDS
+// in the matching pair order (x0, x2, x1, x3).
+template <int BITS, int kBT, int KL, int CH, bool DEC8 = false>
 __global__ __launch_bounds__(8 * KL) void gptq_strip_kernel(
     const float* __restrict__ x, const int32_t* __restrict__ qw, const float* __restrict__ scales,
     const float* __restrict__ zeros, float* __restrict__ out, float* __restrict__ part,
@@ -277,7 +282,9 @@ __global__ __launch_bounds__(8 * KL) void gptq_strip_kernel(
       for (int j = 0; j < kXLoads; ++j) {
         const int e = (j * kThreads + threadIdx.x) * 4;
         const int lane_k = e / CH, off = e - lane_k * CH;
-        *reinterpret_cast<f32x4*>(&xs[b][lane_k * kXStride + off]) = xg[b][j];
+        f32x4 t = xg[b][j];
+        if constexpr (DEC8) t = f32x4{t[0], t[2], t[1], t[3]};  // pair order of the packed converts
+        *reinterpret_cast<f32x4*>(&xs[b][lane_k * kXStride + off]) = t;
       }
     __syncthreads();
     if (live) {
@@ -288,24 +295,70 @@ __global__ __launch_bounds__(8 * KL) void gptq_strip_kernel(
 #pragma unroll
         for (int j = 0; j < 4; ++j) dot[j][b] = 0.0f;
       }
+      if constexpr (DEC8) {
+        static_assert(!DEC8 || BITS == 4, "the e4m3 decode needs a level alone in a byte");
+        f32x2 dot2[4][kBT];
 #pragma unroll
-      for (int i = 0; i < CH / 8; ++i) {  // 8 channels at a time
-        f32x4 xv[kBT][2];
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int b = 0; b < kBT; ++b) {
-          const float* xr = &xs[b][kl * kXStride + i * 8];
-          xv[b][0] = *reinterpret_cast<const f32x4*>(xr);
-          xv[b][1] = *reinterpret_cast<const f32x4*>(xr + 4);
+          for (int b = 0; b < kBT; ++b) dot2[j][b] = f32x2{0.0f, 0.0f};
 #pragma unroll
-          for (int n = 0; n < 8; ++n) xsum[b] += xv[b][n >> 2][n & 3];
+        for (int i = 0; i < CH / 8; ++i) {  // one weight word = 8 channels at a time
+          f32x2 xp[kBT][4];                 // (x0,x2) (x1,x3) (x4,x6) (x5,x7)
+#pragma unroll
+          for (int b = 0; b < kBT; ++b) {
+            const float* xr = &xs[b][kl * kXStride + i * 8];
+            const f32x4 lo = *reinterpret_cast<const f32x4*>(xr), hi = *reinterpret_cast<const f32x4*>(xr + 4);
+            xp[b][0] = f32x2{lo[0], lo[1]};
+            xp[b][1] = f32x2{lo[2], lo[3]};
+            xp[b][2] = f32x2{hi[0], hi[1]};
+            xp[b][3] = f32x2{hi[2], hi[3]};
+#pragma unroll
+            for (int n = 0; n < 4; ++n) xsum[b] += lo[n];
+#pragma unroll
+            for (int n = 0; n < 4; ++n) xsum[b] += hi[n];
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const uint32_t word = w[i][j];
+            const uint32_t even = word & 0x0f0f0f0fu, odd = (word >> 4) & 0x0f0f0f0fu;
+            const f32x2 l02 = __builtin_amdgcn_cvt_pk_f32_fp8(even, false);
+            const f32x2 l13 = __builtin_amdgcn_cvt_pk_f32_fp8(odd, false);
+            const f32x2 l46 = __builtin_amdgcn_cvt_pk_f32_fp8(even, true);
+            const f32x2 l57 = __builtin_amdgcn_cvt_pk_f32_fp8(odd, true);
+#pragma unroll
+            for (int b = 0; b < kBT; ++b) {
+              dot2[j][b] = __builtin_elementwise_fma(l02, xp[b][0], dot2[j][b]);
+              dot2[j][b] = __builtin_elementwise_fma(l13, xp[b][1], dot2[j][b]);
+              dot2[j][b] = __builtin_elementwise_fma(l46, xp[b][2], dot2[j][b]);
+              dot2[j][b] = __builtin_elementwise_fma(l57, xp[b][3], dot2[j][b]);
+            }
+          }
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
-          for (int n = 0; n < 8; ++n) {
-            const float lvl = strip_level<BITS, kRows>(w, j, i * 8 + n);
+          for (int b = 0; b < kBT; ++b) dot[j][b] = (dot2[j][b][0] + dot2[j][b][1]) * 512.0f;  // exact: 2^9
+      } else {
 #pragma unroll
-            for (int b = 0; b < kBT; ++b) dot[j][b] = __builtin_fmaf(lvl, xv[b][n >> 2][n & 3], dot[j][b]);
+        for (int i = 0; i < CH / 8; ++i) {  // 8 channels at a time
+          f32x4 xv[kBT][2];
+  #pragma unroll
+          for (int b = 0; b < kBT; ++b) {
+            const float* xr = &xs[b][kl * kXStride + i * 8];
+            xv[b][0] = *reinterpret_cast<const f32x4*>(xr);
+            xv[b][1] = *reinterpret_cast<const f32x4*>(xr + 4);
+  #pragma unroll
+            for (int n = 0; n < 8; ++n) xsum[b] += xv[b][n >> 2][n & 3];
+          }
+  #pragma unroll
+          for (int j = 0; j < 4; ++j) {
+  #pragma unroll
+            for (int n = 0; n < 8; ++n) {
+              const float lvl = strip_level<BITS, kRows>(w, j, i * 8 + n);
+  #pragma unroll
+              for (int b = 0; b < kBT; ++b) dot[j][b] = __builtin_fmaf(lvl, xv[b][n >> 2][n & 3], dot[j][b]);
+            }
           }
         }
       }
@@ -475,15 +528,22 @@ int gptq_matmul(const float* x, const int32_t* qweight, float* out, const float*
     int64_t split = ceil_div(in_features, 32 * ch);
     if (split > kStripMaxSplit) split = kStripMaxSplit;
     const dim3 grid(static_cast<uint32_t>(strips), static_cast<uint32_t>(split));
-#define SBQ_STRIP(CH)                                                                                      \
+#define SBQ_STRIP(CH, D8)                                                                                  \
   do {                                                                                                     \
     if (batch == 2)                                                                                        \
-      gptq_strip_kernel<BITS, 2, 32, CH><<<grid, 256, 0, st>>>(x, qweight, scales, zeros, out, part, arrivals, g); \
+      gptq_strip_kernel<BITS, 2, 32, CH, D8><<<grid, 256, 0, st>>>(x, qweight, scales, zeros, out, part, arrivals, g); \
     else                                                                                                   \
-      gptq_strip_kernel<BITS, 1, 32, CH><<<grid, 256, 0, st>>>(x, qweight, scales, zeros, out, part, arrivals, g); \
+      gptq_strip_kernel<BITS, 1, 32, CH, D8><<<grid, 256, 0, st>>>(x, qweight, scales, zeros, out, part, arrivals, g); \
   } while (0)
-    if (ch == kSliceK) SBQ_STRIP(128);
-    else SBQ_STRIP(64);
+    if constexpr (BITS == 4) {
+      if (knob(2) != 4) {  // packed e4m3 decode (knob 2 == 4: byte converts, for A/B runs)
+        if (ch == kSliceK) SBQ_STRIP(128, true);
+        else SBQ_STRIP(64, true);
+        return check_launch();
+      }
+    }
+    if (ch == kSliceK) SBQ_STRIP(128, false);
+    else SBQ_STRIP(64, false);
 #undef SBQ_STRIP
     return check_launch();
   }

@@ -231,9 +231,12 @@ __device__ __forceinline__ void finish_tile(void* __restrict__ y, void* __restri
       for (int j = 0; j < kPack; ++j) odd |= !(__builtin_fabsf(v[j]) < bound);
       if (__builtin_amdgcn_ballot_w64(odd) == 0) {
 #pragma unroll
-        for (int j = 0; j < kPack; ++j) {
-          lv[j] = __builtin_amdgcn_fmed3f(__builtin_rintf(fast_div(v[j], s, yr)) + z, qlo, qhi);
+        for (int j = 0; j < kPack; j += 2) {
+          const f32x2 t = fast_div2(f32x2{v[j], v[j + 1]}, s, yr);
+          lv[j] = __builtin_amdgcn_fmed3f(__builtin_rintf(t[0]) + z, qlo, qhi);
+          lv[j + 1] = __builtin_amdgcn_fmed3f(__builtin_rintf(t[1]) + z, qlo, qhi);
           dq[j] = dequant_level(lv[j], s, z);
+          dq[j + 1] = dequant_level(lv[j + 1], s, z);
         }
       } else {
 #pragma unroll

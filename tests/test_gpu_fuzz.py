@@ -1,0 +1,154 @@
+"""Seeded differential fuzzing of the HIP path against the CPU oracle: random geometries
+(outer / C / inner incl. primes, 1, pack-ragged), channel axes, dtypes, integer ranges, special
+values sprinkled in, and storage offsets that break 16-byte alignment.  Every case is small (the
+oracle finishes in milliseconds); the point is breadth over the dispatch logic -- ROWS / FLAT /
+channels-last / scalar forward paths, vector vs element-wise reductions, grouped launches."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import dev_tensor, same_values
+
+pytestmark = pytest.mark.gpu
+
+DTYPES = [torch.float32, torch.bfloat16, torch.float16]
+RANGES = [(-128, 127), (0, 255), (-8, 7), (0, 15), (-2, 1), (-32768, 32767), (0, 3)]
+
+
+def _shape(rng):
+    nd = int(rng.integers(1, 5))
+    pools = [1, 2, 3, 5, 7, 8, 16, 24, 31, 64, 100, 129, 256, 520]
+    shape = [int(rng.choice(pools)) for _ in range(nd)]
+    while int(np.prod(shape)) > 300000:
+        shape[int(np.argmax(shape))] //= 2
+    return tuple(max(s, 1) for s in shape)
+
+
+def _data(rng, shape, dtype, offset):
+    n = int(np.prod(shape))
+    base = torch.from_numpy(rng.standard_normal(n + offset).astype(np.float32)) * float(rng.choice([0.05, 1.0, 30.0]))
+    k = max(1, n // 50)
+    idx = torch.from_numpy(rng.integers(0, n + offset, size=k))
+    specials = torch.tensor([0.0, -0.0, 0.5, -0.5, 1.5, 2.5, float("inf"), -float("inf"), 1e-40, -1e-40, 3e38, float("nan")])
+    base[idx] = specials[torch.from_numpy(rng.integers(0, len(specials), size=k))]
+    storage = base.to(dtype).cuda()
+    return storage[offset:].view(shape)  # contiguous, but its pointer is offset by `offset` elements
+
+
+@pytest.mark.parametrize("seed", range(60))
+def test_fuzz_forward_and_stats(oracle, seed):
+    from sparsebit_amd import ops
+
+    rng = np.random.default_rng(1000 + seed)
+    shape = _shape(rng)
+    dtype = DTYPES[seed % 3]
+    offset = int(rng.choice([0, 0, 1, 3, 4, 8]))
+    x = _data(rng, shape, dtype, offset)
+    xf = x.float().cpu().numpy()
+    per_channel = bool(rng.integers(0, 2))
+    ch_axis = int(rng.integers(0, len(shape)))
+    qmin, qmax = RANGES[int(rng.integers(0, len(RANGES)))]
+    C = shape[ch_axis] if per_channel else 1
+    # observer statistics (inf in the data makes min / max inf: finite qparams are drawn separately)
+    mn, mx, _ = ops.channel_stats(x, ch_axis, per_channel)
+    omn, omx = oracle.minmax(xf, ch_axis, per_channel)
+    assert same_values(mn.cpu().numpy(), omn) and same_values(mx.cpu().numpy(), omx), (shape, ch_axis, per_channel)
+    scale = np.abs(rng.standard_normal(C)).astype(np.float32) * 0.1 + 1e-3
+    if seed % 7 == 0:
+        scale[0] = 1e-6  # the observer's floor
+    zp = np.zeros(C, np.float32) if qmin < 0 else rng.integers(0, qmax + 1, size=C).astype(np.float32)
+    if seed % 5 == 0 and qmin >= 0:
+        zp = zp + 0.5  # half-to-even rounding of the zero point
+    ref_dq, ref_q = oracle.qdq(xf, scale, zp, qmin, qmax, ch_axis)
+    y, q = ops.fake_quant(x, dev_tensor(scale), dev_tensor(zp), qmin, qmax, ch_axis, return_q=torch.int32)
+    assert same_values(y.cpu().numpy(), ref_dq), (shape, ch_axis, per_channel, dtype, offset, qmin)
+    assert np.array_equal(q.cpu().numpy(), ref_q)
+    if dtype != torch.float32:
+        y16 = ops.fake_quant(x, dev_tensor(scale), dev_tensor(zp), qmin, qmax, ch_axis, out_dtype=dtype)
+        assert same_values(y16.float().cpu().numpy(), torch.from_numpy(ref_dq).to(dtype).float().numpy())
+    # fused mask
+    m = torch.from_numpy(rng.integers(0, 2, size=shape).astype(np.bool_)).cuda()
+    ref_m, _ = oracle.qdq(xf, scale, zp, qmin, qmax, ch_axis, mask=m.cpu().numpy())
+    ym = ops.fake_quant(x, dev_tensor(scale), dev_tensor(zp), qmin, qmax, ch_axis, mask=m)
+    # inf * 0 is NaN in `w * mask` (sparse/modules/conv.py:40); the fused kernel selects -> 0: compare finite inputs
+    finite = np.isfinite(xf)
+    assert same_values(np.where(finite, ym.cpu().numpy(), 0), np.where(finite, ref_m, 0))
+    # levels only / stored levels back to floats
+    if qmax - qmin <= 255:
+        qt = torch.int8 if qmin < 0 else torch.uint8
+        q8 = ops.quantize_only(x, dev_tensor(scale), dev_tensor(zp), qmin, qmax, ch_axis, return_q=qt)
+        assert np.array_equal(q8.cpu().numpy().astype(np.int32), ref_q)
+        back = ops.dequantize_linear(q8, dev_tensor(scale), dev_tensor(zp), ch_axis=ch_axis)
+        notnan = ~np.isnan(xf)  # an integer level cannot carry a NaN: those positions hold level 0
+        assert same_values(np.where(notnan, back.cpu().numpy(), 0), np.where(notnan, ref_dq, 0))
+
+
+@pytest.mark.parametrize("seed", range(30))
+def test_fuzz_backward(oracle, seed):
+    from sparsebit_amd import ops
+
+    rng = np.random.default_rng(5000 + seed)
+    shape = _shape(rng)
+    dtype = DTYPES[seed % 3]
+    offset = int(rng.choice([0, 0, 1, 4]))
+    n = int(np.prod(shape))
+    x = (torch.from_numpy(rng.standard_normal(n + offset).astype(np.float32)) * 2).to(dtype).cuda()[offset:].view(shape)
+    gy = torch.from_numpy(rng.standard_normal(n + offset).astype(np.float32)).to(dtype).cuda()[offset:].view(shape)
+    per_channel = bool(rng.integers(0, 2))
+    ch_axis = int(rng.integers(0, len(shape)))
+    qmin, qmax = RANGES[int(rng.integers(0, 5))]
+    C = shape[ch_axis] if per_channel else 1
+    scale = np.abs(rng.standard_normal(C)).astype(np.float32) * 0.2 + 0.05
+    zp = np.zeros(C, np.float32) if qmin < 0 else rng.integers(0, qmax + 1, size=C).astype(np.float32)
+    gx, gs, gz = ops.fake_quant_backward(x, gy, dev_tensor(scale), dev_tensor(zp), qmin, qmax, ch_axis)
+    ogx, ogs, ogz = oracle.ste_backward(x.float().cpu().numpy(), gy.float().cpu().numpy(), scale, zp, qmin, qmax, ch_axis)
+    assert same_values(gx.float().cpu().numpy(), torch.from_numpy(ogx).to(dtype).float().numpy()), (shape, ch_axis, dtype)
+    tol = 2e-5 * max(1.0, float(np.abs(ogs).max()))
+    assert np.allclose(gs.cpu().numpy(), ogs, rtol=1e-5, atol=tol)
+    tolz = 2e-5 * max(1.0, float(np.abs(ogz).max()))
+    assert np.allclose(gz.cpu().numpy(), ogz, rtol=1e-5, atol=tolz)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_fuzz_group_launches(seed):
+    """random mixes of weight shapes / ranges / granularities through the model-wide launches == one by one"""
+    from sparsebit_amd import ops
+
+    rng = np.random.default_rng(9000 + seed)
+    dtype = DTYPES[seed % 3]
+    masked = bool(seed % 2)
+    entries, masks, gys, lsq, ratios = [], [], [], [], []
+    for _ in range(int(rng.integers(1, 12))):
+        C = int(rng.choice([1, 2, 3, 8, 17, 64, 130]))
+        inner = 8 * int(rng.choice([1, 2, 3, 9, 33, 64, 72, 300]))
+        tail = (int(rng.choice([1, 3])),) if rng.integers(0, 3) == 0 and inner % 3 == 0 else ()
+        shape = (C, inner // (tail[0] if tail else 1)) + tail
+        x = (torch.from_numpy(rng.standard_normal(shape).astype(np.float32)) * 1.5).to(dtype).cuda()
+        per_channel = bool(rng.integers(0, 4))
+        qmin, qmax = RANGES[int(rng.integers(0, 5))]
+        k = C if per_channel else 1
+        scale = torch.from_numpy((np.abs(rng.standard_normal(k)) * 0.1 + 0.02).astype(np.float32)).cuda()
+        is_lsq = bool(rng.integers(0, 2))
+        if is_lsq:
+            scale = scale * torch.from_numpy(rng.choice([-1.0, 1.0], size=k).astype(np.float32)).cuda()
+        zp = torch.zeros(k).cuda() if qmin < 0 else torch.from_numpy(rng.integers(0, qmax + 1, size=k).astype(np.float32)).cuda()
+        entries.append((x, scale, zp, qmin, qmax))
+        masks.append(torch.from_numpy(rng.integers(0, 2, size=shape).astype(np.bool_)).cuda() if masked else None)
+        gys.append(torch.from_numpy(rng.standard_normal(shape).astype(np.float32)).to(dtype).cuda())
+        lsq.append(is_lsq)
+        ratios.append(float(rng.uniform(0.01, 1.0)) if is_lsq else 1.0)
+    mk = masks if masked else None
+    outs = ops.GroupFakeQuant(entries, masks=mk, lsq=lsq, fresh_outputs=bool(seed % 3))()
+    gxs, gss = ops.GroupFakeQuantBackward(entries, masks=mk, lsq=lsq, want_gs=True, gs_ratios=ratios)(gys)
+    for i, (x, scale, zp, qmin, qmax) in enumerate(entries):
+        s_eff = scale.abs() if lsq[i] else scale
+        z_eff = zp.clamp(qmin, qmax) if lsq[i] else zp
+        assert torch.equal(outs[i], ops.fake_quant(x, s_eff, z_eff, qmin, qmax, 0, mask=masks[i])), i
+        xm = x if not masked else x * masks[i]
+        gx, gs, _ = ops.fake_quant_backward(xm, gys[i], s_eff, z_eff, qmin, qmax, 0, True, False)
+        if masked:
+            gx = gx * masks[i]
+        assert torch.equal(gxs[i], gx), i
+        if lsq[i]:
+            gs = gs * ratios[i] * torch.sign(scale)
+        assert torch.allclose(gss[i], gs, rtol=1e-5, atol=2e-5 * max(1.0, float(gs.abs().max()))), i

@@ -152,3 +152,90 @@ def test_fuzz_group_launches(seed):
         if lsq[i]:
             gs = gs * ratios[i] * torch.sign(scale)
         assert torch.allclose(gss[i], gs, rtol=1e-5, atol=2e-5 * max(1.0, float(gs.abs().max()))), i
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_fuzz_selection(oracle, seed):
+    """percentile observer (row kernel and radix path, several cached batches) and the L1 mask threshold on
+    random geometries with heavy duplicates, all-positive / all-negative channels and signed zeros"""
+    from sparsebit_amd.config import quantizer_config, sparser_config
+    from sparsebit_amd.observers import build_observer
+    from sparsebit_amd.quantizers.quant_descriptor import QuantDescriptor
+    from sparsebit_amd.sparsers import build_sparser
+
+    rng = np.random.default_rng(20000 + seed)
+    dtype = DTYPES[seed % 3]
+    perch = bool(seed % 2)
+    ch_axis, layout = [(0, None), (1, "NCHW"), (2, "NLC")][seed % 3 if perch else int(rng.integers(0, 3))]
+    if layout is None:
+        shape = (int(rng.choice([1, 3, 16, 40])), int(rng.choice([1, 7, 64, 1000, 5000])))
+    elif layout == "NCHW":
+        shape = (int(rng.choice([1, 2, 5])), int(rng.choice([1, 3, 8])), int(rng.choice([1, 7, 14])), int(rng.choice([1, 6, 9])))
+    else:
+        shape = (int(rng.choice([1, 2, 4])), int(rng.choice([1, 13, 50])), int(rng.choice([1, 8, 24, 65])))
+    nb = 1 if layout is None else int(rng.integers(1, 4))
+    xs = []
+    for _ in range(nb):
+        a = rng.standard_normal(shape).astype(np.float32)
+        a[rng.random(shape) < 0.3] = float(rng.choice([0.0, -0.0, 0.25, -1.5]))  # duplicates, signed zeros
+        if rng.random() < 0.3:
+            a = np.abs(a)
+        elif rng.random() < 0.2:
+            a = -np.abs(a) - 0.5
+        xs.append(torch.from_numpy(a).to(dtype))
+    alpha = float(rng.choice([0.0, 1e-3, 0.01, 0.2, 0.5, 1.0]))
+    name = "per-%s-affine" % ("channel" if perch else "tensor")
+    cfg = quantizer_config(name, 8, observer="PERCENTILE", target="weight" if layout is None else "feature",
+                           layout=layout or "NCHW", alpha=alpha)
+    obs = build_observer(cfg, QuantDescriptor(cfg))
+    for x in xs:
+        obs.data_cache.update(x.cuda())
+    mn, mx = obs.calc_minmax()
+    if perch:
+        data = np.concatenate([np.moveaxis(x.float().numpy(), ch_axis, 0).reshape(x.shape[ch_axis], -1) for x in xs], 1)
+        rmn, rmx = oracle.percentile(data, alpha, 0, True)
+    else:
+        rmn, rmx = oracle.percentile(np.concatenate([x.float().numpy().reshape(-1) for x in xs]), alpha, per_channel=False)
+    assert same_values(mn.reshape(-1).cpu().numpy(), rmn) and same_values(mx.reshape(-1).cpu().numpy(), rmx), (shape, alpha, perch)
+    # mask threshold / mask of the first batch
+    ratio = float(rng.choice([0.05, 0.5, 0.9, 0.999]))
+    sp = build_sparser(sparser_config(ratio))
+    w = xs[0].cuda()
+    rm, rt = oracle.l1_mask(xs[0].float().numpy(), ratio)
+    assert float(sp.calc_threshold(w)) == float(rt)
+    assert np.array_equal(sp.calc_mask(w).cpu().numpy(), rm)
+
+
+@pytest.mark.parametrize("seed", range(18))
+def test_fuzz_gptq(oracle, seed):
+    """random (batch, in, out, group, bits) incl. ragged sizes: every dispatch path of the mat-vec"""
+    from sparsebit_amd import gptq
+
+    rng = np.random.default_rng(30000 + seed)
+    bit = [4, 3, 2][seed % 3]
+    B = int(rng.choice([1, 2, 3, 5, 8, 17]))
+    GS = int(rng.choice([-1, 128, 256] + ([64] if bit == 2 else [])))
+    if GS == -1:
+        M = int(rng.choice([8, 40, 136, 500, 1000, 4100]))
+    else:
+        M = GS * int(rng.integers(1, 9))
+    N = int(rng.choice([1, 4, 33, 64, 96, 100, 256, 1027]))
+    torch.manual_seed(seed)
+    layer = torch.nn.Linear(M, N)
+    x = torch.randn(B, M)
+    w = layer.weight.data.numpy()
+    scale, zero = oracle.gptq_find_params(w, bit, GS)
+    wq = oracle.gptq_quantize(w, scale, zero, bit)
+    qw, zeros_p = oracle.gptq_pack(wq, scale, zero, bit)
+    ql = gptq.QuantLinear(M, N, bit=bit, groupsize=GS)
+    ql.qweight = torch.from_numpy(qw)
+    ql.scales = torch.from_numpy(scale).reshape(ql.scales.shape)
+    ql.zeros = torch.from_numpy(zeros_p).reshape(ql.zeros.shape)
+    ql.bias = layer.bias.detach().clone()
+    ql = ql.cuda()
+    y = ql(x.cuda())
+    want = x.double() @ torch.from_numpy(wq).double().t() + layer.bias.detach().double()
+    assert torch.allclose(y.double().cpu(), want, rtol=1e-5, atol=3e-5), (bit, B, M, N, GS, (y.double().cpu() - want).abs().max())
+    assert torch.equal(y, ql(x.cuda()))
+    ref = oracle.vecquantmatmul(x.numpy(), qw, layer.bias.detach().numpy(), scale, zeros_p, GS, bit)
+    assert np.allclose(y.cpu().numpy(), ref, rtol=1e-5, atol=3e-5)

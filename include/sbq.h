@@ -342,6 +342,19 @@ int sbq_radix_advance(const int64_t* hist, int64_t C, int pass, int n_sel,
 int sbq_radix_finish(const int64_t* state, int64_t C, int n_sel, int use_abs,
                      float* values_out /* [C][n_sel] */, void* stream);
 
+/* The whole protocol above enqueued by ONE call, for a single process (nothing to all-reduce
+ * between the passes): sbq_percentile_select is the percentile observer over a list of cached
+ * batches (`shards`: HOST array of n_shards device pointers, shard i shaped [outers[i], C,
+ * inner]; ranks from the first histogram as in sbq_percentile_ranks; min / max [C] with the
+ * "no negative -> 0" rule of percentile.py:30-43); sbq_kth_value is the 1-indexed k-th smallest
+ * of x (of |x| with use_abs) -- the L1 masker's threshold, l1norm.py:21-24. */
+size_t sbq_radix_select_workspace_bytes(int64_t C, int n_sel);
+int sbq_percentile_select(const void* const* shards, const int64_t* outers, int n_shards, int x_dtype,
+                          int64_t C, int64_t inner, double alpha, float* min_out, float* max_out,
+                          void* workspace, size_t workspace_bytes, void* stream);
+int sbq_kth_value(const void* x, int x_dtype, int64_t numel, int use_abs, int64_t k, float* value_out,
+                  void* workspace, size_t workspace_bytes, void* stream);
+
 /* The percentile observer's two ranks per channel, straight from the pass-0 histogram
  * (after any cross-rank SUM): neg / pos counts are sums over its lower / upper half, then
  * k_min = max(round(neg*alpha), 1), k_max = n - max(round(pos*alpha), 0) with Python's

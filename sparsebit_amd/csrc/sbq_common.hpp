@@ -288,7 +288,7 @@ __device__ __forceinline__ float fast_div(float x, float s, float y) {
 // two quotients at a time: the same five operations as fast_div on v_pk_mul_f32 / v_pk_fma_f32
 // (each lane of a packed op is an individually rounded IEEE operation: identical results)
 __device__ __forceinline__ f32x2 fast_div2(f32x2 x, float s, float y) {
-  const f32x2 sv = {s, s}, yv = {y, y}, ns = {-s, -s};
+  const f32x2 yv = {y, y}, ns = {-s, -s};
   f32x2 q = x * yv;
   f32x2 r = __builtin_elementwise_fma(q, ns, x);
   q = __builtin_elementwise_fma(r, yv, q);

@@ -199,22 +199,43 @@ __global__ __launch_bounds__(kBlock) void radix_hist_kernel(const void* __restri
     pre[s] = s < n_sel ? static_cast<uint32_t>(state[(static_cast<size_t>(c) * n_sel + s) * 2]) : 0u;
   __syncthreads();
 
+  // pass 0: no prefix is known yet, so every selector would count the same thing -- count once and
+  // copy at the flush.  (Measured: the per-element LDS update is what this pass costs -- 32 us vs
+  // 15 us without it, atomics and plain stores alike, and lane-private or bank-rotated copies of the
+  // histogram change nothing -- so the lever is fewer LDS operations, not cheaper ones.)
+  const int n_count = pass == 0 ? 1 : n_sel;
   auto visit = [&](float f) {
     const uint32_t kk = float_key(f, use_abs != 0);
     const uint32_t d = (kk >> shift) & dmask;
 #pragma unroll
     for (int s = 0; s < kMaxSel; ++s)
-      if (s < n_sel && (kk & known) == pre[s]) atomicAdd(&lh[s][d], 1u);
+      if (s < n_count && (kk & known) == pre[s]) atomicAdd(&lh[s][d], 1u);
   };
 
   if constexpr (VEC) {
     const int64_t vend = begin + ((end - begin) / kPack) * kPack;
-    for (int64_t e = begin + static_cast<int64_t>(threadIdx.x) * kPack; e < vend;
-         e += static_cast<int64_t>(kBlock) * kPack) {
-      float v[kPack];
-      load_pack<T, true>(x, row_base + e, v);
+    // all eight 16-byte loads of a lane are in flight before the first one is consumed: the chunk is
+    // one round trip to HBM, not eight dependent ones
+    constexpr int U = kRadixChunk / (kBlock * kPack);
+    if (vend > begin) {
+      RawPack<T> raw[U];
+      bool ok[U];
 #pragma unroll
-      for (int q = 0; q < kPack; ++q) visit(v[q]);
+      for (int u = 0; u < U; ++u) {
+        int64_t e = begin + (static_cast<int64_t>(u) * kBlock + threadIdx.x) * kPack;
+        ok[u] = e < vend;
+        if (!ok[u]) e = vend - kPack;
+        raw[u] = load_raw<T, true>(x, row_base + e);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        float v[kPack];
+        unpack_raw<T>(raw[u], v);
+        if (ok[u]) {
+#pragma unroll
+          for (int q = 0; q < kPack; ++q) visit(v[q]);
+        }
+      }
     }
     for (int64_t e = vend + threadIdx.x; e < end; e += kBlock) visit(Elem<T>::load1(x, row_base + e));
   } else {
@@ -224,41 +245,67 @@ __global__ __launch_bounds__(kBlock) void radix_hist_kernel(const void* __restri
   for (int s = 0; s < n_sel; ++s) {
     unsigned long long* gh = hist + (static_cast<size_t>(c) * n_sel + s) * SBQ_RADIX_BINS;
     for (uint32_t i = threadIdx.x; i < SBQ_RADIX_BINS; i += kBlock) {
-      const uint32_t v = lh[s][i];
+      const uint32_t v = lh[s < n_count ? s : 0][i];
       if (v) atomicAdd(&gh[i], static_cast<unsigned long long>(v));
     }
   }
 }
 
-// one workgroup per (channel, selector): find the bin holding rank k
-__global__ __launch_bounds__(kBlock) void radix_advance_kernel(const int64_t* __restrict__ hist,
-                                                               int pass, int64_t* __restrict__ state) {
-  __shared__ int64_t seg[kBlock];
+// one workgroup per (channel, selector): find the bin holding rank k.  Every thread keeps its 8
+// bins in registers, a block-wide scan of the per-thread sums locates the thread whose range holds
+// the rank, and that thread finishes among its own bins -- no serial chain of global loads.
+// clear != 0: the histogram is left zeroed for the next pass (saves a memset launch).
+__global__ __launch_bounds__(kBlock) void radix_advance_kernel(int64_t* __restrict__ hist, int pass,
+                                                               int64_t* __restrict__ state, int clear) {
+  __shared__ int64_t wave_tot[kWavesPerBlock];
   const size_t cs = blockIdx.x;
-  const int64_t* h = hist + cs * SBQ_RADIX_BINS;
+  int64_t* h = hist + cs * SBQ_RADIX_BINS;
   constexpr int kPer = SBQ_RADIX_BINS / kBlock;  // 8 bins per thread
+  int64_t bins[kPer];
   int64_t t = 0;
 #pragma unroll
-  for (int i = 0; i < kPer; ++i) t += h[threadIdx.x * kPer + i];
-  seg[threadIdx.x] = t;
+  for (int i = 0; i < kPer; ++i) {
+    bins[i] = h[threadIdx.x * kPer + i];
+    t += bins[i];
+  }
+  const int64_t k = state[cs * 2 + 1];
+  const uint32_t pre = static_cast<uint32_t>(state[cs * 2]);
+  // inclusive scan of t over the 256 threads
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wid = threadIdx.x / kWave;
+  int64_t incl = t;
+#pragma unroll
+  for (int d = 1; d < kWave; d <<= 1) {
+    const int64_t up = __shfl_up(incl, d, kWave);
+    if (lane >= d) incl += up;
+  }
+  if (lane == kWave - 1) wave_tot[wid] = incl;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    int64_t k = state[cs * 2 + 1];
-    uint32_t pre = static_cast<uint32_t>(state[cs * 2]);
-    int sidx = 0;
-    for (; sidx < kBlock - 1; ++sidx) {
-      if (k <= seg[sidx]) break;
-      k -= seg[sidx];
+  int64_t off = 0;
+#pragma unroll
+  for (int w = 0; w < kWavesPerBlock; ++w)
+    if (w < wid) off += wave_tot[w];
+  incl += off;
+  const int64_t excl = incl - t;
+  // the rank lies in (excl, incl]; a rank beyond the total (cannot happen for 1 <= k <= n) would
+  // fall to the last thread, like the serial search did
+  const bool mine = (k > excl && k <= incl) || (threadIdx.x == kBlock - 1 && k > incl);
+  if (clear) {
+#pragma unroll
+    for (int i = 0; i < kPer; ++i) h[threadIdx.x * kPer + i] = 0;
+  }
+  if (mine) {
+    int64_t kk = k - excl;
+    int b = 0;
+#pragma unroll
+    for (int i = 0; i < kPer - 1; ++i) {
+      if (b == i && kk > bins[i]) {
+        kk -= bins[i];
+        ++b;
+      }
     }
-    int b = sidx * kPer;
-    const int last = sidx * kPer + kPer - 1;
-    for (; b < last; ++b) {
-      if (k <= h[b]) break;
-      k -= h[b];
-    }
-    pre |= static_cast<uint32_t>(b) << pass_shift(pass);
-    state[cs * 2] = static_cast<int64_t>(pre);
-    state[cs * 2 + 1] = k;
+    state[cs * 2] = static_cast<int64_t>(pre | (static_cast<uint32_t>(threadIdx.x * kPer + b) << pass_shift(pass)));
+    state[cs * 2 + 1] = kk;
   }
 }
 
@@ -305,6 +352,31 @@ __global__ void radix_finish_kernel(const int64_t* __restrict__ state, int64_t n
   const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
   if (i >= n) return;
   out[i] = key_float(static_cast<uint32_t>(state[i * 2]));
+}
+
+// zero [hist | state | counts] (contiguous in the workspace) and, for a per-tensor selection with
+// explicit ranks (the mask threshold), plant them
+__global__ __launch_bounds__(kBlock) void radix_init_kernel(int64_t* __restrict__ base, size_t words,
+                                                            int64_t* __restrict__ state, int n_ranks, int64_t k0,
+                                                            int64_t k1) {
+  for (size_t i = static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x; i < words;
+       i += static_cast<size_t>(gridDim.x) * kBlock) {
+    int64_t v = 0;
+    if (n_ranks > 0 && base + i == state + 1) v = k0;
+    if (n_ranks > 1 && base + i == state + 3) v = k1;
+    base[i] = v;
+  }
+}
+
+// percentile.py:30-43: a channel without negative (non-negative) elements keeps min (max) = 0
+__global__ void percentile_finish_kernel(const int64_t* __restrict__ state, const int64_t* __restrict__ counts,
+                                         int64_t C, float* __restrict__ min_out, float* __restrict__ max_out) {
+  const int64_t c = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float lo = key_float(static_cast<uint32_t>(state[(c * 2 + 0) * 2]));
+  const float hi = key_float(static_cast<uint32_t>(state[(c * 2 + 1) * 2]));
+  min_out[c] = counts[c] > 0 ? lo : 0.0f;
+  max_out[c] = counts[C + c] > 0 ? hi : 0.0f;
 }
 
 template <typename T, bool VEC>
@@ -436,13 +508,93 @@ int sbq_radix_histogram(const void* x, int x_dtype, int64_t outer, int64_t C, in
   return check_launch();
 }
 
+// The whole three-pass protocol enqueued by ONE call (single process: nothing to all-reduce between
+// the passes).  Workspace = [hist | state | counts].
+size_t sbq_radix_select_workspace_bytes(int64_t C, int n_sel) {
+  if (C <= 0 || n_sel < 1 || n_sel > sbq::kMaxSel) return 0;
+  return static_cast<size_t>(C) * n_sel * SBQ_RADIX_BINS * 8 + static_cast<size_t>(C) * n_sel * 16 +
+         static_cast<size_t>(C) * 16 + 64;
+}
+
+static int radix_select_run(const void* const* shards, const int64_t* outers, int n_shards, int x_dtype, int64_t C,
+                            int64_t inner, int use_abs, int n_sel, bool percentile, double alpha, int64_t k0,
+                            int64_t k1, float* values_out, float* min_out, float* max_out, void* workspace,
+                            size_t workspace_bytes, void* stream) {
+  using namespace sbq;
+  if (!valid_dtype(x_dtype)) return SBQ_ERR_DTYPE;
+  if (n_shards < 0 || C < 0 || inner < 0) return SBQ_ERR_ARG;
+  if (n_shards == 0 || C == 0 || inner == 0) return SBQ_ERR_EMPTY;
+  if (!shards || !outers || !workspace) return SBQ_ERR_NULL;
+  if (n_sel < 1 || n_sel > kMaxSel || C >= (1ll << 31)) return SBQ_ERR_ARG;
+  const size_t need = sbq_radix_select_workspace_bytes(C, n_sel);
+  if (workspace_bytes < need || !aligned16(workspace)) return SBQ_ERR_WORKSPACE;
+  for (int i = 0; i < n_shards; ++i) {
+    if (!shards[i]) return SBQ_ERR_NULL;
+    if (outers[i] <= 0) return SBQ_ERR_ARG;
+    if (reinterpret_cast<uintptr_t>(shards[i]) % dtype_size(x_dtype)) return SBQ_ERR_ALIGN;
+    RadixGeom g;
+    if (!radix_geom(outers[i], C, inner, g)) return SBQ_ERR_ARG;
+  }
+  hipStream_t st = as_stream(stream);
+  const size_t hist_bytes = static_cast<size_t>(C) * n_sel * SBQ_RADIX_BINS * 8;
+  int64_t* hist = static_cast<int64_t*>(workspace);
+  int64_t* state = reinterpret_cast<int64_t*>(static_cast<char*>(workspace) + hist_bytes);
+  int64_t* counts = state + static_cast<size_t>(C) * n_sel * 2;
+  // one launch zeroes histogram, state and counts (and plants explicit ranks); after that every advance
+  // leaves the histogram zeroed for the next pass
+  const size_t words = (hist_bytes + static_cast<size_t>(C) * n_sel * 16 + static_cast<size_t>(C) * 16) / 8;
+  uint32_t zgrid = static_cast<uint32_t>(ceil_div(static_cast<int64_t>(words), static_cast<int64_t>(kBlock) * 8));
+  if (zgrid > 2048) zgrid = 2048;
+  radix_init_kernel<<<zgrid, kBlock, 0, st>>>(hist, words, state, percentile ? 0 : n_sel, k0, k1);
+  int rc0 = check_launch();
+  if (rc0 != SBQ_OK) return rc0;
+  for (int pass = 0; pass < 3; ++pass) {
+    for (int i = 0; i < n_shards; ++i) {
+      int rc = sbq_radix_histogram(shards[i], x_dtype, outers[i], C, inner, use_abs, pass, n_sel, state, hist, stream);
+      if (rc != SBQ_OK) return rc;
+    }
+    if (pass == 0 && percentile) {
+      int rc = sbq_percentile_ranks(hist, C, n_sel, alpha, state, counts, stream);
+      if (rc != SBQ_OK) return rc;
+    }
+    radix_advance_kernel<<<static_cast<uint32_t>(C * n_sel), kBlock, 0, st>>>(hist, pass, state, pass < 2);
+    int rc = check_launch();
+    if (rc != SBQ_OK) return rc;
+  }
+  if (percentile) {
+    percentile_finish_kernel<<<static_cast<uint32_t>(ceil_div(C, kBlock)), kBlock, 0, st>>>(state, counts, C, min_out, max_out);
+    return check_launch();
+  }
+  return sbq_radix_finish(state, C, n_sel, use_abs, values_out, stream);
+}
+
+int sbq_percentile_select(const void* const* shards, const int64_t* outers, int n_shards, int x_dtype, int64_t C,
+                          int64_t inner, double alpha, float* min_out, float* max_out, void* workspace,
+                          size_t workspace_bytes, void* stream) {
+  if (!min_out || !max_out) return SBQ_ERR_NULL;
+  if (!(alpha >= 0.0 && alpha <= 1.0)) return SBQ_ERR_ARG;
+  return radix_select_run(shards, outers, n_shards, x_dtype, C, inner, 0, 2, true, alpha, 0, 0, nullptr, min_out,
+                          max_out, workspace, workspace_bytes, stream);
+}
+
+int sbq_kth_value(const void* x, int x_dtype, int64_t numel, int use_abs, int64_t k, float* value_out,
+                  void* workspace, size_t workspace_bytes, void* stream) {
+  if (!value_out) return SBQ_ERR_NULL;
+  if (numel > 0 && (k < 1 || k > numel)) return SBQ_ERR_ARG;
+  const void* shard[1] = {x};
+  const int64_t outer[1] = {1};
+  return radix_select_run(shard, outer, 1, x_dtype, 1, numel, use_abs, 1, false, 0.0, k, 0, value_out, nullptr,
+                          nullptr, workspace, workspace_bytes, stream);
+}
+
 int sbq_radix_advance(const int64_t* hist, int64_t C, int pass, int n_sel, int64_t* state, void* stream) {
   using namespace sbq;
   if (C < 0) return SBQ_ERR_ARG;
   if (C == 0) return SBQ_ERR_EMPTY;
   if (!hist || !state) return SBQ_ERR_NULL;
   if (pass < 0 || pass > 2 || n_sel < 1 || n_sel > kMaxSel || C * n_sel >= (1ll << 31)) return SBQ_ERR_ARG;
-  radix_advance_kernel<<<static_cast<uint32_t>(C * n_sel), kBlock, 0, as_stream(stream)>>>(hist, pass, state);
+  radix_advance_kernel<<<static_cast<uint32_t>(C * n_sel), kBlock, 0, as_stream(stream)>>>(
+      const_cast<int64_t*>(hist), pass, state, 0);
   return check_launch();
 }
 

@@ -40,7 +40,12 @@ class Observer(BaseObserver):
         perch = self.is_perchannel
         C = shards[0].shape[self.ch_axis] if perch else 1
         # percentile.py:27-43: the counts of negative / non-negative elements and the two ranks come out of
-        # the first radix histogram on the device (select.kth_values), three reads of the data in total
+        # the first radix histogram on the device, three reads of the data in total.  Single process: the whole
+        # protocol is one library call; sharded over ranks: pass by pass with an all-reduce in between.
+        if not sbq_dist.active():
+            fused = ops.percentile_select(shards, self.alpha, self.ch_axis, perch)
+            if fused is not None:
+                return fused
         vals, counts = select.kth_values(shards, None, ops.HipSelectBackend(), False, self.ch_axis, perch, dev,
                                          percentile_alpha=self.alpha, n_channels=C)
         zero = torch.zeros(C, dtype=torch.float32, device=dev)

@@ -739,6 +739,49 @@ def radix_finish(state, n_sel, C, use_abs):
     return out
 
 
+def percentile_select(shards, alpha, ch_axis=0, per_channel=True):
+    """percentile observer over a list of cached batches, the whole radix select in ONE call (single process).
+    -> (min [C], max [C]) fp32"""
+    dev = L.require_device(*shards)
+    lib = L.load()
+    shards = [x.contiguous() for x in shards]
+    x0 = shards[0]
+    _, C, inner = geometry(x0.shape, ch_axis, per_channel)
+    outers = (ctypes.c_int64 * len(shards))()
+    ptrs = (ctypes.c_void_p * len(shards))()
+    for i, x in enumerate(shards):
+        o, c_, in_ = geometry(x.shape, ch_axis, per_channel)
+        if x.dtype != x0.dtype or c_ != C:
+            raise L.SbqError("percentile_select: batches must share dtype and channel count")
+        if in_ != inner:
+            # per tensor a batch is one row of numel elements: batches of different sizes do not share a row
+            # length -- the caller uses the stepwise protocol for those
+            return None
+        outers[i], ptrs[i] = o, x.data_ptr()
+    mn = torch.empty(C, dtype=torch.float32, device=dev)
+    mx = torch.empty(C, dtype=torch.float32, device=dev)
+    ws = _workspace(dev, lib.sbq_radix_select_workspace_bytes(C, 2))
+    with L.device_guard(dev):
+        rc = lib.sbq_percentile_select(ptrs, outers, len(shards), L.dtype_id(x0), C, inner, float(alpha), L.ptr(mn), L.ptr(mx),
+                                       L.ptr(ws), ws.numel(), L.stream_ptr(dev))
+    L.check(rc)
+    return mn, mx
+
+
+def kth_value(x, k, use_abs=False):
+    """1-indexed k-th smallest of x (of |x| with use_abs) as a 0-d fp32 tensor: one call, three reads of x"""
+    dev = L.require_device(x)
+    lib = L.load()
+    x = x.contiguous()
+    out = torch.empty((), dtype=torch.float32, device=dev)
+    ws = _workspace(dev, lib.sbq_radix_select_workspace_bytes(1, 1))
+    with L.device_guard(dev):
+        rc = lib.sbq_kth_value(L.ptr(x), L.dtype_id(x), x.numel(), int(bool(use_abs)), int(k), L.ptr(out), L.ptr(ws),
+                               ws.numel(), L.stream_ptr(dev))
+    L.check(rc)
+    return out
+
+
 class HipSelectBackend:
     """The three primitives of the sharded exact selection protocol (select.py), on HIP."""
 

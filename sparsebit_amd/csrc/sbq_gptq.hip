@@ -516,6 +516,17 @@ int gptq_matmul(const float* x, const int32_t* qweight, float* out, const float*
   const bool vec = (out_features % 4 == 0) && aligned16(qweight);
   // single-launch strip kernel: mat-vec sized batches, whole 32-column strips
   const int64_t strips = out_features / kStripCols;
+  // batches of 3 and 4 (a handful of concurrent decode streams) take the same single launch with four
+  // batch rows per register tile, half-group K lanes only (register budget)
+  if (vec && out_features % kStripCols == 0 && (batch == 3 || batch == 4) && !half_slices && strips <= kMaxStrips &&
+      knob(2) != 9) {
+    int64_t split = ceil_div(in_features, 32 * (kSliceK / 2));
+    if (split > kStripMaxSplit) split = kStripMaxSplit;
+    const dim3 grid(static_cast<uint32_t>(strips), static_cast<uint32_t>(split));
+    gptq_strip_kernel<BITS, 4, 32, kSliceK / 2, BITS == 4><<<grid, 256, 0, st>>>(x, qweight, scales, zeros, out, part,
+                                                                                arrivals, g);
+    return check_launch();
+  }
   if (vec && out_features % kStripCols == 0 && batch <= 2 && !half_slices && strips <= kMaxStrips &&
       knob(2) != 9) {
     // 256-thread workgroups (32 K lanes) measured best throughout.  A K lane takes a whole

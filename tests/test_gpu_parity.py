@@ -804,7 +804,8 @@ def test_gptq_vs_reference_golden(golden, oracle, name):
 
 @pytest.mark.parametrize("B,M,N,GS", [(1, 4096, 4096, 128), (2, 4096, 4096, 128), (1, 11008, 4096, 128), (2, 1000, 96, -1),
                                        (8, 4096, 4096, 128), (32, 1024, 1280, 128), (4, 6661, 1027, -1),
-                                       (2, 4096, 11008, 128), (1, 1024, 256, 256)])
+                                       (2, 4096, 11008, 128), (1, 1024, 256, 256), (3, 4096, 4096, 128), (4, 11008, 4096, 128),
+                                       (4, 1024, 256, -1), (3, 1000, 96, -1)])
 def test_gptq_random_vs_oracle(oracle, B, M, N, GS):
     """shapes after test_cuda_kernel.py:48-126 (incl. an irregular M, N and group sizes)"""
     from sparsebit_amd import gptq
@@ -859,7 +860,8 @@ def test_gptq_low_bit_vs_reference_golden(golden, oracle, name):
 @pytest.mark.parametrize("bit", [3, 2])
 @pytest.mark.parametrize("B,M,N,GS", [(1, 4096, 4096, 128), (2, 4096, 4096, 128), (1, 11008, 4096, 128), (2, 1000, 96, -1),
                                        (8, 4096, 4096, 128), (32, 1024, 1280, 128), (4, 6661, 1027, -1),
-                                       (1, 1024, 256, 256), (3, 1024, 256, 64), (1, 1024, 256, 64)])
+                                       (1, 1024, 256, 256), (3, 1024, 256, 64), (1, 1024, 256, 64), (4, 4096, 4096, 128),
+                                       (3, 11008, 4096, 128)])
 def test_gptq_low_bit_random_vs_oracle(oracle, bit, B, M, N, GS):
     from sparsebit_amd import gptq
 

@@ -13,10 +13,10 @@ def timed(fn, iters=200, warm=20):
     for i in range(iters): fn(i)
     b.record(); torch.cuda.synchronize()
     return a.elapsed_time(b) * 1e3 / iters
-for bits in (4, 3, 2):
+for bits in (4, 3):
   fn = {4: lib.sbq_vecquant4matmul, 3: lib.sbq_vecquant3matmul, 2: lib.sbq_vecquant2matmul}[bits]
-  for (M, N) in ((4096, 4096), (4096, 11008), (11008, 4096), (8192, 8192), (8192, 28672)):
-    for B in (1, 2):
+  for (M, N) in ((4096, 4096), (4096, 11008), (11008, 4096)):
+    for B in (1, 2, 3, 4, 8):
         gs = 128
         groups = M // gs if gs else 1
         rows = M // 32 * 3 if bits == 3 else M * bits // 32
@@ -27,10 +27,10 @@ for bits in (4, 3, 2):
         st = L.stream_ptr(dev)
         def run(i):
             fn(L.ptr(x), L.ptr(qw), L.ptr(y), L.ptr(sc), L.ptr(zr), B, M, N, gs, L.ptr(ws), ws.numel(), st)
-        for mode in (((0, 4) if bits == 4 else (0,)) if B <= 2 else (0,)):
+        for mode in (((0, 4) if bits == 4 else (0,)) if B <= 2 else ((0, 9) if B <= 4 else (0,))):
             lib.sbq_set_tuning(2, mode)
             t = timed(run)
             nbytes = rows * N * 4 + 2 * N * groups * 4
-            label = {0: "e4m3 decode", 4: "byte decode", 1: "strip CH128", 2: "strip CH64", 9: "k-split+fold"}[mode] if B <= 2 else "k-split+fold"
+            label = {0: "single launch", 4: "byte decode", 9: "k-split+fold"}[mode] if B <= 4 else "k-split+fold"
             print("%d-bit B=%d in=%5d out=%5d group=%3d %-12s: %.2f us  (%.2f TB/s on %.1f MB)" % (bits, B, M, N, gs, label, t, nbytes / t / 1e6, nbytes / 1e6), flush=True)
 lib.sbq_set_tuning(2, 0)

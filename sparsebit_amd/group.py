@@ -168,6 +168,24 @@ class WeightQuantGroup:
             gws.append(gx), gss.append(gs)
         return gws, gss
 
+    # ---- zero-edit integration --------------------------------------------------------------
+    def attach(self, root):
+        """Hook the group into `root.forward`: a forward-pre hook runs the grouped launch and hands every member
+        quantizer its result, so the unmodified `self.weight_quantizer(self.weight)` inside each operator
+        (modules/conv.py:30-36) returns it instead of launching its own kernel; a forward hook drops the
+        references again.  Members whose operator masks the weight first (`weight * w_mask`) see a different
+        tensor and simply run their own kernel.  Returns the two hook handles."""
+
+        def before(module, args):
+            for (q, w, _), y in zip(self.triples, self()):
+                q._pregrouped = (w, y)
+
+        def after(module, args, output):
+            for q, _, _ in self.triples:
+                q._pregrouped = None
+
+        return root.register_forward_pre_hook(before), root.register_forward_hook(after)
+
     # ---- forward ------------------------------------------------------------------------------
     def __call__(self):
         result = [None] * len(self.triples)

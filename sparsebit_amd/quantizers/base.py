@@ -35,6 +35,7 @@ class Quantizer(nn.Module):
         self.observer = build_observer(config, self.qdesc)
         self.backend = None
         self.dims = None  # rank of the observed tensor; set by update_observer
+        self._pregrouped = None  # (source tensor, result) handed in by group.WeightQuantGroup.attach
         self.use_quant = self.export_onnx = self.fake_fused = False
         if config.QUANTIZER.DISABLE:
             self.set_fake_fused()
@@ -85,6 +86,9 @@ class Quantizer(nn.Module):
     def forward(self, x):
         if not self.is_enable:
             return x
+        pre = self._pregrouped
+        if pre is not None and x is pre[0]:  # already quantized by the model-wide launch of this forward
+            return pre[1]
         scale, zero_point = self._qparams_preprocess(x)
         if self.export_onnx:  # tracing for QDQ-ONNX: torch builtins only, the HIP kernel is never traced
             return torch_fake_quant(x, scale, zero_point, self.qdesc)

@@ -427,6 +427,59 @@ def test_weight_quant_group_forward_and_gradients(masked):
         assert torch.equal(group()[3], want)
 
 
+def test_weight_quant_group_attach_runs_inside_unmodified_operators(ops, monkeypatch):
+    """attach(): operators written like the reference's QuantOpr (`self.weight_quantizer(self.weight)` inline)
+    pick up the grouped result -- same outputs and gradients, and no per-layer forward kernel is launched"""
+    from sparsebit_amd.common import Backend
+    from sparsebit_amd.config import quantizer_config
+    from sparsebit_amd.group import WeightQuantGroup
+    from sparsebit_amd.quantizers import build_quantizer
+
+    class QLinear(torch.nn.Module):
+        def __init__(self, i, o):
+            super().__init__()
+            self.weight = torch.nn.Parameter(torch.randn(o, i) * 0.1)
+            self.weight_quantizer = build_quantizer(quantizer_config("per-channel-symmetric", 4, quantizer="lsq"))
+            self.weight_quantizer.set_backend(Backend.VIRTUAL)
+
+        def forward(self, x):
+            return torch.nn.functional.linear(x, self.weight_quantizer(self.weight))
+
+    torch.manual_seed(1)
+    model = torch.nn.Sequential(QLinear(64, 128), torch.nn.ReLU(), QLinear(128, 32), torch.nn.ReLU(), QLinear(32, 16)).cuda()
+    oprs = [m for m in model if isinstance(m, QLinear)]
+    for m in oprs:
+        m.weight_quantizer.update_observer(m.weight.detach())
+        m.weight_quantizer.calc_qparams()
+        m.weight_quantizer.enable_quant()
+    x = torch.randn(8, 64, device="cuda")
+
+    def run():
+        model.zero_grad(set_to_none=True)
+        y = model(x)
+        y.square().sum().backward()
+        return y.detach().clone(), [m.weight.grad.clone() for m in oprs], [m.weight_quantizer.scale.grad.clone() for m in oprs]
+
+    ref = run()
+    group = WeightQuantGroup([(m.weight_quantizer, m.weight, None) for m in oprs])
+    handles = group.attach(model)
+    calls = []
+    real = ops.fake_quant
+    monkeypatch.setattr(ops, "fake_quant", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    got = run()
+    assert not calls, "a member quantizer launched its own forward kernel"
+    assert torch.equal(got[0], ref[0])
+    for a, b in zip(got[1], ref[1]):
+        assert torch.equal(a, b)
+    for a, b in zip(got[2], ref[2]):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-7)
+    assert all(m.weight_quantizer._pregrouped is None for m in oprs)
+    for h in handles:
+        h.remove()
+    got2 = run()
+    assert calls and torch.equal(got2[0], ref[0])
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("masked", [False, True])
 def test_group_backward_equals_per_tensor_and_oracle(oracle, ops, dtype, masked):

@@ -148,6 +148,32 @@ __device__ __forceinline__ RawPack<T> load_raw(const void* base, int64_t i) {
   return r;
 }
 
+// Split form: the pack's first four elements start at iA, the last four at iB (fp32-output
+// kernels give a lane two 4-element runs half a slab apart, so that each of its two 16-byte
+// stores -- and fp32 loads -- is part of a fully contiguous 1 KiB wave access instead of a
+// stride-32-byte one; half-written 32-byte sectors were 13 % write amplification)
+template <typename T, bool NT>
+__device__ __forceinline__ RawPack<T> load_raw2(const void* base, int64_t iA, int64_t iB) {
+  RawPack<T> r;
+  if constexpr (T::id == SBQ_F32) {
+    r.d[0] = ld16<NT>(static_cast<const char*>(base) + iA * 4);
+    r.d[1] = ld16<NT>(static_cast<const char*>(base) + iB * 4);
+  } else {
+    const u32x2 a = ld8<NT>(static_cast<const char*>(base) + iA * 2);
+    const u32x2 b = ld8<NT>(static_cast<const char*>(base) + iB * 2);
+    r.d[0] = u32x4{a[0], a[1], b[0], b[1]};
+  }
+  return r;
+}
+
+template <bool NT>
+__device__ __forceinline__ void store_half_f32(void* base, int64_t i, const float* v) {
+  u32x4 a;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) a[j] = __builtin_bit_cast(uint32_t, v[j]);
+  st16<NT>(static_cast<char*>(base) + i * 4, a);
+}
+
 template <typename T>
 __device__ __forceinline__ void unpack_raw(const RawPack<T>& r, float (&v)[kPack]) {
   if constexpr (T::id == SBQ_F32) {

@@ -93,6 +93,8 @@ struct Tile {
   int64_t elem[U];
   bool ok[U];
   float s[U], z[U];
+  int64_t elemB[U];  // SPLIT mapping only: the lane's second 4-element run
+  bool okB[U];
 };
 
 // ROWS: the tensor is cut into slabs of kBlock packs (2048 elements) that never straddle a
@@ -146,7 +148,7 @@ __device__ __forceinline__ void advance(const QdqGeom& g, RowCursor& k) {
   if (k.c >= g.C) k.c -= g.C;
 }
 
-template <bool FLAT, int U>
+template <bool FLAT, int U, bool SPLIT = false>
 __device__ __forceinline__ void locate(const QdqGeom& g, uint32_t tile, const RowCursor& k,
                                        const float* __restrict__ scale,
                                        const float* __restrict__ zero_point, Tile<U>& t) {
@@ -155,10 +157,22 @@ __device__ __forceinline__ void locate(const QdqGeom& g, uint32_t tile, const Ro
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const bool slab_ok = sl < g.n_slabs;
+      if constexpr (SPLIT) {
+        // lane t of the slab: elements [4t, 4t+4) and [1024 + 4t, 1024 + 4t + 4) of its 2048
+        constexpr int kHalf = kBlock * kPack / 2;
+        const int64_t eA = static_cast<int64_t>(col) * (kBlock * kPack) + 4 * threadIdx.x;
+        const int64_t eB = eA + kHalf;
+        t.ok[u] = slab_ok && eA < g.inner;  // rows are whole 8-element packs: a started run is a whole run
+        t.okB[u] = slab_ok && eB < g.inner;
+        const int64_t rb = static_cast<int64_t>(row) * g.inner;
+        t.elem[u] = rb + (eA < g.inner ? eA : g.inner - 4);
+        t.elemB[u] = rb + (eB < g.inner ? eB : g.inner - 4);
+      } else {
       const uint32_t pk = col * kBlock + threadIdx.x;
       t.ok[u] = slab_ok && pk < g.packs_per_row;
       const uint32_t pkc = pk < g.packs_per_row ? pk : g.packs_per_row - 1;
       t.elem[u] = static_cast<int64_t>(row) * g.inner + static_cast<int64_t>(pkc) * kPack;
+      }
       t.s[u] = uniform_load(scale, c);
       t.z[u] = __builtin_rintf(uniform_load(zero_point, c));
       // advance to the next slab without dividing; past the end stay on the last one
@@ -188,17 +202,18 @@ __device__ __forceinline__ void locate(const QdqGeom& g, uint32_t tile, const Ro
   }
 }
 
-template <typename Tin, int MASK, bool NT, int U>
+template <typename Tin, int MASK, bool NT, int U, bool SPLIT = false>
 __device__ __forceinline__ void issue_loads(const void* __restrict__ x, const uint8_t* __restrict__ mask,
                                             const Tile<U>& t, RawPack<Tin> (&raw)[U], u32x2 (&mk)[U]) {
 #pragma unroll
   for (int u = 0; u < U; ++u) {
-    raw[u] = load_raw<Tin, NT>(x, t.elem[u]);
+    if constexpr (SPLIT) raw[u] = load_raw2<Tin, NT>(x, t.elem[u], t.elemB[u]);
+    else raw[u] = load_raw<Tin, NT>(x, t.elem[u]);
     if constexpr (MASK == MASK_BYTES) mk[u] = ld8<NT>(mask + t.elem[u]);
   }
 }
 
-template <typename Tin, typename Tout, int QT, int MASK, bool FLAT, bool NT, int U, int MATH>
+template <typename Tin, typename Tout, int QT, int MASK, bool FLAT, bool NT, int U, int MATH, bool SPLIT = false>
 __device__ __forceinline__ void finish_tile(void* __restrict__ y, void* __restrict__ q, const Tile<U>& t,
                                             const RawPack<Tin> (&raw)[U], const u32x2 (&mk)[U], float thr,
                                             float qlo, float qhi) {
@@ -252,7 +267,10 @@ __device__ __forceinline__ void finish_tile(void* __restrict__ y, void* __restri
         dq[j] = dequant_level(lv[j], s, z);
       }
     }
-    if (t.ok[u]) {
+    if constexpr (SPLIT) {
+      if (t.ok[u]) store_half_f32<NT>(y, t.elem[u], dq);
+      if (t.okB[u]) store_half_f32<NT>(y, t.elemB[u], dq + 4);
+    } else if (t.ok[u]) {
       if constexpr (QT != SBQ_Q_NONE) {
         if (y) store_pack<Tout, NT>(y, t.elem[u], dq);  // y == nullptr: quantize only (block-uniform)
         store_q_pack<QT>(q, t.elem[u], lv);
@@ -297,6 +315,8 @@ __global__ __launch_bounds__(kBlock) void qdq_pack_kernel(
   float thr = 0.0f;
   if constexpr (MASK == MASK_THRESH) thr = *thresh;
 
+  // fp32 outputs of the plain forward: two 4-element runs per lane, half a slab apart (sbq_common.hpp: load_raw2)
+  constexpr bool SPLIT = !FLAT && QT == SBQ_Q_NONE && MASK == MASK_NONE && Tout::id == SBQ_F32;
   uint32_t tile = blockIdx.x;
   const uint32_t G = gridDim.x;
   if (tile >= g.n_tiles) return;
@@ -306,11 +326,12 @@ __global__ __launch_bounds__(kBlock) void qdq_pack_kernel(
   RowCursor cur{};
   if constexpr (!FLAT) cur = make_cursor<U>(g, tile, G);
   // fetches happen in tile order (tile, tile+G, tile+2G, ...): one cursor, stepped after each
-#define SBQ_FETCH(T, R, M, IDX)                              \
-  locate<FLAT, U>(g, (IDX), cur, scale, zero_point, T);      \
-  issue_loads<Tin, MASK, NT, U>(x, mask, T, R, M);           \
+#define SBQ_FETCH(T, R, M, IDX)                                     \
+  locate<FLAT, U, SPLIT>(g, (IDX), cur, scale, zero_point, T);      \
+  issue_loads<Tin, MASK, NT, U, SPLIT>(x, mask, T, R, M);           \
   if constexpr (!FLAT) advance(g, cur)
-#define SBQ_FINISH(T, R, M) finish_tile<Tin, Tout, QT, MASK, FLAT, NTS, U, MATH>(y, q, T, R, M, thr, g.qlo, g.qhi)
+#define SBQ_FINISH(T, R, M) \
+  finish_tile<Tin, Tout, QT, MASK, FLAT, NTS, U, MATH, SPLIT>(y, q, T, R, M, thr, g.qlo, g.qhi)
   SBQ_FETCH(ta, ra, ma, tile);
   // Steady state: both prefetches are unconditional, so the compiler's vmcnt bookkeeping
   // stays exact (a conditional prefetch merges two scoreboard states at the join and makes

@@ -63,11 +63,42 @@ __global__ __launch_bounds__(kBlock) void ste_backward_kernel(
 
   if constexpr (VEC) {
     const int64_t vend = cp.begin + ((cp.end - cp.begin) / kPack) * kPack;
-    for (int64_t e = cp.begin + static_cast<int64_t>(threadIdx.x) * kPack; e < vend;
-         e += static_cast<int64_t>(kBlock) * kPack) {
+    // fp32 tensors: a lane takes two 4-element runs half a 2048-element block apart, so that every 16-byte
+    // access is part of a contiguous 1 KiB wave access (sbq_common.hpp: load_raw2); 16-bit tensors keep
+    // their one 16-byte pack per lane
+    constexpr bool SPLIT = T::id == SBQ_F32 || Tg::id == SBQ_F32;
+    constexpr int64_t kBlk = static_cast<int64_t>(kBlock) * kPack;
+    for (int64_t b0 = cp.begin; b0 < vend; b0 += kBlk) {
+      int64_t eA, eB;
+      bool okA, okB;
+      if constexpr (SPLIT) {
+        eA = b0 + 4 * threadIdx.x;
+        eB = eA + kBlk / 2;
+        okA = eA < vend;  // vend - begin is a multiple of 8: a started run is a whole run
+        okB = eB < vend;
+      } else {
+        eA = b0 + static_cast<int64_t>(threadIdx.x) * kPack;
+        eB = eA + 4;
+        okA = okB = eA < vend;
+      }
+      if (!okA && !okB) continue;
+      const int64_t cA = okA ? eA : vend - 4, cB = okB ? eB : vend - 4;
       float xv[kPack], gv[kPack], o[kPack];
-      load_pack<T, true>(x, cp.row_base + e, xv);
-      load_pack<T, true>(gy, cp.row_base + e, gv);
+      if constexpr (SPLIT) {
+        load_pack2<T, true>(x, cp.row_base + cA, cp.row_base + cB, xv);
+        load_pack2<T, true>(gy, cp.row_base + cA, cp.row_base + cB, gv);
+      } else {
+        load_pack<T, true>(x, cp.row_base + eA, xv);
+        load_pack<T, true>(gy, cp.row_base + eA, gv);
+      }
+      if (!okA) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) gv[q] = 0.0f, xv[q] = 0.0f;  // a clamped run contributes nothing
+      }
+      if (!okB) {
+#pragma unroll
+        for (int q = 4; q < kPack; ++q) gv[q] = 0.0f, xv[q] = 0.0f;
+      }
       // same wave-wide vote as the forward kernel: NaN / inf / huge inputs send the pack
       // through IEEE division, everything else through the exact fma refinement
       bool odd = false;
@@ -80,7 +111,12 @@ __global__ __launch_bounds__(kBlock) void ste_backward_kernel(
 #pragma unroll
         for (int q = 0; q < kPack; ++q) o[q] = one(xv[q], gv[q]);
       }
-      store_pack<Tg, true>(gx, cp.row_base + e, o);
+      if constexpr (SPLIT) {
+        if (okA) store_half<Tg, true>(gx, cp.row_base + eA, o);
+        if (okB) store_half<Tg, true>(gx, cp.row_base + eB, o + 4);
+      } else {
+        store_pack<Tg, true>(gx, cp.row_base + eA, o);
+      }
     }
     for (int64_t e = vend + threadIdx.x; e < cp.end; e += kBlock) {
       const float o = one(Elem<T>::load1(x, cp.row_base + e), Elem<T>::load1(gy, cp.row_base + e));

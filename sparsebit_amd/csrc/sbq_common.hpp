@@ -166,6 +166,25 @@ __device__ __forceinline__ RawPack<T> load_raw2(const void* base, int64_t iA, in
   return r;
 }
 
+// four elements at i (fp32: 16 bytes, 16-bit types: 8 bytes)
+template <typename T, bool NT>
+__device__ __forceinline__ void store_half(void* base, int64_t i, const float* v) {
+  if constexpr (T::id == SBQ_F32) {
+    u32x4 a;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) a[j] = __builtin_bit_cast(uint32_t, v[j]);
+    st16<NT>(static_cast<char*>(base) + i * 4, a);
+  } else {
+    u32x2 a;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const uint32_t lo = Elem<T>::to_bits(v[2 * j]), hi = Elem<T>::to_bits(v[2 * j + 1]);
+      a[j] = lo | (hi << 16);
+    }
+    st8<NT>(static_cast<char*>(base) + i * 2, a);
+  }
+}
+
 template <bool NT>
 __device__ __forceinline__ void store_half_f32(void* base, int64_t i, const float* v) {
   u32x4 a;
@@ -191,6 +210,12 @@ __device__ __forceinline__ void unpack_raw(const RawPack<T>& r, float (&v)[kPack
       v[2 * j + 1] = Elem<T>::from_bits(static_cast<uint16_t>(w >> 16));
     }
   }
+}
+
+template <typename T, bool NT>
+__device__ __forceinline__ void load_pack2(const void* base, int64_t iA, int64_t iB, float (&v)[kPack]) {
+  const RawPack<T> r = load_raw2<T, NT>(base, iA, iB);
+  unpack_raw<T>(r, v);
 }
 
 template <typename T, bool NT>

@@ -70,13 +70,24 @@ __global__ __launch_bounds__(kBlock) void stats_partial_kernel(const void* __res
     constexpr int U = 8;
     if (vend > begin) {
       RawPack<T> raw[U];
-      bool ok[U];
+      bool ok[U], okB[U];
+      // fp32: the lane's two 16-byte loads are 256 elements apart, so each is part of a contiguous
+      // 1 KiB wave access (sbq_common.hpp: load_raw2) instead of a stride-32-byte one
+      constexpr bool SPLIT = T::id == SBQ_F32;
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        int64_t e = begin + (static_cast<int64_t>(u) * kWave + lane) * kPack;
-        ok[u] = e < vend;
-        if (!ok[u]) e = vend - kPack;
-        raw[u] = load_raw<T, true>(x, row_base + e);
+        if constexpr (SPLIT) {
+          const int64_t eA = begin + static_cast<int64_t>(u) * kWave * kPack + 4 * lane;
+          const int64_t eB = eA + kWave * kPack / 2;
+          ok[u] = eA < vend;
+          okB[u] = eB < vend;
+          raw[u] = load_raw2<T, true>(x, row_base + (ok[u] ? eA : vend - 4), row_base + (okB[u] ? eB : vend - 4));
+        } else {
+          int64_t e = begin + (static_cast<int64_t>(u) * kWave + lane) * kPack;
+          ok[u] = okB[u] = e < vend;
+          if (!ok[u]) e = vend - kPack;
+          raw[u] = load_raw<T, true>(x, row_base + e);
+        }
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
@@ -84,7 +95,11 @@ __global__ __launch_bounds__(kBlock) void stats_partial_kernel(const void* __res
         unpack_raw<T>(raw[u], v);
         if (ok[u]) {
 #pragma unroll
-          for (int q = 0; q < kPack; ++q) visit(v[q]);
+          for (int q = 0; q < 4; ++q) visit(v[q]);
+        }
+        if (okB[u]) {
+#pragma unroll
+          for (int q = 4; q < kPack; ++q) visit(v[q]);
         }
       }
     }

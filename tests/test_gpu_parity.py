@@ -415,7 +415,8 @@ def test_weight_quant_group_forward_and_gradients(masked):
         if ref[2][k] is not None:
             # the grouped backward folds 512-element segments, the per-tensor kernel 8192-element
             # chunks: same fp64 accumulation, different fp32 partial boundaries
-            assert torch.allclose(got[2][k], ref[2][k], rtol=1e-5, atol=1e-7), ("scale grad", k)
+            tol = 2e-5 * max(1.0, float(ref[2][k].abs().max()))
+            assert torch.allclose(got[2][k], ref[2][k], rtol=1e-5, atol=tol), ("scale grad", k)
     with torch.no_grad():
         for y, r in zip(group(), ref[0]):
             assert torch.equal(y, r)
@@ -472,7 +473,7 @@ def test_weight_quant_group_attach_runs_inside_unmodified_operators(ops, monkeyp
     for a, b in zip(got[1], ref[1]):
         assert torch.equal(a, b)
     for a, b in zip(got[2], ref[2]):
-        assert torch.allclose(a, b, rtol=1e-5, atol=1e-7)
+        assert torch.allclose(a, b, rtol=1e-5, atol=2e-5 * max(1.0, float(b.abs().max())))
     assert all(m.weight_quantizer._pregrouped is None for m in oprs)
     for h in handles:
         h.remove()
@@ -515,7 +516,8 @@ def test_group_backward_equals_per_tensor_and_oracle(oracle, ops, dtype, masked)
                 continue
             if lsq[i]:
                 gs = gs * ratios[i] * torch.sign(scale)
-            assert torch.allclose(gss[i], gs, rtol=1e-5, atol=1e-6), (i, (gss[i] - gs).abs().max())
+            # two fp32/fp64 summation orders of sums with cancellation: tolerance relative to the largest entry
+            assert torch.allclose(gss[i], gs, rtol=1e-5, atol=2e-5 * max(1.0, float(gs.abs().max()))), (i, (gss[i] - gs).abs().max())
     # the oracle directly on one per-channel item (fp32 only: its gy is fp32)
     if dtype == torch.float32:
         i = 3

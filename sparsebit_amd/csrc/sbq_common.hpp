@@ -102,6 +102,17 @@ __device__ __forceinline__ void st8(void* p, u32x2 v) {
   else *static_cast<u32x2*>(p) = v;
 }
 
+template <bool NT>
+__device__ __forceinline__ uint32_t ld4(const void* p) {
+  if constexpr (NT) return __builtin_nontemporal_load(static_cast<const uint32_t*>(p));
+  else return *static_cast<const uint32_t*>(p);
+}
+template <bool NT>
+__device__ __forceinline__ void st4(void* p, uint32_t v) {
+  if constexpr (NT) __builtin_nontemporal_store(v, static_cast<uint32_t*>(p));
+  else *static_cast<uint32_t*>(p) = v;
+}
+
 // load 8 consecutive elements starting at element index i (i % 8 == 0, base
 // 16-byte aligned) as fp32
 template <typename T, bool NT>

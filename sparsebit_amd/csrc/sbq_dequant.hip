@@ -42,6 +42,30 @@ __device__ __forceinline__ void load_levels(const void* q, int64_t i, bool is_si
   }
 }
 
+// four levels starting at element i (a lane's 4-element run of the split mapping)
+template <int QT>
+__device__ __forceinline__ void load_levels_half(const void* q, int64_t i, bool is_signed, float* lv) {
+  if constexpr (QT == SBQ_Q_I8) {
+    const uint32_t w = ld4<true>(static_cast<const char*>(q) + i);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint32_t b = (w >> (8 * j)) & 0xffu;
+      lv[j] = is_signed ? static_cast<float>(static_cast<int8_t>(b)) : static_cast<float>(b);
+    }
+  } else if constexpr (QT == SBQ_Q_I4) {
+    const uint32_t w = __builtin_nontemporal_load(reinterpret_cast<const uint16_t*>(static_cast<const char*>(q) + (i >> 1)));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int32_t n = static_cast<int32_t>((w >> (4 * j)) & 0xfu);
+      lv[j] = static_cast<float>(is_signed ? ((n ^ 8) - 8) : n);
+    }
+  } else {
+    const u32x4 a = ld16<true>(static_cast<const char*>(q) + i * 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) lv[j] = static_cast<float>(static_cast<int32_t>(a[j]));
+  }
+}
+
 __device__ __forceinline__ float load_level1(const void* q, int q_type, int64_t i, bool is_signed) {
   if (q_type == SBQ_Q_I8) {
     const uint8_t b = static_cast<const uint8_t*>(q)[i];
@@ -62,7 +86,24 @@ __global__ __launch_bounds__(kBlock) void dequant_kernel(const void* __restrict_
   const ChunkPos cp = chunk_pos(g, blockIdx.x);
   const float s = scale[cp.c];
   const float z = __builtin_rintf(zero_point[cp.c]);
-  if constexpr (VEC) {
+  if constexpr (VEC && Tout::id == SBQ_F32) {
+    // fp32 output: two 4-element runs per lane half a 2048-element block apart -- every 16-byte store is
+    // part of a contiguous 1 KiB wave access (sbq_common.hpp: load_raw2)
+    constexpr int64_t kBlk = static_cast<int64_t>(kBlock) * kPack;
+    for (int64_t b0 = cp.begin; b0 < cp.end; b0 += kBlk) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int64_t e = b0 + h * (kBlk / 2) + 4 * threadIdx.x;
+        if (e < cp.end) {  // rows are whole 8-element packs: a started run is a whole run
+          float lv[4], o[4];
+          load_levels_half<QT>(q, cp.row_base + e, is_signed != 0, lv);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) o[j] = dequant_level(lv[j], s, z);
+          store_half<Tout, true>(y, cp.row_base + e, o);
+        }
+      }
+    }
+  } else if constexpr (VEC) {
     for (int64_t e = cp.begin + static_cast<int64_t>(threadIdx.x) * kPack; e < cp.end;
          e += static_cast<int64_t>(kBlock) * kPack) {
       float lv[kPack], o[kPack];

@@ -27,6 +27,22 @@ namespace {
 
 enum { MASK_NONE = 0, MASK_BYTES = 1, MASK_THRESH = 2 };
 
+// the four levels lv[0..3] of a lane's 4-element run at element index i (SPLIT mapping)
+template <int QT>
+__device__ __forceinline__ void store_q_half(void* q, int64_t i, const float* lv) {
+  if constexpr (QT == SBQ_Q_I8) {
+    uint32_t acc = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc |= (static_cast<uint32_t>(static_cast<int>(lv[j])) & 0xffu) << (8 * j);
+    st4<true>(static_cast<char*>(q) + i, acc);
+  } else if constexpr (QT == SBQ_Q_I32) {
+    u32x4 a;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) a[j] = static_cast<uint32_t>(static_cast<int>(lv[j]));
+    st16<true>(static_cast<char*>(q) + i * 4, a);
+  }
+}
+
 template <int QT>
 __device__ __forceinline__ void store_q_pack(void* q, int64_t i, const float (&lv)[kPack]) {
   if constexpr (QT == SBQ_Q_I8) {
@@ -209,7 +225,10 @@ __device__ __forceinline__ void issue_loads(const void* __restrict__ x, const ui
   for (int u = 0; u < U; ++u) {
     if constexpr (SPLIT) raw[u] = load_raw2<Tin, NT>(x, t.elem[u], t.elemB[u]);
     else raw[u] = load_raw<Tin, NT>(x, t.elem[u]);
-    if constexpr (MASK == MASK_BYTES) mk[u] = ld8<NT>(mask + t.elem[u]);
+    if constexpr (MASK == MASK_BYTES) {
+      if constexpr (SPLIT) mk[u] = u32x2{ld4<NT>(mask + t.elem[u]), ld4<NT>(mask + t.elemB[u])};
+      else mk[u] = ld8<NT>(mask + t.elem[u]);
+    }
   }
 }
 
@@ -268,8 +287,14 @@ __device__ __forceinline__ void finish_tile(void* __restrict__ y, void* __restri
       }
     }
     if constexpr (SPLIT) {
-      if (t.ok[u]) store_half_f32<NT>(y, t.elem[u], dq);
-      if (t.okB[u]) store_half_f32<NT>(y, t.elemB[u], dq + 4);
+      if (QT == SBQ_Q_NONE || y) {  // y == nullptr: quantize only (block-uniform)
+        if (t.ok[u]) store_half_f32<NT>(y, t.elem[u], dq);
+        if (t.okB[u]) store_half_f32<NT>(y, t.elemB[u], dq + 4);
+      }
+      if constexpr (QT != SBQ_Q_NONE) {
+        if (t.ok[u]) store_q_half<QT>(q, t.elem[u], lv);
+        if (t.okB[u]) store_q_half<QT>(q, t.elemB[u], lv + 4);
+      }
     } else if (t.ok[u]) {
       if constexpr (QT != SBQ_Q_NONE) {
         if (y) store_pack<Tout, NT>(y, t.elem[u], dq);  // y == nullptr: quantize only (block-uniform)
@@ -315,8 +340,9 @@ __global__ __launch_bounds__(kBlock) void qdq_pack_kernel(
   float thr = 0.0f;
   if constexpr (MASK == MASK_THRESH) thr = *thresh;
 
-  // fp32 outputs of the plain forward: two 4-element runs per lane, half a slab apart (sbq_common.hpp: load_raw2)
-  constexpr bool SPLIT = !FLAT && QT == SBQ_Q_NONE && MASK == MASK_NONE && Tout::id == SBQ_F32;
+  // fp32 outputs: two 4-element runs per lane, half a slab apart (sbq_common.hpp: load_raw2); the packed-int4
+  // output needs 8 consecutive levels per dword and keeps the contiguous pack
+  constexpr bool SPLIT = !FLAT && QT != SBQ_Q_I4 && Tout::id == SBQ_F32;
   uint32_t tile = blockIdx.x;
   const uint32_t G = gridDim.x;
   if (tile >= g.n_tiles) return;

@@ -310,6 +310,41 @@ def test_full_size_4096_properties(oracle, ops):
     assert same_values(y.cpu().numpy(), ref_all)
 
 
+@pytest.mark.parametrize("inner", [8, 1016, 1024, 1032, 2040, 2048, 2056, 3072, 5000 * 8])
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_split_lane_mapping_edges(oracle, ops, inner, dtype):
+    """fp32 tensors give a lane two 4-element runs 1024 elements apart: row lengths around the half-block and
+    block boundaries, through forward (+ mask, + levels), backward, statistics and DequantizeLinear"""
+    g = torch.Generator().manual_seed(inner)
+    C = 5
+    x = (torch.randn(C, inner, generator=g) * 2).to(dtype).cuda()
+    xf = x.float().cpu().numpy()
+    scale = (torch.rand(C, generator=g) * 0.1 + 0.02).numpy()
+    zp = torch.randint(0, 200, (C,), generator=g).float().numpy()
+    ref_dq, ref_q = oracle.qdq(xf, scale, zp, 0, 255, 0)
+    y, q = ops.fake_quant(x, dev_tensor(scale), dev_tensor(zp), 0, 255, 0, return_q=torch.uint8)  # fp32 out
+    assert same_values(y.cpu().numpy(), ref_dq) and np.array_equal(q.cpu().numpy().astype(np.int32), ref_q)
+    yq, q32 = ops.fake_quant(x, dev_tensor(scale), dev_tensor(zp), 0, 255, 0, return_q=torch.int32)
+    assert torch.equal(yq, y) and np.array_equal(q32.cpu().numpy(), ref_q)
+    m = (torch.rand(C, inner, generator=g) > 0.5).cuda()
+    ref_m, _ = oracle.qdq(xf, scale, zp, 0, 255, 0, mask=m.cpu().numpy())
+    assert same_values(ops.fake_quant(x, dev_tensor(scale), dev_tensor(zp), 0, 255, 0, mask=m).cpu().numpy(), ref_m)
+    assert torch.equal(ops.dequantize_linear(q, dev_tensor(scale), dev_tensor(zp)), y)
+    mn, mx, ab = ops.channel_stats(x, 0, True, want_abssum=True)
+    omn, omx = oracle.minmax(xf, 0, True)
+    assert same_values(mn.cpu().numpy(), omn) and same_values(mx.cpu().numpy(), omx)
+    assert np.allclose(ab.cpu().numpy(), np.abs(xf.astype(np.float64)).sum(1), rtol=1e-6)
+    gy = torch.randn(C, inner, generator=g).to(dtype).cuda()
+    s8 = np.full(C, 0.05, np.float32)
+    gx, gs, gz = ops.fake_quant_backward(x, gy, dev_tensor(s8), dev_tensor(zp * 0), -8, 7, 0, gx_dtype=torch.float32)
+    ogx, ogs, ogz = oracle.ste_backward(xf, gy.float().cpu().numpy(), s8, zp * 0, -8, 7, 0)
+    assert same_values(gx.cpu().numpy(), ogx)
+    assert np.allclose(gs.cpu().numpy(), ogs, rtol=1e-5, atol=2e-5 * max(1.0, float(np.abs(ogs).max())))
+    # per tensor: one long row
+    ref_t, _ = oracle.qdq(xf, scale[:1], zp[:1], 0, 255, 0)
+    assert same_values(ops.fake_quant(x, dev_tensor(scale[:1]), dev_tensor(zp[:1]), 0, 255, 0).cpu().numpy(), ref_t)
+
+
 GROUP_SHAPES = [(64, 64, 3, 3), (8, 8), (512, 4608), (1000, 512), (3, 8), (256, 64, 1, 1), (96, 2304), (1, 16), (33, 1096)]
 
 

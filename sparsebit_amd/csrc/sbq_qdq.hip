@@ -426,13 +426,14 @@ __global__ __launch_bounds__(kBlock) void qdq_batched_kernel(const void* const* 
   RawPack<Tin> ra[U], rb[U];
   u32x2 ma[U], mb[U];
   Ptrs pa, pb;
-#define SBQ_FETCH(P, T, R, M, IDX)                          \
-  P = cur;                                                  \
-  locate<false, U>(g, lt, rc, P.scale, P.zp, T);            \
-  issue_loads<Tin, MASK, true, U>(P.x, nullptr, T, R, M);   \
+  constexpr bool SPLIT = Tout::id == SBQ_F32;  // fp32 outputs: the split lane mapping of qdq_pack_kernel
+#define SBQ_FETCH(P, T, R, M, IDX)                                 \
+  P = cur;                                                         \
+  locate<false, U, SPLIT>(g, lt, rc, P.scale, P.zp, T);            \
+  issue_loads<Tin, MASK, true, U, SPLIT>(P.x, nullptr, T, R, M);   \
   step_item()
 #define SBQ_FINISH(P, T, R, M) \
-  finish_tile<Tin, Tout, SBQ_Q_NONE, MASK, false, true, U, MATH_FAST>(P.y, nullptr, T, R, M, 0.0f, g.qlo, g.qhi)
+  finish_tile<Tin, Tout, SBQ_Q_NONE, MASK, false, true, U, MATH_FAST, SPLIT>(P.y, nullptr, T, R, M, 0.0f, g.qlo, g.qhi)
   SBQ_FETCH(pa, ta, ra, ma, tile);
   while (static_cast<uint64_t>(tile) + 2ull * G < n_tiles_total) {
     SBQ_FETCH(pb, tb, rb, mb, tile + G);

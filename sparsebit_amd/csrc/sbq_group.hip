@@ -107,8 +107,11 @@ __device__ __forceinline__ void group_finish(const GroupLane& L, const RawPack<T
   for (int j = 0; j < kPack; ++j) odd |= !(__builtin_fabsf(v[j]) < bound);
   if (__builtin_amdgcn_ballot_w64(odd) == 0) {
 #pragma unroll
-    for (int j = 0; j < kPack; ++j)
-      dq[j] = dequant_level(__builtin_amdgcn_fmed3f(__builtin_rintf(fast_div(v[j], s, yr)) + z, qlo, qhi), s, z);
+    for (int j = 0; j < kPack; j += 2) {  // the fma chain on packed fp32 ops: two quotients per instruction
+      const f32x2 t = fast_div2(f32x2{v[j], v[j + 1]}, s, yr);
+      dq[j] = dequant_level(__builtin_amdgcn_fmed3f(__builtin_rintf(t[0]) + z, qlo, qhi), s, z);
+      dq[j + 1] = dequant_level(__builtin_amdgcn_fmed3f(__builtin_rintf(t[1]) + z, qlo, qhi), s, z);
+    }
   } else {
 #pragma unroll
     for (int j = 0; j < kPack; ++j)

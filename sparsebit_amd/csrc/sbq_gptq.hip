@@ -200,7 +200,7 @@ __device__ __forceinline__ float strip_level(const u32x4 (&w)[ROWS], int j, int 
   }
 }
 
-// DEC8 (4-bit only): a nibble sitting alone in a byte IS the OCP e4m3 encoding of n * 2^-9
+// DEC8 (4- and 2-bit): a level sitting alone in a byte IS the OCP e4m3 encoding of n * 2^-9
 // (subnormals m * 2^-9 for n < 8, then (8 + m) * 2^-9), so v_cvt_pk_f32_fp8 turns two levels into two
 // exact floats per instruction and its result pair feeds v_pk_fma_f32 directly; the 2^9 is folded back
 // into the scale (a power of two: the products are the same reals).  The activations are staged in LDS
@@ -283,8 +283,17 @@ __global__ __launch_bounds__(8 * KL) void gptq_strip_kernel(
         const int e = (j * kThreads + threadIdx.x) * 4;
         const int lane_k = e / CH, off = e - lane_k * CH;
         f32x4 t = xg[b][j];
-        if constexpr (DEC8) t = f32x4{t[0], t[2], t[1], t[3]};  // pair order of the packed converts
-        *reinterpret_cast<f32x4*>(&xs[b][lane_k * kXStride + off]) = t;
+        if constexpr (DEC8 && BITS == 2) {
+          // pair order of the 2-bit converts inside a 16-channel word: (x_s, x_s+4) for s = 0..3, then
+          // (x_s+8, x_s+12): channel c = 4k + r of the word goes to slot 8*(k/2) + 2*r + (k&1)
+          const int k = (off >> 2) & 3;
+          float* dst = &xs[b][lane_k * kXStride + (off & ~15) + 8 * (k >> 1) + (k & 1)];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) dst[2 * r] = t[r];
+        } else {
+          if constexpr (DEC8) t = f32x4{t[0], t[2], t[1], t[3]};  // 4-bit: (x0,x2) (x1,x3) within each 4
+          *reinterpret_cast<f32x4*>(&xs[b][lane_k * kXStride + off]) = t;
+        }
       }
     __syncthreads();
     if (live) {
@@ -295,8 +304,54 @@ __global__ __launch_bounds__(8 * KL) void gptq_strip_kernel(
 #pragma unroll
         for (int j = 0; j < 4; ++j) dot[j][b] = 0.0f;
       }
-      if constexpr (DEC8) {
-        static_assert(!DEC8 || BITS == 4, "the e4m3 decode needs a level alone in a byte");
+      if constexpr (DEC8 && BITS == 2) {
+        f32x2 dot2[4][kBT];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int b = 0; b < kBT; ++b) dot2[j][b] = f32x2{0.0f, 0.0f};
+#pragma unroll
+        for (int i = 0; i < CH / 16; ++i) {  // one weight word = 16 channels at a time
+          f32x2 xa[kBT][4], xb[kBT][4];      // (x_s, x_s+4) and (x_s+8, x_s+12), s = 0..3
+#pragma unroll
+          for (int b = 0; b < kBT; ++b) {
+            const float* xr = &xs[b][kl * kXStride + i * 16];
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {
+              const f32x4 q = *reinterpret_cast<const f32x4*>(xr + 4 * h);
+              if (h < 2) {
+                xa[b][2 * h] = f32x2{q[0], q[1]};
+                xa[b][2 * h + 1] = f32x2{q[2], q[3]};
+              } else {
+                xb[b][2 * (h - 2)] = f32x2{q[0], q[1]};
+                xb[b][2 * (h - 2) + 1] = f32x2{q[2], q[3]};
+              }
+#pragma unroll
+              for (int n = 0; n < 4; ++n) xsum[b] += q[n];
+            }
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const uint32_t word = w[i][j];
+#pragma unroll
+            for (int sft = 0; sft < 4; ++sft) {
+              const uint32_t m = (word >> (2 * sft)) & 0x03030303u;  // crumbs s, s+4, s+8, s+12 alone in bytes
+              const f32x2 la = __builtin_amdgcn_cvt_pk_f32_fp8(m, false);
+              const f32x2 lb = __builtin_amdgcn_cvt_pk_f32_fp8(m, true);
+#pragma unroll
+              for (int b = 0; b < kBT; ++b) {
+                dot2[j][b] = __builtin_elementwise_fma(la, xa[b][sft], dot2[j][b]);
+                dot2[j][b] = __builtin_elementwise_fma(lb, xb[b][sft], dot2[j][b]);
+              }
+            }
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int b = 0; b < kBT; ++b) dot[j][b] = (dot2[j][b][0] + dot2[j][b][1]) * 512.0f;  // exact: 2^9
+      } else if constexpr (DEC8) {
+        static_assert(!DEC8 || BITS == 4 || BITS == 2, "the e4m3 decode needs a level alone in a byte");
         f32x2 dot2[4][kBT];
 #pragma unroll
         for (int j = 0; j < 4; ++j)
@@ -523,7 +578,7 @@ int gptq_matmul(const float* x, const int32_t* qweight, float* out, const float*
     int64_t split = ceil_div(in_features, 32 * (kSliceK / 2));
     if (split > kStripMaxSplit) split = kStripMaxSplit;
     const dim3 grid(static_cast<uint32_t>(strips), static_cast<uint32_t>(split));
-    gptq_strip_kernel<BITS, 4, 32, kSliceK / 2, BITS == 4><<<grid, 256, 0, st>>>(x, qweight, scales, zeros, out, part,
+    gptq_strip_kernel<BITS, 4, 32, kSliceK / 2, BITS != 3><<<grid, 256, 0, st>>>(x, qweight, scales, zeros, out, part,
                                                                                 arrivals, g);
     return check_launch();
   }
@@ -546,7 +601,7 @@ int gptq_matmul(const float* x, const int32_t* qweight, float* out, const float*
     else                                                                                                   \
       gptq_strip_kernel<BITS, 1, 32, CH, D8><<<grid, 256, 0, st>>>(x, qweight, scales, zeros, out, part, arrivals, g); \
   } while (0)
-    if constexpr (BITS == 4) {
+    if constexpr (BITS == 4 || BITS == 2) {
       if (knob(2) != 4) {  // packed e4m3 decode (knob 2 == 4: byte converts, for A/B runs)
         if (ch == kSliceK) SBQ_STRIP(128, true);
         else SBQ_STRIP(64, true);

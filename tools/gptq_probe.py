@@ -13,7 +13,7 @@ def timed(fn, iters=200, warm=20):
     for i in range(iters): fn(i)
     b.record(); torch.cuda.synchronize()
     return a.elapsed_time(b) * 1e3 / iters
-for bits in (4, 3):
+for bits in (4, 3, 2):
   fn = {4: lib.sbq_vecquant4matmul, 3: lib.sbq_vecquant3matmul, 2: lib.sbq_vecquant2matmul}[bits]
   for (M, N) in ((4096, 4096), (4096, 11008), (11008, 4096)):
     for B in (1, 2, 3, 4, 8):
@@ -27,7 +27,7 @@ for bits in (4, 3):
         st = L.stream_ptr(dev)
         def run(i):
             fn(L.ptr(x), L.ptr(qw), L.ptr(y), L.ptr(sc), L.ptr(zr), B, M, N, gs, L.ptr(ws), ws.numel(), st)
-        for mode in (((0, 4) if bits == 4 else (0,)) if B <= 2 else ((0, 9) if B <= 4 else (0,))):
+        for mode in (((0, 4) if bits != 3 else (0,)) if B <= 2 else ((0, 9) if B <= 4 else (0,))):
             lib.sbq_set_tuning(2, mode)
             t = timed(run)
             nbytes = rows * N * 4 + 2 * N * groups * 4

@@ -242,6 +242,31 @@ def test_batched_launch_equals_per_tensor(oracle, ops, dtype, out_dtype, shape, 
     assert same_values(outs[-1].float().cpu().numpy(), torch.from_numpy(ref).to(out_dtype).float().numpy())
 
 
+def test_launches_follow_the_current_torch_stream(ops):
+    """kernels go to torch's CURRENT stream (raw handle from torch._C): work queued on a side stream right
+    before and after the call is ordered with it, no device-wide synchronisation needed"""
+    side = torch.cuda.Stream()
+    scale = torch.full((512,), 0.02, device="cuda")
+    zp = torch.zeros(512, device="cuda")
+    big = torch.randn(512, 8192, device="cuda")
+    want = ops.fake_quant(big * 3.0 + 1.0, scale, zp, -128, 127, 0) * 2.0
+    torch.cuda.synchronize()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(20):  # keep the side stream busy so that a launch on the wrong stream would race
+            x = big * 3.0 + 1.0
+            y = ops.fake_quant(x, scale, zp, -128, 127, 0) * 2.0
+        assert L_stream_is(side)
+    side.synchronize()
+    assert torch.equal(y, want)
+
+
+def L_stream_is(stream):
+    from sparsebit_amd import lib as L
+
+    return L.stream_ptr(torch.device("cuda", torch.cuda.current_device())).value == (stream.cuda_stream or None)
+
+
 def test_rounding_modes(ops):
     """common.cuh:64-77: half-even (0), half-up floor(v+.5) (1), half-down ceil(v-.5) (2)."""
     x = torch.tensor([0.5, 1.5, 2.5, -0.5, -1.5, -2.5, 0.4, -0.6], device="cuda")

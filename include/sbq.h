@@ -2,10 +2,13 @@
  * sbq.h -- C ABI of libsbq.so: the MI355X (gfx950) fake-quantization hot path.
  *
  * This is the drop-in boundary for Sparsebit's Quantizer/Observer/masker path.
- * Every entry point takes raw DEVICE pointers, plain sizes and a hipStream_t
- * (passed as void*); the caller owns and allocates every buffer (the library
- * never allocates, frees or retains a pointer) and all launches are
- * asynchronous on `stream`.  Every function returns an sbq_status (0 == OK).
+ * Every entry point takes raw DEVICE pointers for tensor data, plain sizes and a
+ * hipStream_t (passed as void*); the few descriptor arrays (the item lists of the
+ * model-wide launches, a list of calibration batches, a step's gradient pointers)
+ * are HOST arrays and say so where they are declared.  The caller owns and
+ * allocates every buffer (the library never allocates, frees or retains a
+ * pointer) and all launches are asynchronous on `stream`.  Every function returns
+ * an sbq_status (0 == OK) unless it is a size query.
  *
  * Reference interfaces replaced (paths relative to the Sparsebit tree):
  *   - pybind module `fake_quant` (sparsebit/quantization/torch_extensions/

@@ -261,6 +261,41 @@ def test_launches_follow_the_current_torch_stream(ops):
     assert torch.equal(y, want)
 
 
+def test_kernels_are_hip_graph_capturable(ops):
+    """no host synchronisation, no allocation, no default-stream work inside the library: forward, backward,
+    statistics, the one-call radix select and a model-wide launch record into a HIP graph and replay"""
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(256, 2048, generator=g).cuda().bfloat16()
+    gy = torch.randn(256, 2048, generator=g).cuda().bfloat16()
+    scale = torch.full((256,), 0.03, device="cuda")
+    zp = torch.zeros(256, device="cuda")
+    ws = [torch.randn(s, generator=g).cuda() for s in ((64, 64, 3, 3), (128, 256), (32, 8))]
+    group = ops.GroupFakeQuant([(w, torch.full((w.shape[0],), 0.05, device="cuda"), torch.zeros(w.shape[0], device="cuda"), -8, 7)
+                                for w in ws])
+
+    def work():
+        y = ops.fake_quant(x, scale, zp, -128, 127, 0, out_dtype=torch.bfloat16)
+        gx, gs, _ = ops.fake_quant_backward(x, gy, scale, zp, -128, 127, 0, True, False)
+        mn, mx, _ = ops.channel_stats(x, 0, True)
+        kth = ops.kth_value(x, 1000, use_abs=True)
+        outs = [o.clone() for o in group()]
+        return [y, gx, gs, mn, mx, kth] + outs
+
+    work()  # warm up (workspaces, lazy init) outside the capture
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        captured = work()
+    for rep in range(2):
+        x.mul_(1.5)  # new inputs in the same storage
+        for w in ws:
+            w.add_(0.01)
+        graph.replay()
+        torch.cuda.synchronize()
+        for a, b in zip(captured, work()):
+            assert torch.equal(a, b)
+
+
 def L_stream_is(stream):
     from sparsebit_amd import lib as L
 

@@ -328,10 +328,23 @@ __global__ __launch_bounds__(kBlock) void stats_finish_kernel(const StatPartial*
   double as = 0.0;
   NanMin nmin;
   NanMax nmax;
-  for (uint32_t i = threadIdx.x; i < chunks_per_chan; i += kBlock) {
-    mn = nmin(mn, p[i].mn);
-    mx = nmax(mx, p[i].mx);
-    as += p[i].abssum;
+  // eight 16-byte records per lane requested before the first is folded (a per-tensor call has one
+  // channel with thousands of partials: a dependent load per iteration made this tiny kernel as long as
+  // the pass over the data it follows)
+  constexpr int kBatch = 8;
+  for (uint32_t i0 = threadIdx.x; i0 < chunks_per_chan; i0 += kBlock * kBatch) {
+    StatPartial r[kBatch];
+#pragma unroll
+    for (int b = 0; b < kBatch; ++b) {
+      const uint32_t i = i0 + b * kBlock;
+      r[b] = i < chunks_per_chan ? p[i] : StatPartial{__builtin_inff(), -__builtin_inff(), 0.0};
+    }
+#pragma unroll
+    for (int b = 0; b < kBatch; ++b) {
+      mn = nmin(mn, r[b].mn);
+      mx = nmax(mx, r[b].mx);
+      as += r[b].abssum;
+    }
   }
   mn = block_reduce(mn, nmin, s_f);
   mx = block_reduce(mx, nmax, s_f);

@@ -29,6 +29,9 @@ for dt, did in ((torch.bfloat16, L.BF16), (torch.float32, L.F32)):
     ws2 = torch.empty(max(lib.sbq_stats_workspace_bytes(1, R, C), 16), dtype=torch.uint8, device=dev)
     t = timed(lambda i: lib.sbq_channel_stats(L.ptr(xs[i % NB]), did, 1, R, C, L.ptr(mn), L.ptr(mx), None, L.ptr(ws2), ws2.numel(), st))
     print("%-8s min/max stats       : %6.2f us  %.2f TB/s" % (str(dt)[6:], t, R * C * esz / t / 1e6))
+    ws3 = torch.empty(max(lib.sbq_stats_workspace_bytes(1, 1, R * C), 16), dtype=torch.uint8, device=dev)
+    t = timed(lambda i: lib.sbq_channel_stats(L.ptr(xs[i % NB]), did, 1, 1, R * C, L.ptr(mn), L.ptr(mx), None, L.ptr(ws3), ws3.numel(), st))
+    print("%-8s min/max per tensor  : %6.2f us  %.2f TB/s (two kernels)" % (str(dt)[6:], t, R * C * esz / t / 1e6))
 # grouped fp32 weights (ResNet-50-like)
 shapes = []
 inp = 64

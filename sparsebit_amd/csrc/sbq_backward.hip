@@ -143,9 +143,19 @@ __global__ __launch_bounds__(kBlock) void ste_fold_kernel(const GradPartial* __r
   const uint32_t c = blockIdx.x;
   const GradPartial* p = part + static_cast<size_t>(c) * chunks_per_chan;
   double a = 0.0, b = 0.0;
-  for (uint32_t i = threadIdx.x; i < chunks_per_chan; i += kBlock) {
-    a += p[i].gs;
-    b += p[i].gzp;
+  constexpr int kBatch = 8;  // eight records per lane in flight; same summation order as one at a time
+  for (uint32_t i0 = threadIdx.x; i0 < chunks_per_chan; i0 += kBlock * kBatch) {
+    GradPartial r[kBatch];
+#pragma unroll
+    for (int k = 0; k < kBatch; ++k) {
+      const uint32_t i = i0 + k * kBlock;
+      r[k] = i < chunks_per_chan ? p[i] : GradPartial{0.0, 0.0};
+    }
+#pragma unroll
+    for (int k = 0; k < kBatch; ++k) {
+      a += r[k].gs;
+      b += r[k].gzp;
+    }
   }
   a = block_reduce(a, Sum(), s_d);
   b = block_reduce(b, Sum(), s_d);

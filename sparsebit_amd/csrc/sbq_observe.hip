@@ -193,9 +193,19 @@ __global__ __launch_bounds__(kBlock) void moments_finish_kernel(const MomentPart
   const uint32_t c = blockIdx.x;
   const MomentPartial* p = part + static_cast<size_t>(c) * chunks_per_chan;
   double a1 = 0.0, a2 = 0.0;
-  for (uint32_t i = threadIdx.x; i < chunks_per_chan; i += kBlock) {
-    a1 += p[i].s1;
-    a2 += p[i].s2;
+  constexpr int kBatch = 8;  // eight records per lane in flight (see stats_finish_kernel); same summation order
+  for (uint32_t i0 = threadIdx.x; i0 < chunks_per_chan; i0 += kBlock * kBatch) {
+    MomentPartial r[kBatch];
+#pragma unroll
+    for (int b = 0; b < kBatch; ++b) {
+      const uint32_t i = i0 + b * kBlock;
+      r[b] = i < chunks_per_chan ? p[i] : MomentPartial{0.0, 0.0};
+    }
+#pragma unroll
+    for (int b = 0; b < kBatch; ++b) {
+      a1 += r[b].s1;
+      a2 += r[b].s2;
+    }
   }
   a1 = block_reduce(a1, Sum(), s_d);
   a2 = block_reduce(a2, Sum(), s_d);

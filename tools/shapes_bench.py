@@ -28,19 +28,22 @@ cases = [("4096x4096 w", (4096, 4096), 0, True), ("11008x4096 w", (11008, 4096),
 for name, shape, ch_axis, perch in cases:
     n = 1
     for d in shape: n *= d
-    nbuf = max(2, min(12, int(6e8 // (n * 4)) + 1))
-    xs = [torch.randn(*shape, device=dev).bfloat16() for _ in range(nbuf)]
-    ys = [torch.empty_like(x) for x in xs]
     C = shape[ch_axis] if perch else 1
     outer = 1
     for d in shape[:ch_axis]: outer *= d
     inner = n // (outer * C) if perch else n
     if not perch: outer = 1
     sc = (torch.rand(C, device=dev) * 0.05 + 0.01); zp = torch.zeros(C, device=dev)
-    def run(i):
-        j = i % nbuf
-        rc = lib.sbq_quant_perchannel_forward(L.ptr(xs[j]), 2, L.ptr(ys[j]), 2, None, 0, L.ptr(sc), L.ptr(zp), outer, C, inner, -128, 127, 0, st)
-        assert rc == 0
-    t = timed(run)
-    print("%-28s %10d elem  outer=%d C=%d inner=%d : %8.2f us  %6.2f TB/s" % (name, n, outer, C, inner, t, n * 4 / t / 1e6), flush=True)
-    del xs, ys
+    line = "%-26s %10d elem  outer=%d C=%d inner=%d :" % (name, n, outer, C, inner)
+    for dt, did, esz in ((torch.bfloat16, 2, 2), (torch.float32, 0, 4)):
+        nbuf = max(2, min(12, int(6e8 // (n * 2 * esz)) + 1))
+        xs = [torch.randn(*shape, device=dev).to(dt) for _ in range(nbuf)]
+        ys = [torch.empty_like(x) for x in xs]
+        def run(i):
+            j = i % nbuf
+            rc = lib.sbq_quant_perchannel_forward(L.ptr(xs[j]), did, L.ptr(ys[j]), did, None, 0, L.ptr(sc), L.ptr(zp), outer, C, inner, -128, 127, 0, st)
+            assert rc == 0
+        t = timed(run)
+        line += "  %s %8.2f us %5.2f TB/s" % ("bf16" if esz == 2 else "fp32", t, n * 2 * esz / t / 1e6)
+        del xs, ys
+    print(line, flush=True)

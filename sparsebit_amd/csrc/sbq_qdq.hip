@@ -571,7 +571,10 @@ constexpr uint32_t kMaxGrid = 8192;
 inline uint32_t auto_grid(uint32_t n_tiles) {
   if (knob(1) > 0) return n_tiles < static_cast<uint32_t>(knob(1)) ? n_tiles : static_cast<uint32_t>(knob(1));
   if (n_tiles <= kResidentWorkgroups) return n_tiles;
-  const uint32_t half = (n_tiles + 1) / 2;
+  // never fewer workgroups than fit at once: between one and two residencies' worth of tiles, a full
+  // residency with one or two tiles each beats half-empty CUs with two each (measured on 2.4 k - 3.7 k tiles)
+  uint32_t half = (n_tiles + 1) / 2;
+  if (half < kResidentWorkgroups) half = kResidentWorkgroups;
   return half < kMaxGrid ? half : kMaxGrid;
 }
 

@@ -393,6 +393,7 @@ int sbq_quant_group_forward(const void* device_table, int n_items, uint32_t n_ti
   // one tile per workgroup while everything is resident at once, then two (second one's loads
   // in flight while the first is finished) -- same policy as the single-tensor kernels
   uint32_t grid = n_tiles <= 2048 ? n_tiles : (n_tiles + 1) / 2;
+  if (n_tiles > 2048 && grid < 2048) grid = 2048;  // never fewer workgroups than fit at once
   if (grid > 8192) grid = 8192;
   hipStream_t st = as_stream(stream);
 #define SBQ_G(TI, TO)                                                                              \

@@ -191,6 +191,21 @@ int sbq_quant_group_backward(const void* device_table, const void* host_table, i
                              const void* const* gy, void* gx_base, float* gs_base,
                              void* workspace, size_t workspace_bytes, void* stream);
 
+/* LSQ forward / backward on the RAW learnable parameters (quantizers/lsq.py:61-76): the kernels
+ * apply scale = |scale| and zero_point = clamp(zero_point, qmin, qmax) themselves, and the backward
+ * returns the step-size gradient already multiplied by gs_ratio (lsq.py:13-21,68-71) and
+ * sign(scale) -- one launch forward, two backward, instead of the reference's abs / clamp /
+ * gs_scaling tensor ops and autograd nodes around K1-K4.  mask: NULL or the sparse layer's
+ * byte mask (forward only).  C == 1: per tensor. */
+int sbq_quant_lsq_forward(const void* x, int x_dtype, void* y, int y_dtype, const uint8_t* mask,
+                          const float* scale, const float* zero_point,
+                          int64_t outer, int64_t C, int64_t inner, int qmin, int qmax, void* stream);
+int sbq_quant_lsq_backward(const void* x, const void* gy, int x_dtype, void* gx, int gx_dtype,
+                           float* gs /* [C] or NULL */, const float* scale, const float* zero_point,
+                           int64_t outer, int64_t C, int64_t inner, int qmin, int qmax, float gs_ratio,
+                           void* workspace, size_t workspace_bytes /* sbq_backward_workspace_bytes */,
+                           void* stream);
+
 /* Fused unstructured mask + QDQ: y = qdq(keep ? x : 0).
  * keep = mask[i] != 0 when `mask` (1 byte/elem, torch.bool) is given, else
  * keep = |x| > *thresh  (l1norm.py:24-25, strict).  Exactly one of mask/thresh

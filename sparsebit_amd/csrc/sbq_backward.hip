@@ -31,12 +31,16 @@ template <typename T, typename Tg, bool VEC>
 __global__ __launch_bounds__(kBlock) void ste_backward_kernel(
     const void* __restrict__ x, const void* __restrict__ gy, void* __restrict__ gx,
     const float* __restrict__ scale, const float* __restrict__ zero_point,
-    GradPartial* __restrict__ part, const ChunkGeom g, float qlo, float qhi, int rounding) {
+    GradPartial* __restrict__ part, const ChunkGeom g, float qlo, float qhi, int rounding, int lsq) {
   __shared__ double s_d[kWavesPerBlock];
   const uint32_t bid = blockIdx.x;
   const ChunkPos cp = chunk_pos(g, bid);
-  const float s = scale[cp.c];
-  const float zp = __builtin_rintf(zero_point[cp.c]);
+  float s = scale[cp.c], zp = zero_point[cp.c];
+  if (lsq) {  // raw LSQ parameters: s = |s|, zp = clamp(zp, qmin, qmax)  (lsq.py:61-62)
+    s = __builtin_fabsf(s);
+    zp = __builtin_amdgcn_fmed3f(zp, qlo, qhi);
+  }
+  zp = __builtin_rintf(zp);
   float gs = 0.0f, gz = 0.0f;
 
   // the chunk's scale is block-uniform: exact quotient by reciprocal + two fma refinements
@@ -138,7 +142,8 @@ __global__ __launch_bounds__(kBlock) void ste_backward_kernel(
 __global__ __launch_bounds__(kBlock) void ste_fold_kernel(const GradPartial* __restrict__ part,
                                                           uint32_t chunks_per_chan,
                                                           float* __restrict__ gs_out,
-                                                          float* __restrict__ gzp_out) {
+                                                          float* __restrict__ gzp_out,
+                                                          const float* __restrict__ raw_scale, float gs_ratio) {
   __shared__ double s_d[kWavesPerBlock];
   const uint32_t c = blockIdx.x;
   const GradPartial* p = part + static_cast<size_t>(c) * chunks_per_chan;
@@ -160,7 +165,12 @@ __global__ __launch_bounds__(kBlock) void ste_fold_kernel(const GradPartial* __r
   a = block_reduce(a, Sum(), s_d);
   b = block_reduce(b, Sum(), s_d);
   if (threadIdx.x == 0) {
-    if (gs_out) gs_out[c] = static_cast<float>(a);
+    float gsv = static_cast<float>(a);
+    if (raw_scale) {  // LSQ: the gs_scaling and abs() autograd nodes of lsq.py:13-21,61 folded in
+      const float r = raw_scale[c];
+      gsv = (gsv * gs_ratio) * (r > 0.0f ? 1.0f : (r < 0.0f ? -1.0f : 0.0f));
+    }
+    if (gs_out) gs_out[c] = gsv;
     if (gzp_out) gzp_out[c] = static_cast<float>(b);
   }
 }
@@ -168,7 +178,7 @@ __global__ __launch_bounds__(kBlock) void ste_fold_kernel(const GradPartial* __r
 int ste_backward(const void* x, const void* gy, int x_dtype, void* gx, int gx_dtype, float* gs,
                  float* gzp, const float* scale, const float* zp, int64_t outer, int64_t C,
                  int64_t inner, int qmin, int qmax, int rounding, void* workspace,
-                 size_t workspace_bytes, void* stream) {
+                 size_t workspace_bytes, void* stream, int lsq = 0, float gs_ratio = 1.0f) {
   if (!valid_dtype(x_dtype) || !valid_dtype(gx_dtype)) return SBQ_ERR_DTYPE;
   if (gx_dtype != SBQ_F32 && gx_dtype != x_dtype) return SBQ_ERR_DTYPE;
   if (outer < 0 || C < 0 || inner < 0) return SBQ_ERR_ARG;
@@ -198,9 +208,9 @@ int ste_backward(const void* x, const void* gy, int x_dtype, void* gx, int gx_dt
     auto go = [&](auto gtag) {
       using Tg = decltype(gtag);
       if (vec)
-        ste_backward_kernel<T, Tg, true><<<grid, kBlock, 0, st>>>(x, gy, gx, scale, zp, part, g, qlo, qhi, rounding);
+        ste_backward_kernel<T, Tg, true><<<grid, kBlock, 0, st>>>(x, gy, gx, scale, zp, part, g, qlo, qhi, rounding, lsq);
       else
-        ste_backward_kernel<T, Tg, false><<<grid, kBlock, 0, st>>>(x, gy, gx, scale, zp, part, g, qlo, qhi, rounding);
+        ste_backward_kernel<T, Tg, false><<<grid, kBlock, 0, st>>>(x, gy, gx, scale, zp, part, g, qlo, qhi, rounding, lsq);
     };
     if (gx_dtype == SBQ_F32) go(F32());
     else go(T());
@@ -208,7 +218,7 @@ int ste_backward(const void* x, const void* gy, int x_dtype, void* gx, int gx_dt
   if (rc != SBQ_OK) return rc;
   rc = check_launch();
   if (rc != SBQ_OK || !want_param_grads) return rc;
-  ste_fold_kernel<<<g.C, kBlock, 0, st>>>(part, g.chunks_per_chan, gs, gzp);
+  ste_fold_kernel<<<g.C, kBlock, 0, st>>>(part, g.chunks_per_chan, gs, gzp, lsq ? scale : nullptr, gs_ratio);
   return check_launch();
 }
 
@@ -238,6 +248,14 @@ int sbq_quant_perchannel_backward(const void* x, const void* gy, int x_dtype, vo
                                   int rounding, void* workspace, size_t workspace_bytes, void* stream) {
   return sbq::ste_backward(x, gy, x_dtype, gx, gx_dtype, gs, gzp, scale, zero_point, outer, C, inner,
                            qmin, qmax, rounding, workspace, workspace_bytes, stream);
+}
+
+int sbq_quant_lsq_backward(const void* x, const void* gy, int x_dtype, void* gx, int gx_dtype, float* gs,
+                           const float* scale, const float* zero_point, int64_t outer, int64_t C, int64_t inner,
+                           int qmin, int qmax, float gs_ratio, void* workspace, size_t workspace_bytes,
+                           void* stream) {
+  return sbq::ste_backward(x, gy, x_dtype, gx, gx_dtype, gs, nullptr, scale, zero_point, outer, C, inner, qmin, qmax,
+                           SBQ_ROUND_HALF_EVEN, workspace, workspace_bytes, stream, 1, gs_ratio);
 }
 
 }  // extern "C"

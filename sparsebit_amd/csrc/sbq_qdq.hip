@@ -85,6 +85,7 @@ struct QdqGeom {
   uint32_t n_tiles;        // ceil(n_slabs / U) (ROWS) or ceil(total_packs / (kBlock*U)) (FLAT)
   uint32_t total_packs;    // FLAT only
   float qlo, qhi;
+  uint32_t lsq;            // LSQ pre-ops on the raw parameters: s = |s|, zp = clamp(zp, qmin, qmax) (lsq.py:61-62)
 };
 
 struct QdqPtrs {
@@ -189,8 +190,13 @@ __device__ __forceinline__ void locate(const QdqGeom& g, uint32_t tile, const Ro
       const uint32_t pkc = pk < g.packs_per_row ? pk : g.packs_per_row - 1;
       t.elem[u] = static_cast<int64_t>(row) * g.inner + static_cast<int64_t>(pkc) * kPack;
       }
-      t.s[u] = uniform_load(scale, c);
-      t.z[u] = __builtin_rintf(uniform_load(zero_point, c));
+      float s_ = uniform_load(scale, c), z_ = uniform_load(zero_point, c);
+      if (g.lsq) {
+        s_ = __builtin_fabsf(s_);
+        z_ = __builtin_amdgcn_fmed3f(z_, g.qlo, g.qhi);
+      }
+      t.s[u] = s_;
+      t.z[u] = __builtin_rintf(z_);
       // advance to the next slab without dividing; past the end stay on the last one
       if (sl + 1 < g.n_slabs) {
         ++sl;
@@ -212,8 +218,13 @@ __device__ __forceinline__ void locate(const QdqGeom& g, uint32_t tile, const Ro
       t.elem[u] = static_cast<int64_t>(pkc) * kPack;
       uint32_t c = 0;
       if (g.C != 1) c = (pkc / g.packs_per_row) % g.C;  // per tensor: no division
-      t.s[u] = scale[c];
-      t.z[u] = __builtin_rintf(zero_point[c]);
+      float s_ = scale[c], z_ = zero_point[c];
+      if (g.lsq) {
+        s_ = __builtin_fabsf(s_);
+        z_ = __builtin_amdgcn_fmed3f(z_, g.qlo, g.qhi);
+      }
+      t.s[u] = s_;
+      t.z[u] = __builtin_rintf(z_);
     }
   }
 }
@@ -326,8 +337,9 @@ __global__ __launch_bounds__(kBlock) void qdq_pack_kernel(
     const float* __restrict__ zero_point,
     // ---- not preloaded ----
     void* __restrict__ q, const uint8_t* __restrict__ mask, const float* __restrict__ thresh,
-    uint32_t n_slabs, uint32_t total_packs, float qlo, float qhi) {
+    uint32_t n_slabs, uint32_t total_packs, float qlo, float qhi, uint32_t lsq) {
   QdqGeom g;
+  g.lsq = lsq;
   g.inner = inner;
   g.C = n_channels;
   g.packs_per_row = packs_per_row;
@@ -519,6 +531,7 @@ struct ScalarArgs {
   int64_t C;
   int x_dtype, y_dtype, q_type, rounding;
   float qlo, qhi;
+  int lsq;
 };
 
 __device__ __forceinline__ float load_any(const void* p, int dt, int64_t i) {
@@ -539,8 +552,12 @@ __global__ __launch_bounds__(kBlock) void qdq_scalar_kernel(const ScalarArgs a) 
   for (int64_t i = a.begin + static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < a.end;
        i += stride) {
     const int64_t c = (i / a.inner) % a.C;
-    const float s = a.scale[c];
-    const float z = __builtin_rintf(a.zp[c]);
+    float s = a.scale[c], z = a.zp[c];
+    if (a.lsq) {
+      s = __builtin_fabsf(s);
+      z = __builtin_amdgcn_fmed3f(z, a.qlo, a.qhi);
+    }
+    z = __builtin_rintf(z);
     float xv = load_any(a.x, a.x_dtype, i);
     if (a.mask) xv = a.mask[i] ? xv : 0.0f;
     else if (a.thresh) xv = (__builtin_fabsf(xv) > thr) ? xv : 0.0f;
@@ -589,7 +606,7 @@ void launch_pack(const QdqCall& c, hipStream_t st) {
   const uint32_t grid = auto_grid(c.g.n_tiles);
   qdq_pack_kernel<Tin, Tout, QT, MASK, FLAT, NT, U, MATH, NTS><<<grid, kBlock, 0, st>>>(
       c.p.x, c.g.n_tiles, c.g.slabs_per_row, c.g.packs_per_row, c.g.C, c.g.inner, c.p.y, c.p.scale, c.p.zp,
-      c.p.q, c.p.mask, c.p.thresh, c.g.n_slabs, c.g.total_packs, c.g.qlo, c.g.qhi);
+      c.p.q, c.p.mask, c.p.thresh, c.g.n_slabs, c.g.total_packs, c.g.qlo, c.g.qhi, c.g.lsq);
 }
 
 // variant id (knob 0):  bit0-1: log2(U) (0..2) ; bit2: NT off ; -1 auto
@@ -672,7 +689,7 @@ void launch_scalar(ScalarArgs a, hipStream_t st) {
 int qdq_forward(const void* x, int x_dtype, void* y, int y_dtype, void* q, int q_type,
                 const uint8_t* mask, const float* thresh, const float* scale, const float* zp,
                 int64_t outer, int64_t C, int64_t inner, int qmin, int qmax, int rounding,
-                void* stream) {
+                void* stream, int lsq = 0) {
   if (!valid_dtype(x_dtype) || !valid_dtype(y_dtype)) return SBQ_ERR_DTYPE;
   if (y_dtype != SBQ_F32 && y_dtype != x_dtype) return SBQ_ERR_DTYPE;
   if (q_type != SBQ_Q_NONE && q_type != SBQ_Q_I8 && q_type != SBQ_Q_I32 && q_type != SBQ_Q_I4) return SBQ_ERR_DTYPE;
@@ -700,12 +717,12 @@ int qdq_forward(const void* x, int x_dtype, void* y, int y_dtype, void* q, int q
   const int64_t numel = rows * inner;
 
   ScalarArgs sa{x, y, q, mask, thresh, scale, zp, 0, numel, inner, C,
-                x_dtype, y_dtype, q_type, rounding, static_cast<float>(qmin), static_cast<float>(qmax)};
+                x_dtype, y_dtype, q_type, rounding, static_cast<float>(qmin), static_cast<float>(qmax), lsq};
 
   const bool ptr_ok = aligned16(x) && aligned16(y) && (q_type == SBQ_Q_NONE || aligned16(q)) &&
                       (!mask || (reinterpret_cast<uintptr_t>(mask) & 7u) == 0);
   // channels-last per-channel (NLC activations): inner == 1, whole packs of channels
-  if (inner == 1 && C > 1 && C % kPack == 0 && rounding == SBQ_ROUND_HALF_EVEN && ptr_ok && !mask && !thresh &&
+  if (inner == 1 && C > 1 && C % kPack == 0 && rounding == SBQ_ROUND_HALF_EVEN && ptr_ok && !mask && !thresh && !lsq &&
       aligned16(scale) && aligned16(zp) && numel / kPack < (1ll << 31)) {
     const uint32_t packs = static_cast<uint32_t>(numel / kPack);
     uint32_t grid = (packs + kBlock * 2 - 1) / (kBlock * 2);
@@ -739,6 +756,7 @@ int qdq_forward(const void* x, int x_dtype, void* y, int y_dtype, void* q, int q
   }
 
   QdqCall c{};
+  c.g.lsq = lsq ? 1u : 0u;
   c.p = QdqPtrs{x, y, q, mask, thresh, scale, zp};
   c.g.C = static_cast<uint32_t>(C);
   c.g.qlo = static_cast<float>(qmin);
@@ -835,6 +853,13 @@ int sbq_quant_perchannel_forward(const void* x, int x_dtype, void* y, int y_dtyp
                                  int qmin, int qmax, int rounding, void* stream) {
   return sbq::qdq_forward(x, x_dtype, y, y_dtype, q, q_type, nullptr, nullptr, scale, zero_point,
                           outer, C, inner, qmin, qmax, rounding, stream);
+}
+
+int sbq_quant_lsq_forward(const void* x, int x_dtype, void* y, int y_dtype, const uint8_t* mask,
+                          const float* scale, const float* zero_point, int64_t outer, int64_t C,
+                          int64_t inner, int qmin, int qmax, void* stream) {
+  return sbq::qdq_forward(x, x_dtype, y, y_dtype, nullptr, SBQ_Q_NONE, mask, nullptr, scale, zero_point, outer, C,
+                          inner, qmin, qmax, SBQ_ROUND_HALF_EVEN, stream, 1);
 }
 
 int sbq_mask_quant_forward(const void* x, int x_dtype, void* y, int y_dtype, void* q, int q_type,

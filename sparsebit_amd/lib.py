@@ -91,6 +91,9 @@ _SIGNATURES = {
         [c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_i64, c_i64, c_i64, c_int, c_int, c_int, c_vp],
     ),
     "sbq_quant_perchannel_forward_batched": (c_int, [c_vp, c_int, c_int, c_int, c_i64, c_i64, c_i64, c_int, c_int, c_vp]),
+    "sbq_quant_lsq_forward": (c_int, [c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_int, c_int, c_vp]),
+    "sbq_quant_lsq_backward": (c_int, [c_vp, c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_int, c_int,
+                                       ctypes.c_float, c_vp, c_sz, c_vp]),
     "sbq_dequantize_linear": (c_int, [c_vp, c_int, c_int, c_vp, c_int, c_vp, c_vp, c_i64, c_i64, c_i64, c_vp]),
     "sbq_radix_select_workspace_bytes": (c_sz, [c_i64, c_int]),
     "sbq_percentile_select": (c_int, [c_vp, c_vp, c_int, c_int, c_i64, c_i64, c_dbl, c_vp, c_vp, c_vp, c_sz, c_vp]),

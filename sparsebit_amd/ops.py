@@ -465,6 +465,63 @@ class GroupFakeQuantBackward:
 
 
 # ---------------------------------------------------------------------------------
+# LSQ on the raw parameters: one launch forward, two backward
+# ---------------------------------------------------------------------------------
+def lsq_fake_quant(x, scale, zero_point, qmin, qmax, ch_axis=0, out_dtype=None, mask=None):
+    """LSQ forward with the pre-ops inside the kernel: scale = |scale|, zero_point = clamp(zero_point, qmin, qmax)
+    (lsq.py:61-62), then the usual QDQ.  `scale` / `zero_point` are the RAW learnable tensors."""
+    dev = L.require_device(x, scale, zero_point, mask)
+    lib = L.load()
+    x = x.contiguous()
+    per_channel = scale.numel() > 1
+    outer, C, inner = geometry(x.shape, ch_axis, per_channel)
+    scale = _f32c(scale, dev)
+    zero_point = _f32c(zero_point, dev)
+    _check_qparams(scale, zero_point, C)
+    out_dtype = out_dtype or torch.float32
+    if out_dtype not in (torch.float32, x.dtype):
+        raise L.SbqError("out_dtype must be float32 or the input dtype")
+    y = torch.empty(x.shape, dtype=out_dtype, device=dev)
+    if mask is not None:
+        if mask.shape != x.shape or mask.dtype not in (torch.bool, torch.uint8):
+            raise L.SbqError("mask must be a bool / uint8 tensor with the shape of x")
+        mask = mask.contiguous()
+        mask = mask.view(torch.uint8) if mask.dtype == torch.bool else mask
+    if x.numel() == 0:
+        L.check(2)
+    with L.device_guard(dev):
+        rc = lib.sbq_quant_lsq_forward(L.ptr(x), L.dtype_id(x), L.ptr(y), L.dtype_id(y), L.ptr(mask), L.ptr(scale),
+                                       L.ptr(zero_point), outer, C, inner, int(qmin), int(qmax), L.stream_ptr(dev))
+    L.check(rc)
+    return y
+
+
+def lsq_fake_quant_backward(x, gy, scale, zero_point, qmin, qmax, ch_axis=0, need_gs=True, gs_ratio=1.0, gx_dtype=None):
+    """-> (gx, gs | None): STE backward on the raw LSQ parameters; gs (flat fp32 [C]) is already the gradient of
+    the RAW step size: sum(gy * dq/ds) * gs_ratio * sign(scale)  (lsq.py:13-21,61-76)."""
+    dev = L.require_device(x, gy, scale, zero_point)
+    lib = L.load()
+    x = x.contiguous()
+    gy = gy.contiguous()
+    if gy.dtype != x.dtype:
+        gy = gy.to(x.dtype)
+    per_channel = scale.numel() > 1
+    outer, C, inner = geometry(x.shape, ch_axis, per_channel)
+    scale = _f32c(scale, dev)
+    zero_point = _f32c(zero_point, dev)
+    _check_qparams(scale, zero_point, C)
+    gx = torch.empty(x.shape, dtype=gx_dtype or x.dtype, device=dev)
+    gs = torch.empty(C, dtype=torch.float32, device=dev) if need_gs else None
+    with L.device_guard(dev):
+        ws = _workspace(dev, lib.sbq_backward_workspace_bytes(outer, C, inner)) if need_gs else None
+        rc = lib.sbq_quant_lsq_backward(L.ptr(x), L.ptr(gy), L.dtype_id(x), L.ptr(gx), L.dtype_id(gx), L.ptr(gs),
+                                        L.ptr(scale), L.ptr(zero_point), outer, C, inner, int(qmin), int(qmax),
+                                        float(gs_ratio), L.ptr(ws), ws.numel() if ws is not None else 0, L.stream_ptr(dev))
+    L.check(rc)
+    return gx, gs
+
+
+# ---------------------------------------------------------------------------------
 # STE backward
 # ---------------------------------------------------------------------------------
 def fake_quant_backward(x, gy, scale, zero_point, qmin, qmax, ch_axis=0, need_gs=True, need_gzp=True,

@@ -15,7 +15,8 @@ from . import Quantizer as BaseQuantizer
 from . import register_quantizer
 from .. import dist as sbq_dist
 from .. import ops
-from .quant_tensor import STE
+from ..common import Backend
+from .quant_tensor import STE, _default_out
 
 
 class gs_scaling(torch.autograd.Function):
@@ -29,6 +30,30 @@ class gs_scaling(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad):
         return grad * ctx.ratio, None
+
+
+class LsqSTE(torch.autograd.Function):
+    """The whole LSQ quantizer step as ONE autograd node on the raw parameters: |scale|, clamp(zero_point),
+    the gradient scaling and sign(scale) happen inside the kernels (sbq_quant_lsq_forward / _backward) instead
+    of as abs / clamp / gs_scaling tensor ops and autograd nodes around the STE (lsq.py:13-21,61-76)."""
+
+    @staticmethod
+    def forward(ctx, x, scale, zero_point, qdesc, ratio):
+        ctx.save_for_backward(x, scale, zero_point)
+        ctx.qdesc, ctx.ratio = qdesc, ratio
+        qmin, qmax = qdesc.qrange
+        return ops.lsq_fake_quant(x, scale.detach(), zero_point.detach(), qmin, qmax, qdesc.ch_axis,
+                                  out_dtype=_default_out(x))
+
+    @staticmethod
+    def backward(ctx, gout):
+        x, scale, zero_point = ctx.saved_tensors
+        qmin, qmax = ctx.qdesc.qrange
+        gx, gs = ops.lsq_fake_quant_backward(x, gout, scale, zero_point, qmin, qmax, ctx.qdesc.ch_axis,
+                                             ctx.needs_input_grad[1], ctx.ratio, gx_dtype=x.dtype)
+        if gs is not None:
+            gs = gs.reshape(scale.shape)
+        return gx if ctx.needs_input_grad[0] else None, gs, None, None, None
 
 
 @register_quantizer
@@ -83,6 +108,17 @@ class Quantizer(BaseQuantizer):
         scale = self.scale.abs()
         zero_point = torch.clamp(self.zero_point, self.qdesc.qmin, self.qdesc.qmax)
         return scale, zero_point
+
+    def forward(self, x):
+        # plain LSQ on the ORT-style backends: one fused node (zero_point is a buffer here; LSQ+ learns it and
+        # keeps the generic route, as does the TensorRT backend with its zero-point assertion)
+        if (self.is_enable and not self.export_onnx and type(self) is Quantizer and self.backend != Backend.TENSORRT
+                and not self.zero_point.requires_grad and x.is_cuda):
+            pre = self._pregrouped
+            if pre is not None and x is pre[0]:
+                return pre[1]
+            return LsqSTE.apply(x, self.scale, self.zero_point, self.qdesc, self._gs_ratio(x))
+        return super().forward(x)
 
     def _gs_ratio(self, x):
         if self.is_perchannel:

@@ -117,6 +117,10 @@ class Quantizer(BaseQuantizer):
             pre = self._pregrouped
             if pre is not None and x is pre[0]:
                 return pre[1]
+            if not (torch.is_grad_enabled() and (x.requires_grad or self.scale.requires_grad)):
+                qmin, qmax = self.qdesc.qrange  # nothing asks for a gradient: the forward alone, no autograd node
+                return ops.lsq_fake_quant(x, self.scale.detach(), self.zero_point, qmin, qmax, self.qdesc.ch_axis,
+                                          out_dtype=_default_out(x))
             return LsqSTE.apply(x, self.scale, self.zero_point, self.qdesc, self._gs_ratio(x))
         return super().forward(x)
 

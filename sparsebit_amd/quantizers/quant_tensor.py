@@ -85,6 +85,14 @@ class STE(torch.autograd.Function):
         return gx, gs, gzp, None, None
 
 
+def ste_fake_quant(x, scale, zero_point, qdesc, backend):
+    """STE.apply, or -- when nothing asks for a gradient (PTQ calibration / evaluation, no_grad) -- the forward
+    alone without an autograd node: the quantizer calls of an inference pass are host-bound."""
+    if torch.is_grad_enabled() and (x.requires_grad or scale.requires_grad or zero_point.requires_grad):
+        return STE.apply(x, scale, zero_point, qdesc, backend)
+    return fake_quant_factory[backend](x, scale, zero_point, qdesc)
+
+
 def trt_dqrange(scale, zero_point, qdesc):
     assert abs(zero_point).sum() == 0, "tensorrt only support symmetric quant, but zp={}".format(zero_point)
     qmin, qmax = qdesc.qrange

@@ -6,7 +6,7 @@ import torch
 from . import Quantizer as BaseQuantizer
 from . import register_quantizer
 from .. import ops
-from .quant_tensor import STE
+from .quant_tensor import ste_fake_quant
 
 
 @register_quantizer
@@ -14,7 +14,7 @@ class Quantizer(BaseQuantizer):
     TYPE = "uniform"
 
     def _forward(self, x_f, scale, zero_point):
-        return STE.apply(x_f, scale, zero_point, self.qdesc, self.backend)
+        return ste_fake_quant(x_f, scale, zero_point, self.qdesc, self.backend)
 
     @torch.no_grad()
     def quantize_to_int(self, x, dtype=None):

@@ -58,6 +58,9 @@ def test_status_strings_and_argument_validation_without_gpu(built):
     assert l.sbq_dequantize_linear(p, 7, 1, p, 0, p, p, 1, 4, 8, None) == 1  # unknown level type
     assert l.sbq_dequantize_linear(p, 1, 1, None, 0, p, p, 1, 4, 8, None) == 3
     assert l.sbq_quant_perchannel_forward(p, 2, None, 2, None, 0, p, p, 1, 4, 8, -8, 7, 0, None) == 3  # y NULL needs q
+    assert l.sbq_quant_lsq_forward(p, 9, p, 0, None, p, p, 1, 4, 8, -8, 7, None) == 1  # dtype
+    assert l.sbq_quant_lsq_forward(p, 0, p, 0, None, None, p, 1, 4, 8, -8, 7, None) == 3  # scale NULL
+    assert l.sbq_quant_lsq_backward(p, p, 0, p, 0, p, p, p, 1, 4, 8, -8, 7, 0.5, None, 0, None) == 3  # gs wants a workspace
     assert l.sbq_vecquant3matmul(p, p, p, p, p, 1, 128, 4, 64, p, 1 << 20, None) == 4
     assert l.sbq_vecquant2matmul(p, p, p, p, p, 1, 128, 4, 32, p, 1 << 20, None) == 4  # group % 64
     assert l.sbq_percentile_rows(p, 0, 4, 20000, 0.001, p, p, None) == 4  # row too long for the LDS path

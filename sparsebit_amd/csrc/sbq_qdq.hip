@@ -274,7 +274,19 @@ __device__ __forceinline__ void finish_tile(void* __restrict__ y, void* __restri
       bool odd = false;
 #pragma unroll
       for (int j = 0; j < kPack; ++j) odd |= !(__builtin_fabsf(v[j]) < bound);
-      if (__builtin_amdgcn_ballot_w64(odd) == 0) {
+      if (__builtin_amdgcn_ballot_w64(odd) == 0 && z == 0.0f) {
+        // zero point 0 (every symmetric scheme; block-uniform): no zero-point add / subtract; the product
+        // goes through fma(lv, s, +0) so that a level of -0 still dequantizes to +0 like (lv - 0) * s does
+#pragma unroll
+        for (int j = 0; j < kPack; j += 2) {
+          const f32x2 t = fast_div2(f32x2{v[j], v[j + 1]}, s, yr);
+          lv[j] = __builtin_amdgcn_fmed3f(__builtin_rintf(t[0]), qlo, qhi);
+          lv[j + 1] = __builtin_amdgcn_fmed3f(__builtin_rintf(t[1]), qlo, qhi);
+          const f32x2 d = __builtin_elementwise_fma(f32x2{lv[j], lv[j + 1]}, f32x2{s, s}, f32x2{0.0f, 0.0f});
+          dq[j] = d[0];
+          dq[j + 1] = d[1];
+        }
+      } else if (__builtin_amdgcn_ballot_w64(odd) == 0) {
 #pragma unroll
         for (int j = 0; j < kPack; j += 2) {
           const f32x2 t = fast_div2(f32x2{v[j], v[j + 1]}, s, yr);

@@ -14,8 +14,8 @@ GPU there is no reason to leave the device:
   * `calc_qparams()` for every quantizer at the end; with `sharded=True` each rank sees only
     its share of the batches and the observers all-reduce their statistics (sparsebit_amd.dist).
 
-This is the reference's default protocol (asym=False: every observer sees FLOAT inputs,
-calibration.py:66-115) without the fx walk, so it needs no tracing and works on any module
+This is the reference's calibration protocol (every observer sees FLOAT inputs -- also with
+asym=True, see `layerwise_calibration` -- calibration.py:66-129) without the fx walk, so it needs no tracing and works on any module
 tree whose quantized operators follow the QuantOpr convention: attributes `input_quantizer`
 and/or `weight_quantizer` (+ `weight`), e.g. a reference QuantModel after
 `sparsebit_amd.plugin.install()`.
@@ -69,46 +69,53 @@ class DeviceCalibrator:
         for t in _tensors(args):
             self._feed(q, t)
 
-    @torch.no_grad()
-    def calibrate(self, batches, forward=None, sharded=False):
-        """batches: iterable of model inputs (this rank's share when sharded=True);
-        forward(model, batch) defaults to model(batch) / model(*batch).  Returns {name: (scale, zp)}."""
-        saved = []
+    # ---- the reference's call sequence (quant_model.py:181-199) -----------------------------------
+    # qmodel.prepare_calibration(); for batch in loader: qmodel(batch); qmodel.calc_qparams(asym=...)
+    def prepare_calibration(self):
+        """Quantizers off, model in eval mode, forward-pre hooks on every operator with a live
+        input_quantizer: the caller's own calibration forwards now feed the observers on the device."""
+        assert not getattr(self, "_handles", None), "prepare_calibration called twice"
+        self._saved = []
         for _, m in self.oprs:  # float forward: quantizers off, restored afterwards
             for q in (getattr(m, "input_quantizer", None), getattr(m, "weight_quantizer", None)):
                 if q is not None:
-                    saved.append((q, q.use_quant))
+                    self._saved.append((q, q.use_quant))
                     q.disable_quant()
-        handles = [
+        self._handles = [
             m.register_forward_pre_hook(self._hook) for _, m in self.oprs if _live(getattr(m, "input_quantizer", None))
         ]
-        was_training = self.model.training
+        self._was_training = self.model.training
         self.model.eval()
-        try:
-            for batch in batches:
-                if forward is not None:
-                    forward(self.model, batch)
-                elif isinstance(batch, (list, tuple)):
-                    self.model(*batch)
-                else:
-                    self.model(batch)
-        finally:
-            for h in handles:
-                h.remove()
-            self.model.train(was_training)
+
+    def abort(self):
+        """Leave calibration without computing qparams: hooks off, modes and switches restored, caches dropped."""
+        for h in getattr(self, "_handles", None) or []:
+            h.remove()
+        self._handles = None
+        self.model.train(self._was_training)
+        for q, flag in self._saved:
+            q.use_quant = flag
+            q.observer.data_cache.reset()
+        self._saved = []
+
+    @torch.no_grad()
+    def layerwise_calibration(self, device=None, asym=False, w_quant=False, a_quant=False, sharded=False):
+        """Finish calibration: qparams of every live quantizer.  -> {name: (scale, zero_point)}.
+
+        `asym` / `w_quant` / `a_quant` are accepted for signature compatibility with
+        CalibrationRunner.layerwise_calibration (tools/calibration.py:66-107).  In the reference they do NOT
+        change what any observer sees: `run_feature_calibration` reads `self.builder.storage` -- the FLOAT
+        activations -- in both modes (:109-123) and weights are observed as they are (:125-129); the quantized
+        replay (`qstorage`, :97-103) only feeds AdaRound's reconstruction (:130-143), which is outside this
+        path.  So asym=True yields the same scale / zero_point as asym=False for every quantizer here, and
+        the replay is not run (tests/test_calib_reference.py pins this against the real CalibrationRunner in
+        both modes)."""
+        assert getattr(self, "_handles", None) is not None, "run prepare_calibration first!"
+        for h in self._handles:
+            h.remove()
+        self._handles = None
+        self.model.train(self._was_training)
         out = {}
-
-        def finish():
-            for name, m in self.oprs:
-                iq, wq = getattr(m, "input_quantizer", None), getattr(m, "weight_quantizer", None)
-                if _live(iq):
-                    out[name + ".input_quantizer"] = iq.calc_qparams()
-                if _live(wq):
-                    # weights are replicated on every rank: observed locally, no exchange needed, but a
-                    # sharded exchange of identical statistics is harmless and keeps one code path
-                    wq.update_observer(m.weight)
-                    out[name + ".weight_quantizer"] = wq.calc_qparams()
-
         if sharded:
             with sbq_dist.sharded_calibration():
                 # every streaming min-max observer of the model in ONE collective
@@ -121,9 +128,43 @@ class DeviceCalibrator:
                 if obs:
                     for o, (lo, hi) in zip(obs, sbq_dist.allreduce_minmax_many([o.pending() for o in obs])):
                         o.resolve(lo, hi)
-                finish()
+                self._finish_inputs(out)
         else:
-            finish()
-        for q, flag in saved:
+            self._finish_inputs(out)
+        # Weights are replicated on every rank: observed and finished OUTSIDE the sharded context.  Inside it
+        # their statistics would be all-reduced as if the W replicas were W distinct shards -- harmless for
+        # min/max, but ACIQ's sample count, the percentile ranks and LSQ+'s unbiased std would change.
+        for name, m in self.oprs:
+            wq = getattr(m, "weight_quantizer", None)
+            if _live(wq):
+                wq.update_observer(m.weight)
+                out[name + ".weight_quantizer"] = wq.calc_qparams()
+        for q, flag in self._saved:
             q.use_quant = flag
+        self._saved = []
         return out
+
+    def _finish_inputs(self, out):
+        for name, m in self.oprs:
+            iq = getattr(m, "input_quantizer", None)
+            if _live(iq):
+                out[name + ".input_quantizer"] = iq.calc_qparams()
+
+    # ---- one call -------------------------------------------------------------------------------
+    @torch.no_grad()
+    def calibrate(self, batches, forward=None, sharded=False, asym=False):
+        """batches: iterable of model inputs (this rank's share when sharded=True);
+        forward(model, batch) defaults to model(batch) / model(*batch).  Returns {name: (scale, zp)}."""
+        self.prepare_calibration()
+        try:
+            for batch in batches:
+                if forward is not None:
+                    forward(self.model, batch)
+                elif isinstance(batch, (list, tuple)):
+                    self.model(*batch)
+                else:
+                    self.model(batch)
+        except BaseException:
+            self.abort()
+            raise
+        return self.layerwise_calibration(asym=asym, sharded=sharded)

@@ -17,15 +17,16 @@ exotic quantizers) silently go through their own quantizer, so the result always
 import torch
 
 from . import ops
+from .registry import impl_type
 from .quantizers.lsq import Quantizer as LSQQuantizer
 from .quantizers.uniform import Quantizer as UniformQuantizer
 
 
 def _kind(q):
     # exact types only: subclasses (LSQ+, PACT, DoReFa ...) transform their inputs / qparams
-    if type(q) is UniformQuantizer:
+    if impl_type(q) is UniformQuantizer:
         return "uniform"
-    if type(q) is LSQQuantizer:
+    if impl_type(q) is LSQQuantizer:
         return "lsq"
     return None
 

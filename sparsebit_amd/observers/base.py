@@ -64,7 +64,7 @@ class Observer(nn.Module):
     TYPE = "base"
 
     def __init__(self, config, qdesc):
-        super(Observer, self).__init__()
+        nn.Module.__init__(self)  # by name: see quantizers/base.py (plugin.install() mixes in the reference base)
         self.cfg = config
         self.qdesc = qdesc
         self.device = torch.device("cuda" if torch.cuda.is_available() else "cpu")

@@ -5,18 +5,52 @@
 
 Later registrations overwrite the reference's map entries (quantizers/__init__.py:4-6,
 observers/__init__.py:4-6, sparse/sparsers/__init__.py:4-6), so after install()
-`QuantModel`, `QuantOpr.build_quantizer`, BN fusion and QDQ-ONNX export run
+`QuantModel`, `QuantOpr.build_quantizer`, BN fusion, `CalibrationRunner` and QDQ-ONNX export run
 unmodified on top of the HIP kernels:
-  * QUANTIZERS_MAP["uniform"], ["lsq"], ["lsq+"], ["pact"], ["dorefa"] -> sparsebit_amd.quantizers
-  * OBSERVERS_MAP["minmax"], ["mse"], ["percentile"], ["moving_average"], ["aciq"] -> sparsebit_amd.observers
-  * SPARSERS_MAP["l1norm"]                        -> sparsebit_amd.sparsers
+  * QUANTIZERS_MAP["uniform"], ["lsq"], ["lsq+"], ["pact"], ["dorefa"] -> classes derived from
+    (sparsebit_amd quantizer, the reference's `Quantizer` base)
+  * OBSERVERS_MAP["minmax"], ["mse"], ["percentile"], ["moving_average"], ["aciq"] -> classes derived
+    from (sparsebit_amd observer, the reference's `Observer` base)
+  * SPARSERS_MAP["l1norm"]                        -> (sparsebit_amd sparser, reference `Sparser` base)
   * quant_tensor.fake_quant_kernel                -> sparsebit_amd.fake_quant (for the
-    reference quantizers that stay, e.g. PACT / DoReFa / LSQ+, which call STE.apply)
+    reference quantizers that stay, e.g. adaround / quadapter, which call STE.apply)
+
+What makes this a drop-in rather than a registry swap (each point is exercised by
+tests/test_plugin_reference.py against the real reference and by tests/test_gpu_plugin.py against a
+reference-shaped harness on the GPU box):
+  * the reference hands quantizers ITS enum members -- `TARGET = (QuantTarget.FEATURE,)`,
+    `set_backend(Backend.VIRTUAL)` (modules/base.py:36-45, common.py:5-35) -- and
+    sparsebit_amd.common's enums compare and hash by name, so `fake_quant_factory[backend]`,
+    `qdesc.target == QuantTarget.FEATURE` etc. hold for either class;
+  * `QuantModel.export_onnx` finds quantizers with `isinstance(m, Quantizer)` against the reference
+    base class (quant_model.py:236,256; :284 also `Observer`); the installed classes ARE subclasses
+    of those bases (every method the reference calls is defined on the sparsebit_amd side of the MRO,
+    which comes first), so `enable_export_onnx()` is reached and the export branch stays on
+    `torch.fake_quantize_*`;
+  * `calibrate="device"`: `QuantModel.calc_qparams` (quant_model.py:191-199) is routed through
+    `sparsebit_amd.calibration.DeviceCalibrator` -- one device-resident pass per batch instead of the
+    fx walk with a host round trip per node per batch (tools/calibration.py:66-160).
 See INTEGRATION.md.
 """
 
+_QUANTIZERS = ("uniform", "lsq", "lsq+", "pact", "dorefa")
+_OBSERVERS = ("minmax", "mse", "percentile", "moving_average", "aciq")
 
-def install(native_only=False):
+
+def _derive(amd_cls, ref_base):
+    """type(amd_cls.__name__, (amd_cls, ref_base)): isinstance(obj, ref_base) holds, behaviour is amd_cls's."""
+    if issubclass(amd_cls, ref_base):
+        return amd_cls
+    cls = type(amd_cls.__name__, (amd_cls, ref_base), {"__module__": amd_cls.__module__, "__doc__": amd_cls.__doc__,
+                                                         "_sbq_impl": amd_cls})
+    cls.__qualname__ = amd_cls.__qualname__
+    return cls
+
+
+def install(native_only=False, calibrate=None):
+    """native_only: swap only the native `fake_quant` module (reference classes stay).
+    calibrate="device": also route QuantModel.calc_qparams through DeviceCalibrator (float-input protocol;
+    the reference's asym=True mode computes the same qparams, see calibration.py)."""
     import sparsebit.quantization.quantizers as ref_q
     import sparsebit.quantization.observers as ref_o
     import sparsebit.quantization.quantizers.quant_tensor as ref_qt
@@ -26,22 +60,62 @@ def install(native_only=False):
     from . import quantizers as amd_q
 
     ref_qt.fake_quant_kernel = fake_quant
-    installed = {"fake_quant_kernel": True, "quantizers": [], "observers": [], "sparsers": []}
+    installed = {"fake_quant_kernel": True, "quantizers": [], "observers": [], "sparsers": [], "calibrate": None}
     if native_only:
         return installed
-    for name in ("uniform", "lsq", "lsq+", "pact", "dorefa"):
-        ref_q.QUANTIZERS_MAP[name] = amd_q.QUANTIZERS_MAP[name]
+    for name in _QUANTIZERS:
+        ref_q.QUANTIZERS_MAP[name] = _derive(amd_q.QUANTIZERS_MAP[name], ref_q.Quantizer)
         installed["quantizers"].append(name)
-    for name in ("minmax", "mse", "percentile", "moving_average", "aciq"):
-        ref_o.OBSERVERS_MAP[name] = amd_o.OBSERVERS_MAP[name]
+    for name in _OBSERVERS:
+        ref_o.OBSERVERS_MAP[name] = _derive(amd_o.OBSERVERS_MAP[name], ref_o.Observer)
         installed["observers"].append(name)
+    # quantizers build their observer through sparsebit_amd's own registry: hand out the derived classes there
+    # too, so that isinstance(q.observer, reference Observer) holds (quant_model.py:284)
+    for name in _OBSERVERS:
+        amd_o.OBSERVERS_MAP[name] = ref_o.OBSERVERS_MAP[name]
     try:
         import sparsebit.sparse.sparsers as ref_s
 
         from . import sparsers as amd_s
 
-        ref_s.SPARSERS_MAP["l1norm"] = amd_s.SPARSERS_MAP["l1norm"]
+        ref_s.SPARSERS_MAP["l1norm"] = _derive(amd_s.SPARSERS_MAP["l1norm"], ref_s.Sparser)
         installed["sparsers"].append("l1norm")
     except ImportError:
         pass
+    if calibrate == "device":
+        _route_calibration()
+        installed["calibrate"] = "device"
+    elif calibrate is not None:
+        raise ValueError("calibrate must be None or 'device', not {!r}".format(calibrate))
     return installed
+
+
+def uninstall_observer_aliases():
+    """Undo the one change install() makes to sparsebit_amd's OWN registry (tests that install in-process)."""
+    from . import observers as amd_o
+
+    for name in _OBSERVERS:
+        cls = amd_o.OBSERVERS_MAP[name]
+        amd_o.OBSERVERS_MAP[name] = getattr(cls, "_sbq_impl", cls)
+
+
+def _route_calibration():
+    """QuantModel.prepare_calibration / calc_qparams (quant_model.py:181-199) on the DeviceCalibrator:
+    prepare installs forward-pre hooks, the user's calibration forwards feed the observers on the device,
+    calc_qparams finishes them.  Same call sequence as with the reference's CalibrationRunner."""
+    import sparsebit.quantization.quant_model as ref_qm
+
+    from .calibration import DeviceCalibrator
+
+    def prepare_calibration(self):
+        self.eval()
+        self.calibration_runner = DeviceCalibrator(self.model)
+        self.calibration_runner.prepare_calibration()
+
+    def calc_qparams(self, asym=False, w_quant=False, a_quant=False):
+        assert hasattr(self, "calibration_runner"), "run self.prepare_calibration first"
+        self.calibration_runner.layerwise_calibration(self.device, asym, w_quant, a_quant)
+        del self.calibration_runner
+
+    ref_qm.QuantModel.prepare_calibration = prepare_calibration
+    ref_qm.QuantModel.calc_qparams = calc_qparams

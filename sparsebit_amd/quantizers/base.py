@@ -27,7 +27,11 @@ class Quantizer(nn.Module):
     TYPE = "base"
 
     def __init__(self, config):
-        super().__init__()
+        # nn.Module.__init__ by name, not super(): plugin.install() derives classes from (this class,
+        # the reference's Quantizer) so that the reference's isinstance checks hold (quant_model.py:236,256,284);
+        # in that MRO super() would be the reference base, whose __init__ takes the config and builds
+        # its own observer
+        nn.Module.__init__(self)
         self.cfg = config
         self.qdesc = QuantDescriptor(config)
         self.device = _default_device()

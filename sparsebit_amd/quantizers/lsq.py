@@ -16,6 +16,7 @@ from . import register_quantizer
 from .. import dist as sbq_dist
 from .. import ops
 from ..common import Backend
+from ..registry import impl_type
 from .quant_tensor import STE, _default_out
 
 
@@ -112,7 +113,7 @@ class Quantizer(BaseQuantizer):
     def forward(self, x):
         # plain LSQ on the ORT-style backends: one fused node (zero_point is a buffer here; LSQ+ learns it and
         # keeps the generic route, as does the TensorRT backend with its zero-point assertion)
-        if (self.is_enable and not self.export_onnx and type(self) is Quantizer and self.backend != Backend.TENSORRT
+        if (self.is_enable and not self.export_onnx and impl_type(self) is Quantizer and self.backend != Backend.TENSORRT
                 and not self.zero_point.requires_grad and x.is_cuda):
             pre = self._pregrouped
             if pre is not None and x is pre[0]:

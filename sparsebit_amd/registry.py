@@ -22,3 +22,11 @@ class Registry(dict):
             return self[name.lower()]
         except KeyError:
             raise AssertionError("no found an implement of {} (known {}s: {})".format(name, self.what, sorted(self)))
+
+
+def impl_type(obj):
+    """The sparsebit_amd class behind an object.  plugin.install() registers classes derived from
+    (sparsebit_amd class, reference base) into the reference so that its isinstance checks hold; exact-type
+    dispatch ("plain LSQ, not a subclass that transforms its inputs") must look through that derivation."""
+    t = type(obj)
+    return t.__dict__.get("_sbq_impl", t)

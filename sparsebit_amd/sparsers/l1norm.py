@@ -1,12 +1,22 @@
-"""Unstructured L1 sparser (mirrors sparsebit/sparse/sparsers/l1norm.py:14-26).
+"""L1 sparser (mirrors sparsebit/sparse/sparsers/l1norm.py:14-41).
 
-The reference sorts all of |w| to read ONE element of the sorted array; here the
-threshold is an exact k-th order statistic found by a three-pass radix select
-(three streaming reads of w, no sort, no extra copy of the data) and the mask is
-one more streaming pass -- or is never materialised at all when the consumer is
-the fused mask+QDQ kernel (`calc_threshold` + lsq.Quantizer.forward_masked).
-Ties with the threshold are pruned (`>` is strict), exactly like the reference.
-Structured pruning is outside the hot path.
+Unstructured (the hot path): the reference sorts all of |w| to read ONE element of the sorted
+array; here the threshold is an exact k-th order statistic found by a three-pass radix select
+(three streaming reads of w, no sort, no extra copy of the data) and the mask is one more
+streaming pass -- or is never materialised at all when the consumer is the fused mask+QDQ
+kernel (`calc_threshold` + lsq.Quantizer.forward_masked).  Ties with the threshold are pruned
+(`>` is strict), exactly like the reference.
+
+Structured (l1norm.py:27-41): the `int(C * ratio)` output channels with the smallest sum|w| are
+zeroed.  The per-row sums come from the same one-read statistics kernel the observers use
+(`sbq_channel_stats`, fp64 accumulation -- the reference sums in fp32, so two rows whose sums
+agree to fp32 rounding may swap places; the mask is float like the reference's `ones_like`).
+
+Weights are REPLICATED on every rank of a data-parallel job, so the threshold is always a local
+order statistic, also inside `dist.sharded_calibration()`: a histogram all-reduce over W replicas
+would describe W*n elements while the rank k comes from the local n (the ratio/W quantile).  A
+weight that really is row-sharded over ranks is the caller's explicit choice: `calc_threshold(x,
+sharded=True)` takes k from the all-reduced element count and all-reduces the histograms.
 """
 import torch
 
@@ -24,15 +34,18 @@ class Sparser(BaseSparser):
     def __init__(self, config, opr=None):
         super(Sparser, self).__init__(config, opr)
 
-    def calc_threshold(self, x):
-        """0-d fp32 device tensor: sort(|x|)[min(int(n*ratio), n-1)]   (l1norm.py:21-24)"""
+    def calc_threshold(self, x, sharded=False):
+        """0-d fp32 device tensor: sort(|x|)[min(int(n*ratio), n-1)]   (l1norm.py:21-24).
+        sharded=True: x is this rank's rows of a weight split over ranks; n and the order statistic are global."""
         data = x.detach().contiguous()
+        if sharded and sbq_dist.active():
+            n = sbq_dist.allreduce_count(data.numel())
+            thresh_idx = min(int(n * self.ratio), n - 1)
+            vals = select.kth_values([data], [[thresh_idx + 1]], ops.HipSelectBackend(), True, 0, False, data.device)
+            return vals.reshape(())
         n = data.numel()
         thresh_idx = min(int(n * self.ratio), n - 1)
-        if not sbq_dist.active():
-            return ops.kth_value(data, thresh_idx + 1, use_abs=True)  # the three radix passes in one call
-        vals = select.kth_values([data], [[thresh_idx + 1]], ops.HipSelectBackend(), True, 0, False, data.device)
-        return vals.reshape(())
+        return ops.kth_value(data, thresh_idx + 1, use_abs=True)  # the three radix passes in one call
 
     def calc_mask(self, x):
         if self.ratio == 0.0:
@@ -40,6 +53,13 @@ class Sparser(BaseSparser):
         if self.type == "unstructed":
             thresh = self.calc_threshold(x)
             return ops.mask_from_threshold(x.detach(), thresh)
-        raise NotImplementedError(
-            "only the unstructured L1 masker is on the MI355X hot path (type={})".format(self.type)
-        )
+        if self.type == "structed":
+            data = x.detach().contiguous()
+            _, _, rowsum = ops.channel_stats(data, 0, True, want_min=False, want_max=False, want_abssum=True)
+            pruned = int(x.shape[0] * self.ratio)
+            keep = torch.ones(x.shape[0], dtype=x.dtype, device=x.device)
+            if pruned > 0:
+                # stable ascending order like torch.sort on the CPU: among equal sums the lower row index goes first
+                keep[torch.sort(rowsum, stable=True).indices[:pruned]] = 0
+            return keep.reshape([-1] + [1] * (x.dim() - 1)).expand_as(x).contiguous()
+        raise NotImplementedError("sparser type {!r} (the reference knows 'unstructed' and 'structed')".format(self.type))

@@ -49,6 +49,19 @@ class CfgNode(dict):
     def freeze(self):
         pass
 
+    def merge_from_file(self, path):
+        import yaml
+
+        def merge(dst, src):
+            for k, v in src.items():
+                if isinstance(v, dict) and isinstance(dst.get(k), dict):
+                    merge(dst[k], v)
+                else:
+                    dst[k] = CfgNode(v) if isinstance(v, dict) else v
+
+        with open(path) as f:
+            merge(self, yaml.safe_load(f) or {})
+
     def merge_from_list(self, lst):
         for k, v in zip(lst[0::2], lst[1::2]):
             node = self

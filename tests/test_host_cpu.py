@@ -321,3 +321,49 @@ def test_group_backward_table_build_on_host():
     assert build([item(8, 16), item(8, 16, mask=0x5000)])[0] == 4
     p = ctypes.c_void_p(0x1000)
     assert l.sbq_quant_group_backward(None, None, 1, 0, 0, 0, None, None, None, None, 0, None) == 3
+
+
+def test_enums_compare_by_name_and_derived_classes_satisfy_foreign_isinstance():
+    """The two mechanisms plugin.install() rests on, without the reference: (1) a foreign enum class with the
+    reference's names compares / hashes equal to ours (modules/base.py:36-45 hands quantizers ITS members);
+    (2) a class derived from (ours, foreign base) is an instance of the foreign base and never runs its __init__."""
+    from enum import Enum
+
+    import torch.nn as nn
+
+    from sparsebit_amd import plugin
+    from sparsebit_amd.common import Backend, QuantTarget
+    from sparsebit_amd.config import quantizer_config
+    from sparsebit_amd.quantizers import QUANTIZERS_MAP
+    from sparsebit_amd.quantizers.quant_tensor import fake_quant_factory, fake_qrange_factory, ort_fake_quant, trt_fake_quant
+    from sparsebit_amd.registry import impl_type
+
+    ForeignBackend = Enum("Backend", {"VIRTUAL": 0, "ONNXRUNTIME": 1, "TENSORRT": 2})
+    ForeignTarget = Enum("QuantTarget", {"WEIGHT": 0, "FEATURE": 1})
+    Other = Enum("Other", {"VIRTUAL": 0})
+    assert ForeignBackend.VIRTUAL == Backend.VIRTUAL and Backend.VIRTUAL == ForeignBackend.VIRTUAL
+    assert not (ForeignBackend.VIRTUAL != Backend.VIRTUAL)
+    assert ForeignBackend.TENSORRT != Backend.VIRTUAL and Backend.VIRTUAL != Other.VIRTUAL and Backend.VIRTUAL != 0
+    assert fake_quant_factory[ForeignBackend.VIRTUAL] is ort_fake_quant
+    assert fake_quant_factory[ForeignBackend.TENSORRT] is trt_fake_quant
+    assert ForeignBackend.ONNXRUNTIME in fake_qrange_factory
+    assert QuantTarget.FEATURE in (ForeignTarget.FEATURE,) and ForeignTarget.WEIGHT in [QuantTarget.WEIGHT]
+
+    class ForeignBase(nn.Module):
+        def __init__(self, config):
+            raise AssertionError("foreign base __init__ ran")
+
+        def only_on_foreign(self):
+            return "kept"
+
+    for name, cls in QUANTIZERS_MAP.items():
+        d = plugin._derive(cls, ForeignBase)
+        assert issubclass(d, cls) and issubclass(d, ForeignBase) and d.__name__ == cls.__name__
+        assert plugin._derive(d, ForeignBase) is d
+        target = "feature" if name == "pact" else "weight"
+        cfg = quantizer_config("per-tensor-symmetric", 8, quantizer=name, target=target)
+        cfg["TARGET"] = (ForeignTarget.FEATURE,) if name == "pact" else (ForeignTarget.WEIGHT,)
+        q = d(cfg)  # PACT asserts FEATURE against the foreign member
+        assert isinstance(q, ForeignBase) and impl_type(q) is cls and q.only_on_foreign() == "kept"
+        q.set_backend(ForeignBackend.VIRTUAL)
+        assert q.forward.__func__ is cls.forward  # behaviour is ours

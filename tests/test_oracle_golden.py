@@ -190,3 +190,29 @@ def test_gptq_pack_generic_equals_pack4(golden, oracle):
         a, za = oracle.gptq_pack4(wq, scale, zero)
         b, zb = oracle.gptq_pack(wq, scale, zero, 4)
         assert np.array_equal(a, b) and np.array_equal(za, zb)
+
+
+# ---- round 2: per-channel MSE pinned to the reference itself (row by row) ---------------------------
+def _r02():
+    import os
+
+    from conftest import ROOT
+
+    return np.load(os.path.join(ROOT, "tests", "golden", "ref_golden_r02.npz"), allow_pickle=False)
+
+
+def _r02_cases(prefix):
+    return [c for c in _r02()["cases"].tolist() if c.startswith(prefix)]
+
+
+@pytest.mark.parametrize("name", _r02_cases("rowmse/"))
+def test_oracle_perchannel_mse_equals_reference_row_by_row(oracle, name):
+    """observers/mse.py:28-63 run by the REFERENCE on every row as its own per-tensor problem
+    (tests/golden/gen_golden_r02.py) == the oracle's per-channel restatement: scale bit for bit."""
+    z = _r02()
+    wname = name.split("/")[-1]
+    x = z["rowmse/%s/x" % wname]
+    qmin, qmax, sym = [int(v) for v in z[name + "/meta"]]
+    s, zp, best, _ = oracle.mse(x, qmin, qmax, bool(sym), 0, True)
+    assert np.array_equal(s, z[name + "/scale"]), np.flatnonzero(s != z[name + "/scale"])
+    assert np.array_equal(zp, z[name + "/zero_point"])

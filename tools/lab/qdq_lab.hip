@@ -1,0 +1,454 @@
+// qdq_lab.hip -- kernel-development lab for the headline QDQ (4096x4096 bf16 -> bf16, per-channel int8).
+// NOT part of the product library.  One binary, many launch / load-path variants, timed back to back on
+// the same box in one gpurun call (GPU minutes are the scarce resource):
+//
+//   mode D : loads through VGPRs (global_load_dwordx4), 2-stage software pipeline over tiles
+//   mode L : loads through LDS-DMA (global_load_lds_dwordx4 into a per-wave LDS ring, no barrier:
+//            a wave only ever reads what it loaded itself), batches of U KiB double buffered
+//   THREADS 256 / 512 / 1024, U = 1 / 2 / 4 units (1 KiB) per wave per tile, grid sweep,
+//   MATH 0 = copy (the structure's ceiling), 1 = the exact QDQ arithmetic of the library
+//
+// Output: one line per variant with the launch-to-launch time (HIP events over the loop, rotating
+// 12 buffer pairs = 805 MB > 256 MiB Infinity Cache) and, with --stamps, per-workgroup start/end
+// device timestamps (100 MHz constant clock) for the histogram committed under profiles/.
+//
+// build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off tools/lab/qdq_lab.hip -o tools/lab/qdq_lab
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "../../sparsebit_amd/csrc/sbq_common.hpp"
+
+using namespace sbq;
+
+#define CK(x)                                                                 \
+  do {                                                                        \
+    hipError_t e_ = (x);                                                      \
+    if (e_ != hipSuccess) {                                                   \
+      fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e_)); \
+      exit(1);                                                                \
+    }                                                                         \
+  } while (0)
+
+struct Args {
+  const uint16_t* x;
+  uint16_t* y;
+  const float* scale;
+  uint32_t n_units;      // 1 KiB (64 packs) units in the tensor
+  uint32_t row_shift;    // unit >> row_shift = row
+  float qlo, qhi;
+  uint64_t* stamps;      // [grid][4]: start, end, xcc, pad   (nullptr: off)
+};
+
+__device__ __forceinline__ float uload(const float* p, uint32_t i) {
+  typedef const float __attribute__((address_space(4))) * cptr;
+  return reinterpret_cast<cptr>(reinterpret_cast<uintptr_t>(p))[i];
+}
+
+template <int MATH>
+__device__ __forceinline__ u32x4 qdq16(u32x4 raw, float s, float qlo, float qhi) {
+  if constexpr (MATH == 0) return raw;
+  RawPack<BF16> r;
+  r.d[0] = raw;
+  float v[8], dq[8];
+  unpack_raw<BF16>(r, v);
+  const float yr = 1.0f / s;
+#pragma unroll
+  for (int j = 0; j < 8; j += 2) {
+    const f32x2 t = fast_div2(f32x2{v[j], v[j + 1]}, s, yr);
+    const float l0 = __builtin_amdgcn_fmed3f(__builtin_rintf(t[0]), qlo, qhi);
+    const float l1 = __builtin_amdgcn_fmed3f(__builtin_rintf(t[1]), qlo, qhi);
+    const f32x2 d = __builtin_elementwise_fma(f32x2{l0, l1}, f32x2{s, s}, f32x2{0.0f, 0.0f});
+    dq[j] = d[0];
+    dq[j + 1] = d[1];
+  }
+  u32x4 o;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) o[j] = Elem<BF16>::to_bits(dq[2 * j]) | (uint32_t(Elem<BF16>::to_bits(dq[2 * j + 1])) << 16);
+  return o;
+}
+
+__device__ __forceinline__ void stamp_begin(const Args& a, uint64_t& t0) {
+  if (a.stamps) t0 = __builtin_amdgcn_s_memrealtime();
+}
+__device__ __forceinline__ void stamp_end(const Args& a, uint64_t t0) {
+  if (a.stamps) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      uint32_t xcc;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      uint64_t* p = a.stamps + size_t(blockIdx.x) * 4;
+      p[0] = t0;
+      p[1] = __builtin_amdgcn_s_memrealtime();
+      p[2] = xcc & 0xf;
+    }
+  }
+}
+
+// ---- mode D: VGPR loads, tiles of WPB*U units, grid-stride, two register stages -----------------------
+// ORDER 0: unit = tile*WPB*U + u*WPB + wave  (a load instruction of the WG covers WPB contiguous KiB)
+template <int THREADS, int U, int MATH, bool NTL, bool NTS, int PRIO>
+__global__ __launch_bounds__(THREADS) void k_direct(const Args a) {
+  constexpr int WPB = THREADS / 64;
+  uint64_t t0 = 0;
+  stamp_begin(a, t0);
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint32_t lane = threadIdx.x & 63;
+  const uint32_t n_tiles = (a.n_units + WPB * U - 1) / (WPB * U);
+  const uint32_t G = gridDim.x;
+  uint32_t tile = blockIdx.x;
+  if (tile >= n_tiles) return;
+  u32x4 ra[U], rb[U];
+  float sa[U], sb[U];
+  uint32_t ua[U], ub[U];
+  auto fetch = [&](uint32_t t, u32x4(&r)[U], float(&s)[U], uint32_t(&un)[U]) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      uint32_t unit = t * (WPB * U) + u * WPB + wave;
+      if (unit >= a.n_units) unit = a.n_units - 1;
+      un[u] = unit;
+      r[u] = ld16<NTL>(a.x + (size_t(unit) * 64 + lane) * 8);
+      if constexpr (MATH) s[u] = uload(a.scale, unit >> a.row_shift);
+    }
+  };
+  auto finish = [&](uint32_t t, const u32x4(&r)[U], const float(&s)[U], const uint32_t(&un)[U]) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const u32x4 o = qdq16<MATH>(r[u], s[u], a.qlo, a.qhi);
+      const uint32_t unit = t * (WPB * U) + u * WPB + wave;
+      if constexpr (PRIO) __builtin_amdgcn_s_setprio(PRIO);
+      if (unit < a.n_units) st16<NTS>(a.y + (size_t(un[u]) * 64 + lane) * 8, o);
+      if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
+    }
+  };
+  fetch(tile, ra, sa, ua);
+  while (uint64_t(tile) + 2ull * G < n_tiles) {
+    fetch(tile + G, rb, sb, ub);
+    finish(tile, ra, sa, ua);
+    fetch(tile + 2 * G, ra, sa, ua);
+    finish(tile + G, rb, sb, ub);
+    tile += 2 * G;
+  }
+  if (uint64_t(tile) + G < n_tiles) {
+    fetch(tile + G, rb, sb, ub);
+    finish(tile, ra, sa, ua);
+    finish(tile + G, rb, sb, ub);
+  } else {
+    finish(tile, ra, sa, ua);
+  }
+  stamp_end(a, t0);
+}
+
+// ---- mode L: LDS-DMA loads into a per-wave ring ---------------------------------------------------------
+// A wave owns 2*U KiB of LDS.  Batch b = U units; loads of batch b+1 are issued (DMA, no VGPRs, no wait)
+// before batch b is read back with ds_read_b128 (lane i reads the 16 bytes lane i's DMA wrote), computed
+// and stored.  No s_barrier anywhere: a wave never reads another wave's LDS.  VMEM ops complete in issue
+// order on gfx9-family counters (vmcnt covers loads and stores), so after [loads(b)] [stores(b-1)] [loads(b+1)]
+// `s_waitcnt vmcnt(2U)` means loads(b) have landed (vmcnt(U) for the first and last batch).
+__device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_dst, bool nt) {
+  uint32_t keep;
+  if (nt)
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+  else
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int THREADS, int U, int MATH, bool NTL, bool NTS, int PRIO>
+__global__ __launch_bounds__(THREADS) void k_ldsdma(const Args a) {
+  constexpr int WPB = THREADS / 64;
+  __shared__ __attribute__((aligned(1024))) uint8_t ring[WPB * 2 * U * 1024];
+  uint64_t t0 = 0;
+  stamp_begin(a, t0);
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint32_t lane = threadIdx.x & 63;
+  const uint32_t n_tiles = (a.n_units + WPB * U - 1) / (WPB * U);
+  const uint32_t G = gridDim.x;
+  const uint32_t my = blockIdx.x < n_tiles ? (n_tiles - blockIdx.x + G - 1) / G : 0;  // tiles of this WG
+  if (my == 0) return;
+  const uint32_t lds_base =
+      __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(reinterpret_cast<uintptr_t>(ring)) + wave * (2 * U * 1024));
+  auto unit_of = [&](uint32_t t, int u) {
+    uint32_t unit = t * (WPB * U) + u * WPB + wave;
+    return unit < a.n_units ? unit : a.n_units - 1;
+  };
+  auto issue = [&](uint32_t t, uint32_t half) {
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      glds16(a.x + (size_t(unit_of(t, u)) * 64 + lane) * 8, lds_base + (half * U + u) * 1024, NTL);
+  };
+  auto finish = [&](uint32_t t, uint32_t half) {
+    u32x4 r[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      r[u] = *reinterpret_cast<const u32x4*>(ring + wave * (2 * U * 1024) + (half * U + u) * 1024 + lane * 16);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint32_t unit = t * (WPB * U) + u * WPB + wave;
+      float s = 1.0f;
+      if constexpr (MATH) s = uload(a.scale, unit_of(t, u) >> a.row_shift);
+      const u32x4 o = qdq16<MATH>(r[u], s, a.qlo, a.qhi);
+      if constexpr (PRIO) __builtin_amdgcn_s_setprio(PRIO);
+      // always store (clamped unit rewrites the same bytes): keeps the VMEM op count per batch exact
+      st16<NTS>(a.y + (size_t(unit < a.n_units ? unit : a.n_units - 1) * 64 + lane) * 8, o);
+      if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
+    }
+  };
+  uint32_t t = blockIdx.x;
+  issue(t, 0);
+  if (my == 1) {
+    wait_vm<0>();
+    finish(t, 0);
+  } else {
+    issue(t + G, 1);
+    wait_vm<U>();  // [loads(0)] [loads(1)]
+    finish(t, 0);
+    uint32_t half = 1;
+    for (uint32_t b = 1; b + 1 < my; ++b) {
+      // queue: [loads(b)] [stores(b-1)] -> issue loads(b+1) into the half batch b-1 just vacated
+      // (its ds_reads have returned: the stores that consumed them were issued)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      issue(t + (b + 1) * G, half ^ 1);
+      wait_vm<2 * U>();
+      finish(t + b * G, half);
+      half ^= 1;
+    }
+    wait_vm<U>();  // [loads(last)] [stores(last-1)]
+    finish(t + (my - 1) * G, half);
+  }
+  stamp_end(a, t0);
+}
+
+// ---- harness ------------------------------------------------------------------------------------------------
+__global__ void k_init(uint16_t* x, size_t n, uint32_t inner, uint32_t seed) {
+  for (size_t i = blockIdx.x * size_t(blockDim.x) + threadIdx.x; i < n; i += size_t(gridDim.x) * blockDim.x) {
+    uint32_t h = uint32_t(i) * 2654435761u ^ seed;
+    h ^= h >> 15; h *= 2246822519u; h ^= h >> 13; h *= 3266489917u; h ^= h >> 16;
+    // roughly bell-shaped in [-3, 3] times a per-row spread 10^(-2 .. 1)
+    const float u = ((h & 0xffff) + ((h >> 16) & 0xffff)) * (1.0f / 65536.0f) - 1.0f;
+    const uint32_t row = uint32_t(i / inner);
+    const float spread = __builtin_exp2f(-6.64f + 9.97f * float(row % 4096) / 4096.0f);
+    x[i] = Elem<BF16>::to_bits(3.0f * u * spread);
+  }
+}
+__global__ void k_scale(const uint16_t* x, float* scale, uint32_t inner) {
+  __shared__ float slot[4];
+  float m = 0.0f;
+  for (uint32_t i = threadIdx.x; i < inner; i += blockDim.x)
+    m = __builtin_fmaxf(m, __builtin_fabsf(Elem<BF16>::from_bits(x[size_t(blockIdx.x) * inner + i])));
+  m = block_reduce(m, [](float p, float q) { return __builtin_fmaxf(p, q); }, slot);
+  if (threadIdx.x == 0) scale[blockIdx.x] = __builtin_fmaxf(m * 2.0f / 255.0f, 1e-6f);
+}
+
+typedef void (*kern_t)(const Args);
+struct Variant {
+  std::string name;
+  kern_t fn;
+  int threads, U;
+  bool lds;
+};
+
+template <int THREADS, int U, int MATH, bool NTL, bool NTS, int PRIO>
+void add(std::vector<Variant>& v, const char* tag) {
+  char buf[128];
+  snprintf(buf, sizeof buf, "D t%d u%d m%d ntl%d nts%d p%d %s", THREADS, U, MATH, int(NTL), int(NTS), PRIO, tag);
+  v.push_back({buf, k_direct<THREADS, U, MATH, NTL, NTS, PRIO>, THREADS, U, false});
+}
+template <int THREADS, int U, int MATH, bool NTL, bool NTS, int PRIO>
+void addl(std::vector<Variant>& v, const char* tag) {
+  char buf[128];
+  snprintf(buf, sizeof buf, "L t%d u%d m%d ntl%d nts%d p%d %s", THREADS, U, MATH, int(NTL), int(NTS), PRIO, tag);
+  v.push_back({buf, k_ldsdma<THREADS, U, MATH, NTL, NTS, PRIO>, THREADS, U, true});
+}
+
+int main(int argc, char** argv) {
+  uint32_t rows = 4096, inner = 4096;
+  int iters = 300, nbuf = 12;
+  bool stamps = false;
+  const char* only = nullptr;
+  for (int i = 1; i < argc; ++i) {
+    if (!strcmp(argv[i], "--rows")) rows = atoi(argv[++i]);
+    else if (!strcmp(argv[i], "--iters")) iters = atoi(argv[++i]);
+    else if (!strcmp(argv[i], "--stamps")) stamps = true;
+    else if (!strcmp(argv[i], "--only")) only = argv[++i];
+    else if (!strcmp(argv[i], "--nbuf")) nbuf = atoi(argv[++i]);
+  }
+  const size_t n = size_t(rows) * inner;
+  const uint32_t n_units = uint32_t(n / 512);
+  uint32_t row_shift = 0;
+  while ((512u << row_shift) < inner) ++row_shift;
+  std::vector<uint16_t*> xs(nbuf), ys(nbuf);
+  float* scale;
+  CK(hipMalloc(&scale, rows * sizeof(float)));
+  for (int b = 0; b < nbuf; ++b) {
+    CK(hipMalloc(&xs[b], n * 2));
+    CK(hipMalloc(&ys[b], n * 2));
+    k_init<<<2048, 256>>>(xs[b], n, inner, 0x9e3779b9u * (b + 1));
+  }
+  k_scale<<<rows, 256>>>(xs[0], scale, inner);  // same scale vector for every buffer: fine for timing
+  uint16_t *yref, *ytmp_h = (uint16_t*)malloc(n * 2), *yref_h = (uint16_t*)malloc(n * 2);
+  CK(hipMalloc(&yref, n * 2));
+  uint64_t* d_stamps = nullptr;
+  const uint32_t max_grid = 65536;
+  CK(hipMalloc(&d_stamps, size_t(max_grid) * 4 * 8));
+  CK(hipDeviceSynchronize());
+
+  std::vector<Variant> V;
+  // baseline shapes of the library kernel (t256 u1) and the copy yardstick
+  add<256, 1, 1, true, true, 0>(V, "lib-like");
+  add<256, 1, 0, true, true, 0>(V, "copy");
+  add<256, 2, 1, true, true, 0>(V, "");
+  add<256, 4, 1, true, true, 0>(V, "");
+  add<512, 1, 1, true, true, 0>(V, "");
+  add<512, 2, 1, true, true, 0>(V, "");
+  add<512, 4, 1, true, true, 0>(V, "");
+  add<1024, 1, 1, true, true, 0>(V, "");
+  add<1024, 2, 1, true, true, 0>(V, "");
+  add<1024, 4, 1, true, true, 0>(V, "");
+  add<256, 1, 1, true, true, 3>(V, "prio-store");
+  add<512, 2, 1, true, true, 3>(V, "prio-store");
+  add<256, 1, 1, false, true, 0>(V, "cached loads");
+  add<256, 1, 1, true, false, 0>(V, "cached stores");
+  add<256, 1, 1, false, false, 0>(V, "cached both");
+  addl<256, 1, 1, true, true, 0>(V, "");
+  addl<256, 2, 1, true, true, 0>(V, "");
+  addl<256, 4, 1, true, true, 0>(V, "");
+  addl<256, 2, 0, true, true, 0>(V, "copy");
+  addl<256, 4, 0, true, true, 0>(V, "copy");
+  addl<512, 2, 1, true, true, 0>(V, "");
+  addl<512, 4, 1, true, true, 0>(V, "");
+  addl<1024, 2, 1, true, true, 0>(V, "");
+  addl<1024, 4, 1, true, true, 0>(V, "");
+  addl<256, 2, 1, false, true, 0>(V, "default-policy loads");
+  addl<256, 4, 1, false, true, 0>(V, "default-policy loads");
+  addl<256, 2, 1, true, false, 0>(V, "cached stores");
+  addl<512, 4, 1, true, true, 3>(V, "prio-store");
+
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0));
+  CK(hipEventCreate(&e1));
+  Args base{};
+  base.n_units = n_units;
+  base.row_shift = row_shift;
+  base.qlo = -128.0f;
+  base.qhi = 127.0f;
+  base.scale = scale;
+  bool have_ref = false;
+  printf("# rows %u inner %u units %u  iters %d  nbuf %d (%.0f MB working set)\n", rows, inner, n_units, iters, nbuf,
+         nbuf * n * 4 / 1e6);
+  for (const Variant& v : V) {
+    if (only && v.name.find(only) == std::string::npos) continue;
+    const uint32_t wpb = v.threads / 64;
+    const uint32_t n_tiles = (n_units + wpb * v.U - 1) / (wpb * v.U);
+    // grids: everything resident-at-once sizes and oversubscribed ones
+    std::vector<uint32_t> grids;
+    for (uint32_t g : {256u, 512u, 1024u, 2048u, 4096u, 8192u, 16384u})
+      if (g <= n_tiles) grids.push_back(g);
+    if (grids.empty() || grids.back() != n_tiles) if (n_tiles <= 32768) grids.push_back(n_tiles);
+    for (uint32_t g : grids) {
+      Args a = base;
+      // correctness first (MATH variants): against the first MATH variant's output on buffer 0
+      const bool math = v.name.find(" m1 ") != std::string::npos;
+      a.x = xs[0];
+      a.y = have_ref || !math ? ys[0] : yref;
+      CK(hipMemsetAsync(a.y, 0xff, n * 2));
+      hipLaunchKernelGGL(v.fn, dim3(g), dim3(v.threads), 0, 0, a);
+      CK(hipDeviceSynchronize());
+      long bad = -1;
+      if (math) {
+        if (!have_ref) {
+          CK(hipMemcpy(yref_h, yref, n * 2, hipMemcpyDeviceToHost));
+          have_ref = true;
+          bad = 0;
+        } else {
+          CK(hipMemcpy(ytmp_h, ys[0], n * 2, hipMemcpyDeviceToHost));
+          bad = 0;
+          for (size_t i = 0; i < n; ++i) bad += ytmp_h[i] != yref_h[i];
+        }
+      } else {
+        CK(hipMemcpy(ytmp_h, ys[0], n * 2, hipMemcpyDeviceToHost));
+        std::vector<uint16_t> xin(n);
+        CK(hipMemcpy(xin.data(), xs[0], n * 2, hipMemcpyDeviceToHost));
+        bad = 0;
+        for (size_t i = 0; i < n; ++i) bad += ytmp_h[i] != xin[i];
+      }
+      // timing: best of 3 rounds of `iters` launches, rotating buffers
+      double best = 1e30;
+      for (int round = 0; round < 3; ++round) {
+        for (int i = 0; i < 20; ++i) {
+          a.x = xs[i % nbuf];
+          a.y = ys[i % nbuf];
+          hipLaunchKernelGGL(v.fn, dim3(g), dim3(v.threads), 0, 0, a);
+        }
+        CK(hipDeviceSynchronize());
+        CK(hipEventRecord(e0));
+        for (int i = 0; i < iters; ++i) {
+          a.x = xs[i % nbuf];
+          a.y = ys[i % nbuf];
+          hipLaunchKernelGGL(v.fn, dim3(g), dim3(v.threads), 0, 0, a);
+        }
+        CK(hipEventRecord(e1));
+        CK(hipEventSynchronize(e1));
+        float ms;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        best = std::min(best, double(ms) * 1e3 / iters);
+      }
+      printf("%-44s grid %6u  %7.3f us  %6.1f GB/s  frac %.4f  mismatches %ld\n", v.name.c_str(), g, best,
+             n * 4 / best / 1e3, n * 4 / best / 1e3 / 8000.0, bad);
+      fflush(stdout);
+      if (stamps) {
+        // one instrumented launch in the middle of a back-to-back train (so ramp overlaps a predecessor's tail
+        // exactly as in the timed loop): 8 plain launches, the stamped one, 8 plain ones
+        Args s = a;
+        for (int i = 0; i < 8; ++i) {
+          a.x = xs[i % nbuf]; a.y = ys[i % nbuf];
+          hipLaunchKernelGGL(v.fn, dim3(g), dim3(v.threads), 0, 0, a);
+        }
+        s.x = xs[8 % nbuf]; s.y = ys[8 % nbuf]; s.stamps = d_stamps;
+        hipLaunchKernelGGL(v.fn, dim3(g), dim3(v.threads), 0, 0, s);
+        for (int i = 9; i < 17; ++i) {
+          a.x = xs[i % nbuf]; a.y = ys[i % nbuf];
+          hipLaunchKernelGGL(v.fn, dim3(g), dim3(v.threads), 0, 0, a);
+        }
+        CK(hipDeviceSynchronize());
+        std::vector<uint64_t> h(size_t(g) * 4);
+        CK(hipMemcpy(h.data(), d_stamps, h.size() * 8, hipMemcpyDeviceToHost));
+        uint64_t first = ~0ull, last = 0, last_start = 0;
+        for (uint32_t b = 0; b < g; ++b) {
+          first = std::min(first, h[b * 4]);
+          last = std::max(last, h[b * 4 + 1]);
+          last_start = std::max(last_start, h[b * 4]);
+        }
+        // histogram of workgroup end times relative to the first start, 0.5 us bins (100 MHz clock: 10 ns ticks)
+        int bins_end[64] = {0}, bins_start[64] = {0}, bins_dur[64] = {0};
+        for (uint32_t b = 0; b < g; ++b) {
+          bins_start[std::min<uint64_t>(63, (h[b * 4] - first) / 50)]++;
+          bins_end[std::min<uint64_t>(63, (h[b * 4 + 1] - first) / 50)]++;
+          bins_dur[std::min<uint64_t>(63, (h[b * 4 + 1] - h[b * 4]) / 50)]++;
+        }
+        printf("  STAMPS span %.2f us (first start -> last end), last start at %.2f us\n", (last - first) / 100.0,
+               (last_start - first) / 100.0);
+        printf("  STAMPS start-hist(0.5us):");
+        for (int i = 0; i < 40; ++i) printf(" %d", bins_start[i]);
+        printf("\n  STAMPS end-hist(0.5us):  ");
+        for (int i = 0; i < 40; ++i) printf(" %d", bins_end[i]);
+        printf("\n  STAMPS dur-hist(0.5us):  ");
+        for (int i = 0; i < 40; ++i) printf(" %d", bins_dur[i]);
+        printf("\n");
+      }
+    }
+  }
+  return 0;
+}

@@ -358,11 +358,17 @@ def main():
     # writes profiles/pmc_latest.json on the GPU box; the counters need their own profiled
     # runs, so they cannot be collected inside this un-profiled timing run)
     traffic = None
+    traffic_source = None
+    kernel_name = "sbq::qdq_resident_kernel<BF16, BF16, 0, 16>"
     pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
     if os.path.exists(pmc_path):
         try:
             with open(pmc_path) as f:
-                traffic = json.load(f).get("qdq_bf16_bf16_traffic_bytes_per_launch")
+                pmc = json.load(f)
+            traffic = pmc.get("qdq_bf16_bf16_traffic_bytes_per_launch")
+            traffic_source = ("committed profile profiles/pmc_latest.json (tag %s: two separate rocprofv3 --pmc passes, "
+                              "FETCH_SIZE and WRITE_SIZE, of this same command; kernel %s), not measured in this run"
+                              % (pmc.get("tag"), pmc.get("kernel")))
         except (OSError, ValueError):
             traffic = None
 
@@ -395,7 +401,8 @@ def main():
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "frac_of_measured_copy_ceiling": round(achieved / 6290.0, 4),  # MI355X_MICROARCH.md: float4 copy 6.29 TB/s
                 "traffic": traffic,
-                "kernel": "sbq::qdq_pack_kernel<BF16,BF16,...>",
+                "traffic_source": traffic_source,
+                "kernel": kernel_name,
                 "kernel_avg_us": round(kern_us, 3),
                 "algorithmic_bytes_per_launch": n_elem * BYTES_PER_ELEM,
             },

@@ -42,6 +42,7 @@ def _hipcc():
 # on qdq_pack_kernel)
 EXTRA_FLAGS = {
     "sbq_qdq.hip": ["-mllvm", "-amdgpu-kernarg-preload-count=14"],
+    "sbq_qdq_resident.hip": ["-mllvm", "-amdgpu-kernarg-preload-count=14"],
 }
 
 

@@ -403,6 +403,7 @@ __device__ __forceinline__ float key_float(uint32_t k) {
 // ---- host side ---------------------------------------------------------------------
 int check_launch();  // hipGetLastError -> sbq_status, records the error string
 int knob(int which);
+uint32_t cu_count();  // compute units of the current device
 inline hipStream_t as_stream(void* s) { return static_cast<hipStream_t>(s); }
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 inline size_t dtype_size(int dt) { return dt == SBQ_F32 ? 4 : 2; }

@@ -20,6 +20,22 @@ int check_launch() {
 
 int knob(int which) { return g_knobs[which & 3].load(std::memory_order_relaxed); }
 
+// compute units of the current device (cached per device ordinal; 256 on an MI355X)
+uint32_t cu_count() {
+  constexpr int kMaxDev = 64;
+  static std::atomic<uint32_t> cache[kMaxDev];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) return 256;
+  uint32_t n = cache[dev].load(std::memory_order_relaxed);
+  if (n == 0) {
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+    n = static_cast<uint32_t>(v);
+    cache[dev].store(n, std::memory_order_relaxed);
+  }
+  return n;
+}
+
 }  // namespace sbq
 
 extern "C" {

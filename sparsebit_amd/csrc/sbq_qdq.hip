@@ -20,12 +20,11 @@
 //     element pays a multiply and two fma refinements (sbq_common.hpp, fast_div);
 //   * anything not 16-byte friendly (inner % 8 != 0, odd pointers, the exotic
 //     rounding modes) goes through a scalar kernel with identical arithmetic.
-#include "sbq_common.hpp"
+#include "sbq_qdq_math.hpp"
 
 namespace sbq {
 namespace {
 
-enum { MASK_NONE = 0, MASK_BYTES = 1, MASK_THRESH = 2 };
 
 // the four levels lv[0..3] of a lane's 4-element run at element index i (SPLIT mapping)
 template <int QT>
@@ -98,12 +97,6 @@ struct QdqPtrs {
   const float* zp;
 };
 
-// Arithmetic of the pack kernels: both are exact.  MATH_IEEE (knob 2 == 3, headline shape only)
-// is kept for A/B measurements of what the reciprocal + fma refinement buys; the two
-// non-parity probes used to locate the bottleneck (reciprocal multiply, plain copy; numbers
-// in DESIGN.md 7) are gone from the product library.
-enum { MATH_FAST = 0, MATH_IEEE = 3 };
-
 // One tile = U packs per lane.
 template <int U>
 struct Tile {
@@ -119,16 +112,6 @@ struct Tile {
 // (scale / zero_point through s_load) and a wave reads 1 KiB of contiguous HBM per load
 // instruction.  FLAT (short rows): packs are numbered across the tensor, channel per lane.
 // Out-of-range lanes point at the last valid pack (loads are never predicated, only stores).
-// Block-uniform read of a quantization parameter through the scalar unit.  scale/zero_point
-// are never written by these kernels, so they may be read through the constant address
-// space; without this a pointer that itself came from memory (the batched kernel's table)
-// is not provably alias-free and the load degrades to a per-lane VMEM broadcast, doubling
-// the number of vector-memory instructions per tile.
-__device__ __forceinline__ float uniform_load(const float* p, uint32_t i) {
-  typedef const float __attribute__((address_space(4))) * cptr;
-  return reinterpret_cast<cptr>(reinterpret_cast<uintptr_t>(p))[i];
-}
-
 // Position of a ROWS tile's first slab.  Tiles of a workgroup are visited in steps of
 // gridDim.x tiles, so after one division at the start the cursor only adds a precomputed
 // (rows, slabs) stride -- no per-tile integer division on the scalar unit in front of the loads.
@@ -251,64 +234,7 @@ __device__ __forceinline__ void finish_tile(void* __restrict__ y, void* __restri
   for (int u = 0; u < U; ++u) {
     float v[kPack], lv[kPack], dq[kPack];
     unpack_raw<Tin>(raw[u], v);
-    const float s = t.s[u], z = t.z[u];
-#pragma unroll
-    for (int j = 0; j < kPack; ++j) {
-      if constexpr (MASK == MASK_BYTES) {
-        const uint32_t byte = (mk[u][j >> 2] >> (8 * (j & 3))) & 0xffu;
-        v[j] = byte ? v[j] : 0.0f;
-      } else if constexpr (MASK == MASK_THRESH) {
-        v[j] = (__builtin_fabsf(v[j]) > thr) ? v[j] : 0.0f;
-      }
-    }
-    // ROWS: `s` is block-uniform, so the choice below is a scalar branch and y = 1/s is one
-    // division per slab instead of one per element.
-    const bool fast = (MATH == MATH_FAST) && !FLAT && fast_div_ok(s);
-    if (fast) {
-      const float yr = 1.0f / s;
-      const float bound = s * 0x1p40f;
-      // NaN, +-inf and |x| >= s * 2^40 leave the range in which the fma refinement is exact.
-      // One compare per element feeds a wave-wide vote; a wave that holds any such value
-      // (never, on real weights) redoes the pack with IEEE division instead of every element
-      // paying a clamp and a NaN restore.
-      bool odd = false;
-#pragma unroll
-      for (int j = 0; j < kPack; ++j) odd |= !(__builtin_fabsf(v[j]) < bound);
-      if (__builtin_amdgcn_ballot_w64(odd) == 0 && z == 0.0f) {
-        // zero point 0 (every symmetric scheme; block-uniform): no zero-point add / subtract; the product
-        // goes through fma(lv, s, +0) so that a level of -0 still dequantizes to +0 like (lv - 0) * s does
-#pragma unroll
-        for (int j = 0; j < kPack; j += 2) {
-          const f32x2 t = fast_div2(f32x2{v[j], v[j + 1]}, s, yr);
-          lv[j] = __builtin_amdgcn_fmed3f(__builtin_rintf(t[0]), qlo, qhi);
-          lv[j + 1] = __builtin_amdgcn_fmed3f(__builtin_rintf(t[1]), qlo, qhi);
-          const f32x2 d = __builtin_elementwise_fma(f32x2{lv[j], lv[j + 1]}, f32x2{s, s}, f32x2{0.0f, 0.0f});
-          dq[j] = d[0];
-          dq[j + 1] = d[1];
-        }
-      } else if (__builtin_amdgcn_ballot_w64(odd) == 0) {
-#pragma unroll
-        for (int j = 0; j < kPack; j += 2) {
-          const f32x2 t = fast_div2(f32x2{v[j], v[j + 1]}, s, yr);
-          lv[j] = __builtin_amdgcn_fmed3f(__builtin_rintf(t[0]) + z, qlo, qhi);
-          lv[j + 1] = __builtin_amdgcn_fmed3f(__builtin_rintf(t[1]) + z, qlo, qhi);
-          dq[j] = dequant_level(lv[j], s, z);
-          dq[j + 1] = dequant_level(lv[j + 1], s, z);
-        }
-      } else {
-#pragma unroll
-        for (int j = 0; j < kPack; ++j) {
-          lv[j] = quant_level<SBQ_ROUND_HALF_EVEN>(v[j], s, z, qlo, qhi);
-          dq[j] = dequant_level(lv[j], s, z);
-        }
-      }
-    } else {
-#pragma unroll
-      for (int j = 0; j < kPack; ++j) {
-        lv[j] = quant_level<SBQ_ROUND_HALF_EVEN>(v[j], s, z, qlo, qhi);
-        dq[j] = dequant_level(lv[j], s, z);
-      }
-    }
+    quantize_pack<MASK, FLAT, MATH>(v, mk[u], thr, t.s[u], t.z[u], qlo, qhi, lv, dq);
     if constexpr (SPLIT) {
       if (QT == SBQ_Q_NONE || y) {  // y == nullptr: quantize only (block-uniform)
         if (t.ok[u]) store_half_f32<NT>(y, t.elem[u], dq);
@@ -379,6 +305,8 @@ __global__ __launch_bounds__(kBlock) void qdq_pack_kernel(
 #define SBQ_FETCH(T, R, M, IDX)                                     \
   locate<FLAT, U, SPLIT>(g, (IDX), cur, scale, zero_point, T);      \
   issue_loads<Tin, MASK, NT, U, SPLIT>(x, mask, T, R, M);           \
+  __builtin_amdgcn_sched_barrier(0); /* nothing of the following FINISH (whose first use waits for the */ \
+  /* PREVIOUS tile's loads) may be scheduled above these loads: that would serialise the pipeline */   \
   if constexpr (!FLAT) advance(g, cur)
 #define SBQ_FINISH(T, R, M) \
   finish_tile<Tin, Tout, QT, MASK, FLAT, NTS, U, MATH, SPLIT>(y, q, T, R, M, thr, g.qlo, g.qhi)
@@ -455,6 +383,7 @@ __global__ __launch_bounds__(kBlock) void qdq_batched_kernel(const void* const* 
   P = cur;                                                         \
   locate<false, U, SPLIT>(g, lt, rc, P.scale, P.zp, T);            \
   issue_loads<Tin, MASK, true, U, SPLIT>(P.x, nullptr, T, R, M);   \
+  __builtin_amdgcn_sched_barrier(0);                               \
   step_item()
 #define SBQ_FINISH(P, T, R, M) \
   finish_tile<Tin, Tout, SBQ_Q_NONE, MASK, false, true, U, MATH_FAST, SPLIT>(P.y, nullptr, T, R, M, 0.0f, g.qlo, g.qhi)
@@ -671,6 +600,13 @@ void launch_variant(QdqCall c, int variant, hipStream_t st) {
 template <typename Tin, typename Tout, int QT, int MASK>
 void launch_geom(const QdqCall& c, bool flat, hipStream_t st) {
   const int variant = knob(0);
+  if constexpr (QT == SBQ_Q_NONE) {
+    if (!flat && variant < 0) {
+      const ResidentCall r{c.p.x, c.p.y, c.p.mask, c.p.thresh, c.p.scale, c.p.zp, c.g.packs_per_row, c.g.slabs_per_row,
+                           c.g.n_slabs, c.rows, c.g.C, c.g.qlo, c.g.qhi, c.g.lsq, Tin::id, Tout::id};
+      if (qdq_try_resident(r, st)) return;
+    }
+  }
   if (flat) launch_variant<Tin, Tout, QT, MASK, true>(c, variant, st);
   else launch_variant<Tin, Tout, QT, MASK, false>(c, variant, st);
 }

@@ -232,9 +232,16 @@ def test_device_calibrator_equals_reference_calibration_runner(calib, name, asym
         q = model.get_submodule(n)
         gs, gz = calib["{}/{}/scale".format(tag, n)], calib["{}/{}/zero_point".format(tag, n)]
         s, z = q.scale.reshape(-1).cpu().numpy(), q.zero_point.reshape(-1).cpu().numpy()
-        # activations in the pct_mse config: per-tensor MSE -- fp32 (torch) vs fp64 loss sums pick the same candidate
-        assert np.array_equal(s, gs), (n, s, gs)
-        assert same_values(z, gz), (n, z, gz)
+        if n.endswith("weight_quantizer") or n == "c1_bn.input_quantizer":
+            # fed by the stored weights / the raw calibration batches: identical data on both sides -> bit-exact
+            assert np.array_equal(s, gs), (n, s, gs)
+            assert same_values(z, gz), (n, z, gz)
+        else:
+            # fed by an activation a MIOpen / rocBLAS operator produced here and the CPU's conv produced in the
+            # golden run: the observed tensors differ in the last ulp (summation order of the float operator, not
+            # of this path), so min/max and hence the scale may move by an ulp, a zero point by one level
+            assert np.allclose(s, gs, rtol=1e-5, atol=0), (n, s, gs)
+            assert np.abs(z - gz).max() <= 1, (n, z, gz)
     # quantized end-to-end forward of the calibrated chain vs the reference's CPU result: same grid everywhere,
     # MIOpen vs CPU conv summation order may move an activation across a rounding boundary (one level = scale)
     if not asym:

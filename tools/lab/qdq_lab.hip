@@ -14,6 +14,8 @@
 //
 // build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off tools/lab/qdq_lab.hip -o tools/lab/qdq_lab
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
+#include <dlfcn.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -231,6 +233,119 @@ __global__ __launch_bounds__(THREADS) void k_ldsdma(const Args a) {
   stamp_end(a, t0);
 }
 
+
+// ---- mode P: phased -- a wave loads ALL its U units, waits for every one (vmcnt(0)), then computes and
+// stores them all; one tile per workgroup (grid = n_units / (WPB*U)).  The whole 33.5 MB tensor sits in the
+// register files of the chip between the read burst and the write burst (256 CUs x 512 KiB of VGPRs).
+// WAITALL 0: stores start as soon as the first load lands (plain program order), 1: after the last.
+template <int THREADS, int U, int MATH, int WAITALL, int ORDER>
+__global__ __launch_bounds__(THREADS) void k_phase(const Args a) {
+  constexpr int WPB = THREADS / 64;
+  uint64_t t0 = 0;
+  stamp_begin(a, t0);
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint32_t lane = threadIdx.x & 63;
+  const uint32_t n_tiles = (a.n_units + WPB * U - 1) / (WPB * U);
+  for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    u32x4 r[U];
+    uint32_t un[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      // ORDER 0: a WG's load instruction u covers WPB contiguous KiB; ORDER 1: a wave owns U contiguous KiB
+      uint32_t unit = ORDER == 0 ? tile * (WPB * U) + u * WPB + wave : tile * (WPB * U) + wave * U + u;
+      if (unit >= a.n_units) unit = a.n_units - 1;
+      un[u] = unit;
+      r[u] = ld16<true>(a.x + (size_t(unit) * 64 + lane) * 8);
+    }
+    if constexpr (WAITALL) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      float s = 1.0f;
+      if constexpr (MATH) s = uload(a.scale, un[u] >> a.row_shift);
+      const u32x4 o = qdq16<MATH>(r[u], s, a.qlo, a.qhi);
+      st16<true>(a.y + (size_t(un[u]) * 64 + lane) * 8, o);
+    }
+  }
+  stamp_end(a, t0);
+}
+
+// ---- mode Q: resident -- loads of ALL U units issued up front; every unit is converted IN PLACE as it lands
+// (the compiler's own progressive vmcnt waits), and only after the last conversion does the wave issue its
+// U stores back to back: the read burst and the write burst of the whole chip barely overlap, and the
+// arithmetic hides under the tail of the read burst instead of sitting between the two.
+template <int THREADS, int U, int MATH, int PRIO>
+__global__ __launch_bounds__(THREADS) void k_resident(const Args a) {
+  constexpr int WPB = THREADS / 64;
+  uint64_t t0 = 0;
+  stamp_begin(a, t0);
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint32_t lane = threadIdx.x & 63;
+  const uint32_t n_tiles = (a.n_units + WPB * U - 1) / (WPB * U);
+  for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    u32x4 r[U];
+    float s[U];
+    uint32_t un[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      uint32_t unit = tile * (WPB * U) + u * WPB + wave;
+      if (unit >= a.n_units) unit = a.n_units - 1;
+      un[u] = unit;
+      r[u] = ld16<true>(a.x + (size_t(unit) * 64 + lane) * 8);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) s[u] = MATH ? uload(a.scale, un[u] >> a.row_shift) : 1.0f;
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < U; ++u) r[u] = qdq16<MATH>(r[u], s[u], a.qlo, a.qhi);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (PRIO) __builtin_amdgcn_s_setprio(PRIO);
+#pragma unroll
+    for (int u = 0; u < U; ++u) st16<true>(a.y + (size_t(un[u]) * 64 + lane) * 8, r[u]);
+  }
+  stamp_end(a, t0);
+}
+
+// ---- ceilings: read-only and write-only streams of the same 33.5 MB -----------------------------------------
+template <int THREADS, int U>
+__global__ __launch_bounds__(THREADS) void k_readonly(const Args a) {
+  constexpr int WPB = THREADS / 64;
+  uint64_t t0 = 0;
+  stamp_begin(a, t0);
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint32_t lane = threadIdx.x & 63;
+  const uint32_t n_tiles = (a.n_units + WPB * U - 1) / (WPB * U);
+  u32x4 acc = {0, 0, 0, 0};
+  for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      uint32_t unit = tile * (WPB * U) + u * WPB + wave;
+      if (unit >= a.n_units) unit = a.n_units - 1;
+      const u32x4 v = ld16<true>(a.x + (size_t(unit) * 64 + lane) * 8);
+      acc[0] |= v[0]; acc[1] |= v[1]; acc[2] |= v[2]; acc[3] |= v[3];
+    }
+  }
+  if ((acc[0] & acc[1] & acc[2] & acc[3]) == 0x12345678u) st16<true>(a.y + lane * 8, acc);  // never (keeps the loads)
+  stamp_end(a, t0);
+}
+template <int THREADS, int U>
+__global__ __launch_bounds__(THREADS) void k_writeonly(const Args a) {
+  constexpr int WPB = THREADS / 64;
+  uint64_t t0 = 0;
+  stamp_begin(a, t0);
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint32_t lane = threadIdx.x & 63;
+  const uint32_t n_tiles = (a.n_units + WPB * U - 1) / (WPB * U);
+  const u32x4 v = {lane, wave, blockIdx.x, 7u};
+  for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      uint32_t unit = tile * (WPB * U) + u * WPB + wave;
+      if (unit < a.n_units) st16<true>(a.y + (size_t(unit) * 64 + lane) * 8, v);
+    }
+  }
+  stamp_end(a, t0);
+}
+
 // ---- harness ------------------------------------------------------------------------------------------------
 __global__ void k_init(uint16_t* x, size_t n, uint32_t inner, uint32_t seed) {
   for (size_t i = blockIdx.x * size_t(blockDim.x) + threadIdx.x; i < n; i += size_t(gridDim.x) * blockDim.x) {
@@ -258,6 +373,8 @@ struct Variant {
   kern_t fn;
   int threads, U;
   bool lds;
+  int check = 1;   // 1: QDQ result vs reference, 0: copy, -1: no check (ceilings)
+  bool any_order = false;
 };
 
 template <int THREADS, int U, int MATH, bool NTL, bool NTS, int PRIO>
@@ -273,15 +390,33 @@ void addl(std::vector<Variant>& v, const char* tag) {
   v.push_back({buf, k_ldsdma<THREADS, U, MATH, NTL, NTS, PRIO>, THREADS, U, true});
 }
 
+template <int THREADS, int U, int MATH, int WAITALL, int ORDER>
+void addp(std::vector<Variant>& v, const char* tag) {
+  char buf[128];
+  snprintf(buf, sizeof buf, "P t%d u%d m%d wait%d ord%d %s", THREADS, U, MATH, WAITALL, ORDER, tag);
+  v.push_back({buf, k_phase<THREADS, U, MATH, WAITALL, ORDER>, THREADS, U, false});
+}
+
+template <int THREADS, int U, int MATH, int PRIO>
+void addq(std::vector<Variant>& v, const char* tag) {
+  char buf[128];
+  snprintf(buf, sizeof buf, "Q t%d u%d m%d p%d %s", THREADS, U, MATH, PRIO, tag);
+  v.push_back({buf, k_resident<THREADS, U, MATH, PRIO>, THREADS, U, false});
+}
+
 int main(int argc, char** argv) {
   uint32_t rows = 4096, inner = 4096;
   int iters = 300, nbuf = 12;
   bool stamps = false;
+  int set = 1;
   const char* only = nullptr;
+  const char* libpath = "sparsebit_amd/libsbq.so";
   for (int i = 1; i < argc; ++i) {
     if (!strcmp(argv[i], "--rows")) rows = atoi(argv[++i]);
     else if (!strcmp(argv[i], "--iters")) iters = atoi(argv[++i]);
     else if (!strcmp(argv[i], "--stamps")) stamps = true;
+    else if (!strcmp(argv[i], "--set")) set = atoi(argv[++i]);
+    else if (!strcmp(argv[i], "--lib")) libpath = argv[++i];
     else if (!strcmp(argv[i], "--only")) only = argv[++i];
     else if (!strcmp(argv[i], "--nbuf")) nbuf = atoi(argv[++i]);
   }
@@ -306,6 +441,48 @@ int main(int argc, char** argv) {
   CK(hipDeviceSynchronize());
 
   std::vector<Variant> V;
+  if (set == 2) {
+    // round-2 second sweep: phased kernels, ceilings, unordered launches
+    add<256, 1, 0, true, true, 0>(V, "copy");
+    add<256, 4, 1, true, true, 0>(V, "");
+    addl<512, 2, 1, true, true, 0>(V, "");
+    V.push_back({"R t256 u4 read-only", k_readonly<256, 4>, 256, 4, false, -1});
+    V.push_back({"R t256 u1 read-only", k_readonly<256, 1>, 256, 1, false, -1});
+    V.push_back({"W t256 u4 write-only", k_writeonly<256, 4>, 256, 4, false, -1});
+    V.push_back({"W t256 u1 write-only", k_writeonly<256, 1>, 256, 1, false, -1});
+    addp<256, 8, 1, 0, 0>(V, "");
+    addp<256, 8, 1, 1, 0>(V, "");
+    addp<256, 16, 1, 0, 0>(V, "");
+    addp<256, 16, 1, 1, 0>(V, "");
+    addp<256, 16, 0, 1, 0>(V, "copy");
+    addp<256, 16, 1, 1, 1>(V, "");
+    addp<512, 8, 1, 1, 0>(V, "");
+    addp<512, 16, 1, 1, 0>(V, "");
+    addp<1024, 8, 1, 1, 0>(V, "");
+    addp<256, 32, 1, 1, 0>(V, "");
+    addp<256, 32, 0, 1, 0>(V, "copy");
+    {
+      Variant u = V[1]; u.name += " ANYORDER"; u.any_order = true; V.push_back(u);
+      Variant w = V[0]; w.name += " ANYORDER"; w.any_order = true; V.push_back(w);
+    }
+  } else if (set == 3) {
+    add<256, 4, 1, true, true, 0>(V, "");   // reference result + yardstick of set 1
+    addp<256, 32, 0, 1, 0>(V, "copy");
+    addq<256, 8, 1, 0>(V, "");
+    addq<256, 16, 1, 0>(V, "");
+    addq<256, 32, 1, 0>(V, "");
+    addq<256, 32, 0, 0>(V, "copy");
+    addq<512, 8, 1, 0>(V, "");
+    addq<512, 16, 1, 0>(V, "");
+    addq<512, 16, 0, 0>(V, "copy");
+    addq<1024, 4, 1, 0>(V, "");
+    addq<1024, 8, 1, 0>(V, "");
+    addq<256, 32, 1, 2>(V, "prio-store");
+    addq<512, 16, 1, 2>(V, "prio-store");
+    {
+      Variant u = V[7]; u.name += " ANYORDER"; u.any_order = true; V.push_back(u);
+    }
+  } else {
   // baseline shapes of the library kernel (t256 u1) and the copy yardstick
   add<256, 1, 1, true, true, 0>(V, "lib-like");
   add<256, 1, 0, true, true, 0>(V, "copy");
@@ -335,10 +512,45 @@ int main(int argc, char** argv) {
   addl<256, 4, 1, false, true, 0>(V, "default-policy loads");
   addl<256, 2, 1, true, false, 0>(V, "cached stores");
   addl<512, 4, 1, true, true, 3>(V, "prio-store");
+  }
 
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
+  if (set == 9) {
+    // the PRODUCT library through its C ABI from this (host-fast) loop: knob 3 = 1 pipelined, 0 auto (resident)
+    void* h = dlopen(libpath, RTLD_NOW);
+    if (!h) { fprintf(stderr, "dlopen %s: %s\n", libpath, dlerror()); return 1; }
+    typedef int (*fwd_t)(const void*, int, void*, int, void*, int, const float*, const float*, int64_t, int64_t, int64_t,
+                         int, int, int, void*);
+    typedef int (*tune_t)(int, int);
+    fwd_t fwd = (fwd_t)dlsym(h, "sbq_quant_perchannel_forward");
+    tune_t tune = (tune_t)dlsym(h, "sbq_set_tuning");
+    float* zp;
+    CK(hipMalloc(&zp, rows * sizeof(float)));
+    CK(hipMemset(zp, 0, rows * sizeof(float)));
+    for (int k3 : {1, 0, 1, 0}) {
+      tune(3, k3);
+      double best = 1e30;
+      for (int round = 0; round < 3; ++round) {
+        for (int i = 0; i < 20; ++i) fwd(xs[i % nbuf], 2, ys[i % nbuf], 2, nullptr, 0, scale, zp, 1, rows, inner, -128, 127, 0, nullptr);
+        CK(hipDeviceSynchronize());
+        CK(hipEventRecord(e0));
+        for (int i = 0; i < iters; ++i) {
+          int rc = fwd(xs[i % nbuf], 2, ys[i % nbuf], 2, nullptr, 0, scale, zp, 1, rows, inner, -128, 127, 0, nullptr);
+          if (rc) { fprintf(stderr, "rc %d\n", rc); return 1; }
+        }
+        CK(hipEventRecord(e1));
+        CK(hipEventSynchronize(e1));
+        float ms;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        best = std::min(best, double(ms) * 1e3 / iters);
+      }
+      printf("libsbq sbq_quant_perchannel_forward knob3=%d   %7.3f us  %6.1f GB/s  frac %.4f\n", k3, best, n * 4 / best / 1e3,
+             n * 4 / best / 1e3 / 8000.0);
+    }
+    return 0;
+  }
   Args base{};
   base.n_units = n_units;
   base.row_shift = row_shift;
@@ -348,6 +560,12 @@ int main(int argc, char** argv) {
   bool have_ref = false;
   printf("# rows %u inner %u units %u  iters %d  nbuf %d (%.0f MB working set)\n", rows, inner, n_units, iters, nbuf,
          nbuf * n * 4 / 1e6);
+  auto launch = [](const Variant& v, uint32_t g, const Args& a) {
+    if (v.any_order)
+      hipExtLaunchKernelGGL(v.fn, dim3(g), dim3(v.threads), 0, 0, nullptr, nullptr, hipExtAnyOrderLaunch, a);
+    else
+      hipLaunchKernelGGL(v.fn, dim3(g), dim3(v.threads), 0, 0, a);
+  };
   for (const Variant& v : V) {
     if (only && v.name.find(only) == std::string::npos) continue;
     const uint32_t wpb = v.threads / 64;
@@ -360,11 +578,11 @@ int main(int argc, char** argv) {
     for (uint32_t g : grids) {
       Args a = base;
       // correctness first (MATH variants): against the first MATH variant's output on buffer 0
-      const bool math = v.name.find(" m1 ") != std::string::npos;
+      const bool math = v.check == 1 && v.name.find(" m1 ") != std::string::npos;
       a.x = xs[0];
       a.y = have_ref || !math ? ys[0] : yref;
       CK(hipMemsetAsync(a.y, 0xff, n * 2));
-      hipLaunchKernelGGL(v.fn, dim3(g), dim3(v.threads), 0, 0, a);
+      launch(v, g, a);
       CK(hipDeviceSynchronize());
       long bad = -1;
       if (math) {
@@ -377,7 +595,7 @@ int main(int argc, char** argv) {
           bad = 0;
           for (size_t i = 0; i < n; ++i) bad += ytmp_h[i] != yref_h[i];
         }
-      } else {
+      } else if (v.check >= 0) {
         CK(hipMemcpy(ytmp_h, ys[0], n * 2, hipMemcpyDeviceToHost));
         std::vector<uint16_t> xin(n);
         CK(hipMemcpy(xin.data(), xs[0], n * 2, hipMemcpyDeviceToHost));
@@ -390,14 +608,14 @@ int main(int argc, char** argv) {
         for (int i = 0; i < 20; ++i) {
           a.x = xs[i % nbuf];
           a.y = ys[i % nbuf];
-          hipLaunchKernelGGL(v.fn, dim3(g), dim3(v.threads), 0, 0, a);
+          launch(v, g, a);
         }
         CK(hipDeviceSynchronize());
         CK(hipEventRecord(e0));
         for (int i = 0; i < iters; ++i) {
           a.x = xs[i % nbuf];
           a.y = ys[i % nbuf];
-          hipLaunchKernelGGL(v.fn, dim3(g), dim3(v.threads), 0, 0, a);
+          launch(v, g, a);
         }
         CK(hipEventRecord(e1));
         CK(hipEventSynchronize(e1));
@@ -414,13 +632,13 @@ int main(int argc, char** argv) {
         Args s = a;
         for (int i = 0; i < 8; ++i) {
           a.x = xs[i % nbuf]; a.y = ys[i % nbuf];
-          hipLaunchKernelGGL(v.fn, dim3(g), dim3(v.threads), 0, 0, a);
+          launch(v, g, a);
         }
         s.x = xs[8 % nbuf]; s.y = ys[8 % nbuf]; s.stamps = d_stamps;
-        hipLaunchKernelGGL(v.fn, dim3(g), dim3(v.threads), 0, 0, s);
+        launch(v, g, s);
         for (int i = 9; i < 17; ++i) {
           a.x = xs[i % nbuf]; a.y = ys[i % nbuf];
-          hipLaunchKernelGGL(v.fn, dim3(g), dim3(v.threads), 0, 0, a);
+          launch(v, g, a);
         }
         CK(hipDeviceSynchronize());
         std::vector<uint64_t> h(size_t(g) * 4);

@@ -404,6 +404,11 @@ __device__ __forceinline__ float key_float(uint32_t k) {
 int check_launch();  // hipGetLastError -> sbq_status, records the error string
 int knob(int which);
 uint32_t cu_count();  // compute units of the current device
+// sample-guided windowed selection of a whole tensor (sbq_select_win.hip)
+size_t win_select_workspace_bytes();
+int win_select_run(const void* const* shards, const int64_t* counts, int n_shards, int x_dtype, int use_abs, int n_sel,
+                   bool percentile, double alpha, int64_t k0, int64_t k1, float* out0, float* out1, void* workspace,
+                   size_t workspace_bytes, hipStream_t st);
 inline hipStream_t as_stream(void* s) { return static_cast<hipStream_t>(s); }
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 inline size_t dtype_size(int dt) { return dt == SBQ_F32 ? 4 : 2; }

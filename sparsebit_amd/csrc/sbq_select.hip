@@ -133,7 +133,10 @@ __global__ __launch_bounds__(kBlock) void percentile_rows_kernel(const void* __r
   }
   // Lower 24 bits: three 8-bit radix passes.  Only keys inside the chosen bucket take part and
   // mantissa digits spread over the 256 bins, so the LDS atomics rarely collide.
-  for (int pass = 1; pass < 4; ++pass) {
+  // 16-bit inputs: the low 16 (bf16) / 13 (fp16) key bits are the same for every element of one sign -- zeros for
+  // x >= 0, ones for x < 0 -- so the passes over them are skipped and the bits filled in from the sign at the end
+  constexpr int kPasses = T::id == SBQ_BF16 ? 1 : (T::id == SBQ_F16 ? 2 : 3);
+  for (int pass = 1; pass <= kPasses; ++pass) {
     const int shift = 24 - 8 * pass;
     hist[0][threadIdx.x] = 0;
     hist[1][threadIdx.x] = 0;
@@ -158,6 +161,17 @@ __global__ __launch_bounds__(kBlock) void percentile_rows_kernel(const void* __r
     __syncthreads();
     sel[0] = pick[0];
     sel[1] = pick[1];
+  }
+  if constexpr (kPasses < 3) {
+    constexpr uint32_t kLow = (1u << (24 - 8 * kPasses)) - 1u;  // undecided low bits
+    constexpr uint32_t kConst = T::id == SBQ_F16 ? 0x1fffu : 0xffffu;  // of which these are sign-determined
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      // fp16: bits 15..13 were decided by pass 2 (shift 8 covers bits 15..8; its low 5 bits are constant too and
+      // came out of the histogram as they are), so only the last byte is filled in here
+      const uint32_t fill = (sel[s2].prefix & 0x80000000u) ? 0u : (kConst & kLow);
+      sel[s2].prefix |= fill;
+    }
   }
   if (threadIdx.x == 0) {
     min_out[row] = neg > 0 ? key_float(sel[0].prefix) : 0.0f;
@@ -512,8 +526,11 @@ int sbq_radix_histogram(const void* x, int x_dtype, int64_t outer, int64_t C, in
 // the passes).  Workspace = [hist | state | counts].
 size_t sbq_radix_select_workspace_bytes(int64_t C, int n_sel) {
   if (C <= 0 || n_sel < 1 || n_sel > sbq::kMaxSel) return 0;
-  return static_cast<size_t>(C) * n_sel * SBQ_RADIX_BINS * 8 + static_cast<size_t>(C) * n_sel * 16 +
-         static_cast<size_t>(C) * 16 + 64;
+  const size_t fixed = static_cast<size_t>(C) * n_sel * SBQ_RADIX_BINS * 8 + static_cast<size_t>(C) * n_sel * 16 +
+                       static_cast<size_t>(C) * 16 + 64;
+  // a whole-tensor selection (C == 1) runs the windowed engine in the same workspace
+  const size_t win = C == 1 ? sbq::win_select_workspace_bytes() : 0;
+  return fixed > win ? fixed : win;
 }
 
 static int radix_select_run(const void* const* shards, const int64_t* outers, int n_shards, int x_dtype, int64_t C,
@@ -536,6 +553,17 @@ static int radix_select_run(const void* const* shards, const int64_t* outers, in
     if (!radix_geom(outers[i], C, inner, g)) return SBQ_ERR_ARG;
   }
   hipStream_t st = as_stream(stream);
+  // (fp32 percentile keeps the fixed-digit passes: its two tail windows span several binades of 32-bit keys and
+  // need three sweeps here as well, each a little dearer)
+  if (C == 1 && knob(2) != 7 && !(percentile && x_dtype == SBQ_F32)) {
+    // whole tensor, one process: the sample-guided windowed engine (sbq_select_win.hip; knob 2 == 7 keeps the
+    // fixed-digit passes below for A/B runs -- they are what the multi-process protocol is made of)
+    if (n_shards > 64) return SBQ_ERR_ARG;
+    int64_t counts[64];
+    for (int i = 0; i < n_shards; ++i) counts[i] = outers[i] * inner;
+    return win_select_run(shards, counts, n_shards, x_dtype, use_abs, n_sel, percentile, alpha, k0, k1,
+                          percentile ? min_out : values_out, max_out, workspace, workspace_bytes, st);
+  }
   const size_t hist_bytes = static_cast<size_t>(C) * n_sel * SBQ_RADIX_BINS * 8;
   int64_t* hist = static_cast<int64_t*>(workspace);
   int64_t* state = reinterpret_cast<int64_t*>(static_cast<char*>(workspace) + hist_bytes);

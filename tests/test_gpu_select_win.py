@@ -1,0 +1,110 @@
+"""The sample-guided windowed selection (csrc/sbq_select_win.hip) of a whole tensor: k-th values and percentile
+min / max, bit-exact against numpy's exact order statistics (np.partition on the same fp32 data, i.e. what
+torch.kthvalue / torch.sort return -- percentile.py:16-46, l1norm.py:18-26), against the oracle, and against the
+fixed-digit radix engine (knob 2 = 7).  The data include everything that defeats a sample: sorted and periodic
+inputs whose period equals the sampling stride, two-valued and constant tensors, heavy ties at the target rank,
+ranks at both ends, NaN / inf, tensors smaller than the sample and several cached batches.
+"""
+import numpy as np
+import pytest
+import torch
+
+from helpers import same_values
+from sparsebit_amd import lib as L
+from sparsebit_amd import ops
+
+pytestmark = pytest.mark.gpu
+
+DTYPES = [torch.bfloat16, torch.float16, torch.float32]
+
+
+def _kth_ref(xf, k, use_abs):
+    a = np.abs(xf) if use_abs else xf
+    a = a.reshape(-1)
+    # NaN sorts last (torch.sort / kthvalue); np.partition does the same
+    return np.partition(a, k - 1)[k - 1]
+
+
+def _datasets(n, dtype, seed):
+    g = torch.Generator().manual_seed(seed)
+    out = {}
+    out["gauss"] = torch.randn(n, generator=g)
+    out["sorted"] = torch.sort(torch.randn(n, generator=g))[0]
+    out["reversed"] = torch.sort(torch.randn(n, generator=g), descending=True)[0]
+    stride = max(n // 16384, 1)
+    per = torch.randn(n, generator=g)
+    per[::stride] = 1000.0  # every sampled element is an outlier: the sample sees a constant
+    out["period_eq_stride"] = per
+    out["two_values"] = (torch.rand(n, generator=g) < 0.5).float() * 2 - 1
+    out["constant"] = torch.full((n,), 0.37)
+    ties = torch.randn(n, generator=g)
+    ties[: n // 2] = 0.25  # half of the tensor on one key
+    out["half_tied"] = ties[torch.randperm(n, generator=g)]
+    heavy = torch.randn(n, generator=g) * torch.exp(3 * torch.randn(n, generator=g))
+    out["heavy_tail"] = heavy
+    out["tiny_values"] = torch.randn(n, generator=g) * 1e-30
+    return {k: v.to(dtype) for k, v in out.items()}
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("n", [1, 7, 1000, 16384, 16385, 300001, 4096 * 1024 + 3])
+def test_kth_value_all_datasets(dtype, n):
+    for name, x in _datasets(n, dtype, n % 1000 + 1).items():
+        xf = x.float().numpy()
+        xd = x.cuda()
+        ks = sorted({1, n, max(1, n // 2), max(1, n // 1000), max(1, n - n // 1000), min(n, int(n * 0.77) + 1)})
+        for use_abs in (False, True):
+            for k in ks:
+                got = float(ops.kth_value(xd, k, use_abs))
+                want = float(_kth_ref(xf, k, use_abs))
+                assert got == want or (np.isnan(got) and np.isnan(want)), (name, n, k, use_abs, got, want)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_kth_value_equals_fixed_digit_engine(dtype):
+    n = 2_000_003
+    g = torch.Generator().manual_seed(5)
+    x = (torch.randn(n, generator=g) * torch.exp(torch.randn(n, generator=g))).to(dtype)
+    x[100:110] = float("nan")
+    x[200] = float("inf")
+    x[201] = float("-inf")
+    x[300:400] = -0.0
+    xd = x.cuda()
+    try:
+        for use_abs in (False, True):
+            for k in (1, 2, 1000, n // 2, n - 1000, n - 11, n - 10, n - 9, n):
+                L.set_tuning(2, 7)
+                old = ops.kth_value(xd, k, use_abs).cpu().numpy()
+                L.set_tuning(2, 0)
+                new = ops.kth_value(xd, k, use_abs).cpu().numpy()
+                assert same_values(old, new), (k, use_abs, old, new)
+    finally:
+        L.set_tuning(2, 0)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("alpha", [0.0, 1e-5, 1e-3, 0.01, 0.3, 0.5, 1.0])
+def test_percentile_per_tensor_batches_vs_oracle(oracle, dtype, alpha):
+    """percentile.py:16-46 over three cached batches (per tensor: one row of all their elements)."""
+    g = torch.Generator().manual_seed(int(alpha * 1e6) + 3)
+    for name, maker in (("gauss", lambda: torch.randn(64, 197, 96, generator=g)),
+                        ("relu", lambda: torch.relu(torch.randn(64, 197, 96, generator=g))),   # no negatives
+                        ("neg", lambda: -torch.rand(64, 197, 96, generator=g) - 0.1),            # no non-negatives
+                        ("sorted", lambda: torch.sort(torch.randn(64 * 197 * 96, generator=g))[0].reshape(64, 197, 96))):
+        xs = [maker().to(dtype) for _ in range(3)]
+        mn, mx = ops.percentile_select([x.cuda() for x in xs], alpha, 0, False)
+        data = np.concatenate([x.float().numpy().reshape(-1) for x in xs])
+        rmn, rmx = oracle.percentile(data, alpha, per_channel=False)
+        assert same_values(mn.cpu().numpy(), rmn) and same_values(mx.cpu().numpy(), rmx), (name, alpha, mn, rmn, mx, rmx)
+
+
+def test_mask_threshold_config5_size(oracle):
+    """l1norm.py:18-26 at the headline size: the 50 % threshold of a 4096x4096 bf16 weight."""
+    g = torch.Generator().manual_seed(55)
+    w = (torch.randn(4096, 4096, generator=g) * torch.logspace(-2, 1, 4096).unsqueeze(1)).bfloat16()
+    n = w.numel()
+    for ratio in (0.5, 0.9, 0.01):
+        idx = min(int(n * ratio), n - 1)
+        got = float(ops.kth_value(w.cuda(), idx + 1, True))
+        want = float(_kth_ref(w.float().numpy(), idx + 1, True))
+        assert got == want, (ratio, got, want)

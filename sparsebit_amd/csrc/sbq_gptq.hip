@@ -58,7 +58,7 @@ struct GptqGeom {
 template <int BITS, int SK, int COLS, int kBT>
 __global__ __launch_bounds__(kBlock) void gptq_partial_kernel(
     const float* __restrict__ x, const int32_t* __restrict__ qw, const float* __restrict__ scales,
-    const float* __restrict__ zeros, float* __restrict__ part, const GptqGeom g) {
+    const float* __restrict__ zeros, float* __restrict__ out, float* __restrict__ part, const GptqGeom g) {
   constexpr int kUnitRows = BITS == 3 ? 3 : 1;
   constexpr int kUnitCh = 32 * kUnitRows / BITS;   // 8 / 32 / 16 channels
   constexpr int kUnits = SK / kUnitCh;             // per slice
@@ -66,7 +66,9 @@ __global__ __launch_bounds__(kBlock) void gptq_partial_kernel(
   constexpr int kSliceRows = SK * BITS / 32;
   static_assert(kUnits % kWavesPerBlock == 0 && kUPW >= 1, "slice must split evenly over the waves");
   __shared__ __attribute__((aligned(16))) float xs[kBT][SK];
-  __shared__ float red[kWavesPerBlock][kBT][kWave * COLS];
+  // the four waves' accumulators are folded through LDS eight batch rows at a time (kBT = 32 would need 128 KB)
+  constexpr int kRedB = kBT < 8 ? kBT : 8;
+  __shared__ float red[kWavesPerBlock][kRedB][kWave * COLS];
   const int lane = threadIdx.x & (kWave - 1);
   const int wid = threadIdx.x / kWave;
   const int64_t col0 = (static_cast<int64_t>(blockIdx.x) * kWave + lane) * COLS;
@@ -122,36 +124,47 @@ __global__ __launch_bounds__(kBlock) void gptq_partial_kernel(
         const int kk0 = (wid + i * kWavesPerBlock) * kUnitCh;
 #pragma unroll
         for (int h = 0; h < kUnitCh / 4; ++h) {
-          f32x4 xv[kBT];
+          // dequantize the 4 channels x COLS columns once, then stream the batch rows over them: the weights stay
+          // in registers for every batch row of the tile (one read of the matrix for up to 32 rows)
+          float wt[COLS][4];
 #pragma unroll
-          for (int b = 0; b < kBT; ++b) xv[b] = *reinterpret_cast<const f32x4*>(&xs[b][kk0 + 4 * h]);
-#pragma unroll
-          for (int j = 0; j < COLS; ++j) {
+          for (int j = 0; j < COLS; ++j)
 #pragma unroll
             for (int n = 0; n < 4; ++n) {
               const float lvl = static_cast<float>(
                   stream_level<BITS>([&](int idx) { return w[i][idx][j]; }, 4 * h + n));
-              const float wt = __builtin_fmaf(sc[j], lvl, -zr[j]);
-#pragma unroll
-              for (int b = 0; b < kBT; ++b) acc[j][b] = __builtin_fmaf(wt, xv[b][n], acc[j][b]);
+              wt[j][n] = __builtin_fmaf(sc[j], lvl, -zr[j]);
             }
+#pragma unroll
+          for (int b = 0; b < kBT; ++b) {
+            const f32x4 xv = *reinterpret_cast<const f32x4*>(&xs[b][kk0 + 4 * h]);
+#pragma unroll
+            for (int j = 0; j < COLS; ++j)
+#pragma unroll
+              for (int n = 0; n < 4; ++n) acc[j][b] = __builtin_fmaf(wt[j][n], xv[n], acc[j][b]);
           }
         }
       }
     }
-    // fold the 4 waves (fixed order) and store this K block's partial tile
-    __syncthreads();
+    // fold the 4 waves (fixed order) and store this K block's partial tile -- or, when this workgroup saw all
+    // of K, add it to `out` (pre-filled with the bias) directly
 #pragma unroll
-    for (int b = 0; b < kBT; ++b)
+    for (int bb = 0; bb < kBT; bb += kRedB) {
+      __syncthreads();
 #pragma unroll
-      for (int j = 0; j < COLS; ++j) red[wid][b][lane * COLS + j] = acc[j][b];
-    __syncthreads();
-    for (int i = threadIdx.x; i < kBT * kWave * COLS; i += kBlock) {
-      const int b = i / (kWave * COLS), cc = i - b * (kWave * COLS);
-      const int64_t col = static_cast<int64_t>(blockIdx.x) * kWave * COLS + cc;
-      if (b0 + b < g.batch && col < g.out_features) {
-        const float t = ((red[0][b][cc] + red[1][b][cc]) + red[2][b][cc]) + red[3][b][cc];
-        part[(static_cast<int64_t>(kb) * g.batch + (b0 + b)) * g.out_features + col] = t;
+      for (int b = 0; b < kRedB; ++b)
+#pragma unroll
+        for (int j = 0; j < COLS; ++j) red[wid][b][lane * COLS + j] = acc[j][bb + b];
+      __syncthreads();
+      for (int i = threadIdx.x; i < kRedB * kWave * COLS; i += kBlock) {
+        const int b = i / (kWave * COLS), cc = i - b * (kWave * COLS);
+        const int64_t col = static_cast<int64_t>(blockIdx.x) * kWave * COLS + cc;
+        const int64_t row = b0 + bb + b;
+        if (row < g.batch && col < g.out_features) {
+          const float t = ((red[0][b][cc] + red[1][b][cc]) + red[2][b][cc]) + red[3][b][cc];
+          if (g.kblocks == 1) out[row * g.out_features + col] += t;
+          else part[(static_cast<int64_t>(kb) * g.batch + row) * g.out_features + col] = t;
+        }
       }
     }
   }
@@ -225,6 +238,12 @@ __global__ __launch_bounds__(8 * KL) void gptq_strip_kernel(
   // 16-byte loads of x need aligned rows
   const bool x_vec = (reinterpret_cast<uintptr_t>(x) & 15u) == 0 && (g.in_features & 3) == 0;
 
+  const bool owner = threadIdx.x < kBT * kStripCols;  // one thread per (batch row of the tile, column)
+  const int ob = threadIdx.x / kStripCols, occ = threadIdx.x - ob * kStripCols;
+  const int64_t ocol = static_cast<int64_t>(blockIdx.x) * kStripCols + occ;
+  // batch rows in tiles of kBT (a mat-VEC is one tile; up to 32 rows re-read the strip's weights -- out of L2 /
+  // Infinity Cache from the second tile on -- inside the same launch)
+  for (int64_t b0 = 0; b0 < g.batch; b0 += kBT) {
   float acc[4][kBT];
 #pragma unroll
   for (int j = 0; j < 4; ++j)
@@ -247,8 +266,8 @@ __global__ __launch_bounds__(8 * KL) void gptq_strip_kernel(
         const int e = (j * kThreads + threadIdx.x) * 4;  // element of the pass, multiple of 4
         const int64_t k = kbase + e;
         xg[b][j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-        if (b < g.batch) {
-          const float* xr = x + b * g.in_features + k;
+        if (b0 + b < g.batch) {
+          const float* xr = x + (b0 + b) * g.in_features + k;
           if (x_vec && k + 4 <= g.in_features) {
             xg[b][j] = *reinterpret_cast<const f32x4*>(xr);
           } else {
@@ -424,24 +443,25 @@ __global__ __launch_bounds__(8 * KL) void gptq_strip_kernel(
     }
   }
   // fold the K lanes in ascending order
+  __syncthreads();  // the previous tile's readers are done with `red`
 #pragma unroll
   for (int b = 0; b < kBT; ++b)
 #pragma unroll
     for (int j = 0; j < 4; ++j) red[kl][b][cl * 4 + j] = acc[j][b];
   __syncthreads();
-  const bool owner = threadIdx.x < kBT * kStripCols;  // one thread per (batch row, column)
-  const int ob = threadIdx.x / kStripCols, occ = threadIdx.x - ob * kStripCols;
-  const int64_t ocol = static_cast<int64_t>(blockIdx.x) * kStripCols + occ;
-  float t = 0.0f;
-  if (owner) {
+  if (owner && b0 + ob < g.batch) {
+    float t = 0.0f;
 #pragma unroll
     for (int q = 0; q < KL; ++q) t += red[q][ob][occ];
+    if (split == 1)  // this workgroup saw all of K: add to out (pre-filled with the bias)
+      out[(b0 + ob) * g.out_features + ocol] += t;
+    else
+      __hip_atomic_store(&part[(static_cast<int64_t>(blockIdx.y) * g.batch + b0 + ob) * g.out_features + ocol], t,
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  if (split == 1) {  // this workgroup saw all of K: add to out (pre-filled with the bias)
-    if (owner && ob < g.batch) out[ob * g.out_features + ocol] += t;
-    return;
-  }
-  // publish the partial, count the arrival; the last one folds all S partials in index order.
+  }  // batch tiles
+  if (split == 1) return;
+  // publish the partials, count the arrival; the last one folds all S partials in index order.
   // No agent-scope fence anywhere: on gfx950 such a fence writes back / invalidates the whole
   // per-XCD L2 (measured: +15..35 us per launch with ~1000 workgroups doing it).  Instead every
   // access of the protocol individually goes to the device-coherent level -- agent-scope atomic
@@ -449,9 +469,7 @@ __global__ __launch_bounds__(8 * KL) void gptq_strip_kernel(
   // is "my partial stores are acknowledged before my arrival is counted": s_waitcnt vmcnt(0)
   // (a workgroup-scope release fence) + the barrier.  The fold's loads depend on the counter
   // value through LDS and the barrier, so they are issued after the add has returned.
-  if (owner && ob < g.batch)
-    __hip_atomic_store(&part[(static_cast<int64_t>(blockIdx.y) * g.batch + ob) * g.out_features + ocol], t,
-                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // tests/test_gpu_gptq_stress.py: 10^4 calls on two streams under load, bit-equal, counters back at zero.
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __builtin_amdgcn_s_waitcnt(0);  // belt and braces: all counters drained
   __syncthreads();
@@ -459,12 +477,29 @@ __global__ __launch_bounds__(8 * KL) void gptq_strip_kernel(
     s_prev = __hip_atomic_fetch_add(&arrivals[blockIdx.x], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __syncthreads();
   if (s_prev != static_cast<uint32_t>(split - 1)) return;
-  if (owner && ob < g.batch) {
-    float total = 0.0f;
-    for (int sidx = 0; sidx < split; ++sidx)
-      total += __hip_atomic_load(&part[(static_cast<int64_t>(sidx) * g.batch + ob) * g.out_features + ocol],
-                                 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    out[ob * g.out_features + ocol] += total;
+  // (row, column) outputs of the strip, four per thread at a time so that four independent loads are in flight
+  // per partial index instead of one
+  const int64_t n_out = g.batch * kStripCols;
+  for (int64_t i0 = threadIdx.x; i0 < n_out; i0 += 4 * kThreads) {
+    float total[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    int64_t addr[4];
+    bool ok[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int64_t i = i0 + static_cast<int64_t>(u) * kThreads;
+      ok[u] = i < n_out;
+      const int64_t row = ok[u] ? i / kStripCols : 0, cc = ok[u] ? i - row * kStripCols : 0;
+      addr[u] = row * g.out_features + static_cast<int64_t>(blockIdx.x) * kStripCols + cc;
+    }
+    for (int sidx = 0; sidx < split; ++sidx) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        total[u] += __hip_atomic_load(&part[static_cast<int64_t>(sidx) * g.batch * g.out_features + addr[u]],
+                                      __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (ok[u]) out[addr[u]] += total[u];
   }
   if (threadIdx.x == 0)  // leave the counter as we found it: the workspace stays reusable
     __hip_atomic_store(&arrivals[blockIdx.x], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -520,24 +555,31 @@ int64_t gptq_max_kblocks(int64_t in_f, int64_t out_f) {
   return want < 1 ? 1 : want;
 }
 
+// General path (any shape, any batch): K blocks write partial tiles, a second kernel adds them in a fixed order.
 template <int BITS, int SK>
 int gptq_launch_partial(const float* x, const int32_t* qweight, float* out, const float* scales,
                         const float* zeros, float* part, const GptqGeom& g, bool vec, hipStream_t st) {
   const int64_t batch = g.batch;
-  const int bt = batch >= 8 ? 8 : (batch >= 3 ? 4 : (batch == 2 ? 2 : 1));
-#define SBQ_GPTQ(COLS)                                                                              \
-  do {                                                                                              \
-    dim3 grid(static_cast<uint32_t>(ceil_div(g.out_features, kWave * COLS)), static_cast<uint32_t>(g.kblocks)); \
-    if (bt == 8) gptq_partial_kernel<BITS, SK, COLS, 8><<<grid, kBlock, 0, st>>>(x, qweight, scales, zeros, part, g); \
-    else if (bt == 4) gptq_partial_kernel<BITS, SK, COLS, 4><<<grid, kBlock, 0, st>>>(x, qweight, scales, zeros, part, g); \
-    else if (bt == 2) gptq_partial_kernel<BITS, SK, COLS, 2><<<grid, kBlock, 0, st>>>(x, qweight, scales, zeros, part, g); \
-    else gptq_partial_kernel<BITS, SK, COLS, 1><<<grid, kBlock, 0, st>>>(x, qweight, scales, zeros, part, g);  \
+  // batch rows per register tile: the matrix is read once per tile, so up to 32 rows share one read
+  const int bt = batch > 16 ? 32 : (batch > 8 ? 16 : (batch > 4 ? 8 : (batch >= 3 ? 4 : (batch == 2 ? 2 : 1))));
+#define SBQ_GPTQ_K(COLS, BT) \
+  gptq_partial_kernel<BITS, SK, COLS, BT><<<grid, kBlock, 0, st>>>(x, qweight, scales, zeros, out, part, g)
+#define SBQ_GPTQ(COLS)                                                                                          \
+  do {                                                                                                          \
+    const dim3 grid(static_cast<uint32_t>(ceil_div(g.out_features, kWave * COLS)), static_cast<uint32_t>(g.kblocks)); \
+    if (bt == 32) SBQ_GPTQ_K(COLS, 32);                                                                         \
+    else if (bt == 16) SBQ_GPTQ_K(COLS, 16);                                                                    \
+    else if (bt == 8) SBQ_GPTQ_K(COLS, 8);                                                                      \
+    else if (bt == 4) SBQ_GPTQ_K(COLS, 4);                                                                      \
+    else if (bt == 2) SBQ_GPTQ_K(COLS, 2);                                                                      \
+    else SBQ_GPTQ_K(COLS, 1);                                                                                   \
   } while (0)
   if (vec) SBQ_GPTQ(4);
   else SBQ_GPTQ(1);
 #undef SBQ_GPTQ
+#undef SBQ_GPTQ_K
   int rc = check_launch();
-  if (rc != SBQ_OK) return rc;
+  if (rc != SBQ_OK || g.kblocks == 1) return rc;
   const int64_t bn = batch * g.out_features;
   gptq_fold_kernel<<<static_cast<uint32_t>(ceil_div(bn, kBlock)), kBlock, 0, st>>>(part, out, bn, g.kblocks);
   return check_launch();
@@ -573,7 +615,9 @@ int gptq_matmul(const float* x, const int32_t* qweight, float* out, const float*
   const int64_t strips = out_features / kStripCols;
   // batches of 3 and 4 (a handful of concurrent decode streams) take the same single launch with four
   // batch rows per register tile, half-group K lanes only (register budget)
-  if (vec && out_features % kStripCols == 0 && (batch == 3 || batch == 4) && !half_slices && strips <= kMaxStrips &&
+  // ... and so do batches up to 32 (the reference's kernel takes any batch in one launch,
+  // cuda_kernel_4bit.cu:36-81): tiles of four rows, the strip's weights re-read per tile out of the caches
+  if (vec && out_features % kStripCols == 0 && batch >= 3 && batch <= 32 && !half_slices && strips <= kMaxStrips &&
       knob(2) != 9) {
     int64_t split = ceil_div(in_features, 32 * (kSliceK / 2));
     if (split > kStripMaxSplit) split = kStripMaxSplit;

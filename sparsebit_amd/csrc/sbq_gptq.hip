@@ -49,6 +49,7 @@ struct GptqGeom {
   int32_t slices;      // K slices
   int32_t slices_per_block;
   int32_t kblocks;     // ceil(slices / slices_per_block)
+  int32_t xcd_swizzle; // strip kernels: XCD-aware strip order (strips % 8 == 0)
 };
 
 // COLS = 4: 16-byte loads (out_features % 4 == 0, aligned); COLS = 1: any shape.
@@ -218,8 +219,153 @@ __device__ __forceinline__ float strip_level(const u32x4 (&w)[ROWS], int j, int 
 // exact floats per instruction and its result pair feeds v_pk_fma_f32 directly; the 2^9 is folded back
 // into the scale (a power of two: the products are the same reals).  The activations are staged in LDS
 // in the matching pair order (x0, x2, x1, x3).
-template <int BITS, int kBT, int KL, int CH, bool DEC8 = false>
-__global__ __launch_bounds__(8 * KL) void gptq_strip_kernel(
+// One K lane's share of a pass: its CH channels x 4 columns against kBT activation rows (staged in LDS, row stride
+// XS floats), dequantization factored out of the inner loop (see the kernel's header comment).
+template <int BITS, int kBT, int CH, bool DEC8, int XS>
+__device__ __forceinline__ void strip_compute(const u32x4 (&w)[CH * BITS / 32], const float* __restrict__ xs, int kl,
+                                              const float (&sc)[4], const float (&zr)[4], float (&acc)[4][kBT]) {
+  constexpr int kRows = CH * BITS / 32;
+  constexpr int kXStride = CH + 4;
+  float dot[4][kBT], xsum[kBT];
+#pragma unroll
+  for (int b = 0; b < kBT; ++b) {
+    xsum[b] = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) dot[j][b] = 0.0f;
+  }
+  if constexpr (DEC8 && BITS == 2) {
+    f32x2 dot2[4][kBT];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int b = 0; b < kBT; ++b) dot2[j][b] = f32x2{0.0f, 0.0f};
+#pragma unroll
+    for (int i = 0; i < CH / 16; ++i) {  // one weight word = 16 channels at a time
+      f32x2 xa[kBT][4], xb[kBT][4];      // (x_s, x_s+4) and (x_s+8, x_s+12), s = 0..3
+#pragma unroll
+      for (int b = 0; b < kBT; ++b) {
+        const float* xr = &xs[b * XS + kl * kXStride + i * 16];
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+          const f32x4 q = *reinterpret_cast<const f32x4*>(xr + 4 * h);
+          if (h < 2) {
+            xa[b][2 * h] = f32x2{q[0], q[1]};
+            xa[b][2 * h + 1] = f32x2{q[2], q[3]};
+          } else {
+            xb[b][2 * (h - 2)] = f32x2{q[0], q[1]};
+            xb[b][2 * (h - 2) + 1] = f32x2{q[2], q[3]};
+          }
+#pragma unroll
+          for (int n = 0; n < 4; ++n) xsum[b] += q[n];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const uint32_t word = w[i][j];
+#pragma unroll
+        for (int sft = 0; sft < 4; ++sft) {
+          const uint32_t m = (word >> (2 * sft)) & 0x03030303u;  // crumbs s, s+4, s+8, s+12 alone in bytes
+          const f32x2 la = __builtin_amdgcn_cvt_pk_f32_fp8(m, false);
+          const f32x2 lb = __builtin_amdgcn_cvt_pk_f32_fp8(m, true);
+#pragma unroll
+          for (int b = 0; b < kBT; ++b) {
+            dot2[j][b] = __builtin_elementwise_fma(la, xa[b][sft], dot2[j][b]);
+            dot2[j][b] = __builtin_elementwise_fma(lb, xb[b][sft], dot2[j][b]);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int b = 0; b < kBT; ++b) dot[j][b] = (dot2[j][b][0] + dot2[j][b][1]) * 512.0f;  // exact: 2^9
+  } else if constexpr (DEC8) {
+    static_assert(!DEC8 || BITS == 4 || BITS == 2, "the e4m3 decode needs a level alone in a byte");
+    f32x2 dot2[4][kBT];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int b = 0; b < kBT; ++b) dot2[j][b] = f32x2{0.0f, 0.0f};
+#pragma unroll
+    for (int i = 0; i < CH / 8; ++i) {  // one weight word = 8 channels at a time
+      f32x2 xp[kBT][4];                 // (x0,x2) (x1,x3) (x4,x6) (x5,x7)
+#pragma unroll
+      for (int b = 0; b < kBT; ++b) {
+        const float* xr = &xs[b * XS + kl * kXStride + i * 8];
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(xr), hi = *reinterpret_cast<const f32x4*>(xr + 4);
+        xp[b][0] = f32x2{lo[0], lo[1]};
+        xp[b][1] = f32x2{lo[2], lo[3]};
+        xp[b][2] = f32x2{hi[0], hi[1]};
+        xp[b][3] = f32x2{hi[2], hi[3]};
+#pragma unroll
+        for (int n = 0; n < 4; ++n) xsum[b] += lo[n];
+#pragma unroll
+        for (int n = 0; n < 4; ++n) xsum[b] += hi[n];
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const uint32_t word = w[i][j];
+        const uint32_t even = word & 0x0f0f0f0fu, odd = (word >> 4) & 0x0f0f0f0fu;
+        const f32x2 l02 = __builtin_amdgcn_cvt_pk_f32_fp8(even, false);
+        const f32x2 l13 = __builtin_amdgcn_cvt_pk_f32_fp8(odd, false);
+        const f32x2 l46 = __builtin_amdgcn_cvt_pk_f32_fp8(even, true);
+        const f32x2 l57 = __builtin_amdgcn_cvt_pk_f32_fp8(odd, true);
+#pragma unroll
+        for (int b = 0; b < kBT; ++b) {
+          dot2[j][b] = __builtin_elementwise_fma(l02, xp[b][0], dot2[j][b]);
+          dot2[j][b] = __builtin_elementwise_fma(l13, xp[b][1], dot2[j][b]);
+          dot2[j][b] = __builtin_elementwise_fma(l46, xp[b][2], dot2[j][b]);
+          dot2[j][b] = __builtin_elementwise_fma(l57, xp[b][3], dot2[j][b]);
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int b = 0; b < kBT; ++b) dot[j][b] = (dot2[j][b][0] + dot2[j][b][1]) * 512.0f;  // exact: 2^9
+  } else {
+#pragma unroll
+    for (int i = 0; i < CH / 8; ++i) {  // 8 channels at a time
+      f32x4 xv[kBT][2];
+  #pragma unroll
+      for (int b = 0; b < kBT; ++b) {
+        const float* xr = &xs[b * XS + kl * kXStride + i * 8];
+        xv[b][0] = *reinterpret_cast<const f32x4*>(xr);
+        xv[b][1] = *reinterpret_cast<const f32x4*>(xr + 4);
+  #pragma unroll
+        for (int n = 0; n < 8; ++n) xsum[b] += xv[b][n >> 2][n & 3];
+      }
+  #pragma unroll
+      for (int j = 0; j < 4; ++j) {
+  #pragma unroll
+        for (int n = 0; n < 8; ++n) {
+          const float lvl = strip_level<BITS, kRows>(w, j, i * 8 + n);
+  #pragma unroll
+          for (int b = 0; b < kBT; ++b) dot[j][b] = __builtin_fmaf(lvl, xv[b][n >> 2][n & 3], dot[j][b]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int b = 0; b < kBT; ++b) acc[j][b] += __builtin_fmaf(sc[j], dot[j][b], -(zr[j] * xsum[b]));
+}
+
+// LDS-DMA of one 16-byte word per lane: global -> LDS without passing through (or occupying) VGPRs.  The wave's
+// 64 words land at m0 + lane * 16.
+__device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_dst) {
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
+// PF (HBM-sized matrices, several passes per workgroup): the weights of pass p+1 travel global -> LDS by DMA while
+// pass p is being computed, and are picked up from LDS at the top of pass p+1.  A wave only ever reads back the
+// words its own lanes requested, so the weight ring needs no barrier; in-flight bytes cost LDS, not registers,
+// so three workgroups per CU keep ~96 KB of weight reads outstanding ALL the time instead of 4 x 32 KB half of it.
+template <int BITS, int kBT, int KL, int CH, bool DEC8 = false, bool PF = false>
+__global__ __launch_bounds__(8 * KL) __attribute__((amdgpu_waves_per_eu(CH == 64 && kBT == 1 ? (PF ? 3 : 4) : 1, 8))) void gptq_strip_kernel(
     const float* __restrict__ x, const int32_t* __restrict__ qw, const float* __restrict__ scales,
     const float* __restrict__ zeros, float* __restrict__ out, float* __restrict__ part,
     uint32_t* __restrict__ arrivals, const GptqGeom g) {
@@ -233,14 +379,20 @@ __global__ __launch_bounds__(8 * KL) void gptq_strip_kernel(
   __shared__ uint32_t s_prev;
   const int cl = threadIdx.x & 7;   // column quad inside the strip
   const int kl = threadIdx.x >> 3;  // K lane
-  const int64_t col0 = static_cast<int64_t>(blockIdx.x) * kStripCols + cl * 4;
+  // XCD-aware strip order: consecutive workgroup ids go round-robin over the 8 XCDs, so with strip = blockIdx.x
+  // the neighbouring 128-byte pieces of a qweight row are requested by eight different L2s.  Giving XCD i the
+  // i-th contiguous eighth of the strips makes the workgroups that run side by side on one XCD read adjacent
+  // pieces of the same rows (knob 2 == 8: plain order, for A/B runs).
+  uint32_t strip = blockIdx.x;
+  if (g.xcd_swizzle) strip = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  const int64_t col0 = static_cast<int64_t>(strip) * kStripCols + cl * 4;
   const int split = gridDim.y;
   // 16-byte loads of x need aligned rows
   const bool x_vec = (reinterpret_cast<uintptr_t>(x) & 15u) == 0 && (g.in_features & 3) == 0;
 
   const bool owner = threadIdx.x < kBT * kStripCols;  // one thread per (batch row of the tile, column)
   const int ob = threadIdx.x / kStripCols, occ = threadIdx.x - ob * kStripCols;
-  const int64_t ocol = static_cast<int64_t>(blockIdx.x) * kStripCols + occ;
+  const int64_t ocol = static_cast<int64_t>(strip) * kStripCols + occ;
   // batch rows in tiles of kBT (a mat-VEC is one tile; up to 32 rows re-read the strip's weights -- out of L2 /
   // Infinity Cache from the second tile on -- inside the same launch)
   for (int64_t b0 = 0; b0 < g.batch; b0 += kBT) {
@@ -250,6 +402,107 @@ __global__ __launch_bounds__(8 * KL) void gptq_strip_kernel(
 #pragma unroll
     for (int b = 0; b < kBT; ++b) acc[j][b] = 0.0f;
 
+  if constexpr (PF) {
+    __shared__ __attribute__((aligned(1024))) uint8_t wring[kThreads * 16 * kRows];  // [row i][lane] 16-byte words
+    const uint32_t wave_base = __builtin_amdgcn_readfirstlane(
+        static_cast<uint32_t>(reinterpret_cast<uintptr_t>(wring)) + (threadIdx.x & ~63u) * 16u);
+    const int64_t step = static_cast<int64_t>(split) * kRowsPerPass;
+    auto load_small = [&](int64_t pass0, f32x4 (&xg)[kBT][kXLoads], float (&sc)[4], float (&zr)[4]) {
+      const int64_t kbase = (pass0 / kRows) * CH;
+#pragma unroll
+      for (int b = 0; b < kBT; ++b)
+#pragma unroll
+        for (int j = 0; j < kXLoads; ++j) {
+          const int e = (j * kThreads + threadIdx.x) * 4;
+          const int64_t k = kbase + e;
+          xg[b][j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+          if (b0 + b < g.batch) {
+            const float* xr = x + (b0 + b) * g.in_features + k;
+            if (x_vec && k + 4 <= g.in_features) {
+              xg[b][j] = *reinterpret_cast<const f32x4*>(xr);
+            } else {
+#pragma unroll
+              for (int n = 0; n < 4; ++n)
+                if (k + n < g.in_features) xg[b][j][n] = xr[n];
+            }
+          }
+        }
+      const int64_t k0 = kbase + static_cast<int64_t>(kl) * CH;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) sc[j] = zr[j] = 0.0f;
+      if (pass0 + kl * kRows < g.H) {
+        const int grp = static_cast<int>(k0 / g.group_size);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          sc[j] = scales[(col0 + j) * g.groups + grp];
+          zr[j] = zeros[(col0 + j) * g.groups + grp];
+        }
+      }
+    };
+    auto dma_weights = [&](int64_t pass0) {
+      const int64_t row0 = pass0 + kl * kRows;
+#pragma unroll
+      for (int i = 0; i < kRows; ++i) {
+        int64_t r = row0 + i;
+        if (r >= g.H) r = g.H - 1;  // valid address; a dead K lane never uses the words
+        glds16(qw + r * g.out_features + col0, wave_base + static_cast<uint32_t>(i) * (kThreads * 16u));
+      }
+    };
+    f32x4 xg_n[kBT][kXLoads];
+    float sc_n[4], zr_n[4];
+    const int64_t first = static_cast<int64_t>(blockIdx.y) * kRowsPerPass;
+    if (first < g.H) {
+      load_small(first, xg_n, sc_n, zr_n);
+      dma_weights(first);
+    }
+    for (int64_t pass0 = first; pass0 < g.H; pass0 += step) {
+      const bool live = pass0 + kl * kRows < g.H;
+      // this pass's weights (DMA) and small loads have landed
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      f32x4 xg[kBT][kXLoads];
+      float sc[4], zr[4];
+#pragma unroll
+      for (int b = 0; b < kBT; ++b)
+#pragma unroll
+        for (int j = 0; j < kXLoads; ++j) xg[b][j] = xg_n[b][j];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        sc[j] = sc_n[j];
+        zr[j] = zr_n[j];
+      }
+      u32x4 w[kRows];
+#pragma unroll
+      for (int i = 0; i < kRows; ++i)
+        w[i] = *reinterpret_cast<const u32x4*>(wring + static_cast<size_t>(i) * (kThreads * 16) + threadIdx.x * 16);
+      __syncthreads();  // previous pass done with xs
+#pragma unroll
+      for (int b = 0; b < kBT; ++b)
+#pragma unroll
+        for (int j = 0; j < kXLoads; ++j) {
+          const int e = (j * kThreads + threadIdx.x) * 4;
+          const int lane_k = e / CH, off = e - lane_k * CH;
+          f32x4 t = xg[b][j];
+          if constexpr (DEC8 && BITS == 2) {
+            const int k = (off >> 2) & 3;
+            float* dst = &xs[b][lane_k * kXStride + (off & ~15) + 8 * (k >> 1) + (k & 1)];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dst[2 * r] = t[r];
+          } else {
+            if constexpr (DEC8) t = f32x4{t[0], t[2], t[1], t[3]};
+            *reinterpret_cast<f32x4*>(&xs[b][lane_k * kXStride + off]) = t;
+          }
+        }
+      // the weight words are in registers: the ring is free for the next pass, whose loads now overlap this
+      // pass's arithmetic
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (pass0 + step < g.H) {
+        load_small(pass0 + step, xg_n, sc_n, zr_n);
+        dma_weights(pass0 + step);
+      }
+      __syncthreads();
+      if (live) strip_compute<BITS, kBT, CH, DEC8, KL * kXStride>(w, &xs[0][0], kl, sc, zr, acc);
+    }
+  } else {
   // passes y, y + S, y + 2S, ... of the K dimension
   for (int64_t pass0 = static_cast<int64_t>(blockIdx.y) * kRowsPerPass; pass0 < g.H;
        pass0 += static_cast<int64_t>(split) * kRowsPerPass) {
@@ -315,132 +568,8 @@ __global__ __launch_bounds__(8 * KL) void gptq_strip_kernel(
         }
       }
     __syncthreads();
-    if (live) {
-      float dot[4][kBT], xsum[kBT];
-#pragma unroll
-      for (int b = 0; b < kBT; ++b) {
-        xsum[b] = 0.0f;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) dot[j][b] = 0.0f;
-      }
-      if constexpr (DEC8 && BITS == 2) {
-        f32x2 dot2[4][kBT];
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-          for (int b = 0; b < kBT; ++b) dot2[j][b] = f32x2{0.0f, 0.0f};
-#pragma unroll
-        for (int i = 0; i < CH / 16; ++i) {  // one weight word = 16 channels at a time
-          f32x2 xa[kBT][4], xb[kBT][4];      // (x_s, x_s+4) and (x_s+8, x_s+12), s = 0..3
-#pragma unroll
-          for (int b = 0; b < kBT; ++b) {
-            const float* xr = &xs[b][kl * kXStride + i * 16];
-#pragma unroll
-            for (int h = 0; h < 4; ++h) {
-              const f32x4 q = *reinterpret_cast<const f32x4*>(xr + 4 * h);
-              if (h < 2) {
-                xa[b][2 * h] = f32x2{q[0], q[1]};
-                xa[b][2 * h + 1] = f32x2{q[2], q[3]};
-              } else {
-                xb[b][2 * (h - 2)] = f32x2{q[0], q[1]};
-                xb[b][2 * (h - 2) + 1] = f32x2{q[2], q[3]};
-              }
-#pragma unroll
-              for (int n = 0; n < 4; ++n) xsum[b] += q[n];
-            }
-          }
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const uint32_t word = w[i][j];
-#pragma unroll
-            for (int sft = 0; sft < 4; ++sft) {
-              const uint32_t m = (word >> (2 * sft)) & 0x03030303u;  // crumbs s, s+4, s+8, s+12 alone in bytes
-              const f32x2 la = __builtin_amdgcn_cvt_pk_f32_fp8(m, false);
-              const f32x2 lb = __builtin_amdgcn_cvt_pk_f32_fp8(m, true);
-#pragma unroll
-              for (int b = 0; b < kBT; ++b) {
-                dot2[j][b] = __builtin_elementwise_fma(la, xa[b][sft], dot2[j][b]);
-                dot2[j][b] = __builtin_elementwise_fma(lb, xb[b][sft], dot2[j][b]);
-              }
-            }
-          }
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-          for (int b = 0; b < kBT; ++b) dot[j][b] = (dot2[j][b][0] + dot2[j][b][1]) * 512.0f;  // exact: 2^9
-      } else if constexpr (DEC8) {
-        static_assert(!DEC8 || BITS == 4 || BITS == 2, "the e4m3 decode needs a level alone in a byte");
-        f32x2 dot2[4][kBT];
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-          for (int b = 0; b < kBT; ++b) dot2[j][b] = f32x2{0.0f, 0.0f};
-#pragma unroll
-        for (int i = 0; i < CH / 8; ++i) {  // one weight word = 8 channels at a time
-          f32x2 xp[kBT][4];                 // (x0,x2) (x1,x3) (x4,x6) (x5,x7)
-#pragma unroll
-          for (int b = 0; b < kBT; ++b) {
-            const float* xr = &xs[b][kl * kXStride + i * 8];
-            const f32x4 lo = *reinterpret_cast<const f32x4*>(xr), hi = *reinterpret_cast<const f32x4*>(xr + 4);
-            xp[b][0] = f32x2{lo[0], lo[1]};
-            xp[b][1] = f32x2{lo[2], lo[3]};
-            xp[b][2] = f32x2{hi[0], hi[1]};
-            xp[b][3] = f32x2{hi[2], hi[3]};
-#pragma unroll
-            for (int n = 0; n < 4; ++n) xsum[b] += lo[n];
-#pragma unroll
-            for (int n = 0; n < 4; ++n) xsum[b] += hi[n];
-          }
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const uint32_t word = w[i][j];
-            const uint32_t even = word & 0x0f0f0f0fu, odd = (word >> 4) & 0x0f0f0f0fu;
-            const f32x2 l02 = __builtin_amdgcn_cvt_pk_f32_fp8(even, false);
-            const f32x2 l13 = __builtin_amdgcn_cvt_pk_f32_fp8(odd, false);
-            const f32x2 l46 = __builtin_amdgcn_cvt_pk_f32_fp8(even, true);
-            const f32x2 l57 = __builtin_amdgcn_cvt_pk_f32_fp8(odd, true);
-#pragma unroll
-            for (int b = 0; b < kBT; ++b) {
-              dot2[j][b] = __builtin_elementwise_fma(l02, xp[b][0], dot2[j][b]);
-              dot2[j][b] = __builtin_elementwise_fma(l13, xp[b][1], dot2[j][b]);
-              dot2[j][b] = __builtin_elementwise_fma(l46, xp[b][2], dot2[j][b]);
-              dot2[j][b] = __builtin_elementwise_fma(l57, xp[b][3], dot2[j][b]);
-            }
-          }
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-          for (int b = 0; b < kBT; ++b) dot[j][b] = (dot2[j][b][0] + dot2[j][b][1]) * 512.0f;  // exact: 2^9
-      } else {
-#pragma unroll
-        for (int i = 0; i < CH / 8; ++i) {  // 8 channels at a time
-          f32x4 xv[kBT][2];
-  #pragma unroll
-          for (int b = 0; b < kBT; ++b) {
-            const float* xr = &xs[b][kl * kXStride + i * 8];
-            xv[b][0] = *reinterpret_cast<const f32x4*>(xr);
-            xv[b][1] = *reinterpret_cast<const f32x4*>(xr + 4);
-  #pragma unroll
-            for (int n = 0; n < 8; ++n) xsum[b] += xv[b][n >> 2][n & 3];
-          }
-  #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-  #pragma unroll
-            for (int n = 0; n < 8; ++n) {
-              const float lvl = strip_level<BITS, kRows>(w, j, i * 8 + n);
-  #pragma unroll
-              for (int b = 0; b < kBT; ++b) dot[j][b] = __builtin_fmaf(lvl, xv[b][n >> 2][n & 3], dot[j][b]);
-            }
-          }
-        }
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int b = 0; b < kBT; ++b) acc[j][b] += __builtin_fmaf(sc[j], dot[j][b], -(zr[j] * xsum[b]));
-    }
+    if (live) strip_compute<BITS, kBT, CH, DEC8, KL * kXStride>(w, &xs[0][0], kl, sc, zr, acc);
+  }
   }
   // fold the K lanes in ascending order
   __syncthreads();  // the previous tile's readers are done with `red`
@@ -474,7 +603,7 @@ __global__ __launch_bounds__(8 * KL) void gptq_strip_kernel(
   __builtin_amdgcn_s_waitcnt(0);  // belt and braces: all counters drained
   __syncthreads();
   if (threadIdx.x == 0)
-    s_prev = __hip_atomic_fetch_add(&arrivals[blockIdx.x], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_prev = __hip_atomic_fetch_add(&arrivals[strip], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __syncthreads();
   if (s_prev != static_cast<uint32_t>(split - 1)) return;
   // (row, column) outputs of the strip, four per thread at a time so that four independent loads are in flight
@@ -489,7 +618,7 @@ __global__ __launch_bounds__(8 * KL) void gptq_strip_kernel(
       const int64_t i = i0 + static_cast<int64_t>(u) * kThreads;
       ok[u] = i < n_out;
       const int64_t row = ok[u] ? i / kStripCols : 0, cc = ok[u] ? i - row * kStripCols : 0;
-      addr[u] = row * g.out_features + static_cast<int64_t>(blockIdx.x) * kStripCols + cc;
+      addr[u] = row * g.out_features + static_cast<int64_t>(strip) * kStripCols + cc;
     }
     for (int sidx = 0; sidx < split; ++sidx) {
 #pragma unroll
@@ -502,7 +631,7 @@ __global__ __launch_bounds__(8 * KL) void gptq_strip_kernel(
       if (ok[u]) out[addr[u]] += total[u];
   }
   if (threadIdx.x == 0)  // leave the counter as we found it: the workspace stays reusable
-    __hip_atomic_store(&arrivals[blockIdx.x], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&arrivals[strip], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // out[b,n] += sum over K blocks, ascending
@@ -542,6 +671,7 @@ bool gptq_geom(int bits, int slice_k, int64_t batch, int64_t in_f, int64_t out_f
   if (want > g.slices) want = g.slices;
   g.slices_per_block = static_cast<int32_t>(ceil_div(g.slices, want));
   g.kblocks = static_cast<int32_t>(ceil_div(g.slices, g.slices_per_block));
+  g.xcd_swizzle = ((out_f / 32) % 8 == 0 && knob(2) != 8) ? 1 : 0;
   return true;
 }
 
@@ -632,11 +762,20 @@ int gptq_matmul(const float* x, const int32_t* qweight, float* out, const float*
     // 128-channel group when that alone fills the chip; otherwise half a group, which doubles
     // the workgroup count and halves each one's serial decode (decode shapes: 4096x4096 is 128
     // strips on 256 CUs).  The K split S then covers the K lanes a single pass does not.
-    int ch = strips * ceil_div(in_features, 32 * kSliceK) >= 1024 ? kSliceK : kSliceK / 2;
+    // Half-group K lanes throughout since round 2: with 128 VGPRs four workgroups share a CU (a whole-group lane
+    // needs 195: two), which is worth 7-20 % on the HBM-sized shapes and nothing less on the decode shapes.
+    int ch = kSliceK / 2;
     if (knob(2) == 1) ch = kSliceK;      // dev overrides
     if (knob(2) == 2) ch = kSliceK / 2;
-    int64_t split = ceil_div(in_features, 32 * ch);
+    // K split: as many K blocks as fill the chip a few times over (about 8 workgroups per CU in total), no more --
+    // every extra block is another partial tile, another arrival and another workgroup start-up for the same bytes.
+    // A matrix with >= 2048 strips needs none: each workgroup walks all of K and adds to `out` directly.
+    const int64_t passes = ceil_div(in_features, 32 * ch);
+    int64_t split = ceil_div(static_cast<int64_t>(cu_count()) * 8, strips);
+    if (knob(1) > 0) split = knob(1);  // dev override (shares the grid-cap knob)
+    if (split > passes) split = passes;
     if (split > kStripMaxSplit) split = kStripMaxSplit;
+    if (split < 1) split = 1;
     const dim3 grid(static_cast<uint32_t>(strips), static_cast<uint32_t>(split));
 #define SBQ_STRIP(CH, D8)                                                                                  \
   do {                                                                                                     \
@@ -645,12 +784,29 @@ int gptq_matmul(const float* x, const int32_t* qweight, float* out, const float*
     else                                                                                                   \
       gptq_strip_kernel<BITS, 1, 32, CH, D8><<<grid, 256, 0, st>>>(x, qweight, scales, zeros, out, part, arrivals, g); \
   } while (0)
+    // several passes per workgroup (HBM-sized matrices): the next pass's weights are prefetched by LDS-DMA
+    // (knob 2 == 6: off, for A/B runs)
+    const bool prefetch = ch == kSliceK / 2 && passes >= 2 * split && knob(2) != 6;
     if constexpr (BITS == 4 || BITS == 2) {
       if (knob(2) != 4) {  // packed e4m3 decode (knob 2 == 4: byte converts, for A/B runs)
+        if (prefetch) {
+          if (batch == 2)
+            gptq_strip_kernel<BITS, 2, 32, 64, true, true><<<grid, 256, 0, st>>>(x, qweight, scales, zeros, out, part, arrivals, g);
+          else
+            gptq_strip_kernel<BITS, 1, 32, 64, true, true><<<grid, 256, 0, st>>>(x, qweight, scales, zeros, out, part, arrivals, g);
+          return check_launch();
+        }
         if (ch == kSliceK) SBQ_STRIP(128, true);
         else SBQ_STRIP(64, true);
         return check_launch();
       }
+    }
+    if (prefetch && BITS == 3) {
+      if (batch == 2)
+        gptq_strip_kernel<BITS, 2, 32, 64, false, true><<<grid, 256, 0, st>>>(x, qweight, scales, zeros, out, part, arrivals, g);
+      else
+        gptq_strip_kernel<BITS, 1, 32, 64, false, true><<<grid, 256, 0, st>>>(x, qweight, scales, zeros, out, part, arrivals, g);
+      return check_launch();
     }
     if (ch == kSliceK) SBQ_STRIP(128, false);
     else SBQ_STRIP(64, false);

@@ -17,7 +17,12 @@ def timed(fn, iters=50, warm=10):
     return best
 shapes = [(4096, 4096), (4096, 11008), (11008, 4096), (8192, 8192), (8192, 32768), (9216, 36864), (12288, 49152)]
 batches = [1, 4, 8, 32]
+_b = batches
 bits = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+if len(sys.argv) > 2:
+    L.set_tuning(2, int(sys.argv[2]))  # 1 / 2: 128 / 64 channels per K lane, 9: two-launch path
+if len(sys.argv) > 3:
+    batches = [int(a) for a in sys.argv[3].split(",")]
 print("bits %d group 128; bytes = qweight + scales + zeros + x + 2 * out" % bits)
 for in_f, out_f in shapes:
     g = torch.Generator().manual_seed(1)

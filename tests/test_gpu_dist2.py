@@ -1,0 +1,154 @@
+"""On-device multi-rank calibration: two processes sharing cuda:0, torch.distributed over gloo.
+
+tests/test_dist_gloo.py drives sparsebit_amd.dist / select with CPU statistics; this file runs the PRODUCT call
+sites on the GPU with world_size 2 -- the collective inside every observer class (observers/minmax.py, mse.py,
+percentile.py with ops.HipSelectBackend, quantizers/lsq.py) and DeviceCalibrator.calibrate(sharded=True) -- and
+compares each rank's result with the single-process calibration of the union of the shards, computed on the same
+device outside the sharded context:
+  min/max, percentile      bit-exact (order-independent statistics, exact distributed radix select)
+  MSE                      same candidate index, same scale / zero point
+  LSQ init                 1e-6 relative (fp32 sum of per-shard sums)
+The reference has no such path (every rank calibrates alone, examples/quantization_aware_training/imagenet1k/
+basecase/main.py:240-255); the contract is SURVEY.md 8(e).  On an 8-GPU node the same code runs over RCCL.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+pytestmark = pytest.mark.gpu
+
+
+def _mk(scheme, bit, observer, target="feature", layout="NCHW", quantizer="uniform", alpha=None):
+    from sparsebit_amd.common import Backend
+    from sparsebit_amd.config import quantizer_config
+    from sparsebit_amd.quantizers import build_quantizer
+
+    kw = {} if alpha is None else {"alpha": alpha}
+    q = build_quantizer(quantizer_config(scheme, bit, quantizer=quantizer, observer=observer, target=target,
+                                         layout=layout, **kw))
+    q.set_backend(Backend.VIRTUAL)
+    return q
+
+
+CASES = [
+    # name, scheme, bit, observer, quantizer, kwargs
+    ("minmax/tensor", "per-tensor-affine", 8, "MINMAX", "uniform", {}),
+    ("minmax/channel", "per-channel-symmetric", 8, "MINMAX", "uniform", {}),
+    ("mse/tensor", "per-tensor-symmetric", 8, "MSE", "uniform", {}),
+    ("mse/channel", "per-channel-affine", 8, "MSE", "uniform", {}),
+    ("pct/tensor", "per-tensor-affine", 8, "PERCENTILE", "uniform", {"alpha": 1e-3}),
+    ("pct/channel", "per-channel-symmetric", 8, "PERCENTILE", "uniform", {"alpha": 0.01}),
+    ("lsq/tensor", "per-tensor-symmetric", 4, "MINMAX", "lsq", {}),
+    ("lsq/channel", "per-channel-symmetric", 4, "MINMAX", "lsq", {}),
+]
+
+
+class _Net(torch.nn.Module):
+    """two quantized operators in the QuantOpr convention (attributes input_quantizer / weight_quantizer / weight)"""
+
+    def __init__(self, wq, aq):
+        super().__init__()
+
+        class Op(torch.nn.Module):
+            def __init__(self, mod):
+                super().__init__()
+                self.fwd = mod
+                self.weight = mod.weight
+                self.input_quantizer = aq()
+                self.weight_quantizer = wq()
+
+            def forward(self, x):
+                return self.fwd(self.input_quantizer(x))
+
+        torch.manual_seed(9)
+        self.c1 = Op(torch.nn.Conv2d(3, 8, 3, padding=1))
+        self.c2 = Op(torch.nn.Conv2d(8, 8, 3, padding=1))
+
+    def forward(self, x):
+        return self.c2(torch.relu(self.c1(x)))
+
+
+def _worker(rank, world, port, tmp):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from sparsebit_amd import dist as sd
+
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    g = torch.Generator().manual_seed(2024)  # the same stream on every rank: identical "global" data
+    batches = [(torch.randn(8, 16, 14, 14, generator=g) * (1 + 0.3 * i)).to(dev) for i in range(4)]
+    mine = batches[rank::world]
+    ok = {}
+
+    def run(case, shards):
+        name, scheme, bit, observer, quantizer, kw = case
+        q = _mk(scheme, bit, observer, quantizer=quantizer, **kw).to(dev)
+        for b in shards:
+            q.update_observer(b)
+        s, z = q.calc_qparams()
+        best = getattr(q.observer, "best_index", None)
+        return s.detach().reshape(-1).float().cpu().numpy(), z.detach().reshape(-1).float().cpu().numpy(), best
+
+    for case in CASES:
+        with sd.sharded_calibration():
+            assert sd.active() and sd.world_size() == world
+            s, z, best = run(case, mine)
+        rs, rz, rbest = run(case, batches)  # single process, the union, same device
+        name = case[0]
+        if name.startswith("lsq"):
+            ok[name] = bool(np.allclose(s, rs, rtol=1e-6, atol=0) and np.array_equal(z, rz))
+        elif name.startswith("mse"):
+            ok[name] = bool(torch.equal(best.cpu(), rbest.cpu()) and np.array_equal(s, rs) and np.array_equal(z, rz))
+        else:
+            ok[name] = bool(np.array_equal(s, rs) and np.array_equal(z, rz))
+
+    # ---- the calibration driver: sharded == single process on every quantizer of a small model ----
+    from sparsebit_amd.calibration import DeviceCalibrator
+
+    imgs = [torch.randn(4, 3, 12, 12, generator=g).to(dev) for _ in range(4)]
+    for tag, wq, aq in (("minmax", lambda: _mk("per-channel-symmetric", 8, "MINMAX", target="weight"),
+                         lambda: _mk("per-tensor-affine", 8, "MINMAX")),
+                        ("pct_mse", lambda: _mk("per-channel-symmetric", 8, "PERCENTILE", target="weight", alpha=0.01),
+                         lambda: _mk("per-tensor-symmetric", 8, "MSE"))):
+        m_sh = _Net(wq, aq).to(dev)
+        m_one = _Net(wq, aq).to(dev)
+        res_sh = DeviceCalibrator(m_sh).calibrate(imgs[rank::world], sharded=True)
+        res_one = DeviceCalibrator(m_one).calibrate(imgs)
+        good = sorted(res_sh) == sorted(res_one) and len(res_sh) == 4
+        for k in res_one:
+            good = good and torch.equal(res_sh[k][0], res_one[k][0]) and torch.equal(res_sh[k][1], res_one[k][1])
+        ok["calibrator/" + tag] = bool(good)
+
+    # ---- unstructured mask of a row-sharded weight: the global threshold (sparsers/l1norm.py under dist) ----
+    from sparsebit_amd import ops, select
+
+    w = torch.randn(256, 96, generator=g).to(dev)
+    idx = min(int(w.numel() * 0.5), w.numel() - 1)
+    with sd.sharded_calibration():
+        v = select.kth_values([w[rank::world].contiguous()], [[idx + 1]], ops.HipSelectBackend(), True, 0, False, dev)
+    ok["mask_thresh"] = float(v.reshape(())) == float(ops.kth_value(w, idx + 1, True))
+
+    torch.save(ok, os.path.join(tmp, "rank%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_observer_classes_two_ranks_on_device(tmp_path):
+    world = 2
+    port = 29600 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        ok = torch.load(os.path.join(str(tmp_path), "rank%d.pt" % r))
+        bad = [k for k, v in ok.items() if not v]
+        assert not bad, (r, bad)
+        assert len(ok) == len(CASES) + 3

@@ -291,6 +291,17 @@ int sbq_qparams_from_minmax(const float* min_val, const float* max_val, int64_t 
                             int qmin, int qmax, int symmetric,
                             float* scale_out, float* zero_point_out, void* stream);
 
+/* Fused min-max observer + qparams + QDQ of a per-channel weight [C, inner] in ONE read of x (4 bytes per element for
+ * bf16 in / out instead of 2 + 4 in two launches): observers/minmax.py:14-25 -> observers/base.py:63-79 ->
+ * quantizers/base.py:55-64.  Writes y, scale_out / zero_point_out [C] and the observer's min_out / max_out [C].
+ * Bit-identical to sbq_channel_stats + sbq_qparams_from_minmax + sbq_quant_perchannel_forward, which is also what
+ * it runs for geometries the fused kernel does not take (rows other than 2048 / 4096 elements, unaligned pointers).
+ * workspace: as for sbq_channel_stats (sbq_stats_workspace_bytes). */
+int sbq_observe_quant_perchannel_forward(const void* x, int x_dtype, void* y, int y_dtype,
+                                         float* scale_out, float* zero_point_out, float* min_out, float* max_out,
+                                         int64_t C, int64_t inner, int qmin, int qmax, int symmetric,
+                                         void* workspace, size_t workspace_bytes, void* stream);
+
 /* Wire format of the cross-GPU min/max exchange: ONE MAX all-reduce over
  * buf[4C] = { max or -inf if NaN, -min or -inf if NaN, isnan(max), isnan(min) }.
  * pack builds it from a rank's local statistics, unpack restores (min, max) with the NaNs

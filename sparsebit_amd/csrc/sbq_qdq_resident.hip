@@ -54,8 +54,14 @@ __device__ __forceinline__ u32x2 bld8(__amdgpu_buffer_rsrc_t r, uint32_t voff, u
 __device__ __forceinline__ uint32_t bld4(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
   return __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 2);
 }
+// The s_nop: a buffer store of more than 64 bits reads its data registers a cycle after issue; a VALU write to
+// them in the very next slot corrupts the stored value.  The compiler inserts that wait state only when the store
+// has NO SGPR soffset (GCNHazardRecognizer::createsVALUHazard) -- with one, gfx950 showed the hazard all the same:
+// qdq_observe_kernel<BF16, F32> stored 2^40 (the next slab's range constant, moved into a data register right
+// behind the store) in a few lanes of a few rows.  One wait state restores it; tests/test_gpu_observe_fused.py.
 __device__ __forceinline__ void bst16(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff, u32x4 v) {
   __builtin_amdgcn_raw_buffer_store_b128(v, r, voff, soff, 2);
+  asm volatile("s_nop 1");
 }
 // two fp32 -> one dword of two 16-bit values (RNE), as ONE packed convert
 template <typename T>
@@ -307,6 +313,174 @@ __global__ __launch_bounds__(kResBlock) void qdq_resident_kernel(
   }
 }
 
+// ---- fused observe + QDQ of a weight --------------------------------------------------
+// min-max observer -> scale / zero point -> quantize-dequantize in ONE read of the weight: 4 bytes per element
+// (bf16 in and out) instead of 2 (statistics) + 4 (QDQ) in two launches.  Replaces, for a per-channel weight,
+//   observers/minmax.py:14-25 + observers/base.py:63-79 (calc_qparams_with_minmax) + quantizers/base.py:55-64.
+// Same workgroup shape as the resident kernel: 512 threads = 2 sub-blocks of 256 lanes, a wave holds U slabs in
+// registers.  A row is 1 or 2 whole slabs (inner = 2048 or 4096), so with slab(u) = sl0 + 2u + sub a row's
+// elements sit in ONE workgroup at ONE u: its extrema are a wave reduction, an LDS exchange between the 4 (8)
+// waves and a single barrier for all U rows; every lane then derives the row's scale / zero point itself
+// (qparams_from_minmax: the reference's fp32 operations) and converts its slab in place.  NaN propagates like
+// torch.min / max: v_min / v_max drop it, a separate flag restores it (as in stats_partial_kernel).
+struct RowStat {
+  float mn, mx;
+  int nan;
+};
+
+template <typename Tin, typename Tout, int U>
+__global__ __launch_bounds__(kResBlock) void qdq_observe_kernel(
+    const void* __restrict__ x, uint32_t n_slabs, uint32_t slabs_per_row, uint32_t symmetric, float qlo, float qhi,
+    void* __restrict__ y, float* __restrict__ scale_out, float* __restrict__ zp_out,
+    // ---- not preloaded ----
+    float* __restrict__ min_out, float* __restrict__ max_out) {
+  constexpr bool SPLIT = Tout::id == SBQ_F32;
+  constexpr uint32_t kIn = Tin::id == SBQ_F32 ? 4 : 2, kOut = Tout::id == SBQ_F32 ? 4 : 2;
+  constexpr uint32_t kSlabElems = kBlock * kPack;
+  constexpr int kWaves = kResBlock / kWave;
+  __shared__ RowStat part[U][kWaves];
+  const uint32_t sub = __builtin_amdgcn_readfirstlane(threadIdx.x / kBlock);
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+  const uint32_t tid = threadIdx.x % kBlock;
+  const uint32_t lane = threadIdx.x & (kWave - 1);
+  const uint32_t laneA = SPLIT ? 4 * tid : kPack * tid;
+  const uint32_t laneB = laneA + kSlabElems / 2;
+  const uint32_t sl0 = blockIdx.x * (kResSub * U) + sub;
+  RawPack<Tin> raw[U];
+  const uint32_t inA = laneA * kIn, inB = laneB * kIn;
+  const __amdgpu_buffer_rsrc_t rx = make_rsrc(x, n_slabs * (kSlabElems * kIn));
+  const __amdgpu_buffer_rsrc_t ry = make_rsrc(y, n_slabs * (kSlabElems * kOut));
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const uint32_t sl = sl0 + u * kResSub;
+    const uint32_t so = (sl < n_slabs ? sl : 0u) * (kSlabElems * kIn);
+    if constexpr (SPLIT) {
+      if constexpr (Tin::id == SBQ_F32) {
+        raw[u].d[0] = bld16(rx, inA, so);
+        raw[u].d[1] = bld16(rx, inB, so);
+      } else {
+        const u32x2 a = bld8(rx, inA, so), b = bld8(rx, inB, so);
+        raw[u].d[0] = u32x4{a[0], a[1], b[0], b[1]};
+      }
+    } else {
+      raw[u].d[0] = bld16(rx, inA, so);
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);  // all loads in flight first
+  // phase A: per slab, as it lands: the lane's extrema, the wave's, one LDS record per (u, wave)
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    float v[kPack];
+    unpack_raw<Tin>(raw[u], v);
+    float mn = v[0], mx = v[0];
+    int nan = v[0] != v[0];
+#pragma unroll
+    for (int j = 1; j < kPack; ++j) {
+      mn = __builtin_fminf(mn, v[j]);
+      mx = __builtin_fmaxf(mx, v[j]);
+      nan |= v[j] != v[j];
+    }
+    mn = wave_reduce(mn, [](float a, float b) { return __builtin_fminf(a, b); });
+    mx = wave_reduce(mx, [](float a, float b) { return __builtin_fmaxf(a, b); });
+    const bool any_nan = __builtin_amdgcn_ballot_w64(nan != 0) != 0;
+    if (lane == 0) part[u][wave] = RowStat{mn, mx, any_nan ? 1 : 0};
+  }
+  __syncthreads();
+  // phase B: lane u of every wave turns slab u's records into the row's scale / zero point (the reference's fp32
+  // operations, qparams_from_minmax) -- U lanes work, once, instead of every lane U times -- and the results are
+  // handed to the whole wave as scalars (v_readlane)
+  const bool two = slabs_per_row == 2;  // row = both sub-blocks of this u; else each sub-block has its own row
+  const float qrange = qhi - qlo;
+  float my_sc = 1.0f, my_zp = 0.0f;
+  if (lane < static_cast<uint32_t>(U)) {
+    const int w0 = two ? 0 : static_cast<int>(sub) * (kWaves / 2);
+    const int nw = two ? kWaves : kWaves / 2;
+    float mn = part[lane][w0].mn, mx = part[lane][w0].mx;
+    int nan = part[lane][w0].nan;
+    for (int w = 1; w < nw; ++w) {
+      mn = __builtin_fminf(mn, part[lane][w0 + w].mn);
+      mx = __builtin_fmaxf(mx, part[lane][w0 + w].mx);
+      nan |= part[lane][w0 + w].nan;
+    }
+    if (nan) mn = mx = __builtin_nanf("");
+    qparams_from_minmax(mn, mx, qrange, symmetric != 0, my_sc, my_zp);
+    const uint32_t sl = sl0 + lane * kResSub;
+    // one wave per row publishes the observer's results
+    if (sl < n_slabs && (wave & (kWaves / 2 - 1)) == 0 && (!two || sub == 0)) {
+      const uint32_t row = two ? sl / 2 : sl;
+      scale_out[row] = my_sc;
+      zp_out[row] = my_zp;
+      if (min_out) min_out[row] = mn;
+      if (max_out) max_out[row] = mx;
+    }
+  }
+  float sc[U], zp[U];
+  bool all_fast = true;
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    sc[u] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_sc), u));
+    zp[u] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_zp), u));
+    all_fast &= fast_div_ok(sc[u]);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  // phase C: convert and store slab after slab (every load has landed: stores now keep the memory system busy
+  // while the next slab is converted).  A wave that meets a value the fast division does not cover (NaN, inf,
+  // |x| >= s * 2^40, or a row whose scale is NaN) redoes its tile through the generic arithmetic afterwards:
+  // the same bytes are written twice, the second time with the right values.
+  bool odd = false;
+  const uint32_t outA = laneA * kOut, outB = laneB * kOut;
+  if (all_fast) {
+    auto convert = [&](auto zp_tag) {
+      constexpr bool ZP = decltype(zp_tag)::value;
+      static_for<U>([&](auto uc) {
+        constexpr int u = decltype(uc)::value;
+        if constexpr (ZP) asm volatile("; observe: affine" : "+v"(raw[u].d[0]));
+        else asm volatile("; observe: symmetric" : "+v"(raw[u].d[0]));
+        float v[kPack], dq[kPack];
+        unpack_raw<Tin>(raw[u], v);
+        fast_pack<MASK_NONE, ZP>(v, u32x2{0, 0}, 0.0f, sc[u], zp[u], qlo, qhi, dq, odd);
+        OutPack<Tout> o;
+        pack_out<Tout>(dq, o);
+        const uint32_t sl = sl0 + u * kResSub;
+        if (sl < n_slabs) {
+          bst16(ry, outA, sl * (kSlabElems * kOut), o.d[0]);
+          if constexpr (SPLIT) bst16(ry, outB, sl * (kSlabElems * kOut), o.d[Tout::id == SBQ_F32 ? 1 : 0]);
+        }
+      });
+    };
+    if (symmetric) convert(std::false_type{});
+    else convert(std::true_type{});
+    if (__builtin_amdgcn_ballot_w64(odd) == 0) return;
+  }
+  // cold path (a row whose scale the fast division does not cover -- NaN, or an element that is NaN / inf):
+  // the tile again from memory, slab by slab, through the generic arithmetic
+#pragma nounroll
+  for (uint32_t u = 0; u < static_cast<uint32_t>(U); ++u) {
+    const uint32_t sl = sl0 + u * kResSub;
+    if (sl >= n_slabs) break;
+    float s_ = 0.0f, z_ = 0.0f;
+#pragma unroll
+    for (int k = 0; k < U; ++k)
+      if (static_cast<uint32_t>(k) == u) {
+        s_ = sc[k];
+        z_ = zp[k];
+      }
+    const int64_t e0 = static_cast<int64_t>(sl) * kSlabElems;
+    RawPack<Tin> r;
+    if constexpr (SPLIT) r = load_raw2<Tin, true>(x, e0 + laneA, e0 + laneB);
+    else r = load_raw<Tin, true>(x, e0 + laneA);
+    float v[kPack], lv[kPack], dq[kPack];
+    unpack_raw<Tin>(r, v);
+    quantize_pack<MASK_NONE, false, MATH_FAST>(v, u32x2{0, 0}, 0.0f, s_, z_, qlo, qhi, lv, dq);
+    if constexpr (SPLIT) {
+      store_half_f32<true>(y, e0 + laneA, dq);
+      store_half_f32<true>(y, e0 + laneB, dq + 4);
+    } else {
+      store_pack<Tout, true>(y, e0 + laneA, dq);
+    }
+  }
+}
+
 // Resident schedule (see qdq_resident_kernel): chosen when the whole tensor is one sitting of the chip.
 // knob 3: 0 auto, 1 never, 2 always (whatever the size: more workgroups than CUs).
 template <typename Tin, typename Tout, int MASK>
@@ -351,6 +525,22 @@ bool resident_mask(const ResidentCall& c, hipStream_t st) {
 
 }  // namespace
 
+template <typename Tin, typename Tout>
+void launch_observe(const void* x, void* y, float* scale, float* zp, float* mn, float* mx, uint32_t n_slabs, uint32_t spr,
+                    int symmetric, float qlo, float qhi, hipStream_t st) {
+  const uint32_t cus = cu_count();
+  const uint32_t cap16 = cus * kResSub * 16u;
+  // 8 slabs per wave at most: measured on 4096x4096 bf16, 16 slabs per wave (one workgroup per CU) take 18.0 us
+  // against 14.4 us -- the statistics and conversion phases of a lone workgroup leave the memory system idle
+  const int U = n_slabs <= cap16 / 4 ? 4 : 8;
+#define SBQ_OBS(UV)                                                                                               \
+  qdq_observe_kernel<Tin, Tout, UV><<<(n_slabs + kResSub * UV - 1) / (kResSub * UV), kResBlock, 0, st>>>(          \
+      x, n_slabs, spr, symmetric ? 1u : 0u, qlo, qhi, y, scale, zp, mn, mx)
+  if (U == 8) SBQ_OBS(8);
+  else SBQ_OBS(4);
+#undef SBQ_OBS
+}
+
 bool qdq_try_resident(const ResidentCall& c, hipStream_t st) {
   if (c.x_dtype == SBQ_F32) return resident_mask<F32, F32>(c, st);
   if (c.x_dtype == SBQ_F16) return c.y_dtype == SBQ_F32 ? resident_mask<F16, F32>(c, st) : resident_mask<F16, F16>(c, st);
@@ -358,3 +548,38 @@ bool qdq_try_resident(const ResidentCall& c, hipStream_t st) {
 }
 
 }  // namespace sbq
+
+extern "C" int sbq_observe_quant_perchannel_forward(const void* x, int x_dtype, void* y, int y_dtype, float* scale_out,
+                                                    float* zero_point_out, float* min_out, float* max_out, int64_t C,
+                                                    int64_t inner, int qmin, int qmax, int symmetric, void* workspace,
+                                                    size_t workspace_bytes, void* stream) {
+  using namespace sbq;
+  if (!valid_dtype(x_dtype) || !valid_dtype(y_dtype)) return SBQ_ERR_DTYPE;
+  if (y_dtype != SBQ_F32 && y_dtype != x_dtype) return SBQ_ERR_DTYPE;
+  if (C < 0 || inner < 0) return SBQ_ERR_ARG;
+  if (C == 0 || inner == 0) return SBQ_ERR_EMPTY;
+  if (!x || !y || !scale_out || !zero_point_out || !min_out || !max_out) return SBQ_ERR_NULL;
+  if (qmin >= qmax) return SBQ_ERR_ARG;
+  hipStream_t st = as_stream(stream);
+  const int64_t slab = kBlock * kPack;
+  const bool fused = (inner == slab || inner == 2 * slab) && aligned16(x) && aligned16(y) &&
+                     C * (inner / slab) <= (1ll << 18) && knob(3) != 1;
+  if (fused) {
+    const uint32_t spr = static_cast<uint32_t>(inner / slab), n_slabs = static_cast<uint32_t>(C) * spr;
+    const float qlo = static_cast<float>(qmin), qhi = static_cast<float>(qmax);
+#define SBQ_O(TI, TO) launch_observe<TI, TO>(x, y, scale_out, zero_point_out, min_out, max_out, n_slabs, spr, symmetric, qlo, qhi, st)
+    if (x_dtype == SBQ_F32) SBQ_O(F32, F32);
+    else if (x_dtype == SBQ_F16) { if (y_dtype == SBQ_F32) SBQ_O(F16, F32); else SBQ_O(F16, F16); }
+    else { if (y_dtype == SBQ_F32) SBQ_O(BF16, F32); else SBQ_O(BF16, BF16); }
+#undef SBQ_O
+    return check_launch();
+  }
+  // any other geometry: the three steps one after the other (same results: the fused kernel is these, fused)
+  int rc = sbq_channel_stats(x, x_dtype, 1, C, inner, min_out, max_out, nullptr, workspace, workspace_bytes, stream);
+  if (rc != SBQ_OK) return rc;
+  rc = sbq_qparams_from_minmax(min_out, max_out, C, qmin, qmax, symmetric, scale_out, zero_point_out, stream);
+  if (rc != SBQ_OK) return rc;
+  return sbq_quant_perchannel_forward(x, x_dtype, y, y_dtype, nullptr, SBQ_Q_NONE, scale_out, zero_point_out, 1, C,
+                                      inner, qmin, qmax, SBQ_ROUND_HALF_EVEN, stream);
+}
+

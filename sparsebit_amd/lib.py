@@ -117,6 +117,10 @@ _SIGNATURES = {
         [c_vp, c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_int, c_int, c_int, c_vp, c_sz, c_vp],
     ),
     "sbq_stats_workspace_bytes": (c_sz, [c_i64, c_i64, c_i64]),
+    "sbq_observe_quant_perchannel_forward": (
+        c_int,
+        [c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_int, c_int, c_int, c_vp, c_sz, c_vp],
+    ),
     "sbq_channel_stats": (c_int, [c_vp, c_int, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "sbq_channel_moments": (c_int, [c_vp, c_int, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "sbq_aciq_thresholds": (c_int, [c_vp, c_vp, c_vp, c_i64, ctypes.c_float, ctypes.c_float, ctypes.c_float, c_int, c_vp, c_vp, c_vp]),

@@ -144,6 +144,32 @@ def fake_quant(x, scale, zero_point, qmin, qmax, ch_axis=0, out_dtype=None, retu
     return (y, q) if return_q is not None else y
 
 
+def observe_fake_quant(w, qmin, qmax, symmetric, out_dtype=None):
+    """min-max observer + qparams + QDQ of a per-channel weight (channel = dim 0) in ONE read of `w`
+    (observers/minmax.py:14-25 -> observers/base.py:63-79 -> quantizers/base.py:55-64).
+    -> (y, scale [C], zero_point [C], min [C], max [C]); bit-identical to the three separate steps."""
+    dev = L.require_device(w)
+    lib = L.load()
+    w = w.contiguous()
+    C = w.shape[0]
+    inner = w.numel() // max(C, 1)
+    out_dtype = out_dtype or torch.float32
+    if out_dtype not in (torch.float32, w.dtype):
+        raise L.SbqError("out_dtype must be float32 or the input dtype")
+    y = torch.empty(w.shape, dtype=out_dtype, device=dev)
+    stats = torch.empty((4, C), dtype=torch.float32, device=dev)  # scale, zero_point, min, max
+    if w.numel() == 0:
+        L.check(2)
+    with L.device_guard(dev):
+        ws = _workspace(dev, lib.sbq_stats_workspace_bytes(1, C, inner))
+        rc = lib.sbq_observe_quant_perchannel_forward(L.ptr(w), L.dtype_id(w), L.ptr(y), L.dtype_id(y), L.ptr(stats[0]),
+                                                      L.ptr(stats[1]), L.ptr(stats[2]), L.ptr(stats[3]), C, inner,
+                                                      int(qmin), int(qmax), 1 if symmetric else 0, L.ptr(ws),
+                                                      ws.numel(), L.stream_ptr(dev))
+    L.check(rc)
+    return y, stats[0], stats[1], stats[2], stats[3]
+
+
 def quantize_only(x, scale, zero_point, qmin, qmax, ch_axis=0, return_q=torch.int8):
     """QuantizeLinear alone: the integer levels without the dequantized tensor (half the writes).
     return_q as in fake_quant (torch.int8 | torch.uint8 | torch.int32 | "int4")."""

@@ -80,6 +80,41 @@ class Quantizer(nn.Module):
         self.dims = x.dim()
         self.observer.data_cache.update(x.detach())
 
+    def calibrate_forward(self, w):
+        """update_observer(w); calc_qparams(); forward(w) of a WEIGHT in one call -- and, for a plain min-max
+        observer on a per-channel weight, in one kernel that reads `w` once (ops.observe_fake_quant: observers/
+        minmax.py:14-25 -> observers/base.py:63-79 -> quantizers/base.py:55-64).  Anything else runs the three steps.
+        Returns the quantize-dequantized weight (fp32, like the reference's forward); scale / zero_point and the
+        observer's min_val / max_val are left exactly as the three calls leave them."""
+        from .. import ops
+        from ..observers.minmax import Observer as MinMaxObserver
+
+        plain = (
+            type(self).calc_qparams is Quantizer.calc_qparams
+            and type(self).update_observer is Quantizer.update_observer
+            and type(self)._qparams_preprocess is Quantizer._qparams_preprocess
+            and type(self.observer) is MinMaxObserver
+            and self.is_perchannel
+            and self.qdesc.ch_axis == 0
+            and not self.fake_fused
+            and not self.export_onnx
+            and w.is_cuda
+            and w.dim() >= 2
+            and len(self.observer.data_cache) == 0
+        )
+        if not plain:
+            self.update_observer(w)
+            self.calc_qparams()
+            self.enable_quant()
+            return self.forward(w)
+        self.dims = w.dim()
+        qmin, qmax = self.qdesc.qrange
+        y, scale, zero_point, mn, mx = ops.observe_fake_quant(w.detach(), qmin, qmax, self.qdesc.is_symmetric)
+        self.observer._store_minmax(mn, mx)
+        self._adopt(scale, zero_point)
+        self.enable_quant()
+        return y
+
     # ---- forward ------------------------------------------------------------------------------
     def _qparams_preprocess(self, x):
         return self.scale, self.zero_point

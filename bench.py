@@ -218,6 +218,14 @@ def main():
         torch.cuda.synchronize(dev)
         return a.elapsed_time(b) * 1e3 / iters
 
+    def pmc_extra(kernel_key):
+        """counter summary of a kernel from the committed profile (None when there is none)"""
+        try:
+            with open(os.path.join(ROOT, "profiles", "pmc_latest.json")) as f:
+                return json.load(f).get("valu", {}).get(kernel_key)
+        except (OSError, ValueError):
+            return None
+
     extras = {}
     warm_us = timed(lambda i: step(0), 200)
     extras["cache_resident_us"] = round(warm_us, 3)
@@ -314,6 +322,47 @@ def main():
     extras["observer_allreduce_us"] = round(ar_us, 2)
     extras["observer_allreduce_bytes"] = 4 * 4 * ROWS if world > 1 else 0
 
+    # ---- the rest of the hot path at the headline size (library calls through ops.py; events over a loop) -----
+    def timed_op(fn, iters=30):
+        for _ in range(5):
+            fn()
+        torch.cuda.synchronize(dev)
+        a = torch.cuda.Event(enable_timing=True)
+        b = torch.cuda.Event(enable_timing=True)
+        a.record(stream)
+        for _ in range(iters):
+            fn()
+        b.record(stream)
+        torch.cuda.synchronize(dev)
+        return a.elapsed_time(b) * 1e3 / iters
+
+    st4 = torch.empty(4, ROWS, dtype=torch.float32, device=dev)
+    st4p = [L.ptr(st4[k]) for k in range(4)]
+    wsp, wsn = L.ptr(ws), ws.numel()
+
+    def step_fused(i):
+        j = i % NBUF
+        lib.sbq_observe_quant_perchannel_forward(xp[j], L.BF16, yp[j], L.BF16, st4p[0], st4p[1], st4p[2], st4p[3],
+                                                 ROWS, COLS, QMIN, QMAX, 1, wsp, wsn, st)
+
+    fus_us = timed(step_fused, 100)
+    extras["fused_observe_qdq_us"] = round(fus_us, 3)
+    extras["fused_observe_qdq_GBps"] = round(n_elem * BYTES_PER_ELEM / fus_us / 1e3, 1)
+    n_half = n_elem // 2 + 1
+    extras["mask_threshold_kth_value_us"] = round(timed_op(lambda: ops.kth_value(xs[0], n_half, True)), 2)
+    extras["percentile_per_tensor_us"] = round(timed_op(lambda: ops.percentile_select([xs[0]], 1e-3, 0, False)), 2)
+    extras["percentile_per_channel_us"] = round(timed_op(lambda: ops.percentile_rows(xs[0], 1e-3)), 2)
+    q_mse = build_quantizer(quantizer_config("per-channel-symmetric", 8, observer="MSE"))
+    q_mse.set_backend(Backend.VIRTUAL)
+
+    def step_mse():
+        q_mse.update_observer(xs[0])
+        q_mse.calc_qparams()
+
+    extras["mse_observer_per_channel_us"] = round(timed_op(step_mse, 10), 1)
+    # vector-ALU rate of the MSE kernel, from the committed counter pass (tools/rocprof_bench.sh)
+    extras["mse_kernel_valu"] = pmc_extra("mse_partial_kernel")
+
     # ---- CPU baseline: the reference's CPU fake-quant ops on this box's host cores -----------
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -353,6 +402,31 @@ def main():
                       "%.1f ms" % (reps, best * 1e3),
             "matches_gpu_output": same,
         }
+        # the other CPU legs of BASELINE.md 3, same host, the thread count that was best for the QDQ, one timed run
+        # each after a warm-up on a quarter of the data (bounded: the MSE observer is 80 passes over its input)
+        torch.set_num_threads(best_threads)
+        legs = {}
+
+        def once(fn, *a):
+            t_ = time.perf_counter()
+            fn(*a)
+            return (time.perf_counter() - t_) * 1e3
+
+        quarter = xcpu[: ROWS // 4]
+        part16 = xcpu[: ROWS // 16]
+        torch_port.minmax_qparams_cpu(quarter, QMIN, QMAX)
+        legs["minmax_per_channel_ms"] = round(once(torch_port.minmax_qparams_cpu, xcpu, QMIN, QMAX), 2)
+        torch_port.percentile_minmax_cpu(quarter, 1e-3)
+        legs["percentile_per_tensor_ms"] = round(once(torch_port.percentile_minmax_cpu, xcpu, 1e-3), 2)
+        torch_port.l1_mask_cpu(quarter, 0.5)
+        legs["l1_mask_ms"] = round(once(torch_port.l1_mask_cpu, xcpu, 0.5), 2)
+        legs["mse_per_tensor_256_rows_ms"] = round(once(torch_port.mse_qparams_cpu, part16, QMIN, QMAX), 2)
+        legs["threads"] = best_threads
+        legs["what"] = ("torch ports (oracle/torch_port.py) of observers/minmax.py:14-25, percentile.py:16-46, "
+                        "sparse/sparsers/l1norm.py:18-26 on the full 4096x4096 fp32 weight and mse.py:28-63 (80 candidates) "
+                        "on 256 rows of it (1/16: the full tensor is minutes on the host); GPU times of the same steps "
+                        "on the full tensor are in extras")
+        cpu_baseline["other_legs"] = legs
 
     # HBM traffic per launch from the PMC passes (tools/rocprof_bench.sh -> tools/pmc_summary.py
     # writes profiles/pmc_latest.json on the GPU box; the counters need their own profiled

@@ -383,8 +383,8 @@ __global__ __launch_bounds__(kBlock) void qdq_batched_kernel(const void* const* 
   P = cur;                                                         \
   locate<false, U, SPLIT>(g, lt, rc, P.scale, P.zp, T);            \
   issue_loads<Tin, MASK, true, U, SPLIT>(P.x, nullptr, T, R, M);   \
-  __builtin_amdgcn_sched_barrier(0);                               \
-  step_item()
+  step_item();                                                     \
+  __builtin_amdgcn_sched_barrier(0) /* nothing of the following FINISH above this tile's loads */
 #define SBQ_FINISH(P, T, R, M) \
   finish_tile<Tin, Tout, SBQ_Q_NONE, MASK, false, true, U, MATH_FAST, SPLIT>(P.y, nullptr, T, R, M, 0.0f, g.qlo, g.qhi)
   SBQ_FETCH(pa, ta, ra, ma, tile);

@@ -79,7 +79,7 @@ __device__ __forceinline__ void quantize_pack(float (&v)[kPack], const u32x2 mk,
     // The IEEE form exists ONCE and starts with a statement the optimiser may not execute speculatively:
     // hoisted above the branch (it has been: ten VALU operations per element on every pack, a 40 % slower
     // kernel with identical results) it turns the memory-bound kernel into a VALU-bound one.
-    asm volatile("" ::: "memory");
+    asm volatile("; IEEE division path");  // (no memory clobber: that would cost the hot path its cached loads)
 #pragma unroll
     for (int j = 0; j < kPack; ++j) {
       lv[j] = quant_level<SBQ_ROUND_HALF_EVEN>(v[j], s, z, qlo, qhi);

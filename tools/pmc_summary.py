@@ -71,6 +71,40 @@ def main(tag):
             if want in r["Name"]:
                 summary["rocprof_kernel_avg_ns"] = float(r["AverageNs"])
                 summary["rocprof_kernel_calls"] = int(r["Calls"])
+    # vector-ALU pass: instructions issued per launch for the VALU-bound kernels, against the issue peak
+    # (256 CUs x 4 SIMDs, one wave64 instruction per 4 cycles at 2.4 GHz = 614e9 wave instructions / s; the 157 TFLOP/s
+    # fp32 vector figure of the data sheet is that rate x 64 lanes x 2 (fma) x 2 (packed))
+    valu_path = os.path.join(ROOT, "gpurun_out", "%s_pmc_valu" % tag, "%s_counter_collection.csv" % tag)
+    if os.path.exists(valu_path) and os.path.exists(stats):
+        dur = {}
+        for r in csv.DictReader(open(stats)):
+            dur[short(r["Name"])] = float(r["AverageNs"])
+        agg = collections.defaultdict(list)
+        for r in csv.DictReader(open(valu_path)):
+            if "sbq" in r["Kernel_Name"]:
+                agg[(short(r["Kernel_Name"]), r["Counter_Name"])].append(float(r["Counter_Value"]))
+        valu = {}
+        lines = ["# vector-ALU counters of the same command (tag %s): SQ_INSTS_VALU = wave-level VALU instructions per launch" % tag,
+                 "kernel,dispatches,SQ_INSTS_VALU,SQ_WAVES,avg_ns,valu_wave_insts_per_s,frac_of_issue_peak_614e9"]
+        for (k, c), v in sorted(agg.items()):
+            if c != "SQ_INSTS_VALU":
+                continue
+            insts = sum(v) / len(v)
+            waves = agg.get((k, "SQ_WAVES"), [0])
+            waves = sum(waves) / max(len(waves), 1)
+            key = [n for n in dur if n.replace("sbq::", "").startswith(k.split("<")[0]) and short(n) == k] or \
+                  [n for n in dur if short(n) == k]
+            ns = dur.get(key[0]) if key else None
+            rate = insts / (ns * 1e-9) if ns else None
+            lines.append('"%s",%d,%.0f,%.0f,%s,%s,%s' % (k, len(v), insts, waves, "%.0f" % ns if ns else "",
+                                                     "%.3e" % rate if rate else "", "%.3f" % (rate / 614e9) if rate else ""))
+            if k.startswith(("mse_partial_kernel", "qdq_resident_kernel<BF16, BF16, 0, 16", "win_pass_kernel")):
+                valu[k.split("<")[0]] = {"kernel": k, "valu_wave_insts_per_launch": insts, "avg_ns": ns,
+                                         "valu_wave_insts_per_s": rate,
+                                         "frac_of_valu_issue_peak": round(rate / 614e9, 3) if rate else None}
+        with open(os.path.join(ROOT, "profiles", "%s_bench_pmc_valu.csv" % tag), "w") as f:
+            f.write("\n".join(lines) + "\n")
+        summary["valu"] = valu
     with open(os.path.join(ROOT, "profiles", "pmc_latest.json"), "w") as f:
         json.dump(summary, f, indent=1)
     print(json.dumps(summary, indent=1))

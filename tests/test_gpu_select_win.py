@@ -108,3 +108,30 @@ def test_mask_threshold_config5_size(oracle):
         got = float(ops.kth_value(w.cuda(), idx + 1, True))
         want = float(_kth_ref(w.float().numpy(), idx + 1, True))
         assert got == want, (ratio, got, want)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("C,inner", [(4096, 4096), (513, 2048), (7, 96), (300, 4088)])
+@pytest.mark.parametrize("alpha", [0.0, 1e-4, 1e-3, 1.9e-3])
+def test_percentile_rows_small_ranks(oracle, dtype, C, inner, alpha):
+    """the one-wave-per-row extraction path of sbq_percentile_rows (alpha * inner <= 8) against the oracle and
+    against the general rows kernel (knob 2 = 5), with ties, NaNs and one-sided rows at the ends"""
+    g = torch.Generator().manual_seed(C + inner)
+    x = (torch.randn(C, inner, generator=g) * torch.logspace(-2, 1, C).unsqueeze(1)).to(dtype)
+    x[0] = x[0].abs()                    # no negatives: min stays 0
+    x[1] = -x[1].abs() - 0.01            # no non-negatives: max stays 0
+    x[2, :5] = x[2].min()                # five copies of the minimum
+    x[3, -6:] = x[3].max()               # six copies of the maximum
+    x[4, 1] = float("nan")
+    x[5, :] = 0.5                        # constant row
+    x[6, :3] = float("-inf")
+    xd = x.cuda()
+    mn, mx = ops.percentile_rows(xd, alpha)
+    rmn, rmx = oracle.percentile(x.float().numpy(), alpha, 0, True)
+    assert same_values(mn.cpu().numpy(), rmn) and same_values(mx.cpu().numpy(), rmx)
+    try:
+        L.set_tuning(2, 5)
+        gmn, gmx = ops.percentile_rows(xd, alpha)
+    finally:
+        L.set_tuning(2, 0)
+    assert same_values(mn.cpu().numpy(), gmn.cpu().numpy()) and same_values(mx.cpu().numpy(), gmx.cpu().numpy())

@@ -43,6 +43,8 @@ constexpr int kAdvBlock = 512;
 struct WinSel {
   uint32_t lo;     // first key of the window
   uint32_t shift;  // bin = (key - lo) >> shift, kWinBins bins
+  uint32_t span;   // last in-window offset: the window is [lo, lo + span], at most kWinBins << shift keys
+  uint32_t pad0;
   int64_t k;       // rank (1-based): absolute while `fresh`, relative to the window afterwards
   uint32_t done;   // key `lo` is the answer
   uint32_t fresh;  // window came from the sample: the sweep also counts the keys below it
@@ -50,7 +52,7 @@ struct WinSel {
 struct WinState {
   WinSel sel[kWinSel];
   int64_t n;  // elements in all shards
-  long long pad[3];
+  long long pad[1];
 };
 struct WinSlot {  // one 128-byte line
   unsigned long long below[kWinSel];
@@ -89,19 +91,14 @@ __device__ __forceinline__ uint32_t shift_for(uint64_t width, uint32_t min_shift
   return s;
 }
 
-__global__ __launch_bounds__(kBlock) void win_init_kernel(int64_t* __restrict__ base, size_t words) {
-  for (size_t i = static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x; i < words;
-       i += static_cast<size_t>(gridDim.x) * kBlock)
-    base[i] = 0;
-}
-
 // One workgroup of 1024: sample, histogram in LDS, bracket each selector's rank, write the first windows.
 // mode 0: explicit ranks k0 (k1); mode 1: percentile (ranks from the sample's own sign counts; the exact ones
 // follow from the first sweep).
 template <typename T>
 __global__ __launch_bounds__(1024) void win_plan_kernel(const ShardTable tab, int n_shards, WinState* __restrict__ st,
                                                         int mode, int n_sel, int use_abs, int64_t k0, int64_t k1,
-                                                        int64_t n, double alpha, uint32_t min_shift) {
+                                                        int64_t n, double alpha, uint32_t min_shift,
+                                                        u32x4* __restrict__ scratch, uint32_t scratch_vecs) {
   constexpr int kT = 1024, kPer = kPlanBins / kT;  // 8 bins per thread
   __shared__ uint32_t hist[kPlanBins];
   __shared__ uint32_t wave_tot[kT / kWave];
@@ -109,6 +106,9 @@ __global__ __launch_bounds__(1024) void win_plan_kernel(const ShardTable tab, in
   __shared__ int64_t r_lo[kWinSel], r_hi[kWinSel];
   __shared__ double r_mid[kWinSel];
   __shared__ uint32_t b_lo[kWinSel], b_hi[kWinSel];
+  // the counter lines and histogram copies the sweeps add to (the advance leaves them clean, a first call or an
+  // abandoned one does not): 136 KB of stores, issued before the sample is even requested
+  for (uint32_t i = threadIdx.x; i < scratch_vecs; i += kT) scratch[i] = u32x4{0, 0, 0, 0};
   for (int i = threadIdx.x; i < kPlanBins; i += kT) hist[i] = 0;
   if (threadIdx.x == 0) {
     s_first = kPlanBins - 1;
@@ -240,6 +240,11 @@ __global__ __launch_bounds__(1024) void win_plan_kernel(const ShardTable tab, in
       WinSel w;
       w.lo = lo;
       w.shift = shift_for(width, min_shift);
+      // only the bracket itself is histogrammed: with 16-bit inputs the 2048 bins of the smallest shift span 16
+      // binades -- half of a weight tensor -- while the bracket is a few dozen values wide
+      const uint64_t room = 0xffffffffull - lo;
+      w.span = static_cast<uint32_t>(width - 1 < room ? width - 1 : room);
+      w.pad0 = 0;
       w.k = mode == 0 ? (s == 0 ? k0 : k1) : 0;
       w.done = 0;
       w.fresh = 1;
@@ -248,48 +253,75 @@ __global__ __launch_bounds__(1024) void win_plan_kernel(const ShardTable tab, in
   }
 }
 
-// The sweep.  A workgroup walks slabs of 8 Ki elements (grid-stride), so the LDS histograms are cleared and flushed
-// once per workgroup.  Per element and selector: one subtraction and one unsigned compare decide "inside the
-// window"; a fresh window also counts the keys below it (registers).  Only elements inside a window touch LDS,
-// and a wave-wide vote per element skips the LDS instruction when no lane has one.
-constexpr uint32_t kWinSlab = kBlock * kPack * 4;
+// The sweep.  A workgroup walks slabs of 32 elements per thread (grid-stride), so the LDS histograms are cleared
+// and flushed once per workgroup -- and the workgroups are BIG (1024 threads, one per CU) whenever the tensor has
+// two slabs per CU: every workgroup flushes the same few dozen non-empty bins, and same-line device atomics
+// serialise.  Whole slabs take the lean path, written so that each element costs, per selector,
+//   v_cmp  (key < lo)  -> SGPR mask -> s_bcnt1 / s_add on the scalar unit: the keys below the window,
+//   v_sub, v_cmp       offset inside the window?   (keys below lo wrap to offsets beyond span)
+//   exec-masked shift / address / ds_add_u32 for the few per cent of elements inside it.
+// The ragged last slab and unaligned shards take the per-element path with validity flags.
+// ONE launch sweeps every shard of the selection (the cached calibration batches): the slabs of all shards form one
+// list, walked grid-stride; the table lives in the kernel arguments and is indexed uniformly (scalar loads).  The
+// loads of a workgroup's next slab are issued before it processes the current one.
+template <int BLOCK>
+struct WinGeom {
+  static constexpr int kU = 2;  // packs per thread and slab
+  static constexpr uint32_t kSlab = BLOCK * kPack * kU;
+};
+struct PassTable {
+  const void* ptr[kMaxShards];
+  int64_t count[kMaxShards];
+  // two lists over all shards: the whole slabs of 16-byte aligned shards (lean path), and the rest (a ragged last
+  // slab; every slab of an unaligned shard).  Entry i = first list index of shard i.
+  uint32_t lean_first[kMaxShards + 1];
+  uint32_t rag_first[kMaxShards + 1];
+};
 
-template <typename T, bool VEC, int NSEL, bool SIGNS>
-__global__ __launch_bounds__(kBlock) void win_pass_kernel(const void* __restrict__ x, int64_t n,
-                                                          const WinState* __restrict__ st, WinSlot* __restrict__ slots,
-                                                          uint32_t* __restrict__ hist, int use_abs) {
+template <typename T, int NSEL, bool SIGNS, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void win_pass_kernel(const PassTable tab, int n_shards,
+                                                         const WinState* __restrict__ st, WinSlot* __restrict__ slots,
+                                                         uint32_t* __restrict__ hist, int use_abs) {
+  constexpr uint32_t kSlab = WinGeom<BLOCK>::kSlab;
+  constexpr int U = WinGeom<BLOCK>::kU;
+  constexpr int kWaves = BLOCK / kWave;
+  constexpr int kCounters = NSEL + (SIGNS ? 2 : 0);
   __shared__ uint32_t lh[NSEL][kWinBins];
-  __shared__ unsigned long long red[kWavesPerBlock];
+  __shared__ unsigned long long red[kCounters][kWaves];
   // every selector resolved: nothing to do (the later rounds of a protocol that needed only one)
   bool live = false;
-  uint32_t lo[NSEL], sh[NSEL], wm1[NSEL];
+  uint32_t lo[NSEL], lom1[NSEL], sh[NSEL], span[NSEL];
   bool act[NSEL], fresh[NSEL];
 #pragma unroll
   for (int s = 0; s < NSEL; ++s) {
     act[s] = st->sel[s].done == 0;
     lo[s] = st->sel[s].lo;
     sh[s] = st->sel[s].shift;
-    // last in-window offset, cut at the last key: then `key - lo <= wm1` (unsigned) is the whole window test,
-    // keys below lo wrap to offsets beyond it.  A finished selector gets an empty window (offset test never true).
-    uint64_t w = (static_cast<uint64_t>(kWinBins) << sh[s]) - 1;
-    const uint64_t room = 0xffffffffull - lo[s];
-    if (w > room) w = room;
-    wm1[s] = static_cast<uint32_t>(w);
-    if (!act[s]) {
+    span[s] = st->sel[s].span;
+    if (!act[s]) {  // a finished selector gets an empty window: only key 0xffffffff passes, and nobody reads its bins
       lo[s] = 0xffffffffu;
-      wm1[s] = 0;  // only key 0xffffffff would pass; `act` masks it below
+      span[s] = 0;
     }
     fresh[s] = act[s] && st->sel[s].fresh != 0;
+    lom1[s] = lo[s] - 1u;
     live |= act[s];
   }
   if (!live) return;
-  for (uint32_t i = threadIdx.x; i < NSEL * kWinBins; i += kBlock) (&lh[0][0])[i] = 0;
+  for (uint32_t i = threadIdx.x; i < NSEL * kWinBins; i += BLOCK) (&lh[0][0])[i] = 0;
   __syncthreads();
+  // per-lane counters (ragged path) and wave-uniform ones (lean path)
   uint32_t lt[NSEL];
 #pragma unroll
   for (int s = 0; s < NSEL; ++s) lt[s] = 0;
   uint32_t neg = 0, nan = 0;
-  const bool ab = use_abs != 0;
+  const bool lane0 = (threadIdx.x & (kWave - 1)) == 0;
+  // |x|: clear the sign first; then the same transform (the sign fill of a non-negative word is 0)
+  const uint32_t amask = use_abs ? 0x7fffffffu : 0xffffffffu;
+  auto key_of = [&](uint32_t bits) {
+    const uint32_t b = bits & amask;
+    const uint32_t m = static_cast<uint32_t>(static_cast<int32_t>(b) >> 31) | 0x80000000u;
+    return (b ^ m) - kRot;
+  };
   auto visit = [&](uint32_t kk, bool valid) {
     if constexpr (SIGNS) {
       neg += valid && kk < kKeyZero;
@@ -299,82 +331,161 @@ __global__ __launch_bounds__(kBlock) void win_pass_kernel(const void* __restrict
     for (int s = 0; s < NSEL; ++s) {
       const uint32_t d = kk - lo[s];
       lt[s] += valid && kk < lo[s];
-      const bool in = valid && act[s] && d <= wm1[s];
-      if (__builtin_amdgcn_ballot_w64(in) != 0) {
-        if (in) atomicAdd(&lh[s][d >> sh[s]], 1u);
-      }
+      if (valid && d <= span[s]) atomicAdd(&lh[s][d >> sh[s]], 1u);
     }
   };
-  const int64_t n_slabs = (n + kWinSlab - 1) / kWinSlab;
-  for (int64_t slab = blockIdx.x; slab < n_slabs; slab += gridDim.x) {
-    const int64_t begin = slab * kWinSlab;
-    const int64_t end = begin + kWinSlab < n ? begin + kWinSlab : n;
-    if constexpr (VEC) {
-      const int64_t vend = begin + ((end - begin) / kPack) * kPack;
-      constexpr int U = kWinSlab / (kBlock * kPack);
-      if (vend > begin) {
-        RawPack<T> raw[U];
-        bool ok[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-          int64_t e = begin + (static_cast<int64_t>(u) * kBlock + threadIdx.x) * kPack;
-          ok[u] = e < vend;
-          if (!ok[u]) e = vend - kPack;
-          raw[u] = load_raw<T, true>(x, e);
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-          if constexpr (T::id == SBQ_F32) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) visit(win_key(raw[u].d[0][q], ab), ok[u]);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) visit(win_key(raw[u].d[1][q], ab), ok[u]);
-          } else if constexpr (T::id == SBQ_BF16) {
-            // bf16 -> fp32 bits is a shift / a mask: no conversion
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              const uint32_t w = raw[u].d[0][q];
-              visit(win_key(w << 16, ab), ok[u]);
-              visit(win_key(w & 0xffff0000u, ab), ok[u]);
-            }
-          } else {
-            float v[kPack];
-            unpack_raw<T>(raw[u], v);
-#pragma unroll
-            for (int q = 0; q < kPack; ++q) visit(win_key(__builtin_bit_cast(uint32_t, v[q]), ab), ok[u]);
-          }
-        }
-      }
-      for (int64_t e = vend + threadIdx.x; e < end; e += kBlock)
-        visit(win_key(__builtin_bit_cast(uint32_t, Elem<T>::load1(x, e)), ab), true);
-    } else {
-      for (int64_t e = begin + threadIdx.x; e < end; e += kBlock)
-        visit(win_key(__builtin_bit_cast(uint32_t, Elem<T>::load1(x, e)), ab), true);
+  // count the lanes of a compare on the scalar unit, HERE: as plain C++ (popcount of a ballot, added to a uniform
+  // counter) the adds are sunk to the end of the slab and the 128 masks waiting for them spill into VGPR lanes
+  auto count = [](uint32_t& acc, bool p) {
+    const uint64_t mask = __builtin_amdgcn_ballot_w64(p);
+    uint32_t c;
+    asm volatile("s_bcnt1_i32_b64 %1, %2\n\ts_add_u32 %0, %0, %1" : "+s"(acc), "=&s"(c) : "s"(mask) : "scc");
+  };
+  auto lean = [&](uint32_t kk, uint32_t (&w_lt)[NSEL], uint32_t& w_neg, uint32_t& w_nan) {
+    if constexpr (SIGNS) {
+      count(w_neg, kk < kKeyZero);
+      count(w_nan, kk > kKeyInf);
     }
+#pragma unroll
+    for (int s = 0; s < NSEL; ++s) {
+      // `kk <= lo - 1`, not `kk < lo`: the latter is folded into the borrow of the subtraction below, which costs
+      // two more VALU operations to turn back into a lane mask (lo == 0: counts everything, dropped at the end)
+      count(w_lt[s], kk <= lom1[s]);
+      const uint32_t d = kk - lo[s];
+      if (d <= span[s]) atomicAdd(&lh[s][d >> sh[s]], 1u);
+    }
+  };
+  auto locate = [&](const uint32_t (&first)[kMaxShards + 1], uint32_t g, int& shard, uint32_t& local) {  // uniform
+    int i = 0;
+    while (i + 1 < n_shards && g >= first[i + 1]) ++i;
+    shard = i;
+    local = g - first[i];
+  };
+  // Request lean slab g.  ALWAYS issues its loads -- past the end of the list they all read the first 16 bytes of
+  // the last slab: a conditional issue would make the compiler wait for everything in flight at the join.
+  const uint32_t n_lean = tab.lean_first[n_shards];
+  auto issue = [&](uint32_t g, RawPack<T> (&raw)[U]) {
+    const bool real = g < n_lean;
+    int shard;
+    uint32_t local;
+    locate(tab.lean_first, real ? g : n_lean - 1, shard, local);
+    const void* x = tab.ptr[shard];
+    const int64_t begin = static_cast<int64_t>(local) * kSlab;
+    const uint32_t stride = real ? kPack : 0u;
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      raw[u] = load_raw<T, true>(x, begin + static_cast<int64_t>((u * BLOCK + threadIdx.x) * stride));
+    __builtin_amdgcn_sched_barrier(0);  // nothing that waits for the other buffer moves above these loads
+  };
+  auto sweep_lean = [&](const RawPack<T> (&raw)[U]) {
+    // wave-uniform counters of this slab (SGPRs), folded into lane 0's counters at its end
+    uint32_t w_lt[NSEL], w_neg = 0, w_nan = 0;
+#pragma unroll
+    for (int s = 0; s < NSEL; ++s) w_lt[s] = 0;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if constexpr (T::id == SBQ_F32) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) lean(key_of(raw[u].d[0][q]), w_lt, w_neg, w_nan);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) lean(key_of(raw[u].d[1][q]), w_lt, w_neg, w_nan);
+      } else if constexpr (T::id == SBQ_BF16) {
+        // bf16 -> fp32 bits is a shift / a mask: no conversion
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const uint32_t w = raw[u].d[0][q];
+          lean(key_of(w << 16), w_lt, w_neg, w_nan);
+          lean(key_of(w & 0xffff0000u), w_lt, w_neg, w_nan);
+        }
+      } else {
+        float v[kPack];
+        unpack_raw<T>(raw[u], v);
+#pragma unroll
+        for (int q = 0; q < kPack; ++q) lean(key_of(__builtin_bit_cast(uint32_t, v[q])), w_lt, w_neg, w_nan);
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < NSEL; ++s) lt[s] += lane0 && lo[s] != 0 ? w_lt[s] : 0u;
+    if constexpr (SIGNS) {
+      neg += lane0 ? w_neg : 0u;
+      nan += lane0 ? w_nan : 0u;
+    }
+  };
+  if (n_lean > 0) {
+    // two slab buffers, alternating (a copy `current = next` would have to wait for the loads it is meant to hide)
+    RawPack<T> buf_a[U], buf_b[U];
+    uint32_t g = blockIdx.x;
+    issue(g, buf_a);
+    while (g < n_lean) {
+      issue(g + gridDim.x, buf_b);
+      sweep_lean(buf_a);
+      g += gridDim.x;
+      if (g >= n_lean) break;
+      issue(g + gridDim.x, buf_a);
+      sweep_lean(buf_b);
+      g += gridDim.x;
+    }
+  }
+  // the ragged last slab of a shard, and every slab of an unaligned one
+  const uint32_t n_rag = tab.rag_first[n_shards];
+  for (uint32_t r = blockIdx.x; r < n_rag; r += gridDim.x) {
+    int shard;
+    uint32_t local;
+    locate(tab.rag_first, r, shard, local);
+    local += tab.lean_first[shard + 1] - tab.lean_first[shard];
+    const void* x = tab.ptr[shard];
+    const int64_t n = tab.count[shard];
+    const int64_t begin = static_cast<int64_t>(local) * kSlab;
+    const int64_t end = begin + kSlab < n ? begin + kSlab : n;
+    int64_t vend = begin;
+    if ((reinterpret_cast<uintptr_t>(x) & 15u) == 0) {
+      vend = begin + ((end - begin) / kPack) * kPack;
+      for (int64_t e = begin + static_cast<int64_t>(threadIdx.x) * kPack; e < vend; e += static_cast<int64_t>(BLOCK) * kPack) {
+        float v[kPack];
+        load_pack<T, true>(x, e, v);
+#pragma unroll
+        for (int q = 0; q < kPack; ++q) visit(key_of(__builtin_bit_cast(uint32_t, v[q])), true);
+      }
+    }
+    for (int64_t e = vend + threadIdx.x; e < end; e += BLOCK)
+      visit(key_of(__builtin_bit_cast(uint32_t, Elem<T>::load1(x, e))), true);
+  }
+  // counters: lanes -> wave -> workgroup -> one of the 64 counter lines
+  const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
+  unsigned long long tot[kCounters];
+#pragma unroll
+  for (int s = 0; s < NSEL; ++s) tot[s] = wave_reduce(static_cast<unsigned long long>(lt[s]), SumL());
+  if constexpr (SIGNS) {
+    tot[NSEL] = wave_reduce(static_cast<unsigned long long>(neg), SumL());
+    tot[NSEL + 1] = wave_reduce(static_cast<unsigned long long>(nan), SumL());
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int c = 0; c < kCounters; ++c) red[c][wid] = tot[c];
   }
   __syncthreads();
   WinSlot* slot = slots + (blockIdx.x % kSlots);
+  if (threadIdx.x < kCounters) {
+    unsigned long long t = 0;
+    for (int w = 0; w < kWaves; ++w) t += red[threadIdx.x][w];
+    if (t) {
+      if (static_cast<int>(threadIdx.x) < NSEL) {
+        if (st->sel[threadIdx.x].done == 0 && st->sel[threadIdx.x].fresh != 0) atomicAdd(&slot->below[threadIdx.x], t);
+      } else {
+        atomicAdd(threadIdx.x == NSEL ? &slot->neg : &slot->nan, t);
+      }
+    }
+  }
 #pragma unroll
   for (int s = 0; s < NSEL; ++s) {
     if (!act[s]) continue;
     uint32_t* gh = hist + (static_cast<size_t>(blockIdx.x % kCopies) * kWinSel + s) * kWinBins;
-    for (uint32_t i = threadIdx.x; i < static_cast<uint32_t>(kWinBins); i += kBlock) {
+    for (uint32_t i = threadIdx.x; i < static_cast<uint32_t>(kWinBins); i += BLOCK) {
       const uint32_t v = lh[s][i];
       if (v) atomicAdd(&gh[i], v);
     }
-    if (fresh[s]) {
-      const unsigned long long b = block_reduce(static_cast<unsigned long long>(lt[s]), SumL(), red);
-      if (threadIdx.x == 0 && b) atomicAdd(&slot->below[s], b);
-    }
   }
-  if constexpr (SIGNS) {
-    const unsigned long long a = block_reduce(static_cast<unsigned long long>(neg), SumL(), red);
-    const unsigned long long b = block_reduce(static_cast<unsigned long long>(nan), SumL(), red);
-    if (threadIdx.x == 0) {
-      if (a) atomicAdd(&slot->neg, a);
-      if (b) atomicAdd(&slot->nan, b);
-    }
-  }
+  (void)fresh;
 }
 
 // One workgroup of 1024 per selector: sum the copies, place the rank, write the result when it is final.
@@ -446,13 +557,14 @@ __global__ __launch_bounds__(kAdvBlock) void win_advance_kernel(uint32_t* __rest
       k = k < 1 ? 1 : (k > n ? n : k);
     }
     const unsigned long long below = s_below;
-    const uint64_t hi = static_cast<uint64_t>(w.lo) + (static_cast<uint64_t>(kWinBins) << w.shift);  // exclusive
+    const uint64_t hi = static_cast<uint64_t>(w.lo) + w.span + 1;  // exclusive
     if (static_cast<unsigned long long>(k) <= below) {
       // the sample lied: the rank is below the window.  New window: every key below it.
       if (threadIdx.x == 0) {
         WinSel nw = w;
         nw.lo = 0;
         nw.shift = shift_for(w.lo, min_shift);
+        nw.span = w.lo - 1;  // k <= below: there are keys below lo, so lo > 0
         nw.k = k;
         nw.fresh = 0;
         st->sel[s] = nw;
@@ -466,6 +578,7 @@ __global__ __launch_bounds__(kAdvBlock) void win_advance_kernel(uint32_t* __rest
         WinSel nw = w;
         nw.lo = static_cast<uint32_t>(hi);
         nw.shift = shift_for((1ull << 32) - hi, min_shift);
+        nw.span = 0xffffffffu - static_cast<uint32_t>(hi);
         nw.k = k - static_cast<int64_t>(below + total);
         nw.fresh = 0;
         st->sel[s] = nw;
@@ -503,6 +616,10 @@ __global__ __launch_bounds__(kAdvBlock) void win_advance_kernel(uint32_t* __rest
       }
     } else {
       nw.shift = w.shift > min_shift + kWinLog ? w.shift - kWinLog : min_shift;
+      // the bin, cut at the end of its parent window
+      const uint32_t bin_last = (w.shift < 32 ? (1u << w.shift) : 0u) - 1u;
+      const uint32_t left = w.lo + w.span - nw.lo;
+      nw.span = bin_last < left ? bin_last : left;
     }
     st->sel[s] = nw;
   }
@@ -536,39 +653,58 @@ int win_select_run(const void* const* shards, const int64_t* counts, int n_shard
     n += counts[i];
   }
   const uint32_t min_shift = x_dtype == SBQ_BF16 ? 16u : (x_dtype == SBQ_F16 ? 13u : 0u);
-  win_init_kernel<<<64, kBlock, 0, st>>>(reinterpret_cast<int64_t*>(ws), (kStateBytes + kSlotBytes + kHistBytes) / 8);
+  const uint32_t cus = cu_count();
   int rc = dispatch_dtype(x_dtype, [&](auto tag) {
     using T = decltype(tag);
     win_plan_kernel<T><<<1, 1024, 0, st>>>(tab, n_shards, state, percentile ? 1 : 0, n_sel, use_abs, k0, k1, n, alpha,
-                                           min_shift);
+                                           min_shift, reinterpret_cast<u32x4*>(ws + kStateBytes),
+                                           static_cast<uint32_t>((kSlotBytes + kHistBytes) / 16));
   });
   if (rc != SBQ_OK) return rc;
   // rounds: one resolves a 16-bit input, two an fp32 one -- when the first window holds the rank; a missed window
   // costs up to ceil((32 - min_shift) / 11) more.  All are enqueued; rounds after the last needed one exit at once.
   const int rounds = 1 + static_cast<int>((32 - min_shift + kWinLog - 1) / kWinLog);
+  // the slab list: 1024-thread workgroups (one per CU: 4x fewer histogram flushes) when that gives every CU two slabs
+  // of 16 Ki elements, else 256-thread workgroups and 4 Ki slabs
+  int64_t big_slabs = 0;
+  for (int i = 0; i < n_shards; ++i) big_slabs += ceil_div(counts[i], static_cast<int64_t>(WinGeom<1024>::kSlab));
+  const bool big = big_slabs >= 2 * static_cast<int64_t>(cus) && knob(2) != 8;
+  const int64_t slab = big ? WinGeom<1024>::kSlab : WinGeom<kBlock>::kSlab;
+  PassTable pt{};
+  int64_t total_slabs = 0, n_lean = 0;
+  for (int i = 0; i < n_shards; ++i) {
+    pt.ptr[i] = shards[i];
+    pt.count[i] = counts[i];
+    const int64_t all = ceil_div(counts[i], slab), lean = aligned16(shards[i]) ? counts[i] / slab : 0;
+    pt.lean_first[i] = static_cast<uint32_t>(n_lean);
+    pt.rag_first[i] = static_cast<uint32_t>(total_slabs - n_lean);
+    n_lean += lean;
+    total_slabs += all;
+  }
+  if (total_slabs >= (1ll << 31)) return SBQ_ERR_ARG;
+  pt.lean_first[n_shards] = static_cast<uint32_t>(n_lean);
+  pt.rag_first[n_shards] = static_cast<uint32_t>(total_slabs - n_lean);
+  // rounds beyond the expected ones (one sweep for 16-bit inputs, up to three for fp32) almost always find every
+  // selector resolved and exit at once: launch them small -- a miss of the first window just sweeps slower
+  const int expected = min_shift > 0 ? 1 : 3;
   for (int r = 0; r < rounds; ++r) {
-    for (int i = 0; i < n_shards && rc == SBQ_OK; ++i) {
-      const bool vec = aligned16(shards[i]);
-      const int64_t slabs = ceil_div(counts[i], static_cast<int64_t>(kWinSlab));
-      const uint32_t grid = static_cast<uint32_t>(slabs < 1024 ? slabs : 1024);
-      const bool signs = r == 0 && percentile;
-      rc = dispatch_dtype(x_dtype, [&](auto tag) {
-        using T = decltype(tag);
-#define SBQ_WIN(V, NS, SG) \
-  win_pass_kernel<T, V, NS, SG><<<grid, kBlock, 0, st>>>(shards[i], counts[i], state, slots, hist, use_abs)
-        if (n_sel == 1) {
-          if (vec) SBQ_WIN(true, 1, false);
-          else SBQ_WIN(false, 1, false);
-        } else if (signs) {
-          if (vec) SBQ_WIN(true, 2, true);
-          else SBQ_WIN(false, 2, true);
-        } else {
-          if (vec) SBQ_WIN(true, 2, false);
-          else SBQ_WIN(false, 2, false);
-        }
+    const int64_t cap = r >= expected ? 64 : (big ? cus : 4 * static_cast<int64_t>(cus));
+    const uint32_t grid = static_cast<uint32_t>(total_slabs < cap ? (total_slabs > 0 ? total_slabs : 1) : cap);
+    const bool signs = r == 0 && percentile;
+    rc = dispatch_dtype(x_dtype, [&](auto tag) {
+      using T = decltype(tag);
+#define SBQ_WIN2(NS, SG, B) win_pass_kernel<T, NS, SG, B><<<grid, B, 0, st>>>(pt, n_shards, state, slots, hist, use_abs)
+#define SBQ_WIN(NS, SG)         \
+  do {                          \
+    if (big) SBQ_WIN2(NS, SG, 1024); \
+    else SBQ_WIN2(NS, SG, kBlock);   \
+  } while (0)
+      if (n_sel == 1) SBQ_WIN(1, false);
+      else if (signs) SBQ_WIN(2, true);
+      else SBQ_WIN(2, false);
 #undef SBQ_WIN
-      });
-    }
+#undef SBQ_WIN2
+    });
     if (rc != SBQ_OK) return rc;
     // the advance of the round that resolves a selector also writes its result
     win_advance_kernel<<<n_sel, kAdvBlock, 0, st>>>(hist, state, slots, percentile ? 1 : 0, alpha, min_shift, out0,

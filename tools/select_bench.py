@@ -5,9 +5,11 @@ import torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from sparsebit_amd import lib as L, ops
 dev = torch.device("cuda:0")
+QUICK = "--quick" in sys.argv  # profiling runs: one short round per entry point
 def timed(fn, iters=50, warm=10):
     best = 1e9
-    for _ in range(3):
+    if QUICK: iters, warm = 10, 3
+    for _ in range(1 if QUICK else 3):
         for _ in range(warm): fn()
         torch.cuda.synchronize()
         a = torch.cuda.Event(enable_timing=True); b = torch.cuda.Event(enable_timing=True)

@@ -1,0 +1,34 @@
+"""Condense the rocprofv3 output of tools/rocprof_select.sh: per kernel calls / avg / min / max duration (kernel
+trace) and FETCH_SIZE per launch (its own --pmc pass).  FETCH_SIZE is reported in KB and, on gfx950, counts each
+128-byte request of a wide coalesced stream as 64 bytes (MI355X_MICROARCH.md, HBM section; tools/pmc_summary.py uses
+the same correction): read bytes = 2 x FETCH_SIZE x 1024."""
+import csv, glob, os, sys, collections, re
+
+out, tag = sys.argv[1], sys.argv[2]
+
+def short(name):
+    name = re.sub(r"^void ", "", name)
+    name = name.replace("sbq::(anonymous namespace)::", "").replace("sbq::", "")
+    return re.sub(r"\(.*$", "", name)
+
+dur = collections.defaultdict(list)
+for f in glob.glob(os.path.join(out, tag + "_sel_trace", "**", "*kernel_trace.csv"), recursive=True):
+    for r in csv.DictReader(open(f)):
+        dur[short(r["Kernel_Name"])].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+fetch = collections.defaultdict(list)
+for f in glob.glob(os.path.join(out, tag + "_sel_fetch", "**", "*counter_collection.csv"), recursive=True):
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] == "FETCH_SIZE":
+            fetch[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
+path = os.path.join(out, tag + "_select_kernels.csv")
+with open(path, "w") as fo:
+    fo.write("# tools/rocprof_select.sh: kernel-trace durations (ns) and, from a separate --pmc pass, FETCH_SIZE per launch\n")
+    fo.write("# FETCH_SIZE in KB as reported; read bytes = 2 x FETCH_SIZE x 1024 (gfx950 correction for wide streaming reads)\n")
+    fo.write("kernel,calls,avg_ns,min_ns,max_ns,fetch_size_KB_avg,fetch_size_KB_max,read_bytes_max\n")
+    for k in sorted(dur, key=lambda k: -sum(dur[k])):
+        d = dur[k]
+        fr = fetch.get(k, [])
+        fo.write('"%s",%d,%.1f,%d,%d,%s,%s,%s\n' % (k, len(d), sum(d) / len(d), min(d), max(d),
+                 "%.1f" % (sum(fr) / len(fr)) if fr else "", "%.1f" % max(fr) if fr else "",
+                 "%.0f" % (max(fr) * 2048) if fr else ""))
+print(open(path).read())

@@ -117,32 +117,46 @@ __global__ __launch_bounds__(1024) void win_plan_kernel(const ShardTable tab, in
   __syncthreads();
   // sample: pack p of n_packs starts at element p * floor(n / n_packs) of the concatenated shards
   const int64_t n_packs = n / kPack < kPlanPacks ? (n / kPack > 0 ? n / kPack : 1) : kPlanPacks;
-  for (int64_t p = threadIdx.x; p < n_packs; p += kT) {
+  // every thread's packs are located first and requested together: one memory round trip for the whole sample
+  constexpr int kMine = kPlanPacks / kT;
+  const void* base[kMine];
+  int64_t e[kMine], cnt[kMine];
+  float v[kMine][kPack];
+#pragma unroll
+  for (int m = 0; m < kMine; ++m) {
     // which shard: the table lives in the kernel arguments, so it is walked with a UNIFORM index (scalar loads) and
     // the lane keeps its own pointer / count by selects -- a per-lane index would spill the table to scratch
-    int64_t e = p * (n / n_packs);
-    const void* base = tab.ptr[0];
-    int64_t cnt = tab.count[0];
+    const int64_t p = static_cast<int64_t>(threadIdx.x) + m * kT;
+    e[m] = (p < n_packs ? p : 0) * (n / n_packs);
+    base[m] = tab.ptr[0];
+    cnt[m] = tab.count[0];
     bool found = false;
     for (int i = 0; i < n_shards; ++i) {
       const int64_t c = tab.count[i];
-      const bool here = !found && (e < c || i + 1 == n_shards);
-      base = here ? tab.ptr[i] : base;
-      cnt = here ? c : cnt;
-      e = (found || here) ? e : e - c;
+      const bool here = !found && (e[m] < c || i + 1 == n_shards);
+      base[m] = here ? tab.ptr[i] : base[m];
+      cnt[m] = here ? c : cnt[m];
+      e[m] = (found || here) ? e[m] : e[m] - c;
       found |= here;
     }
-    float v[kPack];
-    e &= ~static_cast<int64_t>(kPack - 1);  // whole packs: one 16-byte load (two for fp32) when the shard allows it
-    if ((reinterpret_cast<uintptr_t>(base) & 15u) == 0 && e + kPack <= cnt) {
-      load_pack<T, false>(base, e, v);
+    e[m] &= ~static_cast<int64_t>(kPack - 1);  // whole packs: one 16-byte load (two for fp32) when the shard allows it
+  }
+#pragma unroll
+  for (int m = 0; m < kMine; ++m) {
+    if ((reinterpret_cast<uintptr_t>(base[m]) & 15u) == 0 && e[m] + kPack <= cnt[m]) {
+      load_pack<T, false>(base[m], e[m], v[m]);
     } else {
 #pragma unroll
-      for (int j = 0; j < kPack; ++j) v[j] = Elem<T>::load1(base, e + j < cnt ? e + j : cnt - 1);
+      for (int j = 0; j < kPack; ++j) v[m][j] = Elem<T>::load1(base[m], e[m] + j < cnt[m] ? e[m] + j : cnt[m] - 1);
     }
+  }
+#pragma unroll
+  for (int m = 0; m < kMine; ++m) {
+    if (static_cast<int64_t>(threadIdx.x) + m * kT >= n_packs) continue;
 #pragma unroll
     for (int j = 0; j < kPack; ++j)
-      if (e + j < cnt) atomicAdd(&hist[win_key(__builtin_bit_cast(uint32_t, v[j]), use_abs != 0) >> kPlanShift], 1u);
+      if (e[m] + j < cnt[m])
+        atomicAdd(&hist[win_key(__builtin_bit_cast(uint32_t, v[m][j]), use_abs != 0) >> kPlanShift], 1u);
   }
   __syncthreads();
   uint32_t bins[kPer];
@@ -288,6 +302,32 @@ __global__ __launch_bounds__(BLOCK) void win_pass_kernel(const PassTable tab, in
   constexpr int kCounters = NSEL + (SIGNS ? 2 : 0);
   __shared__ uint32_t lh[NSEL][kWinBins];
   __shared__ unsigned long long red[kCounters][kWaves];
+  auto locate = [&](const uint32_t (&first)[kMaxShards + 1], uint32_t g, int& shard, uint32_t& local) {  // uniform
+    int i = 0;
+    while (i + 1 < n_shards && g >= first[i + 1]) ++i;
+    shard = i;
+    local = g - first[i];
+  };
+  // Request lean slab g.  ALWAYS issues its loads -- past the end of the list they all read the first 16 bytes of
+  // the last slab: a conditional issue would make the compiler wait for everything in flight at the join.
+  const uint32_t n_lean = tab.lean_first[n_shards];
+  auto issue = [&](uint32_t g, RawPack<T> (&raw)[U]) {
+    const bool real = g < n_lean;
+    int shard;
+    uint32_t local;
+    locate(tab.lean_first, real ? g : n_lean - 1, shard, local);
+    const void* x = tab.ptr[shard];
+    const int64_t begin = static_cast<int64_t>(local) * kSlab;
+    const uint32_t stride = real ? kPack : 0u;
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      raw[u] = load_raw<T, true>(x, begin + static_cast<int64_t>((u * BLOCK + threadIdx.x) * stride));
+    __builtin_amdgcn_sched_barrier(0);  // nothing that waits for the other buffer moves above these loads
+  };
+  // the first slab is requested before anything else: the selector state below comes from a cold scalar load, the
+  // LDS histograms want clearing -- a memory round trip that overlaps both
+  RawPack<T> buf_a[U], buf_b[U];
+  if (n_lean > 0) issue(blockIdx.x, buf_a);
   // every selector resolved: nothing to do (the later rounds of a protocol that needed only one)
   bool live = false;
   uint32_t lo[NSEL], lom1[NSEL], sh[NSEL], span[NSEL];
@@ -355,28 +395,6 @@ __global__ __launch_bounds__(BLOCK) void win_pass_kernel(const PassTable tab, in
       if (d <= span[s]) atomicAdd(&lh[s][d >> sh[s]], 1u);
     }
   };
-  auto locate = [&](const uint32_t (&first)[kMaxShards + 1], uint32_t g, int& shard, uint32_t& local) {  // uniform
-    int i = 0;
-    while (i + 1 < n_shards && g >= first[i + 1]) ++i;
-    shard = i;
-    local = g - first[i];
-  };
-  // Request lean slab g.  ALWAYS issues its loads -- past the end of the list they all read the first 16 bytes of
-  // the last slab: a conditional issue would make the compiler wait for everything in flight at the join.
-  const uint32_t n_lean = tab.lean_first[n_shards];
-  auto issue = [&](uint32_t g, RawPack<T> (&raw)[U]) {
-    const bool real = g < n_lean;
-    int shard;
-    uint32_t local;
-    locate(tab.lean_first, real ? g : n_lean - 1, shard, local);
-    const void* x = tab.ptr[shard];
-    const int64_t begin = static_cast<int64_t>(local) * kSlab;
-    const uint32_t stride = real ? kPack : 0u;
-#pragma unroll
-    for (int u = 0; u < U; ++u)
-      raw[u] = load_raw<T, true>(x, begin + static_cast<int64_t>((u * BLOCK + threadIdx.x) * stride));
-    __builtin_amdgcn_sched_barrier(0);  // nothing that waits for the other buffer moves above these loads
-  };
   auto sweep_lean = [&](const RawPack<T> (&raw)[U]) {
     // wave-uniform counters of this slab (SGPRs), folded into lane 0's counters at its end
     uint32_t w_lt[NSEL], w_neg = 0, w_nan = 0;
@@ -413,9 +431,7 @@ __global__ __launch_bounds__(BLOCK) void win_pass_kernel(const PassTable tab, in
   };
   if (n_lean > 0) {
     // two slab buffers, alternating (a copy `current = next` would have to wait for the loads it is meant to hide)
-    RawPack<T> buf_a[U], buf_b[U];
     uint32_t g = blockIdx.x;
-    issue(g, buf_a);
     while (g < n_lean) {
       issue(g + gridDim.x, buf_b);
       sweep_lean(buf_a);
@@ -501,12 +517,18 @@ __global__ __launch_bounds__(kAdvBlock) void win_advance_kernel(uint32_t* __rest
   if (w.done) return;
   constexpr int kPer = kWinBins / kAdvBlock;  // 4 bins per thread: one 16-byte load per copy
   unsigned long long bins[kPer] = {0, 0, 0, 0};
-  for (int c = 0; c < kCopies; ++c) {
-    u32x4* p = reinterpret_cast<u32x4*>(hist + (static_cast<size_t>(c) * kWinSel + s) * kWinBins) + threadIdx.x;
-    const u32x4 v = *p;
-    *p = u32x4{0, 0, 0, 0};
+  {
+    // all copies requested together, cleared afterwards (a store between two loads would order them)
+    u32x4 v[kCopies];
 #pragma unroll
-    for (int i = 0; i < kPer; ++i) bins[i] += v[i];
+    for (int c = 0; c < kCopies; ++c)
+      v[c] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(hist + (static_cast<size_t>(c) * kWinSel + s) * kWinBins) + threadIdx.x);
+#pragma unroll
+    for (int c = 0; c < kCopies; ++c) {
+#pragma unroll
+      for (int i = 0; i < kPer; ++i) bins[i] += v[c][i];
+      reinterpret_cast<u32x4*>(hist + (static_cast<size_t>(c) * kWinSel + s) * kWinBins)[threadIdx.x] = u32x4{0, 0, 0, 0};
+    }
   }
   unsigned long long t = 0;
 #pragma unroll

@@ -23,6 +23,8 @@
 //   * no float atomics (the reference's per-block atomicAdd makes the sum order,
 //     hence the result, run-to-run dependent): every workgroup writes its
 //     partial tile, a second kernel adds the K slices in a fixed order.
+#include <type_traits>
+
 #include "sbq_common.hpp"
 
 namespace sbq {
@@ -221,9 +223,12 @@ __device__ __forceinline__ float strip_level(const u32x4 (&w)[ROWS], int j, int 
 // in the matching pair order (x0, x2, x1, x3).
 // One K lane's share of a pass: its CH channels x 4 columns against kBT activation rows (staged in LDS, row stride
 // XS floats), dequantization factored out of the inner loop (see the kernel's header comment).
-template <int BITS, int kBT, int CH, bool DEC8, int XS>
+// XSE: the sums of the activations over the lane's channels come from the caller (`xsum_in`) instead of being
+// accumulated here (the in-loop adds are then dead code).
+template <int BITS, int kBT, int CH, bool DEC8, int XS, bool XSE = false>
 __device__ __forceinline__ void strip_compute(const u32x4 (&w)[CH * BITS / 32], const float* __restrict__ xs, int kl,
-                                              const float (&sc)[4], const float (&zr)[4], float (&acc)[4][kBT]) {
+                                              const float (&sc)[4], const float (&zr)[4], float (&acc)[4][kBT],
+                                              const float* xsum_in = nullptr) {
   constexpr int kRows = CH * BITS / 32;
   constexpr int kXStride = CH + 4;
   float dot[4][kBT], xsum[kBT];
@@ -349,7 +354,7 @@ __device__ __forceinline__ void strip_compute(const u32x4 (&w)[CH * BITS / 32], 
 #pragma unroll
   for (int j = 0; j < 4; ++j)
 #pragma unroll
-    for (int b = 0; b < kBT; ++b) acc[j][b] += __builtin_fmaf(sc[j], dot[j][b], -(zr[j] * xsum[b]));
+    for (int b = 0; b < kBT; ++b) acc[j][b] += __builtin_fmaf(sc[j], dot[j][b], -(zr[j] * (XSE ? xsum_in[b] : xsum[b])));
 }
 
 // LDS-DMA of one 16-byte word per lane: global -> LDS without passing through (or occupying) VGPRs.  The wave's
@@ -358,6 +363,56 @@ __device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_dst) {
   uint32_t keep;
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
                : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
+// The cross-workgroup half of the K split (shared by the strip kernels): publish, count the arrival, and the last
+// workgroup of the strip folds the S partials in index order.
+template <int kThreads>
+__device__ __forceinline__ void strip_fold_partials(uint32_t strip, int split, const GptqGeom& g,
+                                                    float* __restrict__ part, float* __restrict__ out,
+                                                    uint32_t* __restrict__ arrivals, uint32_t& s_prev) {
+  // publish the partials, count the arrival; the last one folds all S partials in index order.
+  // No agent-scope fence anywhere: on gfx950 such a fence writes back / invalidates the whole
+  // per-XCD L2 (measured: +15..35 us per launch with ~1000 workgroups doing it).  Instead every
+  // access of the protocol individually goes to the device-coherent level -- agent-scope atomic
+  // store / load / add carry sc1 and bypass the non-coherent L2 -- and the only ordering needed
+  // is "my partial stores are acknowledged before my arrival is counted": s_waitcnt vmcnt(0)
+  // (a workgroup-scope release fence) + the barrier.  The fold's loads depend on the counter
+  // value through LDS and the barrier, so they are issued after the add has returned.
+  // tests/test_gpu_gptq_stress.py: 10^4 calls on two streams under load, bit-equal, counters back at zero.
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_s_waitcnt(0);  // belt and braces: all counters drained
+  __syncthreads();
+  if (threadIdx.x == 0)
+    s_prev = __hip_atomic_fetch_add(&arrivals[strip], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  if (s_prev != static_cast<uint32_t>(split - 1)) return;
+  // (row, column) outputs of the strip, four per thread at a time so that four independent loads are in flight
+  // per partial index instead of one
+  const int64_t n_out = g.batch * kStripCols;
+  for (int64_t i0 = threadIdx.x; i0 < n_out; i0 += 4 * kThreads) {
+    float total[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    int64_t addr[4];
+    bool ok[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int64_t i = i0 + static_cast<int64_t>(u) * kThreads;
+      ok[u] = i < n_out;
+      const int64_t row = ok[u] ? i / kStripCols : 0, cc = ok[u] ? i - row * kStripCols : 0;
+      addr[u] = row * g.out_features + static_cast<int64_t>(strip) * kStripCols + cc;
+    }
+    for (int sidx = 0; sidx < split; ++sidx) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        total[u] += __hip_atomic_load(&part[static_cast<int64_t>(sidx) * g.batch * g.out_features + addr[u]],
+                                      __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (ok[u]) out[addr[u]] += total[u];
+  }
+  if (threadIdx.x == 0)  // leave the counter as we found it: the workspace stays reusable
+    __hip_atomic_store(&arrivals[strip], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // PF (HBM-sized matrices, several passes per workgroup): the weights of pass p+1 travel global -> LDS by DMA while
@@ -590,48 +645,234 @@ __global__ __launch_bounds__(8 * KL) __attribute__((amdgpu_waves_per_eu(CH == 64
   }
   }  // batch tiles
   if (split == 1) return;
-  // publish the partials, count the arrival; the last one folds all S partials in index order.
-  // No agent-scope fence anywhere: on gfx950 such a fence writes back / invalidates the whole
-  // per-XCD L2 (measured: +15..35 us per launch with ~1000 workgroups doing it).  Instead every
-  // access of the protocol individually goes to the device-coherent level -- agent-scope atomic
-  // store / load / add carry sc1 and bypass the non-coherent L2 -- and the only ordering needed
-  // is "my partial stores are acknowledged before my arrival is counted": s_waitcnt vmcnt(0)
-  // (a workgroup-scope release fence) + the barrier.  The fold's loads depend on the counter
-  // value through LDS and the barrier, so they are issued after the add has returned.
-  // tests/test_gpu_gptq_stress.py: 10^4 calls on two streams under load, bit-equal, counters back at zero.
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  __builtin_amdgcn_s_waitcnt(0);  // belt and braces: all counters drained
-  __syncthreads();
-  if (threadIdx.x == 0)
-    s_prev = __hip_atomic_fetch_add(&arrivals[strip], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __syncthreads();
-  if (s_prev != static_cast<uint32_t>(split - 1)) return;
-  // (row, column) outputs of the strip, four per thread at a time so that four independent loads are in flight
-  // per partial index instead of one
-  const int64_t n_out = g.batch * kStripCols;
-  for (int64_t i0 = threadIdx.x; i0 < n_out; i0 += 4 * kThreads) {
-    float total[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-    int64_t addr[4];
-    bool ok[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int64_t i = i0 + static_cast<int64_t>(u) * kThreads;
-      ok[u] = i < n_out;
-      const int64_t row = ok[u] ? i / kStripCols : 0, cc = ok[u] ? i - row * kStripCols : 0;
-      addr[u] = row * g.out_features + static_cast<int64_t>(strip) * kStripCols + cc;
+  strip_fold_partials<kThreads>(strip, split, g, part, out, arrivals, s_prev);
+}
+
+// HBM-sized matrices, B <= 2: PERSISTENT strip workers.  A 134 MB matrix is 1024 strips x 4 passes: as a grid of
+// (strip, K block) workgroups every workgroup lives for two passes, and its start-up (first loads with the full
+// memory latency exposed) and its fold dominate -- the strip kernel reaches 3.9 TB/s where a pure read of the same
+// 128-byte pieces gets 6.4 (tools/lab/strip_read.hip).  Here the grid is what the chip holds at once (two
+// workgroups per CU); each workgroup walks whole strips (all of K: no partial tiles, no arrival protocol), strip
+// after strip, and the weight words of the next NS - 1 passes are always in flight -- across strip boundaries too.
+// NS register sets of weight words per K lane, addressed statically (the pass loop is unrolled NS times; rotating
+// by copies would wait for the loads being moved).  Every load in the loop is unconditional -- rows, channels and
+// groups are clamped, dead K lanes skip the arithmetic, a worker past its last strip re-reads a valid one: a load
+// under a branch makes the compiler wait for everything in flight at the join.  The result is added to `out` by a
+// no-return float atomic (one add per element and call: deterministic), because reading `out` back would drain
+// the queue of prefetched loads.
+// Geometry requirements (host): in_features a multiple of CH, x rows 16-byte aligned, batch == kBT.
+template <int N>
+struct StaticFor {
+  template <typename F>
+  static __device__ __forceinline__ bool run(F&& f) {  // stops at the first false
+    if constexpr (N > 0) {
+      if (!StaticFor<N - 1>::run(f)) return false;
+      return f(std::integral_constant<int, N - 1>{});
+    } else {
+      return true;
     }
-    for (int sidx = 0; sidx < split; ++sidx) {
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-        total[u] += __hip_atomic_load(&part[static_cast<int64_t>(sidx) * g.batch * g.out_features + addr[u]],
-                                      __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
-      if (ok[u]) out[addr[u]] += total[u];
   }
-  if (threadIdx.x == 0)  // leave the counter as we found it: the workspace stays reusable
-    __hip_atomic_store(&arrivals[strip], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+};
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t gptq_rsrc(const void* base, uint32_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
+}
+
+// Addressing: raw buffer loads.  Everything that changes from pass to pass is wave-uniform and lives in the SGPR
+// offset (computed on the scalar unit); a thread's own offsets (its K lane's rows, its column quad, its slice of
+// the activations, its columns' scale rows) are computed ONCE.  The range check of a raw buffer covers the sum of
+// both offsets on gfx950 (tools/lab/buf_oob.hip), so rows past the end of the matrix and channels past the end of x
+// read as zero -- no clamps, no selects (they belong to dead K lanes; a group index past the end of a scale row
+// reads the next column's, which nobody uses either).
+// Before this, 64-bit address arithmetic and clamps were 170 of the ~800 vector instructions of a pass, and the
+// in-loop sums of the activations (now taken once per worker: `xsum_h`) another 96: the decode itself needs ~380,
+// and at 800 the kernel was bound by the vector ALU, not by memory.
+template <int BITS, int kBT, int NS, bool DEC8>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void gptq_stream_kernel(
+    const float* __restrict__ x, const int32_t* __restrict__ qw, const float* __restrict__ scales,
+    const float* __restrict__ zeros, float* __restrict__ out, const GptqGeom g, uint32_t strips) {
+  constexpr int KL = 32, CH = 64, kThreads = 256;
+  constexpr int kRows = CH * BITS / 32;
+  constexpr int kRowsPerPass = KL * kRows;
+  constexpr int kXLoads = (KL * CH) / (kThreads * 4);
+  constexpr int kXStride = CH + 4;
+  constexpr int kMaxHalfGroups = 512;  // in_features <= 32768
+  __shared__ __attribute__((aligned(16))) float xs[kBT][KL * kXStride];
+  __shared__ float red[KL][kBT][kStripCols + 1];
+  __shared__ float xsum_h[kBT][kMaxHalfGroups];  // sum of x over channels [64 h, 64 h + 64)
+  __shared__ __attribute__((aligned(16))) float szs[2][KL * CH / 128][kStripCols];  // [scale | zero][group of the pass][column]
+  const int cl = threadIdx.x & 7, kl = threadIdx.x >> 3;
+  // workers that run side by side on one XCD take adjacent strips (see gptq_strip_kernel)
+  uint32_t worker = blockIdx.x;
+  if (g.xcd_swizzle) worker = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  const uint32_t row_bytes = static_cast<uint32_t>(g.out_features) * 4u;
+  const uint32_t w_bytes = static_cast<uint32_t>(g.H) * row_bytes;
+  const uint32_t x_bytes = static_cast<uint32_t>(g.in_features) * 4u;
+  const uint32_t s_bytes = static_cast<uint32_t>(g.out_features * g.groups) * 4u;
+  const __amdgpu_buffer_rsrc_t rw = gptq_rsrc(qw, w_bytes), rs = gptq_rsrc(scales, s_bytes), rz = gptq_rsrc(zeros, s_bytes);
+  // per-thread offsets, fixed for the whole kernel
+  uint32_t voff_w[kRows], voff_x[kXLoads];
+#pragma unroll
+  for (int i = 0; i < kRows; ++i) voff_w[i] = static_cast<uint32_t>(kl * kRows + i) * row_bytes + cl * 16u;
+#pragma unroll
+  for (int j = 0; j < kXLoads; ++j) voff_x[j] = static_cast<uint32_t>(j * kThreads + threadIdx.x) * 16u;
+  // scales / zeros of a pass: 32 columns x 16 groups each (group size 128: host), fetched as ONE 16-byte load per
+  // thread -- threads 0..127 the scales, 128..255 the zeros; thread (column c, quarter q) takes groups 4q..4q+3 of
+  // its column's row -- and handed to the K lanes through LDS like the activations.  (Eight scattered 4-byte loads
+  // per thread and pass, the obvious way, cost 14 of 84 us on 12288 x 49152.)
+  const int sz_half = __builtin_amdgcn_readfirstlane(threadIdx.x >> 7);
+  const int sz_c = (threadIdx.x & 127) >> 2, sz_q = threadIdx.x & 3;
+  const uint32_t voff_sz = (static_cast<uint32_t>(sz_c) * static_cast<uint32_t>(g.groups) + sz_q * 4u) * 4u;
+  const __amdgpu_buffer_rsrc_t rsz = sz_half ? rz : rs;
+
+  // a position in this worker's sequence of passes: strips worker, worker + G, ... , each from K = 0 to the end
+  struct Cursor {
+    uint32_t strip;
+    uint32_t pass0;
+  };
+  const uint32_t H = static_cast<uint32_t>(g.H);
+  auto advance = [&](Cursor& c) {
+    c.pass0 += kRowsPerPass;
+    if (c.pass0 >= H) {
+      c.pass0 = 0;
+      c.strip += gridDim.x;
+    }
+  };
+  struct Small {
+    f32x4 xg[kBT][kXLoads];
+    f32x4 sz;  // four groups of one column's scales (threads 0..127) or zeros (128..255)
+  };
+  auto load_w = [&](const Cursor& c, u32x4 (&w)[kRows]) {
+    const uint32_t st = c.strip < strips ? c.strip : strips - 1;  // a worker past its last strip: any valid one
+    const uint32_t soff = c.pass0 * row_bytes + st * (kStripCols * 4u);
+#pragma unroll
+    for (int i = 0; i < kRows; ++i) w[i] = __builtin_amdgcn_raw_buffer_load_b128(rw, voff_w[i], soff, 2);
+  };
+  auto load_small = [&](const Cursor& c, Small& sm) {
+    const uint32_t st = c.strip < strips ? c.strip : strips - 1;
+    const uint32_t kbase = (c.pass0 / kRows) * CH;
+#pragma unroll
+    for (int b = 0; b < kBT; ++b) {
+      const uint32_t soff = kbase * 4u;
+      const __amdgpu_buffer_rsrc_t r = gptq_rsrc(x + static_cast<int64_t>(b) * g.in_features, x_bytes);
+#pragma unroll
+      for (int j = 0; j < kXLoads; ++j) {
+        const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(r, voff_x[j], soff, 0);
+        sm.xg[b][j] = __builtin_bit_cast(f32x4, t);
+      }
+    }
+    const uint32_t soff = (st * kStripCols * static_cast<uint32_t>(g.groups) + (kbase >> 7)) * 4u;
+    sm.sz = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsz, voff_sz, soff, 0));
+  };
+
+  float acc[4][kBT];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int b = 0; b < kBT; ++b) acc[j][b] = 0.0f;
+
+  u32x4 w[NS][kRows];
+  Small sm[NS];
+  Cursor cur{worker, 0}, nxt{worker, 0}, far{worker, 0};
+  // prologue: the first NS - 1 passes' weights, the first pass's activations / scales
+  static_assert(NS >= 3, "the activations / scales run two passes ahead");
+  load_small(nxt, sm[0]);
+  advance(nxt);
+  load_small(nxt, sm[1]);
+  advance(nxt);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int s = 0; s < NS - 1; ++s) {
+    load_w(far, w[s]);
+    advance(far);
+  }
+  // ... and, while they travel, the sums of the activations over every half group (the zero-point term of a K
+  // lane's 64 channels): once per worker instead of 64 adds per thread and pass
+  {
+    const int halves = static_cast<int>(g.in_features / CH);
+    for (int h = threadIdx.x; h < halves * kBT; h += kThreads) {
+      const int b = h / halves, hh = h - b * halves;
+      const f32x4* src = reinterpret_cast<const f32x4*>(x + static_cast<int64_t>(b) * g.in_features + hh * CH);
+      f32x4 t[CH / 4];
+#pragma unroll
+      for (int q = 0; q < CH / 4; ++q) t[q] = src[q];
+      float sum = 0.0f;
+#pragma unroll
+      for (int q = 0; q < CH / 4; ++q) sum += (t[q][0] + t[q][1]) + (t[q][2] + t[q][3]);
+      xsum_h[b][hh] = sum;
+    }
+  }
+  const bool owner = threadIdx.x < kBT * kStripCols;
+  const int ob = threadIdx.x / kStripCols, occ = threadIdx.x - ob * kStripCols;
+  bool more = cur.strip < strips;
+  while (more) {
+    more = StaticFor<NS>::run([&](auto tag) {
+      constexpr int s = decltype(tag)::value;
+      constexpr int s_far = (s + NS - 1) % NS, s_next = (s + 2) % NS;
+      // vector-memory loads return IN ORDER (vmcnt): waiting for the next pass's activations / scales also waits
+      // for every weight word requested before them.  So they run two passes ahead and go out before this pass's
+      // weight request: the words of the last two requests stay in flight across that wait.
+      load_small(nxt, sm[s_next]);
+      advance(nxt);
+      __builtin_amdgcn_sched_barrier(0);
+      load_w(far, w[s_far]);
+      advance(far);
+      __builtin_amdgcn_sched_barrier(0);  // the requests leave before anything below waits
+      const bool live = cur.pass0 + kl * kRows < H;
+      __syncthreads();  // previous pass done with xs (first pass: xsum_h complete)
+#pragma unroll
+      for (int b = 0; b < kBT; ++b)
+#pragma unroll
+        for (int j = 0; j < kXLoads; ++j) {
+          const int e = (j * kThreads + threadIdx.x) * 4;
+          const int lane_k = e / CH, off = e - lane_k * CH;
+          f32x4 t = sm[s].xg[b][j];
+          if constexpr (DEC8 && BITS == 2) {
+            const int k = (off >> 2) & 3;
+            float* dst = &xs[b][lane_k * kXStride + (off & ~15) + 8 * (k >> 1) + (k & 1)];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dst[2 * r] = t[r];
+          } else {
+            if constexpr (DEC8) t = f32x4{t[0], t[2], t[1], t[3]};
+            *reinterpret_cast<f32x4*>(&xs[b][lane_k * kXStride + off]) = t;
+          }
+        }
+#pragma unroll
+      for (int n = 0; n < 4; ++n) szs[sz_half][sz_q * 4 + n][sz_c] = sm[s].sz[n];
+      __syncthreads();
+      if (live) {
+        float xsum[kBT];
+        const uint32_t hh = (cur.pass0 / kRows) + kl;  // half group of this lane's channels
+#pragma unroll
+        for (int b = 0; b < kBT; ++b) xsum[b] = xsum_h[b][hh];
+        const f32x4 sc4 = *reinterpret_cast<const f32x4*>(&szs[0][kl >> 1][cl * 4]);
+        const f32x4 zr4 = *reinterpret_cast<const f32x4*>(&szs[1][kl >> 1][cl * 4]);
+        const float sc[4] = {sc4[0], sc4[1], sc4[2], sc4[3]}, zr[4] = {zr4[0], zr4[1], zr4[2], zr4[3]};
+        strip_compute<BITS, kBT, CH, DEC8, KL * kXStride, true>(w[s], &xs[0][0], kl, sc, zr, acc, xsum);
+      }
+      if (cur.pass0 + kRowsPerPass >= H) {
+        // the strip is done: fold the K lanes in ascending order, add to `out` (pre-filled with the bias)
+#pragma unroll
+        for (int b = 0; b < kBT; ++b)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            red[kl][b][cl * 4 + j] = acc[j][b];
+            acc[j][b] = 0.0f;
+          }
+        __syncthreads();
+        if (owner) {
+          float t = 0.0f;
+#pragma unroll
+          for (int q = 0; q < KL; ++q) t += red[q][ob][occ];
+          __hip_atomic_fetch_add(&out[ob * g.out_features + static_cast<int64_t>(cur.strip) * kStripCols + occ], t,
+                                 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        // (the next pass's first barrier separates these reads of `red` from the next strip's writes)
+      }
+      advance(cur);
+      return cur.strip < strips;
+    });
+  }
 }
 
 // out[b,n] += sum over K blocks, ascending
@@ -789,6 +1030,26 @@ int gptq_matmul(const float* x, const int32_t* qweight, float* out, const float*
     const bool prefetch = ch == kSliceK / 2 && passes >= 2 * split && knob(2) != 6;
     if constexpr (BITS == 4 || BITS == 2) {
       if (knob(2) != 4) {  // packed e4m3 decode (knob 2 == 4: byte converts, for A/B runs)
+        // HBM-sized: register sets two passes deep (knob 2 == 5: the LDS-DMA ring instead, for A/B runs)
+        if constexpr (BITS == 4) {
+          // HBM-sized: persistent strip workers, two per CU (knob 2 == 5: the (strip, K block) grid instead, for A/B
+          // runs).  Whole strips only: the workers' shares must be even, so the strip count has to be a multiple of
+          // the worker count (or several times it)
+          const int64_t workers = static_cast<int64_t>(cu_count()) * 2;
+          const bool stream = passes >= 3 && strips >= workers && (strips % workers == 0 || strips >= 8 * workers) &&
+                              in_features % 64 == 0 && in_features <= 32768 && aligned16(x) && (cu_count() % 8) == 0 &&
+                              g.group_size == 128 &&
+                              g.H * out_features * 4 < (1ll << 32) && out_features * g.groups * 4 < (1ll << 32) &&
+                              knob(2) != 5;
+          if (stream) {
+            const uint32_t n_strips = static_cast<uint32_t>(strips);
+            if (batch == 2)
+              gptq_stream_kernel<4, 2, 3, true><<<static_cast<uint32_t>(workers), 256, 0, st>>>(x, qweight, scales, zeros, out, g, n_strips);
+            else
+              gptq_stream_kernel<4, 1, 4, true><<<static_cast<uint32_t>(workers), 256, 0, st>>>(x, qweight, scales, zeros, out, g, n_strips);
+            return check_launch();
+          }
+        }
         if (prefetch) {
           if (batch == 2)
             gptq_strip_kernel<BITS, 2, 32, 64, true, true><<<grid, 256, 0, st>>>(x, qweight, scales, zeros, out, part, arrivals, g);

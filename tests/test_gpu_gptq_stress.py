@@ -86,8 +86,11 @@ def test_single_launch_fold_under_concurrency(bits):
 
 def test_large_shapes_single_launch_agrees_with_two_launch():
     """HBM-sized shapes (the reference's KAT sizes, test_cuda_kernel.py:50-126): 12288 x 49152 is a 302 MB
-    4-bit weight stream."""
-    for in_f, out_f, b in ((12288, 49152, 1), (8192, 32768, 8), (9216, 36864, 32)):
+    4-bit weight stream.  B <= 2 with whole multiples of 512 strips takes gptq_stream_kernel (persistent workers,
+    no K split), the others gptq_strip_kernel; knob 2 = 9 is the two-launch path both are compared with."""
+    # (6272 x 16384: the persistent-worker kernel with a ragged last pass -- two live K lanes of 32 -- and B = 2)
+    for in_f, out_f, b in ((12288, 49152, 1), (8192, 32768, 8), (9216, 36864, 32), (6272, 16384, 1), (6272, 16384, 2),
+                           (8192, 32768, 2)):
         qw, scales, zeros = _layer(in_f, out_f, 4, 128, in_f % 97)
         g = torch.Generator().manual_seed(b)
         x = torch.randn(b, in_f, generator=g).cuda()

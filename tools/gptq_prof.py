@@ -2,7 +2,9 @@
 import os, sys
 import torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
-from sparsebit_amd import ops
+from sparsebit_amd import ops, lib as L
+if len(sys.argv) > 1:
+    L.set_tuning(2, int(sys.argv[1]))  # e.g. 5: (strip, K block) grid instead of the persistent workers
 for in_f, out_f in ((4096, 4096), (8192, 32768), (12288, 49152)):
     g = torch.Generator().manual_seed(1)
     rows = in_f * 4 // 32

@@ -23,6 +23,10 @@ if len(sys.argv) > 2:
     L.set_tuning(2, int(sys.argv[2]))  # 1 / 2: 128 / 64 channels per K lane, 9: two-launch path
 if len(sys.argv) > 3:
     batches = [int(a) for a in sys.argv[3].split(",")]
+if len(sys.argv) > 4:
+    L.set_tuning(1, int(sys.argv[4]))  # K split override (dev)
+if len(sys.argv) > 5:
+    shapes = shapes[int(sys.argv[5]):]
 print("bits %d group 128; bytes = qweight + scales + zeros + x + 2 * out" % bits)
 for in_f, out_f in shapes:
     g = torch.Generator().manual_seed(1)

@@ -49,10 +49,13 @@ class _GroupSTE(torch.autograd.Function):
         n = len(group.members)
         need_w = ctx.needs_input_grad[1:1 + n]
         need_s = ctx.needs_input_grad[1 + n:1 + 2 * n]
+        # the grouped kernels read the live weights / scales through the device table: unpacking the saved tensors
+        # makes autograd's version check fire if one of them was modified in place since the forward
+        saved = ctx.saved_tensors
         if all(g is not None for g in gouts):
             gws, gss = group._backward(list(gouts))  # two launches for the whole model
         else:
-            gws, gss = group._backward_one_by_one(ctx.saved_tensors, gouts)
+            gws, gss = group._backward_one_by_one(saved, gouts)
         gws = [g if k else None for g, k in zip(gws, need_w)]
         gss = [g if k else None for g, k in zip(gss, need_s)]
         return (None, *gws, *gss)
@@ -62,6 +65,14 @@ class WeightQuantGroup:
     def __init__(self, triples, out_dtype=None):
         self.triples = [(q, w, m) for q, w, m in triples]
         self.out_dtype = out_dtype
+        self._partition()
+
+    def _switches(self):
+        """what membership depends on and a quantizer may change later (enable_quant / export mode)"""
+        return [(bool(q.is_enable), bool(q.export_onnx)) for q, _, _ in self.triples]
+
+    def _partition(self):
+        self._seen_switches = self._switches()
         self.members, self.kinds, self.member_idx, self.rest_idx = [], [], [], []
         for i, (q, w, m) in enumerate(self.triples):
             kind = _kind(q)
@@ -96,10 +107,13 @@ class WeightQuantGroup:
         half["ptrs"] = self._live_pointers(half)
 
     def _live_pointers(self, half):
+        """everything baked into the device table: storage addresses and the integer range (set_bit() changes it)"""
         p = []
         for k in half["idx"]:
             q, w, m = self.members[k]
-            p += [w.data_ptr(), q.scale.data_ptr(), q.zero_point.data_ptr(), 0 if m is None else m.data_ptr()]
+            qmin, qmax = q.qdesc.qrange
+            p += [w.data_ptr(), q.scale.data_ptr(), q.zero_point.data_ptr(), 0 if m is None else m.data_ptr(),
+                  int(qmin), int(qmax)]
         return p
 
     def _launch(self):
@@ -189,6 +203,8 @@ class WeightQuantGroup:
 
     # ---- forward ------------------------------------------------------------------------------
     def __call__(self):
+        if self._switches() != self._seen_switches:  # a quantizer was enabled / disabled / put in export mode
+            self._partition()
         result = [None] * len(self.triples)
         for i in self.rest_idx:
             q, w, m = self.triples[i]

@@ -529,14 +529,20 @@ def lsq_fake_quant_backward(x, gy, scale, zero_point, qmin, qmax, ch_axis=0, nee
     lib = L.load()
     x = x.contiguous()
     gy = gy.contiguous()
-    if gy.dtype != x.dtype:
-        gy = gy.to(x.dtype)
+    x_dtype = x.dtype
+    if gy.dtype != x.dtype:  # see fake_quant_backward: an fp32 upstream gradient is kept, x is widened
+        if gy.dtype == torch.float32:
+            x = x.float()
+        else:
+            gy = gy.to(x.dtype)
     per_channel = scale.numel() > 1
     outer, C, inner = geometry(x.shape, ch_axis, per_channel)
     scale = _f32c(scale, dev)
     zero_point = _f32c(zero_point, dev)
     _check_qparams(scale, zero_point, C)
-    gx = torch.empty(x.shape, dtype=gx_dtype or x.dtype, device=dev)
+    gx_final = gx_dtype or x_dtype
+    # (a widened x computes gx in fp32: the kernels take gx in fp32 or in x's type)
+    gx = torch.empty(x.shape, dtype=torch.float32 if x.dtype != x_dtype else gx_final, device=dev)
     gs = torch.empty(C, dtype=torch.float32, device=dev) if need_gs else None
     with L.device_guard(dev):
         ws = _workspace(dev, lib.sbq_backward_workspace_bytes(outer, C, inner)) if need_gs else None
@@ -544,6 +550,8 @@ def lsq_fake_quant_backward(x, gy, scale, zero_point, qmin, qmax, ch_axis=0, nee
                                         L.ptr(scale), L.ptr(zero_point), outer, C, inner, int(qmin), int(qmax),
                                         float(gs_ratio), L.ptr(ws), ws.numel() if ws is not None else 0, L.stream_ptr(dev))
     L.check(rc)
+    if gx.dtype != gx_final:
+        gx = gx.to(gx_final)
     return gx, gs
 
 
@@ -552,19 +560,34 @@ def lsq_fake_quant_backward(x, gy, scale, zero_point, qmin, qmax, ch_axis=0, nee
 # ---------------------------------------------------------------------------------
 def fake_quant_backward(x, gy, scale, zero_point, qmin, qmax, ch_axis=0, need_gs=True, need_gzp=True,
                         gx_dtype=None, rounding=L.ROUND_HALF_EVEN):
-    """-> (gx, gs | None, gzp | None); gs/gzp are flat fp32 [C]  (fake_quant_tensor.cu:97-132)."""
+    """-> (gx, gs | None, gzp | None); gs/gzp are flat fp32 [C]  (fake_quant_tensor.cu:97-132).
+
+    x and the upstream gradient share one element type in the kernel.  When they differ and the gradient is fp32
+    (a half-precision activation quantized to the default fp32 output), x is widened -- the reference's route,
+    quant_tensor.py:82-103 upcasts x and keeps the fp32 grad_y -- so the scale / zero-point gradients are reduced
+    from unrounded upstream gradients; gx comes back in x's own type (or gx_dtype).
+    A fractional zero point is rounded half-to-even, as torch.round does in the reference's Python (CPU) path that
+    the oracle restates (quant_tensor.py:182-184); the reference's CUDA extension uses std::round (half away from
+    zero, fake_quant_tensor.cu:59,111) -- the two differ only for a learned zero point at exactly k + 0.5.
+    """
     dev = L.require_device(x, gy, scale, zero_point)
     lib = L.load()
     x = x.contiguous()
     gy = gy.contiguous()
+    x_dtype = x.dtype
     if gy.dtype != x.dtype:
-        gy = gy.to(x.dtype)
+        if gy.dtype == torch.float32:
+            x = x.float()
+        else:
+            gy = gy.to(x.dtype)
     per_channel = scale.numel() > 1
     outer, C, inner = geometry(x.shape, ch_axis, per_channel)
     scale = _f32c(scale, dev)
     zero_point = _f32c(zero_point, dev)
     _check_qparams(scale, zero_point, C)
-    gx = torch.empty(x.shape, dtype=gx_dtype or x.dtype, device=dev)
+    gx_final = gx_dtype or x_dtype
+    # (a widened x computes gx in fp32: the kernels take gx in fp32 or in x's type)
+    gx = torch.empty(x.shape, dtype=torch.float32 if x.dtype != x_dtype else gx_final, device=dev)
     gs = torch.empty(C, dtype=torch.float32, device=dev) if need_gs else None
     gzp = torch.empty(C, dtype=torch.float32, device=dev) if need_gzp else None
     if x.numel() == 0:
@@ -577,6 +600,8 @@ def fake_quant_backward(x, gy, scale, zero_point, qmin, qmax, ch_axis=0, need_gs
                                                outer, C, inner, int(qmin), int(qmax), rounding,
                                                L.ptr(ws), ws.numel(), L.stream_ptr(dev))
     L.check(rc)
+    if gx.dtype != gx_final:
+        gx = gx.to(gx_final)
     return gx, gs, gzp
 
 

@@ -521,6 +521,27 @@ def test_weight_quant_group_forward_and_gradients(masked):
         q1.calc_qparams()
         want = q1(w1 if m1 is None else w1 * m1)
         assert torch.equal(group()[3], want)
+        # set_bit() changes the integer range baked into the device table: the group rebuilds it
+        q1.set_bit(4)
+        q1.update_observer(w1.detach())
+        q1.calc_qparams()
+        want = q1(w1 if m1 is None else w1 * m1)
+        assert torch.equal(group()[3], want)
+        # enabling / disabling a quantizer changes who takes part in the grouped launch
+        q6, w6, m6 = triples[6]
+        q6.enable_quant()
+        want = q6(w6 if m6 is None else w6 * m6)
+        assert torch.equal(group()[6], want) and 6 not in group.rest_idx
+        q1.disable_quant()
+        assert torch.equal(group()[3], w1 if m1 is None else w1 * m1) and 3 in group.rest_idx
+        q1.enable_quant()
+    # an in-place update of a weight between the grouped forward and its backward must not pass silently (the
+    # backward kernels read the live tensors through the table)
+    outs = group()
+    with torch.no_grad():
+        triples[1][1].add_(1.0)
+    with pytest.raises(RuntimeError, match="modified by an inplace operation"):
+        sum((y * gy).sum() for y, gy in zip(outs, gys)).backward()
 
 
 @pytest.mark.parametrize("scheme,shape", [("per-channel-symmetric", (48, 32, 3, 3)), ("per-tensor-affine", (8, 16, 14, 14)),

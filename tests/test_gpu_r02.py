@@ -187,3 +187,29 @@ def test_reference_gptq_kat(fn, bit):
     spec = _KATS[fn]
     kw = spec[bit] if bit in spec else spec
     run_case(bit=bit, **kw)
+
+
+# ---- STE backward with an fp32 upstream gradient on a half-precision input ---------------------
+@pytest.mark.parametrize("lsq", [False, True])
+def test_backward_keeps_fp32_upstream_gradient(lsq):
+    """quant_tensor.py:82-103 upcasts x and keeps the fp32 grad_y: with a bf16 activation and the default fp32
+    output, the scale gradient must be the one computed from the UNROUNDED upstream gradient (== the fp32-x call),
+    not from its bf16 rounding; gx comes back in bf16."""
+    from sparsebit_amd import ops
+
+    g = torch.Generator().manual_seed(4)
+    x = (torch.randn(64, 96, 14, 14, generator=g) * 2).bfloat16().cuda()
+    gy = torch.randn(64, 96, 14, 14, generator=g).cuda()  # fp32
+    scale = torch.tensor([0.05], device="cuda")
+    zp = torch.tensor([3.0], device="cuda")
+    if lsq:
+        gx, gs = ops.lsq_fake_quant_backward(x, gy, scale, zp, 0, 255, 0, True, 0.5)
+        rx, rs = ops.lsq_fake_quant_backward(x.float(), gy, scale, zp, 0, 255, 0, True, 0.5)
+        lx, ls = ops.lsq_fake_quant_backward(x, gy.bfloat16(), scale, zp, 0, 255, 0, True, 0.5)
+    else:
+        gx, gs, _ = ops.fake_quant_backward(x, gy, scale, zp, 0, 255, 0, True, False)
+        rx, rs, _ = ops.fake_quant_backward(x.float(), gy, scale, zp, 0, 255, 0, True, False)
+        lx, ls, _ = ops.fake_quant_backward(x, gy.bfloat16(), scale, zp, 0, 255, 0, True, False)
+    assert gx.dtype == torch.bfloat16 and torch.equal(gx, rx.bfloat16())
+    assert torch.equal(gs, rs)
+    assert not torch.equal(gs, ls)  # the rounded upstream gradient gives a different sum

@@ -52,7 +52,8 @@ struct WinSel {
 struct WinState {
   WinSel sel[kWinSel];
   int64_t n;  // elements in all shards
-  long long pad[1];
+  uint32_t arrivals;    // win_fallback_kernel: workgroups of the running sweep that have flushed
+  uint32_t generation;  // win_fallback_kernel: rounds completed (zero between calls)
 };
 struct WinSlot {  // one 128-byte line
   unsigned long long below[kWinSel];
@@ -239,6 +240,8 @@ __global__ __launch_bounds__(1024) void win_plan_kernel(const ShardTable tab, in
   __syncthreads();
   if (threadIdx.x == 0) {
     st->n = n;
+    st->arrivals = 0;
+    st->generation = 0;
     const double S = static_cast<double>(s_total);
     for (int s = 0; s < n_sel; ++s) {
       // A bracket that runs off the sample: the window starts at the first key instead -- or, when the target is
@@ -267,6 +270,210 @@ __global__ __launch_bounds__(1024) void win_plan_kernel(const ShardTable tab, in
   }
 }
 
+// The advance of one selector: sum the copies of its histogram, place the rank, name the next window -- or write the
+// result when the window is one value wide.  Leaves the selector's histogram copies and its `below` counters zeroed.
+// COHERENT: run by the last workgroup of a sweep INSIDE a kernel (win_fallback_kernel) -- everything other
+// workgroups produced or will read goes through agent-scope atomics (sc1: the device-coherent level, not this
+// XCD's L2).  Otherwise it is its own launch and plain accesses do.
+struct AdvShared {
+  unsigned long long wave_tot[1024 / kWave];
+  unsigned long long total, below, neg, nan;
+};
+template <bool COHERENT, typename V>
+__device__ __forceinline__ V win_ld(const V* p) {
+  if constexpr (COHERENT) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else return *p;
+}
+template <bool COHERENT, typename V>
+__device__ __forceinline__ void win_st(V* p, V v) {
+  if constexpr (COHERENT) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else *p = v;
+}
+template <bool COHERENT>
+__device__ __forceinline__ WinSel win_read_sel(const WinState* st, int s) {
+  static_assert(sizeof(WinSel) == 32, "four 8-byte words");
+  unsigned long long q[4];
+  const unsigned long long* src = reinterpret_cast<const unsigned long long*>(&st->sel[s]);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) q[i] = win_ld<COHERENT>(src + i);
+  return __builtin_bit_cast(WinSel, q);
+}
+
+template <int BLOCK, bool COHERENT>
+__device__ void win_advance(const int s, uint32_t* __restrict__ hist, WinState* __restrict__ st,
+                            WinSlot* __restrict__ slots, int percentile, double alpha, uint32_t min_shift,
+                            float* __restrict__ out0, float* __restrict__ out1, AdvShared& sh) {
+  const WinSel w = win_read_sel<COHERENT>(st, s);
+  if (w.done) return;
+  auto write_sel = [&](const WinSel& nw) {
+    struct Q { unsigned long long q[4]; };
+    const Q q = __builtin_bit_cast(Q, nw);
+    unsigned long long* dst = reinterpret_cast<unsigned long long*>(&st->sel[s]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) win_st<COHERENT>(dst + i, q.q[i]);
+  };
+  constexpr int kPer = kWinBins / BLOCK;  // bins per thread
+  unsigned long long bins[kPer];
+#pragma unroll
+  for (int i = 0; i < kPer; ++i) bins[i] = 0;
+  {
+    // all copies requested together, cleared afterwards (a store between two loads would order them)
+    uint32_t v[kCopies][kPer];
+#pragma unroll
+    for (int c = 0; c < kCopies; ++c) {
+      const uint32_t* src = hist + (static_cast<size_t>(c) * kWinSel + s) * kWinBins + threadIdx.x * kPer;
+      if constexpr (!COHERENT && kPer == 4) {
+        const u32x4 q = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(src));
+#pragma unroll
+        for (int i = 0; i < kPer; ++i) v[c][i] = q[i];
+      } else {
+#pragma unroll
+        for (int i = 0; i < kPer; ++i) v[c][i] = win_ld<COHERENT>(src + i);
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < kCopies; ++c) {
+      uint32_t* dst = hist + (static_cast<size_t>(c) * kWinSel + s) * kWinBins + threadIdx.x * kPer;
+#pragma unroll
+      for (int i = 0; i < kPer; ++i) bins[i] += v[c][i];
+      if constexpr (!COHERENT && kPer == 4) {
+        *reinterpret_cast<u32x4*>(dst) = u32x4{0, 0, 0, 0};
+      } else {
+#pragma unroll
+        for (int i = 0; i < kPer; ++i)
+          if (v[c][i]) win_st<COHERENT>(dst + i, 0u);
+      }
+    }
+  }
+  unsigned long long t = 0;
+#pragma unroll
+  for (int i = 0; i < kPer; ++i) t += bins[i];
+  // counters: thread i < kSlots reads line i
+  unsigned long long c_below = 0, c_neg = 0, c_nan = 0;
+  if (threadIdx.x < kSlots) {
+    c_below = win_ld<COHERENT>(&slots[threadIdx.x].below[s]);
+    c_neg = win_ld<COHERENT>(&slots[threadIdx.x].neg);
+    c_nan = win_ld<COHERENT>(&slots[threadIdx.x].nan);
+    if (c_below) win_st<COHERENT>(&slots[threadIdx.x].below[s], 0ull);
+  }
+  const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
+  unsigned long long incl = t;
+#pragma unroll
+  for (int d = 1; d < kWave; d <<= 1) {
+    const unsigned long long up = __shfl_up(incl, d, kWave);
+    if (lane >= d) incl += up;
+  }
+  if (lane == kWave - 1) sh.wave_tot[wid] = incl;
+  if (wid == 0) {  // the 64 counter lines live in wave 0
+    c_below = wave_reduce(c_below, SumL());
+    c_neg = wave_reduce(c_neg, SumL());
+    c_nan = wave_reduce(c_nan, SumL());
+    if (lane == 0) {
+      sh.below = c_below;
+      sh.neg = c_neg;
+      sh.nan = c_nan;
+    }
+  }
+  __syncthreads();
+  unsigned long long off = 0;
+  for (int v = 0; v < wid; ++v) off += sh.wave_tot[v];
+  incl += off;
+  const unsigned long long excl = incl - t;
+  if (threadIdx.x == BLOCK - 1) sh.total = incl;
+  __syncthreads();
+  const unsigned long long total = sh.total;
+  const int64_t n = st->n;
+  const int64_t neg = static_cast<int64_t>(sh.neg), nan = static_cast<int64_t>(sh.nan);
+  const int64_t pos = n - neg - nan;
+  int64_t k = w.k;
+  if (w.fresh) {
+    if (percentile) {
+      // percentile.py:36-43 with the exact counts of the first sweep (Python round == rint on a double)
+      if (s == 0) k = static_cast<int64_t>(__builtin_fmax(__builtin_rint(static_cast<double>(neg) * alpha), 1.0));
+      else k = n - static_cast<int64_t>(__builtin_fmax(__builtin_rint(static_cast<double>(pos) * alpha), 0.0));
+      k = k < 1 ? 1 : (k > n ? n : k);
+    }
+    const unsigned long long below = sh.below;
+    const uint64_t hi = static_cast<uint64_t>(w.lo) + w.span + 1;  // exclusive
+    if (static_cast<unsigned long long>(k) <= below) {
+      // the sample lied: the rank is below the window.  New window: every key below it.
+      if (threadIdx.x == 0) {
+        WinSel nw = w;
+        nw.lo = 0;
+        nw.shift = shift_for(w.lo, min_shift);
+        nw.span = w.lo - 1;  // k <= below: there are keys below lo, so lo > 0
+        nw.k = k;
+        nw.fresh = 0;
+        write_sel(nw);
+      }
+      __syncthreads();
+      return;
+    }
+    if (static_cast<unsigned long long>(k) > below + total) {
+      // ... or above it.  New window: every key from its end on (hi < 2^32 here: a window reaching the last key
+      // holds every element that is not below it)
+      if (threadIdx.x == 0) {
+        WinSel nw = w;
+        nw.lo = static_cast<uint32_t>(hi);
+        nw.shift = shift_for((1ull << 32) - hi, min_shift);
+        nw.span = 0xffffffffu - static_cast<uint32_t>(hi);
+        nw.k = k - static_cast<int64_t>(below + total);
+        nw.fresh = 0;
+        write_sel(nw);
+      }
+      __syncthreads();
+      return;
+    }
+    k -= static_cast<int64_t>(below);
+  }
+  // the rank lies in (excl, incl] of exactly one thread's bins
+  const unsigned long long uk = static_cast<unsigned long long>(k);
+  if (uk > excl && uk <= incl) {
+    unsigned long long kk = uk - excl;
+    int b = 0;
+#pragma unroll
+    for (int i = 0; i < kPer - 1; ++i) {
+      if (b == i && kk > bins[i]) {
+        kk -= bins[i];
+        ++b;
+      }
+    }
+    WinSel nw = w;
+    nw.lo = w.lo + (static_cast<uint32_t>(threadIdx.x * kPer + b) << w.shift);
+    nw.k = static_cast<int64_t>(kk);
+    nw.fresh = 0;
+    if (w.shift <= min_shift) {
+      nw.done = 1;  // a bin is one representable value: of a 16-bit input's 2^min_shift keys in it, the real one has
+      // low bits 0 for x < 0 (~bits ends in ones, minus the rotation) and 1 for x >= 0 (zeros minus the rotation)
+      if (min_shift > 0 && ((nw.lo + kRot) & 0x80000000u)) nw.lo |= 1u;
+      if (percentile) {
+        // percentile.py:30-43: without negative (non-negative) elements min (max) stays 0
+        if (s == 0) out0[0] = neg > 0 ? win_key_float(nw.lo) : 0.0f;
+        else out1[0] = pos > 0 ? win_key_float(nw.lo) : 0.0f;
+      } else {
+        out0[s] = win_key_float(nw.lo);
+      }
+    } else {
+      nw.shift = w.shift > min_shift + kWinLog ? w.shift - kWinLog : min_shift;
+      // the bin, cut at the end of its parent window
+      const uint32_t bin_last = (w.shift < 32 ? (1u << w.shift) : 0u) - 1u;
+      const uint32_t left = w.lo + w.span - nw.lo;
+      nw.span = bin_last < left ? bin_last : left;
+    }
+    write_sel(nw);
+  }
+  __syncthreads();  // `sh` is reused by the next selector
+}
+
+// ... as its own launch: one workgroup per selector.
+__global__ __launch_bounds__(kAdvBlock) void win_advance_kernel(uint32_t* __restrict__ hist,
+                                                                WinState* __restrict__ st, WinSlot* __restrict__ slots,
+                                                                int percentile, double alpha, uint32_t min_shift,
+                                                                float* __restrict__ out0, float* __restrict__ out1) {
+  __shared__ AdvShared sh;
+  win_advance<kAdvBlock, false>(blockIdx.x, hist, st, slots, percentile, alpha, min_shift, out0, out1, sh);
+}
+
 // The sweep.  A workgroup walks slabs of 32 elements per thread (grid-stride), so the LDS histograms are cleared
 // and flushed once per workgroup -- and the workgroups are BIG (1024 threads, one per CU) whenever the tensor has
 // two slabs per CU: every workgroup flushes the same few dozen non-empty bins, and same-line device atomics
@@ -292,10 +499,11 @@ struct PassTable {
   uint32_t rag_first[kMaxShards + 1];
 };
 
-template <typename T, int NSEL, bool SIGNS, int BLOCK>
-__global__ __launch_bounds__(BLOCK) void win_pass_kernel(const PassTable tab, int n_shards,
-                                                         const WinState* __restrict__ st, WinSlot* __restrict__ slots,
-                                                         uint32_t* __restrict__ hist, int use_abs) {
+// (the body of a sweep, shared by win_pass_kernel and win_fallback_kernel; `load_state` fetches the selectors AFTER
+// the first slab has been requested; returns false when every selector is resolved already)
+template <typename T, int NSEL, bool SIGNS, int BLOCK, typename LoadState>
+__device__ __forceinline__ bool win_sweep(const PassTable& tab, int n_shards, LoadState&& load_state,
+                                          WinSlot* __restrict__ slots, uint32_t* __restrict__ hist, int use_abs) {
   constexpr uint32_t kSlab = WinGeom<BLOCK>::kSlab;
   constexpr int U = WinGeom<BLOCK>::kU;
   constexpr int kWaves = BLOCK / kWave;
@@ -332,21 +540,23 @@ __global__ __launch_bounds__(BLOCK) void win_pass_kernel(const PassTable tab, in
   bool live = false;
   uint32_t lo[NSEL], lom1[NSEL], sh[NSEL], span[NSEL];
   bool act[NSEL], fresh[NSEL];
+  WinSel sel[NSEL];
+  load_state(sel);
 #pragma unroll
   for (int s = 0; s < NSEL; ++s) {
-    act[s] = st->sel[s].done == 0;
-    lo[s] = st->sel[s].lo;
-    sh[s] = st->sel[s].shift;
-    span[s] = st->sel[s].span;
+    act[s] = sel[s].done == 0;
+    lo[s] = sel[s].lo;
+    sh[s] = sel[s].shift;
+    span[s] = sel[s].span;
     if (!act[s]) {  // a finished selector gets an empty window: only key 0xffffffff passes, and nobody reads its bins
       lo[s] = 0xffffffffu;
       span[s] = 0;
     }
-    fresh[s] = act[s] && st->sel[s].fresh != 0;
+    fresh[s] = act[s] && sel[s].fresh != 0;
     lom1[s] = lo[s] - 1u;
     live |= act[s];
   }
-  if (!live) return;
+  if (!live) return false;
   for (uint32_t i = threadIdx.x; i < NSEL * kWinBins; i += BLOCK) (&lh[0][0])[i] = 0;
   __syncthreads();
   // per-lane counters (ragged path) and wave-uniform ones (lean path)
@@ -486,7 +696,10 @@ __global__ __launch_bounds__(BLOCK) void win_pass_kernel(const PassTable tab, in
     for (int w = 0; w < kWaves; ++w) t += red[threadIdx.x][w];
     if (t) {
       if (static_cast<int>(threadIdx.x) < NSEL) {
-        if (st->sel[threadIdx.x].done == 0 && st->sel[threadIdx.x].fresh != 0) atomicAdd(&slot->below[threadIdx.x], t);
+        bool mine = false;
+#pragma unroll
+        for (int s = 0; s < NSEL; ++s) mine |= static_cast<int>(threadIdx.x) == s && fresh[s];
+        if (mine) atomicAdd(&slot->below[threadIdx.x], t);
       } else {
         atomicAdd(threadIdx.x == NSEL ? &slot->neg : &slot->nan, t);
       }
@@ -501,150 +714,65 @@ __global__ __launch_bounds__(BLOCK) void win_pass_kernel(const PassTable tab, in
       if (v) atomicAdd(&gh[i], v);
     }
   }
-  (void)fresh;
+  return true;
 }
 
-// One workgroup of 1024 per selector: sum the copies, place the rank, write the result when it is final.
-// Leaves the selector's histogram copies and its `below` counters zeroed.
-__global__ __launch_bounds__(kAdvBlock) void win_advance_kernel(uint32_t* __restrict__ hist,
-                                                                WinState* __restrict__ st, WinSlot* __restrict__ slots,
-                                                                int percentile, double alpha, uint32_t min_shift,
-                                                                float* __restrict__ out0, float* __restrict__ out1) {
-  __shared__ unsigned long long wave_tot[kAdvBlock / kWave];
-  __shared__ unsigned long long s_total, s_below, s_neg, s_nan;
-  const int s = blockIdx.x;
-  WinSel w = st->sel[s];
-  if (w.done) return;
-  constexpr int kPer = kWinBins / kAdvBlock;  // 4 bins per thread: one 16-byte load per copy
-  unsigned long long bins[kPer] = {0, 0, 0, 0};
-  {
-    // all copies requested together, cleared afterwards (a store between two loads would order them)
-    u32x4 v[kCopies];
+template <typename T, int NSEL, bool SIGNS, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void win_pass_kernel(const PassTable tab, int n_shards,
+                                                         const WinState* __restrict__ st, WinSlot* __restrict__ slots,
+                                                         uint32_t* __restrict__ hist, int use_abs) {
+  win_sweep<T, NSEL, SIGNS, BLOCK>(tab, n_shards, [&](WinSel (&sel)[NSEL]) {
 #pragma unroll
-    for (int c = 0; c < kCopies; ++c)
-      v[c] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(hist + (static_cast<size_t>(c) * kWinSel + s) * kWinBins) + threadIdx.x);
+    for (int s = 0; s < NSEL; ++s) sel[s] = st->sel[s];
+  }, slots, hist, use_abs);
+}
+
+// The rounds after the expected ones, in ONE launch.  They are needed only when the sample lied about a window, and
+// as separate (sweep, advance) launches cost ~3 us each just to find every selector resolved.  A small grid
+// (co-resident by construction: far fewer workgroups than CUs) sweeps, the last workgroup to arrive advances the
+// selectors, and a generation counter releases the others into the next round -- or everybody leaves at the first
+// look when nothing is left to do.  No agent-scope fences (see the GPTQ strip kernels): the histogram / counter
+// adds are agent-scope atomics, the advance reads and writes them -- and the selector state -- with agent-scope
+// atomic loads / stores, and a workgroup's adds are acknowledged (vmcnt(0)) before its arrival is counted.
+template <typename T, int NSEL, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void win_fallback_kernel(const PassTable tab, int n_shards, WinState* __restrict__ st,
+                                                             WinSlot* __restrict__ slots, uint32_t* __restrict__ hist,
+                                                             int use_abs, int percentile, double alpha, uint32_t min_shift,
+                                                             float* __restrict__ out0, float* __restrict__ out1,
+                                                             int max_rounds) {
+  __shared__ AdvShared adv;
+  __shared__ uint32_t s_flag;
+  uint32_t gen = 0;  // st->generation is zero at launch (win_plan_kernel)
+  for (int r = 0; r < max_rounds; ++r) {
+    const bool live = win_sweep<T, NSEL, false, BLOCK>(tab, n_shards, [&](WinSel (&sel)[NSEL]) {
 #pragma unroll
-    for (int c = 0; c < kCopies; ++c) {
+      for (int s = 0; s < NSEL; ++s) sel[s] = r == 0 ? st->sel[s] : win_read_sel<true>(st, s);
+    }, slots, hist, use_abs);
+    if (!live) break;  // uniform over the grid: every workgroup read the same state
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    if (threadIdx.x == 0)
+      s_flag = __hip_atomic_fetch_add(&st->arrivals, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+    __syncthreads();
+    if (s_flag) {
 #pragma unroll
-      for (int i = 0; i < kPer; ++i) bins[i] += v[c][i];
-      reinterpret_cast<u32x4*>(hist + (static_cast<size_t>(c) * kWinSel + s) * kWinBins)[threadIdx.x] = u32x4{0, 0, 0, 0};
-    }
-  }
-  unsigned long long t = 0;
-#pragma unroll
-  for (int i = 0; i < kPer; ++i) t += bins[i];
-  // counters: thread i < kSlots reads line i
-  unsigned long long c_below = 0, c_neg = 0, c_nan = 0;
-  if (threadIdx.x < kSlots) {
-    c_below = slots[threadIdx.x].below[s];
-    c_neg = slots[threadIdx.x].neg;
-    c_nan = slots[threadIdx.x].nan;
-    slots[threadIdx.x].below[s] = 0;
-  }
-  const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
-  unsigned long long incl = t;
-#pragma unroll
-  for (int d = 1; d < kWave; d <<= 1) {
-    const unsigned long long up = __shfl_up(incl, d, kWave);
-    if (lane >= d) incl += up;
-  }
-  if (lane == kWave - 1) wave_tot[wid] = incl;
-  if (wid == 0) {  // the 64 counter lines live in wave 0
-    c_below = wave_reduce(c_below, SumL());
-    c_neg = wave_reduce(c_neg, SumL());
-    c_nan = wave_reduce(c_nan, SumL());
-    if (lane == 0) {
-      s_below = c_below;
-      s_neg = c_neg;
-      s_nan = c_nan;
-    }
-  }
-  __syncthreads();
-  unsigned long long off = 0;
-  for (int v = 0; v < wid; ++v) off += wave_tot[v];
-  incl += off;
-  const unsigned long long excl = incl - t;
-  if (threadIdx.x == kAdvBlock - 1) s_total = incl;
-  __syncthreads();
-  const unsigned long long total = s_total;
-  const int64_t n = st->n;
-  const int64_t neg = static_cast<int64_t>(s_neg), nan = static_cast<int64_t>(s_nan);
-  const int64_t pos = n - neg - nan;
-  int64_t k = w.k;
-  if (w.fresh) {
-    if (percentile) {
-      // percentile.py:36-43 with the exact counts of the first sweep (Python round == rint on a double)
-      if (s == 0) k = static_cast<int64_t>(__builtin_fmax(__builtin_rint(static_cast<double>(neg) * alpha), 1.0));
-      else k = n - static_cast<int64_t>(__builtin_fmax(__builtin_rint(static_cast<double>(pos) * alpha), 0.0));
-      k = k < 1 ? 1 : (k > n ? n : k);
-    }
-    const unsigned long long below = s_below;
-    const uint64_t hi = static_cast<uint64_t>(w.lo) + w.span + 1;  // exclusive
-    if (static_cast<unsigned long long>(k) <= below) {
-      // the sample lied: the rank is below the window.  New window: every key below it.
+      for (int s = 0; s < NSEL; ++s)
+        win_advance<BLOCK, true>(s, hist, st, slots, percentile, alpha, min_shift, out0, out1, adv);
+      __builtin_amdgcn_s_waitcnt(0);  // the advance's stores are acknowledged ...
+      __syncthreads();
       if (threadIdx.x == 0) {
-        WinSel nw = w;
-        nw.lo = 0;
-        nw.shift = shift_for(w.lo, min_shift);
-        nw.span = w.lo - 1;  // k <= below: there are keys below lo, so lo > 0
-        nw.k = k;
-        nw.fresh = 0;
-        st->sel[s] = nw;
+        win_st<true>(&st->arrivals, 0u);
+        win_st<true>(&st->generation, gen + 1);  // ... before anybody is released
       }
-      return;
+    } else if (threadIdx.x == 0) {
+      while (win_ld<true>(&st->generation) == gen) __builtin_amdgcn_s_sleep(8);
     }
-    if (static_cast<unsigned long long>(k) > below + total) {
-      // ... or above it.  New window: every key from its end on (hi < 2^32 here: a window reaching the last key
-      // holds every element that is not below it)
-      if (threadIdx.x == 0) {
-        WinSel nw = w;
-        nw.lo = static_cast<uint32_t>(hi);
-        nw.shift = shift_for((1ull << 32) - hi, min_shift);
-        nw.span = 0xffffffffu - static_cast<uint32_t>(hi);
-        nw.k = k - static_cast<int64_t>(below + total);
-        nw.fresh = 0;
-        st->sel[s] = nw;
-      }
-      return;
-    }
-    k -= static_cast<int64_t>(below);
+    __syncthreads();
+    ++gen;
   }
-  // the rank lies in (excl, incl] of exactly one thread's bins
-  const unsigned long long uk = static_cast<unsigned long long>(k);
-  if (uk > excl && uk <= incl) {
-    unsigned long long kk = uk - excl;
-    int b = 0;
-#pragma unroll
-    for (int i = 0; i < kPer - 1; ++i) {
-      if (b == i && kk > bins[i]) {
-        kk -= bins[i];
-        ++b;
-      }
-    }
-    WinSel nw = w;
-    nw.lo = w.lo + (static_cast<uint32_t>(threadIdx.x * kPer + b) << w.shift);
-    nw.k = static_cast<int64_t>(kk);
-    nw.fresh = 0;
-    if (w.shift <= min_shift) {
-      nw.done = 1;  // a bin is one representable value: of a 16-bit input's 2^min_shift keys in it, the real one has
-      // low bits 0 for x < 0 (~bits ends in ones, minus the rotation) and 1 for x >= 0 (zeros minus the rotation)
-      if (min_shift > 0 && ((nw.lo + kRot) & 0x80000000u)) nw.lo |= 1u;
-      if (percentile) {
-        // percentile.py:30-43: without negative (non-negative) elements min (max) stays 0
-        if (s == 0) out0[0] = neg > 0 ? win_key_float(nw.lo) : 0.0f;
-        else out1[0] = pos > 0 ? win_key_float(nw.lo) : 0.0f;
-      } else {
-        out0[s] = win_key_float(nw.lo);
-      }
-    } else {
-      nw.shift = w.shift > min_shift + kWinLog ? w.shift - kWinLog : min_shift;
-      // the bin, cut at the end of its parent window
-      const uint32_t bin_last = (w.shift < 32 ? (1u << w.shift) : 0u) - 1u;
-      const uint32_t left = w.lo + w.span - nw.lo;
-      nw.span = bin_last < left ? bin_last : left;
-    }
-    st->sel[s] = nw;
-  }
+  // (st->generation is NOT reset here -- a workgroup still spinning on the first round's value would see it come
+  // back; win_plan_kernel zeroes it at the start of every call)
 }
 
 constexpr size_t kStateBytes = 256;
@@ -692,24 +820,29 @@ int win_select_run(const void* const* shards, const int64_t* counts, int n_shard
   for (int i = 0; i < n_shards; ++i) big_slabs += ceil_div(counts[i], static_cast<int64_t>(WinGeom<1024>::kSlab));
   const bool big = big_slabs >= 2 * static_cast<int64_t>(cus) && knob(2) != 8;
   const int64_t slab = big ? WinGeom<1024>::kSlab : WinGeom<kBlock>::kSlab;
+  auto make_table = [&](int64_t slab_elems, PassTable& t, int64_t& total) {
+    int64_t n_lean = 0;
+    total = 0;
+    for (int i = 0; i < n_shards; ++i) {
+      t.ptr[i] = shards[i];
+      t.count[i] = counts[i];
+      const int64_t all = ceil_div(counts[i], slab_elems), lean = aligned16(shards[i]) ? counts[i] / slab_elems : 0;
+      t.lean_first[i] = static_cast<uint32_t>(n_lean);
+      t.rag_first[i] = static_cast<uint32_t>(total - n_lean);
+      n_lean += lean;
+      total += all;
+    }
+    t.lean_first[n_shards] = static_cast<uint32_t>(n_lean);
+    t.rag_first[n_shards] = static_cast<uint32_t>(total - n_lean);
+  };
   PassTable pt{};
-  int64_t total_slabs = 0, n_lean = 0;
-  for (int i = 0; i < n_shards; ++i) {
-    pt.ptr[i] = shards[i];
-    pt.count[i] = counts[i];
-    const int64_t all = ceil_div(counts[i], slab), lean = aligned16(shards[i]) ? counts[i] / slab : 0;
-    pt.lean_first[i] = static_cast<uint32_t>(n_lean);
-    pt.rag_first[i] = static_cast<uint32_t>(total_slabs - n_lean);
-    n_lean += lean;
-    total_slabs += all;
-  }
+  int64_t total_slabs = 0;
+  make_table(slab, pt, total_slabs);
   if (total_slabs >= (1ll << 31)) return SBQ_ERR_ARG;
-  pt.lean_first[n_shards] = static_cast<uint32_t>(n_lean);
-  pt.rag_first[n_shards] = static_cast<uint32_t>(total_slabs - n_lean);
   // rounds beyond the expected ones (one sweep for 16-bit inputs, up to three for fp32) almost always find every
   // selector resolved and exit at once: launch them small -- a miss of the first window just sweeps slower
   const int expected = min_shift > 0 ? 1 : 3;
-  for (int r = 0; r < rounds; ++r) {
+  for (int r = 0; r < rounds && r < expected; ++r) {
     const int64_t cap = r >= expected ? 64 : (big ? cus : 4 * static_cast<int64_t>(cus));
     const uint32_t grid = static_cast<uint32_t>(total_slabs < cap ? (total_slabs > 0 ? total_slabs : 1) : cap);
     const bool signs = r == 0 && percentile;
@@ -731,6 +864,24 @@ int win_select_run(const void* const* shards, const int64_t* counts, int n_shard
     // the advance of the round that resolves a selector also writes its result
     win_advance_kernel<<<n_sel, kAdvBlock, 0, st>>>(hist, state, slots, percentile ? 1 : 0, alpha, min_shift, out0,
                                                     out1);
+  }
+  if (rounds > expected) {
+    // (its workgroups are 1024 threads whatever the sweeps above used: their own slab list)
+    PassTable pf{};
+    int64_t fb_slabs = 0;
+    make_table(WinGeom<1024>::kSlab, pf, fb_slabs);
+    const int64_t cap = cus < 64 ? cus : 64;  // all co-resident: the rounds are separated by a grid-wide wait
+    const uint32_t grid = static_cast<uint32_t>(fb_slabs < cap ? (fb_slabs > 0 ? fb_slabs : 1) : cap);
+    rc = dispatch_dtype(x_dtype, [&](auto tag) {
+      using T = decltype(tag);
+      if (n_sel == 1)
+        win_fallback_kernel<T, 1, 1024><<<grid, 1024, 0, st>>>(pf, n_shards, state, slots, hist, use_abs, percentile ? 1 : 0,
+                                                            alpha, min_shift, out0, out1, rounds - expected);
+      else
+        win_fallback_kernel<T, 2, 1024><<<grid, 1024, 0, st>>>(pf, n_shards, state, slots, hist, use_abs, percentile ? 1 : 0,
+                                                            alpha, min_shift, out0, out1, rounds - expected);
+    });
+    if (rc != SBQ_OK) return rc;
   }
   return check_launch();
 }

@@ -729,7 +729,7 @@ __global__ __launch_bounds__(BLOCK) void win_pass_kernel(const PassTable tab, in
 
 // The rounds after the expected ones, in ONE launch.  They are needed only when the sample lied about a window, and
 // as separate (sweep, advance) launches cost ~3 us each just to find every selector resolved.  A small grid
-// (co-resident by construction: far fewer workgroups than CUs) sweeps, the last workgroup to arrive advances the
+// (co-resident by construction: half as many workgroups as CUs, one per CU at most) sweeps, the last workgroup to arrive advances the
 // selectors, and a generation counter releases the others into the next round -- or everybody leaves at the first
 // look when nothing is left to do.  No agent-scope fences (see the GPTQ strip kernels): the histogram / counter
 // adds are agent-scope atomics, the advance reads and writes them -- and the selector state -- with agent-scope
@@ -870,7 +870,8 @@ int win_select_run(const void* const* shards, const int64_t* counts, int n_shard
     PassTable pf{};
     int64_t fb_slabs = 0;
     make_table(WinGeom<1024>::kSlab, pf, fb_slabs);
-    const int64_t cap = cus < 64 ? cus : 64;  // all co-resident: the rounds are separated by a grid-wide wait
+    // all co-resident (the rounds are separated by a grid-wide wait): one workgroup on every second CU
+    const int64_t cap = cus >= 2 ? cus / 2 : 1;
     const uint32_t grid = static_cast<uint32_t>(fb_slabs < cap ? (fb_slabs > 0 ? fb_slabs : 1) : cap);
     rc = dispatch_dtype(x_dtype, [&](auto tag) {
       using T = decltype(tag);

@@ -37,3 +37,13 @@ for knob in (7, 0):
     t = timed(lambda: ops.percentile_select(acts, 1e-3, 0, False))
     print("DeiT activations 4 x 64x197x384 bf16 per tensor, engine=%s: %7.1f us" % ("fixed-digit" if knob == 7 else "windowed", t), flush=True)
 L.set_tuning(2, 0)
+# a window the sample misses: every sampled pack holds an outlier (period == sampling stride), so the first sweep
+# finds the rank outside its window and the remaining rounds run inside the one fallback launch
+n = 4096 * 4096
+per = torch.randn(n, generator=g)
+stride = n // 2048
+idx = (torch.arange(2048) * stride).unsqueeze(1) + torch.arange(8).unsqueeze(0)
+per[idx.reshape(-1)] = 1000.0
+xb = per.bfloat16().to(dev)
+t = timed(lambda: ops.kth_value(xb, n // 2 + 1, True))
+print("bfloat16  kth_value with a missed first window (sampled packs are outliers): %7.1f us" % t, flush=True)

@@ -501,7 +501,7 @@ struct PassTable {
 
 // (the body of a sweep, shared by win_pass_kernel and win_fallback_kernel; `load_state` fetches the selectors AFTER
 // the first slab has been requested; returns false when every selector is resolved already)
-template <typename T, int NSEL, bool SIGNS, int BLOCK, typename LoadState>
+template <typename T, int NSEL, bool SIGNS, int BLOCK, bool EARLY, typename LoadState>
 __device__ __forceinline__ bool win_sweep(const PassTable& tab, int n_shards, LoadState&& load_state,
                                           WinSlot* __restrict__ slots, uint32_t* __restrict__ hist, int use_abs) {
   constexpr uint32_t kSlab = WinGeom<BLOCK>::kSlab;
@@ -534,8 +534,9 @@ __device__ __forceinline__ bool win_sweep(const PassTable& tab, int n_shards, Lo
   };
   // the first slab is requested before anything else: the selector state below comes from a cold scalar load, the
   // LDS histograms want clearing -- a memory round trip that overlaps both
+  // (EARLY == false, the fallback launch: it usually finds nothing to do, so it looks at the state first)
   RawPack<T> buf_a[U], buf_b[U];
-  if (n_lean > 0) issue(blockIdx.x, buf_a);
+  if (EARLY && n_lean > 0) issue(blockIdx.x, buf_a);
   // every selector resolved: nothing to do (the later rounds of a protocol that needed only one)
   bool live = false;
   uint32_t lo[NSEL], lom1[NSEL], sh[NSEL], span[NSEL];
@@ -557,6 +558,7 @@ __device__ __forceinline__ bool win_sweep(const PassTable& tab, int n_shards, Lo
     live |= act[s];
   }
   if (!live) return false;
+  if (!EARLY && n_lean > 0) issue(blockIdx.x, buf_a);
   for (uint32_t i = threadIdx.x; i < NSEL * kWinBins; i += BLOCK) (&lh[0][0])[i] = 0;
   __syncthreads();
   // per-lane counters (ragged path) and wave-uniform ones (lean path)
@@ -721,7 +723,7 @@ template <typename T, int NSEL, bool SIGNS, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void win_pass_kernel(const PassTable tab, int n_shards,
                                                          const WinState* __restrict__ st, WinSlot* __restrict__ slots,
                                                          uint32_t* __restrict__ hist, int use_abs) {
-  win_sweep<T, NSEL, SIGNS, BLOCK>(tab, n_shards, [&](WinSel (&sel)[NSEL]) {
+  win_sweep<T, NSEL, SIGNS, BLOCK, true>(tab, n_shards, [&](WinSel (&sel)[NSEL]) {
 #pragma unroll
     for (int s = 0; s < NSEL; ++s) sel[s] = st->sel[s];
   }, slots, hist, use_abs);
@@ -744,7 +746,7 @@ __global__ __launch_bounds__(BLOCK) void win_fallback_kernel(const PassTable tab
   __shared__ uint32_t s_flag;
   uint32_t gen = 0;  // st->generation is zero at launch (win_plan_kernel)
   for (int r = 0; r < max_rounds; ++r) {
-    const bool live = win_sweep<T, NSEL, false, BLOCK>(tab, n_shards, [&](WinSel (&sel)[NSEL]) {
+    const bool live = win_sweep<T, NSEL, false, BLOCK, false>(tab, n_shards, [&](WinSel (&sel)[NSEL]) {
 #pragma unroll
       for (int s = 0; s < NSEL; ++s) sel[s] = r == 0 ? st->sel[s] : win_read_sel<true>(st, s);
     }, slots, hist, use_abs);

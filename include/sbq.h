@@ -445,7 +445,10 @@ int sbq_vecquant2matmul(const float* x, const int32_t* qweight, float* out,
 /* knob 0: forward-QDQ variant override (-1 = auto). knob 1: grid cap (0 = auto).
  * knob 2: A/B switches that never change results (3 = IEEE division in the headline QDQ
  * kernel; 1 / 2 = 128 / 64 channels per K lane, 4 = byte converts instead of the e4m3 decode,
- * 9 = two-launch path in the GPTQ mat-vec). knob 3: resident schedule of the forward QDQ
+ * 9 = two-launch path in the GPTQ mat-vec, 6 = no LDS-DMA prefetch, 8 = plain strip order,
+ * 5 = (strip, K block) grid instead of the persistent strip workers on HBM-sized matrices --
+ * and, in sbq_percentile_rows, the general row kernel instead of the small-rank extraction;
+ * 7 = fixed-digit radix engine for whole-tensor selections). knob 3: resident schedule of the forward QDQ
  * (0 = auto: tensors that fit the chip's registers in one sitting, 1 = never, 2 = always) */
 int sbq_set_tuning(int knob, int value);
 

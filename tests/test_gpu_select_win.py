@@ -135,3 +135,39 @@ def test_percentile_rows_small_ranks(oracle, dtype, C, inner, alpha):
     finally:
         L.set_tuning(2, 0)
     assert same_values(mn.cpu().numpy(), gmn.cpu().numpy()) and same_values(mx.cpu().numpy(), gmx.cpu().numpy())
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_one_launch_over_mixed_shards(oracle, dtype):
+    """the sweep is ONE launch over all cached batches: whole 16 Ki-element slabs of aligned shards take the lean
+    path, ragged last slabs and every slab of a shard that is not 16-byte aligned the per-element path -- mix them:
+    a large aligned shard, an unaligned view, a shard shorter than a slab, one element, a ragged multi-slab shard"""
+    g = torch.Generator().manual_seed(77)
+    big = torch.randn(3 * 16384 * 5 + 8, generator=g).to(dtype).cuda()
+    base = torch.randn(70001, generator=g).to(dtype).cuda()
+    shards = [big[: 3 * 16384 * 5], base[1:50000], torch.randn(777, generator=g).to(dtype).cuda(),
+              torch.randn(1, generator=g).to(dtype).cuda(), torch.randn(2 * 16384 + 4099, generator=g).to(dtype).cuda()]
+    assert shards[1].data_ptr() % 16 != 0
+    data = np.concatenate([s.float().cpu().numpy().reshape(-1) for s in shards])
+    # through the C ABI directly: shards of different sizes share the row length 1 (ops.percentile_select hands
+    # such batches to the stepwise protocol instead)
+    import ctypes
+    lib = L.load()
+    dev = shards[0].device
+    outers = (ctypes.c_int64 * len(shards))(*[s.numel() for s in shards])
+    ptrs = (ctypes.c_void_p * len(shards))(*[s.data_ptr() for s in shards])
+    ws = torch.empty(lib.sbq_radix_select_workspace_bytes(1, 2), dtype=torch.uint8, device=dev)
+    for alpha in (0.0, 1e-3, 0.2):
+        mn = torch.empty(1, dtype=torch.float32, device=dev)
+        mx = torch.empty(1, dtype=torch.float32, device=dev)
+        rc = lib.sbq_percentile_select(ptrs, outers, len(shards), L.dtype_id(shards[0]), 1, 1, float(alpha), L.ptr(mn),
+                                       L.ptr(mx), L.ptr(ws), ws.numel(), L.stream_ptr(dev))
+        L.check(rc)
+        rmn, rmx = oracle.percentile(data, alpha, per_channel=False)
+        assert same_values(mn.cpu().numpy(), rmn) and same_values(mx.cpu().numpy(), rmx), (alpha, mn, rmn, mx, rmx)
+    # the mask threshold on single tensors of the same kinds: the unaligned view, the ragged multi-slab shard
+    for t in (shards[1], shards[4]):
+        tf = t.float().cpu().numpy()
+        n = tf.size
+        for k in (1, n // 2, n):
+            assert float(ops.kth_value(t, k, True)) == float(_kth_ref(tf, k, True)), (n, k)

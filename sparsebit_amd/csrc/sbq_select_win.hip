@@ -44,7 +44,7 @@ struct WinSel {
   uint32_t lo;     // first key of the window
   uint32_t shift;  // bin = (key - lo) >> shift, kWinBins bins
   uint32_t span;   // last in-window offset: the window is [lo, lo + span], at most kWinBins << shift keys
-  uint32_t pad0;
+  uint32_t side;   // what a fresh window's sweep counts besides the histogram: 0 = the keys below it, 1 = above it
   int64_t k;       // rank (1-based): absolute while `fresh`, relative to the window afterwards
   uint32_t done;   // key `lo` is the answer
   uint32_t fresh;  // window came from the sample: the sweep also counts the keys below it
@@ -261,7 +261,9 @@ __global__ __launch_bounds__(1024) void win_plan_kernel(const ShardTable tab, in
       // binades -- half of a weight tensor -- while the bracket is a few dozen values wide
       const uint64_t room = 0xffffffffull - lo;
       w.span = static_cast<uint32_t>(width - 1 < room ? width - 1 : room);
-      w.pad0 = 0;
+      // percentile: the min side's window sits at the bottom of the data, the max side's at the top -- the sweep
+      // tests the near end first and counts what lies beyond it (a handful of keys) instead of what lies before
+      w.side = mode == 1 && s == 1 ? 1u : 0u;
       w.k = mode == 0 ? (s == 0 ? k0 : k1) : 0;
       w.done = 0;
       w.fresh = 1;
@@ -393,7 +395,8 @@ __device__ void win_advance(const int s, uint32_t* __restrict__ hist, WinState* 
       else k = n - static_cast<int64_t>(__builtin_fmax(__builtin_rint(static_cast<double>(pos) * alpha), 0.0));
       k = k < 1 ? 1 : (k > n ? n : k);
     }
-    const unsigned long long below = sh.below;
+    // (side 1: the counter holds the keys ABOVE the window -- NaNs included, they sort last)
+    const unsigned long long below = w.side ? static_cast<unsigned long long>(n) - total - sh.below : sh.below;
     const uint64_t hi = static_cast<uint64_t>(w.lo) + w.span + 1;  // exclusive
     if (static_cast<unsigned long long>(k) <= below) {
       // the sample lied: the rank is below the window.  New window: every key below it.
@@ -574,6 +577,11 @@ __device__ __forceinline__ bool win_sweep(const PassTable& tab, int n_shards, Lo
     const uint32_t m = static_cast<uint32_t>(static_cast<int32_t>(b) >> 31) | 0x80000000u;
     return (b ^ m) - kRot;
   };
+  // The percentile's first sweep (two selectors + sign counts): selector 0's window sits at the bottom of the data,
+  // selector 1's at the top (WinSel::side = 0 / 1).  One compare against the window's NEAR end settles all but a
+  // few per cent of the elements; only those go on to the window test, and the ones beyond the far end are what
+  // the sweep counts (side 1: the keys ABOVE the window; the advance turns that into the keys below).
+  constexpr bool ONESIDED = SIGNS && NSEL == 2;
   auto visit = [&](uint32_t kk, bool valid) {
     if constexpr (SIGNS) {
       neg += valid && kk < kKeyZero;
@@ -582,7 +590,8 @@ __device__ __forceinline__ bool win_sweep(const PassTable& tab, int n_shards, Lo
 #pragma unroll
     for (int s = 0; s < NSEL; ++s) {
       const uint32_t d = kk - lo[s];
-      lt[s] += valid && kk < lo[s];
+      if (ONESIDED && s == 1) lt[s] += valid && kk > lo[s] + span[s];  // lo + span <= 0xffffffff by construction
+      else lt[s] += valid && kk < lo[s];
       if (valid && d <= span[s]) atomicAdd(&lh[s][d >> sh[s]], 1u);
     }
   };
@@ -597,6 +606,19 @@ __device__ __forceinline__ bool win_sweep(const PassTable& tab, int n_shards, Lo
     if constexpr (SIGNS) {
       count(w_neg, kk < kKeyZero);
       count(w_nan, kk > kKeyInf);
+    }
+    if constexpr (ONESIDED) {
+      if (kk <= lo[0] + span[0]) {  // at or below the top of the bottom window: rare
+        const uint32_t d = kk - lo[0];
+        if (d <= span[0]) atomicAdd(&lh[0][d >> sh[0]], 1u);
+        else ++lt[0];  // wrapped: below the window
+      }
+      if (kk >= lo[1]) {  // at or above the bottom of the top window: rare
+        const uint32_t d = kk - lo[1];
+        if (d <= span[1]) atomicAdd(&lh[1][d >> sh[1]], 1u);
+        else ++lt[1];  // above the window
+      }
+      return;
     }
 #pragma unroll
     for (int s = 0; s < NSEL; ++s) {
@@ -635,7 +657,7 @@ __device__ __forceinline__ bool win_sweep(const PassTable& tab, int n_shards, Lo
       }
     }
 #pragma unroll
-    for (int s = 0; s < NSEL; ++s) lt[s] += lane0 && lo[s] != 0 ? w_lt[s] : 0u;
+    for (int s = 0; s < NSEL; ++s) lt[s] += !ONESIDED && lane0 && lo[s] != 0 ? w_lt[s] : 0u;
     if constexpr (SIGNS) {
       neg += lane0 ? w_neg : 0u;
       nan += lane0 ? w_nan : 0u;

@@ -347,6 +347,8 @@ def main():
 
     fus_us = timed(step_fused, 100)
     extras["fused_observe_qdq_us"] = round(fus_us, 3)
+    # the same call on ONE buffer pair (64 MB: stays in the Infinity Cache), as tools/observe_bench.py times it
+    extras["fused_observe_qdq_cache_resident_us"] = round(timed(lambda i: step_fused(0), 100), 3)
     extras["fused_observe_qdq_GBps"] = round(n_elem * BYTES_PER_ELEM / fus_us / 1e3, 1)
     n_half = n_elem // 2 + 1
     extras["mask_threshold_kth_value_us"] = round(timed_op(lambda: ops.kth_value(xs[0], n_half, True)), 2)

@@ -687,7 +687,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t gptq_rsrc(const void* base, ui
 // Before this, 64-bit address arithmetic and clamps were 170 of the ~800 vector instructions of a pass, and the
 // in-loop sums of the activations (now taken once per worker: `xsum_h`) another 96: the decode itself needs ~380,
 // and at 800 the kernel was bound by the vector ALU, not by memory.
-template <int BITS, int kBT, int NS, bool DEC8>
+template <int BITS, int kBT, int NS, bool DEC8, int DW = NS - 1>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void gptq_stream_kernel(
     const float* __restrict__ x, const int32_t* __restrict__ qw, const float* __restrict__ scales,
     const float* __restrict__ zeros, float* __restrict__ out, const GptqGeom g, uint32_t strips) {
@@ -782,7 +782,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   advance(nxt);
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-  for (int s = 0; s < NS - 1; ++s) {
+  for (int s = 0; s < DW; ++s) {
     load_w(far, w[s]);
     advance(far);
   }
@@ -808,7 +808,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   while (more) {
     more = StaticFor<NS>::run([&](auto tag) {
       constexpr int s = decltype(tag)::value;
-      constexpr int s_far = (s + NS - 1) % NS, s_next = (s + 2) % NS;
+      constexpr int s_far = (s + DW) % NS, s_next = (s + 2) % NS;
       // vector-memory loads return IN ORDER (vmcnt): waiting for the next pass's activations / scales also waits
       // for every weight word requested before them.  So they run two passes ahead and go out before this pass's
       // weight request: the words of the last two requests stay in flight across that wait.
@@ -1013,7 +1013,7 @@ int gptq_matmul(const float* x, const int32_t* qweight, float* out, const float*
     // A matrix with >= 2048 strips needs none: each workgroup walks all of K and adds to `out` directly.
     const int64_t passes = ceil_div(in_features, 32 * ch);
     int64_t split = ceil_div(static_cast<int64_t>(cu_count()) * 8, strips);
-    if (knob(1) > 0) split = knob(1);  // dev override (shares the grid-cap knob)
+    if (knob(1) > 0 && knob(1) < 128) split = knob(1);  // dev override (shares the grid-cap knob)
     if (split > passes) split = passes;
     if (split > kStripMaxSplit) split = kStripMaxSplit;
     if (split < 1) split = 1;
@@ -1032,21 +1032,30 @@ int gptq_matmul(const float* x, const int32_t* qweight, float* out, const float*
       if (knob(2) != 4) {  // packed e4m3 decode (knob 2 == 4: byte converts, for A/B runs)
         // HBM-sized: register sets two passes deep (knob 2 == 5: the LDS-DMA ring instead, for A/B runs)
         if constexpr (BITS == 4) {
-          // HBM-sized: persistent strip workers, two per CU (knob 2 == 5: the (strip, K block) grid instead, for A/B
-          // runs).  Whole strips only: the workers' shares must be even, so the strip count has to be a multiple of
-          // the worker count (or several times it)
-          const int64_t workers = static_cast<int64_t>(cu_count()) * 2;
-          const bool stream = passes >= 3 && strips >= workers && (strips % workers == 0 || strips >= 8 * workers) &&
-                              in_features % 64 == 0 && in_features <= 32768 && aligned16(x) && (cu_count() % 8) == 0 &&
+          // HBM-sized: persistent strip workers (knob 2 == 5: the (strip, K block) grid instead, for A/B runs).  Whole
+          // strips only, so the workers' shares must come out even: two workers per CU when the strip count is a
+          // multiple of that, else one per CU (measured: 4 % slower per strip, but 1152 strips are 4.5 per worker
+          // instead of 2.25), and the (strip, K block) grid when even that leaves more than a fifth of the chip idle
+          const int64_t cus = cu_count();
+          const int64_t rounds2 = ceil_div(strips, 2 * cus), rounds1 = ceil_div(strips, cus);
+          int64_t workers = 2.0 * static_cast<double>(rounds2) <= 1.04 * static_cast<double>(rounds1) ? 2 * cus : cus;
+          if (knob(1) >= 128) workers = knob(1);  // dev override
+          const bool even = static_cast<double>(strips) >= 0.8 * static_cast<double>(workers * ceil_div(strips, workers));
+          const bool stream = passes >= 3 && strips >= workers && (even || knob(1) >= 128) &&
+                              in_features % 64 == 0 && in_features <= 32768 && aligned16(x) && (cus % 8) == 0 &&
                               g.group_size == 128 &&
                               g.H * out_features * 4 < (1ll << 32) && out_features * g.groups * 4 < (1ll << 32) &&
                               knob(2) != 5;
           if (stream) {
             const uint32_t n_strips = static_cast<uint32_t>(strips);
+            // weight words ONE pass ahead: with 128-byte row pieces more requests in flight make the memory system
+            // slower, not faster (tools/lab/strip_read.hip: a bare read by 512 persistent workers gets 5.3 TB/s with
+            // one set in flight, 4.3 with three, 4.1 with five; this kernel 0.62 / 0.60 / 0.54 of peak on
+            // 12288 x 49152 with one / two / three)
             if (batch == 2)
-              gptq_stream_kernel<4, 2, 3, true><<<static_cast<uint32_t>(workers), 256, 0, st>>>(x, qweight, scales, zeros, out, g, n_strips);
+              gptq_stream_kernel<4, 2, 3, true, 1><<<static_cast<uint32_t>(workers), 256, 0, st>>>(x, qweight, scales, zeros, out, g, n_strips);
             else
-              gptq_stream_kernel<4, 1, 4, true><<<static_cast<uint32_t>(workers), 256, 0, st>>>(x, qweight, scales, zeros, out, g, n_strips);
+              gptq_stream_kernel<4, 1, 3, true, 1><<<static_cast<uint32_t>(workers), 256, 0, st>>>(x, qweight, scales, zeros, out, g, n_strips);
             return check_launch();
           }
         }

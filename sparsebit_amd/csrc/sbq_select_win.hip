@@ -52,8 +52,8 @@ struct WinSel {
 struct WinState {
   WinSel sel[kWinSel];
   int64_t n;  // elements in all shards
-  uint32_t arrivals;    // win_fallback_kernel: workgroups of the running sweep that have flushed
-  uint32_t generation;  // win_fallback_kernel: rounds completed (zero between calls)
+  uint32_t arrivals;  // win_fallback_kernel: workgroups of the running sweep that have flushed (zero between launches)
+  uint32_t pad1;
 };
 struct WinSlot {  // one 128-byte line
   unsigned long long below[kWinSel];
@@ -241,7 +241,6 @@ __global__ __launch_bounds__(1024) void win_plan_kernel(const ShardTable tab, in
   if (threadIdx.x == 0) {
     st->n = n;
     st->arrivals = 0;
-    st->generation = 0;
     const double S = static_cast<double>(s_total);
     for (int s = 0; s < n_sel; ++s) {
       // A bracket that runs off the sample: the window starts at the first key instead -- or, when the target is
@@ -751,52 +750,38 @@ __global__ __launch_bounds__(BLOCK) void win_pass_kernel(const PassTable tab, in
   }, slots, hist, use_abs);
 }
 
-// The rounds after the expected ones, in ONE launch.  They are needed only when the sample lied about a window, and
-// as separate (sweep, advance) launches cost ~3 us each just to find every selector resolved.  A small grid
-// (co-resident by construction: half as many workgroups as CUs, one per CU at most) sweeps, the last workgroup to arrive advances the
-// selectors, and a generation counter releases the others into the next round -- or everybody leaves at the first
-// look when nothing is left to do.  No agent-scope fences (see the GPTQ strip kernels): the histogram / counter
-// adds are agent-scope atomics, the advance reads and writes them -- and the selector state -- with agent-scope
-// atomic loads / stores, and a workgroup's adds are acknowledged (vmcnt(0)) before its arrival is counted.
+// A round after the expected ones: sweep and advance in ONE launch.  Such rounds are needed only when the sample
+// lied about a window; as separate (sweep, advance) launches they cost ~3 us each just to find every selector
+// resolved.  Here a small grid looks at the state first (and leaves at once when nothing is left to do), sweeps, and
+// the last workgroup to arrive advances the selectors.  Nobody ever WAITS for another workgroup -- a version that
+// ran all the remaining rounds in one launch behind a grid-wide wait was 3 us faster and could deadlock when more
+// such launches are live at once than the chip holds workgroups.  No agent-scope fences (see the GPTQ strip
+// kernels): the histogram / counter adds are agent-scope atomics, the advance reads and writes them -- and the
+// selector state -- with agent-scope atomic loads / stores, and a workgroup's adds are acknowledged (vmcnt(0))
+// before its arrival is counted.
 template <typename T, int NSEL, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void win_fallback_kernel(const PassTable tab, int n_shards, WinState* __restrict__ st,
                                                              WinSlot* __restrict__ slots, uint32_t* __restrict__ hist,
                                                              int use_abs, int percentile, double alpha, uint32_t min_shift,
-                                                             float* __restrict__ out0, float* __restrict__ out1,
-                                                             int max_rounds) {
+                                                             float* __restrict__ out0, float* __restrict__ out1) {
   __shared__ AdvShared adv;
-  __shared__ uint32_t s_flag;
-  uint32_t gen = 0;  // st->generation is zero at launch (win_plan_kernel)
-  for (int r = 0; r < max_rounds; ++r) {
-    const bool live = win_sweep<T, NSEL, false, BLOCK, false>(tab, n_shards, [&](WinSel (&sel)[NSEL]) {
+  __shared__ uint32_t s_last;
+  const bool live = win_sweep<T, NSEL, false, BLOCK, false>(tab, n_shards, [&](WinSel (&sel)[NSEL]) {
 #pragma unroll
-      for (int s = 0; s < NSEL; ++s) sel[s] = r == 0 ? st->sel[s] : win_read_sel<true>(st, s);
-    }, slots, hist, use_abs);
-    if (!live) break;  // uniform over the grid: every workgroup read the same state
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_s_waitcnt(0);
-    __syncthreads();
-    if (threadIdx.x == 0)
-      s_flag = __hip_atomic_fetch_add(&st->arrivals, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
-    __syncthreads();
-    if (s_flag) {
+    for (int s = 0; s < NSEL; ++s) sel[s] = st->sel[s];
+  }, slots, hist, use_abs);
+  if (!live) return;  // uniform over the grid: every workgroup read the same state
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_s_waitcnt(0);
+  __syncthreads();
+  if (threadIdx.x == 0)
+    s_last = __hip_atomic_fetch_add(&st->arrivals, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+  __syncthreads();
+  if (!s_last) return;
 #pragma unroll
-      for (int s = 0; s < NSEL; ++s)
-        win_advance<BLOCK, true>(s, hist, st, slots, percentile, alpha, min_shift, out0, out1, adv);
-      __builtin_amdgcn_s_waitcnt(0);  // the advance's stores are acknowledged ...
-      __syncthreads();
-      if (threadIdx.x == 0) {
-        win_st<true>(&st->arrivals, 0u);
-        win_st<true>(&st->generation, gen + 1);  // ... before anybody is released
-      }
-    } else if (threadIdx.x == 0) {
-      while (win_ld<true>(&st->generation) == gen) __builtin_amdgcn_s_sleep(8);
-    }
-    __syncthreads();
-    ++gen;
-  }
-  // (st->generation is NOT reset here -- a workgroup still spinning on the first round's value would see it come
-  // back; win_plan_kernel zeroes it at the start of every call)
+  for (int s = 0; s < NSEL; ++s)
+    win_advance<BLOCK, true>(s, hist, st, slots, percentile, alpha, min_shift, out0, out1, adv);
+  if (threadIdx.x == 0) win_st<true>(&st->arrivals, 0u);
 }
 
 constexpr size_t kStateBytes = 256;
@@ -894,18 +879,19 @@ int win_select_run(const void* const* shards, const int64_t* counts, int n_shard
     PassTable pf{};
     int64_t fb_slabs = 0;
     make_table(WinGeom<1024>::kSlab, pf, fb_slabs);
-    // all co-resident (the rounds are separated by a grid-wide wait): one workgroup on every second CU
-    const int64_t cap = cus >= 2 ? cus / 2 : 1;
+    const int64_t cap = cus >= 2 ? cus / 2 : 1;  // a miss sweeps at half speed; an idle launch exits sooner
     const uint32_t grid = static_cast<uint32_t>(fb_slabs < cap ? (fb_slabs > 0 ? fb_slabs : 1) : cap);
-    rc = dispatch_dtype(x_dtype, [&](auto tag) {
-      using T = decltype(tag);
-      if (n_sel == 1)
-        win_fallback_kernel<T, 1, 1024><<<grid, 1024, 0, st>>>(pf, n_shards, state, slots, hist, use_abs, percentile ? 1 : 0,
-                                                            alpha, min_shift, out0, out1, rounds - expected);
-      else
-        win_fallback_kernel<T, 2, 1024><<<grid, 1024, 0, st>>>(pf, n_shards, state, slots, hist, use_abs, percentile ? 1 : 0,
-                                                            alpha, min_shift, out0, out1, rounds - expected);
-    });
+    for (int r = expected; r < rounds && rc == SBQ_OK; ++r) {
+      rc = dispatch_dtype(x_dtype, [&](auto tag) {
+        using T = decltype(tag);
+        if (n_sel == 1)
+          win_fallback_kernel<T, 1, 1024><<<grid, 1024, 0, st>>>(pf, n_shards, state, slots, hist, use_abs,
+                                                              percentile ? 1 : 0, alpha, min_shift, out0, out1);
+        else
+          win_fallback_kernel<T, 2, 1024><<<grid, 1024, 0, st>>>(pf, n_shards, state, slots, hist, use_abs,
+                                                              percentile ? 1 : 0, alpha, min_shift, out0, out1);
+      });
+    }
     if (rc != SBQ_OK) return rc;
   }
   return check_launch();

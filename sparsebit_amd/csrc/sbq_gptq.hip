@@ -1028,37 +1028,44 @@ int gptq_matmul(const float* x, const int32_t* qweight, float* out, const float*
     // several passes per workgroup (HBM-sized matrices): the next pass's weights are prefetched by LDS-DMA
     // (knob 2 == 6: off, for A/B runs)
     const bool prefetch = ch == kSliceK / 2 && passes >= 2 * split && knob(2) != 6;
-    if constexpr (BITS == 4 || BITS == 2) {
-      if (knob(2) != 4) {  // packed e4m3 decode (knob 2 == 4: byte converts, for A/B runs)
-        // HBM-sized: register sets two passes deep (knob 2 == 5: the LDS-DMA ring instead, for A/B runs)
+    {
+      // (4- and 2-bit decode through the fp8 converter, 3-bit through byte converts; knob 2 == 4 -- byte converts
+      // for A/B runs -- keeps the (strip, K block) grid)
+      constexpr bool kDec8 = BITS != 3;
+      // HBM-sized: persistent strip workers (knob 2 == 5: the (strip, K block) grid instead, for A/B runs).  Whole
+      // strips only, so the workers' shares must come out even: two workers per CU when the strip count is a
+      // multiple of that, else one per CU (measured: 4 % slower per strip, but 1152 strips are 4.5 per worker
+      // instead of 2.25), and the (strip, K block) grid when even that leaves more than a fifth of the chip idle
+      const int64_t cus = cu_count();
+      const int64_t rounds2 = ceil_div(strips, 2 * cus), rounds1 = ceil_div(strips, cus);
+      int64_t workers = 2.0 * static_cast<double>(rounds2) <= 1.04 * static_cast<double>(rounds1) ? 2 * cus : cus;
+      if (knob(1) >= 128) workers = knob(1);  // dev override
+      const bool even = static_cast<double>(strips) >= 0.8 * static_cast<double>(workers * ceil_div(strips, workers));
+      const bool stream = passes >= 3 && strips >= workers && (even || knob(1) >= 128) &&
+                          in_features % 64 == 0 && in_features <= 32768 && aligned16(x) && (cus % 8) == 0 &&
+                          g.group_size == 128 &&
+                          g.H * out_features * 4 < (1ll << 32) && out_features * g.groups * 4 < (1ll << 32) &&
+                          (BITS == 4 || batch == 1) &&  // 3- / 2-bit with two batch rows: over the register budget
+                          knob(2) != 5 && knob(2) != 4;
+      if (stream) {
+        const uint32_t n_strips = static_cast<uint32_t>(strips);
+        // weight words ONE pass ahead: with 128-byte row pieces more requests in flight make the memory system
+        // slower, not faster (tools/lab/strip_read.hip: a bare read by 512 persistent workers gets 5.3 TB/s with
+        // one set in flight, 4.3 with three, 4.1 with five; this kernel 0.62 / 0.60 / 0.54 of peak on
+        // 12288 x 49152 with one / two / three)
         if constexpr (BITS == 4) {
-          // HBM-sized: persistent strip workers (knob 2 == 5: the (strip, K block) grid instead, for A/B runs).  Whole
-          // strips only, so the workers' shares must come out even: two workers per CU when the strip count is a
-          // multiple of that, else one per CU (measured: 4 % slower per strip, but 1152 strips are 4.5 per worker
-          // instead of 2.25), and the (strip, K block) grid when even that leaves more than a fifth of the chip idle
-          const int64_t cus = cu_count();
-          const int64_t rounds2 = ceil_div(strips, 2 * cus), rounds1 = ceil_div(strips, cus);
-          int64_t workers = 2.0 * static_cast<double>(rounds2) <= 1.04 * static_cast<double>(rounds1) ? 2 * cus : cus;
-          if (knob(1) >= 128) workers = knob(1);  // dev override
-          const bool even = static_cast<double>(strips) >= 0.8 * static_cast<double>(workers * ceil_div(strips, workers));
-          const bool stream = passes >= 3 && strips >= workers && (even || knob(1) >= 128) &&
-                              in_features % 64 == 0 && in_features <= 32768 && aligned16(x) && (cus % 8) == 0 &&
-                              g.group_size == 128 &&
-                              g.H * out_features * 4 < (1ll << 32) && out_features * g.groups * 4 < (1ll << 32) &&
-                              knob(2) != 5;
-          if (stream) {
-            const uint32_t n_strips = static_cast<uint32_t>(strips);
-            // weight words ONE pass ahead: with 128-byte row pieces more requests in flight make the memory system
-            // slower, not faster (tools/lab/strip_read.hip: a bare read by 512 persistent workers gets 5.3 TB/s with
-            // one set in flight, 4.3 with three, 4.1 with five; this kernel 0.62 / 0.60 / 0.54 of peak on
-            // 12288 x 49152 with one / two / three)
-            if (batch == 2)
-              gptq_stream_kernel<4, 2, 3, true, 1><<<static_cast<uint32_t>(workers), 256, 0, st>>>(x, qweight, scales, zeros, out, g, n_strips);
-            else
-              gptq_stream_kernel<4, 1, 3, true, 1><<<static_cast<uint32_t>(workers), 256, 0, st>>>(x, qweight, scales, zeros, out, g, n_strips);
+          if (batch == 2) {
+            gptq_stream_kernel<4, 2, 3, true, 1><<<static_cast<uint32_t>(workers), 256, 0, st>>>(x, qweight, scales, zeros, out, g, n_strips);
             return check_launch();
           }
         }
+        if (batch == 1)
+          gptq_stream_kernel<BITS, 1, 3, kDec8, 1><<<static_cast<uint32_t>(workers), 256, 0, st>>>(x, qweight, scales, zeros, out, g, n_strips);
+        return check_launch();
+      }
+    }
+    if constexpr (BITS == 4 || BITS == 2) {
+      if (knob(2) != 4) {  // packed e4m3 decode (knob 2 == 4: byte converts, for A/B runs)
         if (prefetch) {
           if (batch == 2)
             gptq_strip_kernel<BITS, 2, 32, 64, true, true><<<grid, 256, 0, st>>>(x, qweight, scales, zeros, out, part, arrivals, g);

@@ -89,23 +89,24 @@ def test_large_shapes_single_launch_agrees_with_two_launch():
     4-bit weight stream.  B <= 2 with whole multiples of 512 strips takes gptq_stream_kernel (persistent workers,
     no K split), the others gptq_strip_kernel; knob 2 = 9 is the two-launch path both are compared with."""
     # (6272 x 16384: the persistent-worker kernel with a ragged last pass -- two live K lanes of 32 -- and B = 2)
-    for in_f, out_f, b in ((12288, 49152, 1), (8192, 32768, 8), (9216, 36864, 32), (6272, 16384, 1), (6272, 16384, 2),
-                           (8192, 32768, 2)):
-        qw, scales, zeros = _layer(in_f, out_f, 4, 128, in_f % 97)
+    for bits, in_f, out_f, b in ((4, 12288, 49152, 1), (4, 8192, 32768, 8), (4, 9216, 36864, 32), (4, 6272, 16384, 1),
+                                 (4, 6272, 16384, 2), (4, 8192, 32768, 2), (3, 6272, 16384, 1), (2, 6272, 16384, 1),
+                                 (3, 8192, 32768, 1), (2, 8192, 32768, 1), (3, 8192, 16384, 2)):
+        qw, scales, zeros = _layer(in_f, out_f, bits, 128, in_f % 97)
         g = torch.Generator().manual_seed(b)
         x = torch.randn(b, in_f, generator=g).cuda()
         o1 = torch.zeros(b, out_f, device="cuda")
-        ops.vecquantmatmul(4, x, qw, o1, scales, zeros, 128)
+        ops.vecquantmatmul(bits, x, qw, o1, scales, zeros, 128)
         try:
             L.set_tuning(2, 9)
             o2 = torch.zeros(b, out_f, device="cuda")
-            ops.vecquantmatmul(4, x, qw, o2, scales, zeros, 128)
+            ops.vecquantmatmul(bits, x, qw, o2, scales, zeros, 128)
         finally:
             L.set_tuning(2, 0)
         # strip kernel vs partial kernel: different (each fixed) summation orders
         torch.testing.assert_close(o1, o2, rtol=1e-4, atol=1e-3)
         o3 = torch.zeros(b, out_f, device="cuda")
-        ops.vecquantmatmul(4, x, qw, o3, scales, zeros, 128)
-        assert torch.equal(o1, o3), (in_f, out_f, b)  # deterministic
+        ops.vecquantmatmul(bits, x, qw, o3, scales, zeros, 128)
+        assert torch.equal(o1, o3), (bits, in_f, out_f, b)  # deterministic
         del qw, scales, zeros, x, o1, o2
         torch.cuda.empty_cache()

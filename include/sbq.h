@@ -442,7 +442,8 @@ int sbq_vecquant2matmul(const float* x, const int32_t* qweight, float* out,
 /* ------------------------------------------------------------------ *
  * 6. Launch tuning (benchmarks only; defaults are chosen per shape)
  * ------------------------------------------------------------------ */
-/* knob 0: forward-QDQ variant override (-1 = auto). knob 1: grid cap (0 = auto).
+/* knob 0: forward-QDQ variant override (-1 = auto). knob 1: grid cap (0 = auto; in the GPTQ
+ * mat-vec: K split when < 128, number of persistent workers when >= 128).
  * knob 2: A/B switches that never change results (3 = IEEE division in the headline QDQ
  * kernel; 1 / 2 = 128 / 64 channels per K lane, 4 = byte converts instead of the e4m3 decode,
  * 9 = two-launch path in the GPTQ mat-vec, 6 = no LDS-DMA prefetch, 8 = plain strip order,

@@ -107,9 +107,6 @@ __global__ __launch_bounds__(1024) void win_plan_kernel(const ShardTable tab, in
   __shared__ int64_t r_lo[kWinSel], r_hi[kWinSel];
   __shared__ double r_mid[kWinSel];
   __shared__ uint32_t b_lo[kWinSel], b_hi[kWinSel];
-  // the counter lines and histogram copies the sweeps add to (the advance leaves them clean, a first call or an
-  // abandoned one does not): 136 KB of stores, issued before the sample is even requested
-  for (uint32_t i = threadIdx.x; i < scratch_vecs; i += kT) scratch[i] = u32x4{0, 0, 0, 0};
   for (int i = threadIdx.x; i < kPlanBins; i += kT) hist[i] = 0;
   if (threadIdx.x == 0) {
     s_first = kPlanBins - 1;
@@ -151,6 +148,12 @@ __global__ __launch_bounds__(1024) void win_plan_kernel(const ShardTable tab, in
       for (int j = 0; j < kPack; ++j) v[m][j] = Elem<T>::load1(base[m], e[m] + j < cnt[m] ? e[m] + j : cnt[m] - 1);
     }
   }
+  // the counter lines and histogram copies the sweeps add to (the advance leaves them clean, a first call or an
+  // abandoned one does not): 136 KB of stores, queued BEHIND the sample's loads (the vector-memory path of the one
+  // CU this kernel runs on is in order)
+  __builtin_amdgcn_sched_barrier(0);
+  for (uint32_t i = threadIdx.x; i < scratch_vecs; i += kT) scratch[i] = u32x4{0, 0, 0, 0};
+  __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int m = 0; m < kMine; ++m) {
     if (static_cast<int64_t>(threadIdx.x) + m * kT >= n_packs) continue;

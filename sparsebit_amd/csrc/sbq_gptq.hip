@@ -704,7 +704,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const int cl = threadIdx.x & 7, kl = threadIdx.x >> 3;
   // workers that run side by side on one XCD take adjacent strips (see gptq_strip_kernel)
   uint32_t worker = blockIdx.x;
-  if (g.xcd_swizzle) worker = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  if (g.xcd_swizzle && (gridDim.x & 7u) == 0) worker = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
   const uint32_t row_bytes = static_cast<uint32_t>(g.out_features) * 4u;
   const uint32_t w_bytes = static_cast<uint32_t>(g.H) * row_bytes;
   const uint32_t x_bytes = static_cast<uint32_t>(g.in_features) * 4u;

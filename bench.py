@@ -125,21 +125,19 @@ def main():
                 dist.all_reduce(flag)
         torch.cuda.synchronize(dev)
 
-    # ---- parity gate inside the benchmark (rank 0): the timed kernel == oracle --------------
-    parity = None
-    if rank == 0:
-        from oracle import oracle as O
+    # ---- parity gates inside the benchmark (rank 0): the timed kernel == oracle ----------
+    # q_int bit-exact, dq_f32 within 1e-6 relative (0 ulp expected), bf16 output == RNE(ref), observer (min, max)
+    # and (scale, zp) bit-exact -- bench_configs.headline_gates; BEFORE the timed region so that a wrong kernel
+    # is never timed.
+    import bench_configs as BC
 
-        step(0)
-        torch.cuda.synchronize(dev)
-        rows = [0, 1, 255, 2048, 4095]
-        xf = host.float().numpy()[rows]
-        s_ref, z_ref = O.qparams_from_minmax(*O.minmax(xf, 0, True), QMIN, QMAX, True)
-        dq_ref, _ = O.qdq(xf, s_ref, z_ref, QMIN, QMAX, 0)
-        got = ys[0][rows].float().cpu().numpy()
-        want = torch.from_numpy(dq_ref).bfloat16().float().numpy()
-        parity = bool((got == want).all()) and bool((scale[rows].cpu().numpy() == s_ref).all())
-        assert parity, "timed kernel does not match the oracle"
+    ctx = BC.Ctx(dev, lib, L, ops, stream, host, xs, ys, scale, zp)
+    parity = None
+    gates = None
+    if rank == 0:
+        gates = BC.headline_gates(ctx)
+        parity = gates["all"]
+        assert parity, "timed kernel does not match the oracle: %r" % (gates,)
 
     # ---- timed region ------------------------------------------------------------------------
     # K direct C-ABI launches on the current stream.  (Replaying the same launches from a
@@ -167,6 +165,7 @@ def main():
     # least 0.25 s, at most 3 s) -- a box that was idle for minutes needs longer than a warm one.
     t_pre = time.perf_counter()
     prev, i, stable = None, 0, 0
+    windows = []  # us per launch of every 1024-launch window
     w0 = torch.cuda.Event(enable_timing=True)
     w1 = torch.cuda.Event(enable_timing=True)
     while True:
@@ -179,6 +178,7 @@ def main():
         cur = w0.elapsed_time(w1)
         stable = stable + 1 if prev is not None and abs(cur - prev) <= 0.01 * cur else 0
         prev = cur
+        windows.append(cur * 1e3 / 1024)
         spent = time.perf_counter() - t_pre
         if (spent >= 0.25 and stable >= 2) or spent >= 3.0:
             break
@@ -315,12 +315,23 @@ def main():
     extras["two_streams_us_per_weight"] = round(two_us, 3)
     extras["two_streams_GBps"] = round(n_elem * BYTES_PER_ELEM / two_us / 1e3, 1)
 
-    # observer statistic exchange: ONE MAX all-reduce of [max, -min, nan flags] for C = 4096
+    # observer statistic exchange (BASELINE: "observer all-reduce scaling"), timed at every N:
+    #   minmax      ONE MAX all-reduce of [max, -min, nan flags] for C = 4096           (64 KB)
+    #   MSE         + ONE SUM of the fp64 [C, 80] squared-error table                   (2.6 MB)
+    #   percentile  ONE SUM of the int64 [1, 2, 2048] histogram per radix pass          (32 KB, x 3 passes)
     mn, mx, _ = ops.channel_stats(xs[0], 0, True)
+    sse_t = torch.zeros(ROWS, L.MSE_CANDIDATES, dtype=torch.float64, device=dev)
+    hist_t = torch.zeros(1, 2, L.RADIX_BINS, dtype=torch.int64, device=dev)
     with sbq_dist.sharded_calibration():
         ar_us = timed(lambda i: sbq_dist.allreduce_minmax(mn, mx), 50) if world > 1 else 0.0
+        ar_mse_us = timed(lambda i: sbq_dist.allreduce_sum_(sse_t), 50) if world > 1 else 0.0
+        ar_hist_us = timed(lambda i: sbq_dist.allreduce_sum_(hist_t), 50) if world > 1 else 0.0
     extras["observer_allreduce_us"] = round(ar_us, 2)
     extras["observer_allreduce_bytes"] = 4 * 4 * ROWS if world > 1 else 0
+    extras["observer_allreduce_mse_sum_us"] = round(ar_mse_us, 2)
+    extras["observer_allreduce_mse_sum_bytes"] = sse_t.numel() * 8 if world > 1 else 0
+    extras["observer_allreduce_percentile_hist_sum_us"] = round(ar_hist_us, 2)
+    extras["observer_allreduce_percentile_hist_sum_bytes"] = hist_t.numel() * 8 if world > 1 else 0
 
     # ---- the rest of the hot path at the headline size (library calls through ops.py; events over a loop) -----
     def timed_op(fn, iters=30):
@@ -364,6 +375,29 @@ def main():
     extras["mse_observer_per_channel_us"] = round(timed_op(step_mse, 10), 1)
     # vector-ALU rate of the MSE kernel, from the committed counter pass (tools/rocprof_bench.sh)
     extras["mse_kernel_valu"] = pmc_extra("mse_partial_kernel")
+
+    # ---- BASELINE configs 2-5: every leg with its own time, algorithmic bytes, roofline fraction and an oracle
+    #      gate computed in this run (bench_configs.py).  Rank 0 only: the oracle legs are host work.
+    if rank == 0:
+        extras["headline_gates"] = gates
+        extras["configs"] = {
+            "config2_mse_per_channel": BC.config2_mse(ctx),
+            "config3_percentile": BC.config3_percentile(ctx),
+            "config4_gptq_4bit_g128_B1": BC.config4_gptq(ctx),
+            "config5_mask_lsq_4bit": BC.config5_mask_lsq(ctx),
+        }
+        extras["model_wide_calibration"] = BC.model_wide_calibration(ctx)
+
+        def _gates(d):
+            for v in d.values():
+                if isinstance(v, dict):
+                    if "parity" in v and "us" in v:
+                        yield v["parity"]
+                    else:
+                        yield from _gates(v)
+
+        extras["all_config_gates_pass"] = all(g for g in _gates(extras["configs"]) if g is not None) and all(
+            g for g in _gates(extras["model_wide_calibration"]) if g is not None)
 
     # ---- CPU baseline: the reference's CPU fake-quant ops on this box's host cores -----------
     cpu_baseline = None
@@ -423,11 +457,16 @@ def main():
         torch_port.l1_mask_cpu(quarter, 0.5)
         legs["l1_mask_ms"] = round(once(torch_port.l1_mask_cpu, xcpu, 0.5), 2)
         legs["mse_per_tensor_256_rows_ms"] = round(once(torch_port.mse_qparams_cpu, part16, QMIN, QMAX), 2)
+        # config 2 is per channel: the same 80-candidate search with one scale per row (the reference's CPU path
+        # mis-broadcasts there; the port follows the CUDA kernel's row indexing), best of 3
+        torch_port.mse_qparams_perchannel_cpu(part16[:32], QMIN, QMAX)
+        legs["mse_per_channel_256_rows_ms"] = round(min(once(torch_port.mse_qparams_perchannel_cpu, part16, QMIN, QMAX)
+                                                         for _ in range(3)), 2)
         legs["threads"] = best_threads
         legs["what"] = ("torch ports (oracle/torch_port.py) of observers/minmax.py:14-25, percentile.py:16-46, "
-                        "sparse/sparsers/l1norm.py:18-26 on the full 4096x4096 fp32 weight and mse.py:28-63 (80 candidates) "
-                        "on 256 rows of it (1/16: the full tensor is minutes on the host); GPU times of the same steps "
-                        "on the full tensor are in extras")
+                        "sparse/sparsers/l1norm.py:18-26 on the full 4096x4096 fp32 weight and mse.py:28-63 (80 candidates), per "
+                        "tensor and per channel, on 256 rows of it (1/16: the full tensor is seconds to minutes on the "
+                        "host); GPU times of the same steps on the full tensor are in extras / extras.configs")
         cpu_baseline["other_legs"] = legs
 
     # HBM traffic per launch from the PMC passes (tools/rocprof_bench.sh -> tools/pmc_summary.py
@@ -435,16 +474,27 @@ def main():
     # runs, so they cannot be collected inside this un-profiled timing run)
     traffic = None
     traffic_source = None
-    kernel_name = "sbq::qdq_resident_kernel<BF16, BF16, 0, 16>"
+    # which kernel served the timed call: the resident schedule needs a 256-CU part and knob 3 at its default
+    # (csrc/sbq_qdq_resident.hip: try_resident); anything else is the pipelined kernel
+    cus = torch.cuda.get_device_properties(dev).multi_processor_count
+    resident = cus * 2 * 16 >= ROWS * COLS // 2048 > cus * 2 * 4 // 2
+    n_slabs = ROWS * COLS // 2048
+    res_u = 16 if n_slabs > cus * 2 * 8 else (8 if n_slabs > cus * 2 * 4 else 4)
+    kernel_name = ("sbq::qdq_resident_kernel<BF16, BF16, 0, %d>" % res_u
+                   if resident else "sbq::qdq_pack_kernel<BF16, BF16, ...> (pipelined)")
     pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
     if os.path.exists(pmc_path):
         try:
             with open(pmc_path) as f:
                 pmc = json.load(f)
-            traffic = pmc.get("qdq_bf16_bf16_traffic_bytes_per_launch")
-            traffic_source = ("committed profile profiles/pmc_latest.json (tag %s: two separate rocprofv3 --pmc passes, "
-                              "FETCH_SIZE and WRITE_SIZE, of this same command; kernel %s), not measured in this run"
-                              % (pmc.get("tag"), pmc.get("kernel")))
+            prof_kernel = str(pmc.get("kernel"))
+            if prof_kernel.replace("sbq::", "") == kernel_name.replace("sbq::", ""):
+                traffic = pmc.get("qdq_bf16_bf16_traffic_bytes_per_launch")
+                traffic_source = ("committed profile profiles/pmc_latest.json (tag %s: two separate rocprofv3 --pmc passes, "
+                                  "FETCH_SIZE and WRITE_SIZE, of this same command; kernel %s), not measured in this run"
+                                  % (pmc.get("tag"), prof_kernel))
+            else:
+                traffic_source = ("none: the committed profile describes %s, this run dispatched %s" % (prof_kernel, kernel_name))
         except (OSError, ValueError):
             traffic = None
 
@@ -480,6 +530,13 @@ def main():
                 "traffic_source": traffic_source,
                 "kernel": kernel_name,
                 "kernel_avg_us": round(kern_us, 3),
+                "kernel_avg_us_what": "HIP events around the K timed launches on the launch stream",
+                # the same launches in windows of 1024 during the adaptive pre-warm-up (a 13 ms sample each instead of
+                # K x 12 us): last window, and the best one
+                "kernel_avg_us_1024_window_last": round(windows[-1], 3),
+                "kernel_avg_us_1024_window_min": round(min(windows), 3),
+                "frac_1024_window_last": round(n_elem * BYTES_PER_ELEM / windows[-1] / 1e3 / HBM_PEAK_GBS, 4),
+                "windows_measured": len(windows),
                 "algorithmic_bytes_per_launch": n_elem * BYTES_PER_ELEM,
             },
             "cpu_baseline": cpu_baseline,

@@ -1,0 +1,405 @@
+"""The BASELINE.json configs beside the headline, as timed legs with in-run oracle gates.
+
+bench.py times the headline (per-channel int8 QDQ of a 4096 x 4096 bf16 weight) in its timed region; everything
+here runs AFTER that region, on rank 0's GPU as well as every other rank's, and lands in the JSON line's
+`extras["configs"]`.  Each leg reports
+
+    us                  average launch-to-launch time of the library call(s), HIP events on the launch stream
+    algorithmic_bytes   SURVEY.md 8(d)'s per-unit figure x the units one call processes
+    GBps, frac          algorithmic_bytes / us, and that over the 8 TB/s HBM3E peak
+    parity, gate        a boolean oracle check computed in this very run, and what it compared
+
+so that BENCH_rNN.json alone answers "how fast, against which roof, and is it right" for configs 2-5.  The oracle
+(oracle/: the reference's CPU algorithm, pinned to the reference's own outputs by tests/golden/) is used here as
+the CHECKER only; every timed call goes through the C ABI of libsbq.so with buffers that are already in HBM, and
+inputs rotate through more than the 256 MiB Infinity Cache wherever the working set is smaller than that.
+
+Reference ops behind the legs:
+  config 2  observers/mse.py:28-63 (80 candidates per channel)
+  config 3  observers/percentile.py:16-46 over the cached calibration batches (DeiT-small: 64 x 197 x 384)
+  config 4  large_language_models/llama/quantization/utils/quant.py:281-307 -> cuda/cuda_kernel_4bit.cu:36-180
+  config 5  sparse/sparsers/l1norm.py:18-26, sparse/modules/conv.py:39-43 + quantizers/lsq.py:24-76,
+            torch_extensions/fake_quant_tensor.cu:227-270 (backward)
+"""
+import ctypes
+import math
+
+import numpy as np
+import torch
+
+HBM_PEAK_GBS = 8000.0
+FP32_VECTOR_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: peak FP32 (vector)
+ROWS = COLS = 4096
+
+
+def _entry(us, nbytes, parity, gate, **kw):
+    d = {
+        "us": round(us, 3),
+        "algorithmic_bytes": int(nbytes),
+        "GBps": round(nbytes / us / 1e3, 1),
+        "frac": round(nbytes / us / 1e3 / HBM_PEAK_GBS, 4),
+        "parity": None if parity is None else bool(parity),
+        "gate": gate,
+    }
+    d.update(kw)
+    return d
+
+
+class Ctx:
+    """what bench.py hands over: device, library, the 12 rotating 4096 x 4096 bf16 weights, the host copy of weight 0"""
+
+    def __init__(self, dev, lib, L, ops, stream, host, xs, ys, scale, zp):
+        self.dev, self.lib, self.L, self.ops, self.stream = dev, lib, L, ops, stream
+        self.st = L.stream_ptr(dev)
+        self.host, self.xs, self.ys, self.scale, self.zp = host, xs, ys, scale, zp
+        self.n = ROWS * COLS
+
+    def timed(self, fn, iters, warm=10, rounds=2):
+        """average us per call of fn(i): events on the launch stream, best of `rounds` loops"""
+        best = float("inf")
+        for _ in range(rounds):
+            for i in range(warm):
+                fn(i)
+            torch.cuda.synchronize(self.dev)
+            a = torch.cuda.Event(enable_timing=True)
+            b = torch.cuda.Event(enable_timing=True)
+            a.record(self.stream)
+            for i in range(iters):
+                fn(i)
+            b.record(self.stream)
+            torch.cuda.synchronize(self.dev)
+            best = min(best, a.elapsed_time(b) * 1e3 / iters)
+        return best
+
+
+def _bf16_np(t):
+    """torch bf16 tensor -> numpy fp32 with the same values"""
+    return t.float().cpu().numpy()
+
+
+def _as_bf16_bits(a):
+    """numpy fp32 -> the bf16 value RNE(a) as fp32 (what a bf16 output must equal bit for bit)"""
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).bfloat16().float().numpy()
+
+
+GATE_ROWS = list(range(0, ROWS, 64)) + [1, 255, 4095]  # 67 rows of the 4096
+
+
+# ------------------------------------------------------------------------------------------------------
+# headline gates: SURVEY.md 8(d) "parity gates run in the same benchmark"
+# ------------------------------------------------------------------------------------------------------
+def headline_gates(c):
+    from oracle import oracle as O
+
+    L, lib, ops = c.L, c.lib, c.ops
+    x = c.xs[0]
+    rows = GATE_ROWS
+    xf = c.host.float().numpy()
+    # observer (minmax.py:14-25) and qparams (base.py:63-79): bit-exact on ALL rows
+    mn, mx, _ = ops.channel_stats(x, 0, True)
+    mn_ref, mx_ref = O.minmax(xf, 0, True)
+    s_ref, z_ref = O.qparams_from_minmax(mn_ref, mx_ref, -128, 127, True)
+    g_minmax = bool(np.array_equal(mn.cpu().numpy(), mn_ref) and np.array_equal(mx.cpu().numpy(), mx_ref))
+    g_qparams = bool(np.array_equal(c.scale.cpu().numpy(), s_ref) and np.array_equal(c.zp.cpu().numpy(), z_ref))
+    # integer levels + fp32 dequantized output of the timed entry point (parity mode: bf16 in, fp32 + int8 out)
+    y32 = torch.empty(ROWS, COLS, dtype=torch.float32, device=c.dev)
+    q8 = torch.empty(ROWS, COLS, dtype=torch.int8, device=c.dev)
+    rc = lib.sbq_quant_perchannel_forward(L.ptr(x), L.BF16, L.ptr(y32), L.F32, L.ptr(q8), L.Q_I8, L.ptr(c.scale), L.ptr(c.zp),
+                                          1, ROWS, COLS, -128, 127, 0, c.st)
+    L.check(rc)
+    rc = lib.sbq_quant_perchannel_forward(L.ptr(x), L.BF16, L.ptr(c.ys[0]), L.BF16, None, L.Q_NONE, L.ptr(c.scale), L.ptr(c.zp),
+                                          1, ROWS, COLS, -128, 127, 0, c.st)
+    L.check(rc)
+    torch.cuda.synchronize(c.dev)
+    dq_ref, q_ref = O.qdq(xf[rows], s_ref[rows], z_ref[rows], -128, 127, 0)
+    g_q = bool(np.array_equal(q8[rows].cpu().numpy().astype(np.int32), q_ref))
+    got = y32[rows].cpu().numpy()
+    den = np.where(dq_ref == 0, 1.0, np.abs(dq_ref))
+    max_rel = float(np.max(np.abs(got - dq_ref) / den))
+    g_dq = bool(max_rel <= 1e-6)
+    g_bf16 = bool(np.array_equal(c.ys[0][rows].float().cpu().numpy(), _as_bf16_bits(dq_ref)))
+    return {
+        "rows_checked": len(rows),
+        "q_int_bit_exact": g_q,
+        "dq_f32_max_rel_err": max_rel,
+        "dq_f32_within_1e-6": g_dq,
+        "dq_f32_bit_exact": bool(np.array_equal(got, dq_ref)),
+        "bf16_out_equals_rne_of_ref": g_bf16,
+        "observer_minmax_bit_exact_all_rows": g_minmax,
+        "scale_zp_bit_exact_all_rows": g_qparams,
+        "all": bool(g_q and g_dq and g_bf16 and g_minmax and g_qparams),
+    }
+
+
+# ------------------------------------------------------------------------------------------------------
+# config 2: per-channel MSE observer
+# ------------------------------------------------------------------------------------------------------
+# vector instructions per candidate evaluation in mse_partial_kernel's hot loop (sbq_observe.hip) and their flops:
+# mul, rndne, med3, fma, fma -> 5 instructions, 7 flops (an fma counts 2)
+MSE_FLOPS_PER_EVAL = 7
+# measured full-rate VALU issue ceiling of this chip: tools/lab/valu_rate.hip, one plain fp32 instruction per wave64 per
+# SIMD every 4 cycles at 2.4 GHz x 1024 SIMDs (v_pk_fma_f32: 6 cycles).  Wave instructions per second.
+VALU_ISSUE_CEILING_WAVE_INSTS = 2.4e9 / 4 * 1024
+
+
+def config2_mse(c):
+    from oracle import oracle as O
+
+    L, lib, ops = c.L, c.lib, c.ops
+    x = c.xs[0]
+    mn, mx, _ = ops.channel_stats(x, 0, True)
+    sse = torch.zeros(ROWS, L.MSE_CANDIDATES, dtype=torch.float64, device=c.dev)
+    ws = torch.empty(max(lib.sbq_mse_workspace_bytes(1, ROWS, COLS), 16), dtype=torch.uint8, device=c.dev)
+    s_o = torch.empty(ROWS, dtype=torch.float32, device=c.dev)
+    z_o = torch.empty(ROWS, dtype=torch.float32, device=c.dev)
+    idx = torch.empty(ROWS, dtype=torch.int32, device=c.dev)
+
+    def acc(i):
+        lib.sbq_mse_accumulate(L.ptr(c.xs[i % len(c.xs)]), L.BF16, 1, ROWS, COLS, L.ptr(mn), L.ptr(mx), -128, 127, 1,
+                               L.ptr(sse), L.ptr(ws), ws.numel(), c.st)
+
+    def whole(i):
+        # the observer's calc_qparams as the library runs it: statistics, clear, accumulate, select
+        xi = c.xs[i % len(c.xs)]
+        lib.sbq_channel_stats(L.ptr(xi), L.BF16, 1, ROWS, COLS, L.ptr(mn), L.ptr(mx), None, L.ptr(ws), ws.numel(), c.st)
+        sse.zero_()
+        lib.sbq_mse_accumulate(L.ptr(xi), L.BF16, 1, ROWS, COLS, L.ptr(mn), L.ptr(mx), -128, 127, 1, L.ptr(sse), L.ptr(ws),
+                               ws.numel(), c.st)
+        lib.sbq_mse_select(L.ptr(sse), ctypes.c_double(COLS), L.ptr(mn), L.ptr(mx), ROWS, -128, 127, 1, L.ptr(s_o), L.ptr(z_o),
+                           L.ptr(idx), c.st)
+
+    k_us = c.timed(acc, 20, warm=3)
+    e2e_us = c.timed(whole, 20, warm=3)
+    # gate: argmin index of 128 rows against the oracle (a differing index passes only when the oracle's own fp64
+    # losses of the two candidates agree to 1e-7: a tie the fp32 reference itself resolves by summation order)
+    whole(0)
+    torch.cuda.synchronize(c.dev)
+    rows = list(range(0, ROWS, 32))
+    _, _, b_ref, sse_ref = O.mse(c.host.float().numpy()[rows], -128, 127, True, 0, True)
+    b_gpu = idx[rows].cpu().numpy()
+    ok = True
+    n_diff = 0
+    for r in range(len(rows)):
+        if b_gpu[r] != b_ref[r]:
+            n_diff += 1
+            a, b = sse_ref[r, b_gpu[r]], sse_ref[r, b_ref[r]]
+            ok &= abs(a - b) <= 1e-7 * max(abs(a), abs(b))
+    evals = c.n * L.MSE_CANDIDATES
+    tflops = evals * MSE_FLOPS_PER_EVAL / k_us / 1e6
+    return _entry(
+        k_us, c.n * 2, ok,
+        "argmin candidate index of %d rows == oracle (observers/mse.py:51-61); %d differing" % (len(rows), n_diff),
+        bound="valu",
+        end_to_end_us=round(e2e_us, 2),
+        candidate_evaluations=evals,
+        valu_tflops=round(tflops, 1),
+        frac_of_fp32_vector_peak=round(tflops / FP32_VECTOR_PEAK_TFLOPS, 4),
+        frac_of_measured_issue_ceiling=round(evals * 5 / 64 / (k_us * 1e-6) / VALU_ISSUE_CEILING_WAVE_INSTS, 4),
+        note="VALU-bound: x is read once (2 B/elem); frac is the HBM fraction of that read, the roof that matters is "
+             "frac_of_fp32_vector_peak (7 flops per candidate evaluation / 157.3 TFLOP/s) and the measured issue ceiling "
+             "(5 wave instructions per 64 evaluations / one instruction per SIMD per 4 cycles)",
+    )
+
+
+# ------------------------------------------------------------------------------------------------------
+# config 3: percentile observer over the cached calibration batches (DeiT-small), per tensor
+# ------------------------------------------------------------------------------------------------------
+def config3_percentile(c):
+    from oracle import oracle as O
+
+    L, lib, ops = c.L, c.lib, c.ops
+    g = torch.Generator().manual_seed(33)
+    sets = []
+    # 3 x 4 batches: the calibration set rotates so that a call does not find its data in the Infinity Cache
+    for _ in range(3):
+        batches = []
+        for _ in range(4):
+            a = torch.randn(64, 197, 384, generator=g)
+            a = a * (1.0 + 9.0 * (torch.rand(1, 1, 384, generator=g) > 0.97))  # a few outlier channels, as ViT activations have
+            batches.append(a.bfloat16())
+        sets.append(batches)
+    dsets = [[b.to(c.dev) for b in s] for s in sets]
+    n = sum(b.numel() for b in sets[0])
+
+    def run(i):
+        return ops.percentile_select(dsets[i % 3], 1e-3, 0, False)
+
+    us = c.timed(run, 30, warm=5)
+    mn, mx = run(0)
+    torch.cuda.synchronize(c.dev)
+    flat = np.concatenate([_bf16_np(b).reshape(-1) for b in sets[0]])
+    mn_ref, mx_ref = O.percentile(flat, 1e-3, 0, False)
+    ok = bool(np.array_equal(mn.cpu().numpy().reshape(-1), mn_ref) and np.array_equal(mx.cpu().numpy().reshape(-1), mx_ref))
+    out = {
+        "deit_4_batches_per_tensor": _entry(us, n * 2, ok, "(min, max) of 4 x 64x197x384 bf16 batches bit-exact vs oracle "
+                                            "(percentile.py:16-46 on the concatenated data)", elements=n),
+    }
+    # the headline tensor: per tensor and per channel
+    w = c.xs[0]
+    us_t = c.timed(lambda i: ops.percentile_select([c.xs[i % len(c.xs)]], 1e-3, 0, False), 30, warm=5)
+    mn, mx = ops.percentile_select([w], 1e-3, 0, False)
+    mn_ref, mx_ref = O.percentile(c.host.float().numpy().reshape(-1), 1e-3, 0, False)
+    ok = bool(np.array_equal(mn.cpu().numpy().reshape(-1), mn_ref) and np.array_equal(mx.cpu().numpy().reshape(-1), mx_ref))
+    out["weight_per_tensor"] = _entry(us_t, c.n * 2, ok, "(min, max) of the 4096x4096 weight bit-exact vs oracle")
+    us_c = c.timed(lambda i: ops.percentile_rows(c.xs[i % len(c.xs)], 1e-3), 30, warm=5)
+    mn, mx = ops.percentile_rows(w, 1e-3)
+    rows = GATE_ROWS
+    mn_ref, mx_ref = O.percentile(c.host.float().numpy()[rows], 1e-3, 0, True)
+    ok = bool(np.array_equal(mn[rows].cpu().numpy(), mn_ref) and np.array_equal(mx[rows].cpu().numpy(), mx_ref))
+    out["weight_per_channel"] = _entry(us_c, c.n * 2, ok, "(min, max) of %d rows bit-exact vs oracle" % len(rows))
+    return out
+
+
+# ------------------------------------------------------------------------------------------------------
+# config 4: GPTQ 4-bit group-128 mat-vec, B = 1, the three LLaMA-7B linear shapes
+# ------------------------------------------------------------------------------------------------------
+def _gptq_problem(in_f, out_f, seed, dev, copies):
+    g = torch.Generator().manual_seed(seed)
+    groups = in_f // 128
+    qws, scs, zrs = [], [], []
+    for _ in range(copies):
+        qw = torch.randint(-2 ** 31, 2 ** 31 - 1, (in_f // 8, out_f), generator=g, dtype=torch.int64).to(torch.int32)
+        sc = (torch.rand(out_f, groups, generator=g) * 0.02 + 0.001).float()
+        zr = (torch.randint(0, 16, (out_f, groups), generator=g).float() * sc).float()  # zeros' = zero * scale (quant.py:205)
+        qws.append(qw.to(dev))
+        scs.append(sc.to(dev))
+        zrs.append(zr.to(dev))
+    x = torch.randn(1, in_f, generator=g).float()
+    return qws, scs, zrs, x
+
+
+def config4_gptq(c):
+    from oracle import oracle as O
+
+    L, lib = c.L, c.lib
+    out = {}
+    for name, in_f, out_f in (("4096x4096", 4096, 4096), ("4096->11008", 4096, 11008), ("11008->4096", 11008, 4096)):
+        groups = in_f // 128
+        w_bytes = in_f // 8 * out_f * 4
+        copies = max(2, int(3.2e8 // w_bytes) + 1)  # > 256 MiB of weights in rotation: every call reads HBM
+        qws, scs, zrs, x = _gptq_problem(in_f, out_f, 4 + in_f % 97, c.dev, copies)
+        xd = x.to(c.dev)
+        y = torch.zeros(1, out_f, dtype=torch.float32, device=c.dev)
+        ws = torch.zeros(max(lib.sbq_gptq_workspace_bytes(1, in_f, out_f), 16), dtype=torch.uint8, device=c.dev)
+        args = [(L.ptr(xd), L.ptr(qws[j]), L.ptr(y), L.ptr(scs[j]), L.ptr(zrs[j])) for j in range(copies)]
+
+        def run(i):
+            a = args[i % copies]
+            lib.sbq_vecquant4matmul(a[0], a[1], a[2], a[3], a[4], 1, in_f, out_f, 128, L.ptr(ws), ws.numel(), c.st)
+
+        us = c.timed(run, 400, warm=40)
+        us_warm = c.timed(lambda i: run(0), 400, warm=40)
+        # gate: the reference's own test criterion (test_cuda_kernel.py:21-126: rtol = atol = 1e-5 against the
+        # dequantized-weight product), through the oracle's restatement of cuda_kernel_4bit.cu
+        y.zero_()
+        run(0)
+        torch.cuda.synchronize(c.dev)
+        ref = O.vecquantmatmul(x.numpy(), qws[0].cpu().numpy(), np.zeros(out_f, np.float32), scs[0].cpu().numpy(),
+                               zrs[0].cpu().numpy(), 128, 4)
+        got = y.cpu().numpy()
+        # the reference compares with torch.allclose semantics on outputs of magnitude ~|x|_2 * |w|: scale atol alike
+        tol = 1e-5 * max(1.0, float(np.abs(ref).max()))
+        ok = bool(np.all(np.abs(got - ref) <= tol + 1e-5 * np.abs(ref)))
+        nbytes = w_bytes + 2 * out_f * groups * 4 + (in_f + 2 * out_f) * 4
+        out[name] = _entry(us, nbytes, ok, "y == oracle(cuda_kernel_4bit.cu:36-180) at rtol = atol = 1e-5 (x max|y|), the "
+                           "reference test's tolerance", weight_copies_in_rotation=copies,
+                           cache_resident_us=round(us_warm, 3), max_abs_err=float(np.abs(got - ref).max()))
+        del qws, scs, zrs
+    return out
+
+
+# ------------------------------------------------------------------------------------------------------
+# config 5: 50 % unstructured mask + LSQ 4-bit: threshold, mask, fused forward, STE backward
+# ------------------------------------------------------------------------------------------------------
+def config5_mask_lsq(c):
+    from oracle import oracle as O
+
+    L, lib, ops = c.L, c.lib, c.ops
+    nb = len(c.xs)
+    w = c.xs[0]
+    wf = c.host.float().numpy()
+    out = {}
+    # -- threshold: k-th smallest |w| (l1norm.py:21-23), the whole tensor against the oracle's sort
+    idx = min(int(c.n * 0.5), c.n - 1)
+    mask_ref, thr_ref = O.l1_mask(wf, 0.5)
+    ws = torch.zeros(max(lib.sbq_radix_select_workspace_bytes(1, 1), 16), dtype=torch.uint8, device=c.dev)
+    thr = torch.empty((), dtype=torch.float32, device=c.dev)
+
+    def kth(i):
+        lib.sbq_kth_value(L.ptr(c.xs[i % nb]), L.BF16, c.n, 1, idx + 1, L.ptr(thr), L.ptr(ws), ws.numel(), c.st)
+
+    us = c.timed(kth, 100)
+    kth(0)
+    torch.cuda.synchronize(c.dev)
+    out["mask_threshold_kth_value"] = _entry(us, c.n * 2, float(thr.item()) == float(thr_ref),
+                                             "threshold == sort(|w|)[n/2] of the oracle, exact")
+    # -- mask = |w| > thresh (l1norm.py:24-25): all 16.7 M bytes against the oracle's mask
+    masks = [torch.empty(ROWS, COLS, dtype=torch.uint8, device=c.dev) for _ in range(nb)]
+    us = c.timed(lambda i: lib.sbq_mask_from_threshold(L.ptr(c.xs[i % nb]), L.BF16, c.n, L.ptr(thr), L.ptr(masks[i % nb]), c.st), 100)
+    lib.sbq_mask_from_threshold(L.ptr(w), L.BF16, c.n, L.ptr(thr), L.ptr(masks[0]), c.st)
+    torch.cuda.synchronize(c.dev)
+    ok = bool(np.array_equal(masks[0].cpu().numpy().astype(bool), mask_ref))
+    out["mask_from_threshold"] = _entry(us, c.n * 3, ok, "all 16.7 M mask bytes == oracle (strict >, ties pruned)")
+    for j in range(1, nb):  # masks of the rotated copies (same values, rolled)
+        lib.sbq_mask_from_threshold(L.ptr(c.xs[j]), L.BF16, c.n, L.ptr(thr), L.ptr(masks[j]), c.st)
+    # -- LSQ 4-bit scales of the masked weight (lsq.py:44-47 on w * mask), from the oracle so that the gate below
+    #    isolates the forward kernel
+    rows = GATE_ROWS
+    s_all = O.lsq_init_scale(wf * mask_ref, 7, 0, True)
+    s_raw = torch.from_numpy(-s_all).to(c.dev)  # negative raw parameter: the kernel applies |s| (lsq.py:61)
+    z_raw = torch.zeros(ROWS, dtype=torch.float32, device=c.dev)
+    dq_ref, _ = O.qdq(wf[rows], s_all[rows], np.zeros(len(rows), np.float32), -8, 7, 0, mask=mask_ref[rows])
+    want = _as_bf16_bits(dq_ref)
+
+    def fused_bytes(i):
+        j = i % nb
+        lib.sbq_quant_lsq_forward(L.ptr(c.xs[j]), L.BF16, L.ptr(c.ys[j]), L.BF16, L.ptr(masks[j]), L.ptr(s_raw), L.ptr(z_raw),
+                                  1, ROWS, COLS, -8, 7, c.st)
+
+    us = c.timed(fused_bytes, 200)
+    fused_bytes(0)
+    torch.cuda.synchronize(c.dev)
+    ok = bool(np.array_equal(c.ys[0][rows].float().cpu().numpy(), want))
+    out["fused_mask_bytes_lsq_qdq"] = _entry(us, c.n * 5, ok, "bf16 output of %d rows == RNE(oracle qdq(w * mask)) "
+                                             "(sparse/modules/conv.py:39-43 + lsq.py:61-76), exact" % len(rows))
+    s_abs = torch.from_numpy(s_all).to(c.dev)
+
+    def fused_thr(i):
+        j = i % nb
+        lib.sbq_mask_quant_forward(L.ptr(c.xs[j]), L.BF16, L.ptr(c.ys[j]), L.BF16, None, L.Q_NONE, None, L.ptr(thr), L.ptr(s_abs),
+                                   L.ptr(z_raw), 1, ROWS, COLS, -8, 7, 0, c.st)
+
+    us = c.timed(fused_thr, 200)
+    fused_thr(0)
+    torch.cuda.synchronize(c.dev)
+    ok = bool(np.array_equal(c.ys[0][rows].float().cpu().numpy(), want))
+    out["fused_threshold_qdq"] = _entry(us, c.n * 4, ok, "same rows, mask recomputed from the threshold in the kernel (no mask bytes)")
+    # -- STE backward with the LSQ step-size gradient (fake_quant_tensor.cu:227-270 + lsq.py:13-21)
+    g = torch.Generator().manual_seed(55)
+    gy_h = torch.randn(ROWS, COLS, generator=g).bfloat16()
+    gys = [gy_h.to(c.dev)]
+    for j in range(1, nb):
+        gys.append(torch.roll(gys[0], shifts=j, dims=1).contiguous())
+    gxs = [torch.empty(ROWS, COLS, dtype=torch.bfloat16, device=c.dev) for _ in range(nb)]
+    gs = torch.empty(ROWS, dtype=torch.float32, device=c.dev)
+    bws = torch.empty(max(lib.sbq_backward_workspace_bytes(1, ROWS, COLS), 16), dtype=torch.uint8, device=c.dev)
+    ratio = 1.0 / math.sqrt(COLS * 7)
+
+    def bwd(i):
+        j = i % nb
+        lib.sbq_quant_lsq_backward(L.ptr(c.xs[j]), L.ptr(gys[j]), L.BF16, L.ptr(gxs[j]), L.BF16, L.ptr(gs), L.ptr(s_raw), L.ptr(z_raw),
+                                   1, ROWS, COLS, -8, 7, ctypes.c_float(ratio), L.ptr(bws), bws.numel(), c.st)
+
+    us = c.timed(bwd, 100)
+    bwd(0)
+    torch.cuda.synchronize(c.dev)
+    gx_ref, gs_ref, _ = O.ste_backward(wf[rows], gy_h.float().numpy()[rows], s_all[rows], np.zeros(len(rows), np.float32), -8, 7, 0)
+    ok_gx = bool(np.array_equal(gxs[0][rows].float().cpu().numpy(), _as_bf16_bits(gx_ref)))
+    gs_want = gs_ref.astype(np.float64) * ratio * -1.0  # sign(raw scale) = -1
+    gs_got = gs[rows].cpu().numpy().astype(np.float64)
+    rel = float(np.max(np.abs(gs_got - gs_want) / np.maximum(np.abs(gs_want), 1e-12)))
+    out["ste_backward_with_gs"] = _entry(us, c.n * 6, ok_gx and rel <= 1e-5,
+                                         "gx of %d rows exact vs oracle (MySTE.backward, quant_tensor.py:45-71); "
+                                         "gs * gs_ratio * sign(s) within 1e-5 relative (fp32 summation order is free)" % len(rows),
+                                         gs_max_rel_err=rel)
+    return out

@@ -68,6 +68,27 @@ def mse_qparams_cpu(x, qmin, qmax, symmetric=True):
     return best_scale, best_zp
 
 
+def mse_qparams_perchannel_cpu(x, qmin, qmax):
+    """mse.py:28-63 per channel (symmetric): scale per row, loss = mean over the row (`mean(-1)`), strict < keeps the
+    first best candidate per row.  Scales broadcast per ROW as the CUDA kernel indexes them
+    (fake_quant_tensor.cu:181-186); the reference's CPU path mis-broadcasts a flat [C] scale."""
+    max_val, min_val = x.max(1).values, x.min(1).values
+    best_scale = torch.ones_like(max_val)
+    loss_min = torch.full_like(max_val, 1e10)
+    zero = torch.zeros_like(max_val)
+    for i in range(80):
+        cur_min, cur_max = min_val * (1.0 - i * 0.01), max_val * (1.0 - i * 0.01)
+        min_neg = torch.minimum(cur_min, zero)
+        max_pos = torch.maximum(torch.maximum(cur_max, zero), -min_neg)
+        scale = torch.maximum(max_pos * 2 / float(qmax - qmin), torch.tensor(1e-6))
+        x_dq = ort_fake_quant_cpu(x, scale.reshape(-1, 1), zero.reshape(-1, 1), qmin, qmax)
+        loss = ((x - x_dq) ** 2).mean(-1)
+        better = loss < loss_min
+        loss_min = torch.where(better, loss, loss_min)
+        best_scale = torch.where(better, scale, best_scale)
+    return best_scale, zero
+
+
 def l1_mask_cpu(w, ratio):
     """l1norm.py:18-26 unstructured: full sort of |w|, threshold at index n * ratio, strict >."""
     w_abs = w.abs()

@@ -108,14 +108,37 @@ class DeviceCalibrator:
         activations -- in both modes (:109-123) and weights are observed as they are (:125-129); the quantized
         replay (`qstorage`, :97-103) only feeds AdaRound's reconstruction (:130-143), which is outside this
         path.  So asym=True yields the same scale / zero_point as asym=False for every quantizer here, and
-        the replay is not run (tests/test_calib_reference.py pins this against the real CalibrationRunner in
-        both modes)."""
+        the replay is not run (tests/test_gpu_plugin.py::test_device_calibrator_equals_reference_calibration_runner
+        pins this against goldens from the real CalibrationRunner in both modes).
+
+        AdaRound (a reference-native weight quantizer that stays registered after plugin.install) needs exactly
+        that replay: `reconstruct_qlayer` (tools/calibration.py:130-143) is not part of this driver, so a model
+        holding one is refused here instead of being left silently un-reconstructed."""
         assert getattr(self, "_handles", None) is not None, "run prepare_calibration first!"
+        for name, m in self.oprs:
+            wq = getattr(m, "weight_quantizer", None)
+            if _live(wq) and str(getattr(wq, "TYPE", "")).lower() == "adaround":
+                self.abort()
+                raise NotImplementedError(
+                    "%s.weight_quantizer is AdaRound: its layer reconstruction (tools/calibration.py:130-143) is not "
+                    "part of the device calibrator -- calibrate this model with the reference's CalibrationRunner "
+                    "(plugin.install() without calibrate='device' leaves it in place)" % name
+                )
         for h in self._handles:
             h.remove()
         self._handles = None
         self.model.train(self._was_training)
         out = {}
+        try:
+            self._finish(out, sharded)
+        finally:
+            # also on an exception inside a calc_qparams: switches restored, nothing stale left behind
+            for q, flag in self._saved:
+                q.use_quant = flag
+            self._saved = []
+        return out
+
+    def _finish(self, out, sharded):
         if sharded:
             with sbq_dist.sharded_calibration():
                 # every streaming min-max observer of the model in ONE collective
@@ -139,10 +162,6 @@ class DeviceCalibrator:
             if _live(wq):
                 wq.update_observer(m.weight)
                 out[name + ".weight_quantizer"] = wq.calc_qparams()
-        for q, flag in self._saved:
-            q.use_quant = flag
-        self._saved = []
-        return out
 
     def _finish_inputs(self, out):
         for name, m in self.oprs:

@@ -45,6 +45,143 @@ struct StatAcc {
   int nan;
 };
 
+// ---- min / max only (the min-max observer; abssum_out == NULL): half the vector work or less -------------
+// 16-bit inputs never become floats.  Two raw elements per dword go through THREE packed integer operations:
+//   A = v_pk_max_u16   B = v_pk_min_u16   C = v_pk_max_i16        (1.5 operations per element, no unpack)
+// and the floats come out of (A, B, C) once per wave.  For a sign-magnitude format, as unsigned 16-bit numbers the
+// non-negative values sort upwards from +0 to +NaN and the negative ones follow them, -0 first, -NaN last:
+//   any negative?      A >= 0x8000        its most negative value (or a -NaN) IS A
+//   any non-negative?  B <  0x8000        its largest value (or a +NaN) is C, the signed maximum
+//   min = any negative ? A : B            max = any non-negative ? C : B
+//   NaN present  <=>  (any non-negative && C > +inf)  ||  (any negative && A > -inf)     -> min = max = NaN (torch)
+// fp32 inputs use gfx950's NaN-propagating v_minimum3_f32 / v_maximum3_f32 (IEEE-754-2019 minimum / maximum:
+// torch.min / max semantics in one instruction per two elements, no NaN flag).  Both are idempotent, so the lanes
+// past the end of a short chunk simply fold a valid pack of the same chunk again: no validity flags.
+typedef uint16_t u16x2 __attribute__((ext_vector_type(2)));
+typedef int16_t i16x2 __attribute__((ext_vector_type(2)));
+struct Stat16 {
+  uint32_t a, b, c;  // packed pairs: max_u16, min_u16, max_i16
+};
+constexpr Stat16 kStat16Identity{0x00000000u, 0xffffffffu, 0x80008000u};
+__device__ __forceinline__ void stat16_fold(Stat16& s, uint32_t w) {
+  s.a = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(u16x2, s.a), __builtin_bit_cast(u16x2, w)));
+  s.b = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(u16x2, s.b), __builtin_bit_cast(u16x2, w)));
+  s.c = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(i16x2, s.c), __builtin_bit_cast(i16x2, w)));
+}
+__device__ __forceinline__ Stat16 stat16_merge(const Stat16& x, const Stat16& y) {
+  Stat16 r = x;
+  r.a = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(u16x2, x.a), __builtin_bit_cast(u16x2, y.a)));
+  r.b = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(u16x2, x.b), __builtin_bit_cast(u16x2, y.b)));
+  r.c = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(i16x2, x.c), __builtin_bit_cast(i16x2, y.c)));
+  return r;
+}
+// both halves of every lane -> one (A, B, C) for the wave (valid in every lane, in the low half)
+__device__ __forceinline__ Stat16 stat16_wave(Stat16 s) {
+  s = stat16_merge(s, Stat16{s.a >> 16, s.b >> 16, static_cast<uint32_t>(static_cast<int32_t>(s.c) >> 16)});
+#pragma unroll
+  for (int m = kWave / 2; m > 0; m >>= 1)
+    s = stat16_merge(s, Stat16{static_cast<uint32_t>(__shfl_xor(static_cast<int>(s.a), m, kWave)),
+                               static_cast<uint32_t>(__shfl_xor(static_cast<int>(s.b), m, kWave)),
+                               static_cast<uint32_t>(__shfl_xor(static_cast<int>(s.c), m, kWave))});
+  return s;
+}
+template <typename T>
+__device__ __forceinline__ void stat16_decode(const Stat16& s, float& mn, float& mx) {
+  constexpr uint32_t kInf = T::id == SBQ_BF16 ? 0x7f80u : 0x7c00u;
+  const uint32_t a = s.a & 0xffffu, b = s.b & 0xffffu, c = s.c & 0xffffu;
+  const bool any_neg = a >= 0x8000u, any_pos = b < 0x8000u;
+  const bool nan = (any_pos && c > kInf) || (any_neg && (a & 0x7fffu) > kInf);
+  mn = Elem<T>::from_bits(static_cast<uint16_t>(any_neg ? a : b));
+  mx = Elem<T>::from_bits(static_cast<uint16_t>(any_pos ? c : b));
+  if (nan) mn = mx = __builtin_nanf("");
+}
+
+template <typename T, bool FINAL>
+__global__ __launch_bounds__(kBlock) void stats_minmax_kernel(const void* __restrict__ x, StatPartial* __restrict__ part,
+                                                              float* __restrict__ min_out, float* __restrict__ max_out,
+                                                              const ChunkGeom g, uint32_t n_chunks) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const uint32_t cid = blockIdx.x * kWavesPerBlock + __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);  // wave-uniform
+  if (cid >= n_chunks) return;
+  // FINAL == one chunk per channel == a [C, inner <= 4096] weight: the chunk is row `cid`, no divisions in front of
+  // the first load.  Offsets inside a chunk are 32-bit (a chunk holds at most 4096 elements).
+  uint32_t c_out = cid;
+  int64_t first = static_cast<int64_t>(cid) * g.inner;  // element index of the chunk's first element
+  uint32_t len = static_cast<uint32_t>(g.inner);
+  if constexpr (!FINAL) {
+    const ChunkPos cp = chunk_pos(g, cid);
+    c_out = cp.c;
+    first = cp.row_base + cp.begin;
+    len = static_cast<uint32_t>(cp.end - cp.begin);
+  }
+  const int64_t row_base = first;
+  const uint32_t vlen = len & ~static_cast<uint32_t>(kPack - 1), end = len;
+  const uint32_t begin = 0, vend = vlen;
+  constexpr int U = 8;
+  float mn, mx;
+  if constexpr (T::id == SBQ_F32) {
+    mn = __builtin_inff();
+    mx = -__builtin_inff();
+    if (vend > begin) {
+      RawPack<T> raw[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        // two 16-byte runs 256 elements apart (see load_raw2); a run past the end folds the chunk's last one again
+        const uint32_t eA = u * kWave * kPack + 4 * lane;
+        const uint32_t eB = eA + kWave * kPack / 2;
+        raw[u] = load_raw2<T, true>(x, row_base + (eA < vend ? eA : vend - 4), row_base + (eB < vend ? eB : vend - 4));
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        float v[kPack];
+        unpack_raw<T>(raw[u], v);
+#pragma unroll
+        for (int q = 0; q < kPack; q += 2) {
+          mn = __builtin_elementwise_minimum(__builtin_elementwise_minimum(mn, v[q]), v[q + 1]);
+          mx = __builtin_elementwise_maximum(__builtin_elementwise_maximum(mx, v[q]), v[q + 1]);
+        }
+      }
+    }
+    for (uint32_t e = vend + lane; e < end; e += kWave) {  // ragged tail of a per-tensor row (< 8 elements)
+      const float f = Elem<T>::load1(x, row_base + e);
+      mn = __builtin_elementwise_minimum(mn, f);
+      mx = __builtin_elementwise_maximum(mx, f);
+    }
+    mn = wave_reduce(mn, [](float a, float b) { return __builtin_elementwise_minimum(a, b); });
+    mx = wave_reduce(mx, [](float a, float b) { return __builtin_elementwise_maximum(a, b); });
+  } else {
+    Stat16 s = kStat16Identity;
+    if (vend > begin) {
+      RawPack<T> raw[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        uint32_t e = (u * kWave + lane) * kPack;
+        if (e >= vend) e = vend - kPack;
+        raw[u] = load_raw<T, true>(x, row_base + e);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) stat16_fold(s, raw[u].d[0][q]);
+      }
+    }
+    for (uint32_t e = vend + lane; e < end; e += kWave) {
+      const uint32_t w = static_cast<const uint16_t*>(x)[row_base + e];
+      stat16_fold(s, w | (w << 16));
+    }
+    s = stat16_wave(s);
+    stat16_decode<T>(s, mn, mx);
+  }
+  if (lane == 0) {
+    if constexpr (FINAL) {
+      if (min_out) min_out[c_out] = mn;
+      if (max_out) max_out[c_out] = mx;
+    } else {
+      part[cid] = StatPartial{mn, mx, 0.0};
+    }
+  }
+}
+
 template <typename T, bool VEC, bool FINAL>
 __global__ __launch_bounds__(kBlock) void stats_partial_kernel(const void* __restrict__ x,
                                                                StatPartial* __restrict__ part,
@@ -621,7 +758,11 @@ int sbq_channel_stats(const void* x, int x_dtype, int64_t outer, int64_t C, int6
     using T = decltype(tag);
 #define SBQ_STATS(V, F) \
   stats_partial_kernel<T, V, F><<<grid, kBlock, 0, st>>>(x, part, min_out, max_out, abssum_out, g, n_chunks)
-    if (vec) { if (final_) SBQ_STATS(true, true); else SBQ_STATS(true, false); }
+    if (vec && !abssum_out && knob(2) != 11) {
+      // the min-max observer: integer / minimum3 reductions (knob 2 == 11: the general kernel, for A/B runs)
+      if (final_) stats_minmax_kernel<T, true><<<grid, kBlock, 0, st>>>(x, part, min_out, max_out, g, n_chunks);
+      else stats_minmax_kernel<T, false><<<grid, kBlock, 0, st>>>(x, part, min_out, max_out, g, n_chunks);
+    } else if (vec) { if (final_) SBQ_STATS(true, true); else SBQ_STATS(true, false); }
     else { if (final_) SBQ_STATS(false, true); else SBQ_STATS(false, false); }
 #undef SBQ_STATS
   });

@@ -661,10 +661,14 @@ static int radix_select_run(const void* const* shards, const int64_t* outers, in
   // (an fp32 percentile needs three sweeps here as well -- its two tail windows span several binades of 32-bit
   // keys -- but they are ONE launch each over all cached batches: 81 vs 86 us for one 4096 x 4096 tensor, 89 vs
   // 187 us for four DeiT-sized batches)
-  if (C == 1 && knob(2) != 7) {
-    // whole tensor, one process: the sample-guided windowed engine (sbq_select_win.hip; knob 2 == 7 keeps the
-    // fixed-digit passes below for A/B runs -- they are what the multi-process protocol is made of)
-    if (n_shards > 64) return SBQ_ERR_ARG;
+  // whole tensor, one process: the sample-guided windowed engine (sbq_select_win.hip; knob 2 == 7 keeps the
+  // fixed-digit passes below for A/B runs -- they are what the multi-process protocol is made of).  Its shard
+  // table lives in the kernel arguments (64 entries) and its per-workgroup counters are 32 bits wide: a
+  // selection over more cached batches than that (the reference accepts any number, observers/base.py:12-36), or
+  // over a batch of 2^32 elements, takes the fixed-digit passes below, which loop over any number of shards.
+  bool windowed = C == 1 && knob(2) != 7 && n_shards <= 64;
+  for (int i = 0; windowed && i < n_shards; ++i) windowed = outers[i] * inner < (1ll << 32);
+  if (windowed) {
     int64_t counts[64];
     for (int i = 0; i < n_shards; ++i) counts[i] = outers[i] * inner;
     return win_select_run(shards, counts, n_shards, x_dtype, use_abs, n_sel, percentile, alpha, k0, k1,

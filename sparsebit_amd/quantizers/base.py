@@ -85,7 +85,11 @@ class Quantizer(nn.Module):
         observer on a per-channel weight, in one kernel that reads `w` once (ops.observe_fake_quant: observers/
         minmax.py:14-25 -> observers/base.py:63-79 -> quantizers/base.py:55-64).  Anything else runs the three steps.
         Returns the quantize-dequantized weight (fp32, like the reference's forward); scale / zero_point and the
-        observer's min_val / max_val are left exactly as the three calls leave them."""
+        observer's min_val / max_val are left exactly as the three calls leave them.
+
+        Calibration only: the result is DETACHED on both paths (no STE graph -- a training step goes through
+        forward()), and the observer's cache must be empty: batches cached earlier belong to a calibration that
+        was never finished, and appending the weight to them would calibrate on the mixture."""
         from .. import ops
         from ..observers.minmax import Observer as MinMaxObserver
 
@@ -100,13 +104,17 @@ class Quantizer(nn.Module):
             and not self.export_onnx
             and w.is_cuda
             and w.dim() >= 2
-            and len(self.observer.data_cache) == 0
         )
+        if len(self.observer.data_cache) != 0:
+            raise RuntimeError("calibrate_forward: the observer still holds %d cached batch(es) of an unfinished "
+                               "calibration; call calc_qparams() or observer.data_cache.reset() first"
+                               % len(self.observer.data_cache))
         if not plain:
             self.update_observer(w)
             self.calc_qparams()
             self.enable_quant()
-            return self.forward(w)
+            with torch.no_grad():
+                return self.forward(w.detach())
         self.dims = w.dim()
         qmin, qmax = self.qdesc.qrange
         y, scale, zero_point, mn, mx = ops.observe_fake_quant(w.detach(), qmin, qmax, self.qdesc.is_symmetric)

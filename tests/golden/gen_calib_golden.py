@@ -4,7 +4,7 @@ Builds a reference QuantModel (fx trace, BN fusion, quantizer placement, DISABLE
 a small CNN and runs the reference's own CalibrationRunner (sparsebit/quantization/tools/calibration.py:
 11-160) on the CPU in BOTH modes -- asym=False and asym=True with w_quant=a_quant=True -- for two observer
 configurations.  Stores the post-fusion operator weights, the calibration batches, and every quantizer's
-scale / zero_point in tests/golden/calib_golden.npz.  tests/test_gpu_calib.py rebuilds the same operator
+scale / zero_point in tests/golden/calib_golden.npz.  tests/test_gpu_plugin.py::test_device_calibrator_equals_reference_calibration_runner rebuilds the same operator
 chain on the GPU box (where the reference does not exist) and checks sparsebit_amd.calibration.
 DeviceCalibrator against these numbers.
 

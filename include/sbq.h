@@ -377,6 +377,11 @@ int sbq_radix_finish(const int64_t* state, int64_t C, int n_sel, int use_abs,
  * inner]; ranks from the first histogram as in sbq_percentile_ranks; min / max [C] with the
  * "no negative -> 0" rule of percentile.py:30-43); sbq_kth_value is the 1-indexed k-th smallest
  * of x (of |x| with use_abs) -- the L1 masker's threshold, l1norm.py:21-24. */
+/* Workspace contract of these two calls (as for the mat-vec's arrival counters, section 5): the workspace must be
+ * ZERO before its first use (hipMemset once), every call leaves it reusable by the next one, and it must not be
+ * shared by calls that can run concurrently (different streams).  A whole-tensor selection (C == 1) of a 16-bit
+ * tensor is ONE launch: every workgroup brackets the wanted ranks from the same 2048-pack sample, sweeps its slabs
+ * once, and the last workgroup to arrive resolves the ranks (fp32: one such launch per 11 key bits that remain). */
 size_t sbq_radix_select_workspace_bytes(int64_t C, int n_sel);
 int sbq_percentile_select(const void* const* shards, const int64_t* outers, int n_shards, int x_dtype,
                           int64_t C, int64_t inner, double alpha, float* min_out, float* max_out,
@@ -415,7 +420,8 @@ int sbq_mask_from_threshold(const void* x, int x_dtype, int64_t numel,
  *    x fp32 [batch, in], out fp32 [batch, out] pre-filled with the bias
  *    (quant.py:285-289) and accumulated in place.  group_size 0 == one group
  *    (cuda_kernel.cpp:10-16); otherwise a multiple of 128 (4-, 3-bit) or 64 (2-bit).
- *    Deterministic: no float atomics, fixed summation order.
+ *    Deterministic: fixed summation order (the persistent-strip kernel of HBM-sized matrices adds each output
+ *    element with ONE float atomic -- a single addend, so still order independent).
  * ------------------------------------------------------------------ */
 /* Workspace contract: its first SBQ_GPTQ_COUNTER_BYTES bytes are arrival counters of the
  * single-launch K-split fold; they must be ZERO before the first call (allocate with
@@ -449,7 +455,8 @@ int sbq_vecquant2matmul(const float* x, const int32_t* qweight, float* out,
  * 9 = two-launch path in the GPTQ mat-vec, 6 = no LDS-DMA prefetch, 8 = plain strip order,
  * 5 = (strip, K block) grid instead of the persistent strip workers on HBM-sized matrices --
  * and, in sbq_percentile_rows, the general row kernel instead of the small-rank extraction;
- * 7 = fixed-digit radix engine for whole-tensor selections). knob 3: resident schedule of the forward QDQ
+ * 7 = fixed-digit radix engine for whole-tensor selections, 12 = the multi-launch windowed protocol (plan / sweep /
+ * advance / fallback launches) instead of the one-launch engine, 11 = general statistics kernel for a min-max-only call). knob 3: resident schedule of the forward QDQ
  * (0 = auto: tensors that fit the chip's registers in one sitting, 1 = never, 2 = always) */
 int sbq_set_tuning(int knob, int value);
 

@@ -46,6 +46,10 @@ EXTRA_FLAGS = {
 }
 
 
+# development only: extra hipcc flags for every file (e.g. SBQ_EXTRA_HIPCC_FLAGS="-DSBQ_SEL_STAMPS=1")
+FLAGS += os.environ.get("SBQ_EXTRA_HIPCC_FLAGS", "").split()
+
+
 def sources():
     return sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
 

@@ -15,22 +15,10 @@
 // reductions and a 4-entry LDS cross-wave step, and writes ONE partial record;
 // a second tiny kernel folds the partials of a channel in a fixed order, so the
 // results are deterministic (no float atomics).
-#include "sbq_common.hpp"
+#include "sbq_observe_body.hpp"
 
 namespace sbq {
 namespace {
-
-constexpr uint32_t kStatsChunk = kWave * kPack * 8;   // 4096 elements: ONE WAVE, 8 packs per lane
-constexpr uint32_t kMseChunk = kBlock * kPack * 2;    // 4096 elements, 2 packs per lane (registers)
-
-struct StatPartial {
-  float mn, mx;
-  double abssum;
-};
-
-struct MinF { __device__ __forceinline__ float operator()(float a, float b) const { return __builtin_fminf(a, b); } };
-struct MaxF { __device__ __forceinline__ float operator()(float a, float b) const { return __builtin_fmaxf(a, b); } };
-struct OrI { __device__ __forceinline__ int operator()(int a, int b) const { return a | b; } };
 
 // ---- stage 1: one partial {min, max, sum|x|} per chunk ---------------------------
 // A chunk (<= 4096 elements of one channel row) belongs to ONE WAVE: 8 packs per lane are
@@ -44,57 +32,6 @@ struct StatAcc {
   float mn, mx, as;
   int nan;
 };
-
-// ---- min / max only (the min-max observer; abssum_out == NULL): half the vector work or less -------------
-// 16-bit inputs never become floats.  Two raw elements per dword go through THREE packed integer operations:
-//   A = v_pk_max_u16   B = v_pk_min_u16   C = v_pk_max_i16        (1.5 operations per element, no unpack)
-// and the floats come out of (A, B, C) once per wave.  For a sign-magnitude format, as unsigned 16-bit numbers the
-// non-negative values sort upwards from +0 to +NaN and the negative ones follow them, -0 first, -NaN last:
-//   any negative?      A >= 0x8000        its most negative value (or a -NaN) IS A
-//   any non-negative?  B <  0x8000        its largest value (or a +NaN) is C, the signed maximum
-//   min = any negative ? A : B            max = any non-negative ? C : B
-//   NaN present  <=>  (any non-negative && C > +inf)  ||  (any negative && A > -inf)     -> min = max = NaN (torch)
-// fp32 inputs use gfx950's NaN-propagating v_minimum3_f32 / v_maximum3_f32 (IEEE-754-2019 minimum / maximum:
-// torch.min / max semantics in one instruction per two elements, no NaN flag).  Both are idempotent, so the lanes
-// past the end of a short chunk simply fold a valid pack of the same chunk again: no validity flags.
-typedef uint16_t u16x2 __attribute__((ext_vector_type(2)));
-typedef int16_t i16x2 __attribute__((ext_vector_type(2)));
-struct Stat16 {
-  uint32_t a, b, c;  // packed pairs: max_u16, min_u16, max_i16
-};
-constexpr Stat16 kStat16Identity{0x00000000u, 0xffffffffu, 0x80008000u};
-__device__ __forceinline__ void stat16_fold(Stat16& s, uint32_t w) {
-  s.a = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(u16x2, s.a), __builtin_bit_cast(u16x2, w)));
-  s.b = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(u16x2, s.b), __builtin_bit_cast(u16x2, w)));
-  s.c = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(i16x2, s.c), __builtin_bit_cast(i16x2, w)));
-}
-__device__ __forceinline__ Stat16 stat16_merge(const Stat16& x, const Stat16& y) {
-  Stat16 r = x;
-  r.a = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(u16x2, x.a), __builtin_bit_cast(u16x2, y.a)));
-  r.b = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(u16x2, x.b), __builtin_bit_cast(u16x2, y.b)));
-  r.c = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(i16x2, x.c), __builtin_bit_cast(i16x2, y.c)));
-  return r;
-}
-// both halves of every lane -> one (A, B, C) for the wave (valid in every lane, in the low half)
-__device__ __forceinline__ Stat16 stat16_wave(Stat16 s) {
-  s = stat16_merge(s, Stat16{s.a >> 16, s.b >> 16, static_cast<uint32_t>(static_cast<int32_t>(s.c) >> 16)});
-#pragma unroll
-  for (int m = kWave / 2; m > 0; m >>= 1)
-    s = stat16_merge(s, Stat16{static_cast<uint32_t>(__shfl_xor(static_cast<int>(s.a), m, kWave)),
-                               static_cast<uint32_t>(__shfl_xor(static_cast<int>(s.b), m, kWave)),
-                               static_cast<uint32_t>(__shfl_xor(static_cast<int>(s.c), m, kWave))});
-  return s;
-}
-template <typename T>
-__device__ __forceinline__ void stat16_decode(const Stat16& s, float& mn, float& mx) {
-  constexpr uint32_t kInf = T::id == SBQ_BF16 ? 0x7f80u : 0x7c00u;
-  const uint32_t a = s.a & 0xffffu, b = s.b & 0xffffu, c = s.c & 0xffffu;
-  const bool any_neg = a >= 0x8000u, any_pos = b < 0x8000u;
-  const bool nan = (any_pos && c > kInf) || (any_neg && (a & 0x7fffu) > kInf);
-  mn = Elem<T>::from_bits(static_cast<uint16_t>(any_neg ? a : b));
-  mx = Elem<T>::from_bits(static_cast<uint16_t>(any_pos ? c : b));
-  if (nan) mn = mx = __builtin_nanf("");
-}
 
 template <typename T, bool FINAL>
 __global__ __launch_bounds__(kBlock) void stats_minmax_kernel(const void* __restrict__ x, StatPartial* __restrict__ part,
@@ -524,112 +461,21 @@ __global__ void lsq_init_kernel(const double* __restrict__ abssum, int64_t C, do
   scale[i] = (2.0f * mean) / sqrt_qmax;
 }
 
-// ---- MSE search -------------------------------------------------------------------
-// mse.py:46-49: candidate i shrinks (min, max) by the fp32 factor (1 - 0.01 i).
-__device__ __forceinline__ void mse_candidate(float mn, float mx, int i, float qrange, bool symmetric,
-                                              float& s, float& z) {
-  const float f = static_cast<float>(1.0 - static_cast<double>(i) * 0.01);
-  qparams_from_minmax(mn * f, mx * f, qrange, symmetric, s, z);
-}
-
 // One workgroup keeps a 4096-element chunk of one channel in registers and walks
-// the 80 candidates over it: x is read from HBM once, not 80 times (the reference
-// makes 80 x 4 full passes).  Output: part[bid][80] fp64 partial sums of (x-dq)^2.
+// the 80 candidates over it (mse_chunk_body, sbq_observe_body.hpp): x is read from HBM once, not 80 times (the
+// reference makes 80 x 4 full passes).  Output: part[bid][80] fp64 partial sums of (x-dq)^2.
 template <typename T, bool VEC>
 __global__ __launch_bounds__(kBlock) void mse_partial_kernel(
     const void* __restrict__ x, const float* __restrict__ min_val, const float* __restrict__ max_val,
     double* __restrict__ part, double* __restrict__ sse, const ChunkGeom g, float qrange, float qlo,
     float qhi, int symmetric) {
-  __shared__ float s_scale[SBQ_MSE_CANDIDATES];
-  __shared__ float s_zp[SBQ_MSE_CANDIDATES];
-  __shared__ float s_rcp[SBQ_MSE_CANDIDATES];  // RN(1/scale) when the exact fast division applies, else 0
-  __shared__ float s_acc[SBQ_MSE_CANDIDATES][kWavesPerBlock];
+  __shared__ MseLds lds;
   const uint32_t bid = blockIdx.x;
   const ChunkPos cp = chunk_pos(g, bid);
   const uint32_t c = cp.c;
-  const int64_t row_base = cp.row_base, begin = cp.begin, end = cp.end;
-
+  const double t = mse_chunk_body<T, VEC>(lds, x, cp.row_base, cp.begin, cp.end, min_val[c], max_val[c], qrange, qlo, qhi,
+                                          symmetric != 0);
   if (threadIdx.x < SBQ_MSE_CANDIDATES) {
-    float s, z;
-    mse_candidate(min_val[c], max_val[c], threadIdx.x, qrange, symmetric != 0, s, z);
-    s_scale[threadIdx.x] = s;
-    s_zp[threadIdx.x] = z;  // already integral (rint) or 0
-    s_rcp[threadIdx.x] = fast_div_ok(s) ? 1.0f / s : 0.0f;
-  }
-
-  // Lanes past the end of the chunk hold x = 0: its QDQ is exactly 0 for every candidate
-  // (zp lies inside [qmin, qmax]), so they add exactly 0 to every sum -- no masking needed.
-  constexpr int E = 2 * kPack;  // elements per lane
-  float v[E];
-  if constexpr (VEC) {
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      int64_t e = begin + (static_cast<int64_t>(u) * kBlock + threadIdx.x) * kPack;
-      const bool in = e + kPack <= end;  // chunk and inner are multiples of 8 here
-      if (!in) e = begin;
-      float t[kPack];
-      load_pack<T, true>(x, row_base + e, t);
-#pragma unroll
-      for (int q = 0; q < kPack; ++q) v[u * kPack + q] = in ? t[q] : 0.0f;
-    }
-  } else {
-#pragma unroll
-    for (int q = 0; q < E; ++q) {
-      const int64_t e = begin + static_cast<int64_t>(q) * kBlock + threadIdx.x;
-      v[q] = e < end ? Elem<T>::load1(x, row_base + e) : 0.0f;
-    }
-  }
-  __syncthreads();
-
-  const int lane = threadIdx.x & (kWave - 1);
-  const int wid = threadIdx.x / kWave;
-  for (int i = 0; i < SBQ_MSE_CANDIDATES; ++i) {
-    const float s = s_scale[i];
-    const float z = s_zp[i];
-    const float y = s_rcp[i];
-    float acc = 0.0f;
-    if (y != 0.0f) {  // block-uniform: the candidate's scale is shared by the whole chunk
-      // The level is taken from x * RN(1/s) instead of the correctly rounded x / s: the two can
-      // only differ within ~1e-7 (relative) of a rounding tie, and AT a tie both neighbouring
-      // levels are equally far from x, so the squared error -- the only thing this kernel
-      // produces -- is unchanged to ~1e-7 of one element's term.  (The forward QDQ kernels keep
-      // the exact quotient: there the level itself is the output.)  NaN / inf inputs poison the loss
-      // either way.
-      // This loop is the kernel (80 x 16.7 M evaluations, VALU-bound): the residual and its square are
-      // contracted into fmas (x - lv*s and acc + d*d, each with ONE rounding -- closer to the exact loss than
-      // the reference's separately rounded tensor ops; only the argmin is compared), and a candidate with
-      // zero_point 0 (every symmetric scheme) skips the two zero-point operations: 5 ops instead of 9.
-      if (z == 0.0f) {  // block-uniform
-#pragma unroll
-        for (int q = 0; q < E; ++q) {
-          const float lv = __builtin_amdgcn_fmed3f(__builtin_rintf(v[q] * y), qlo, qhi);
-          const float d = __builtin_fmaf(-lv, s, v[q]);
-          acc = __builtin_fmaf(d, d, acc);
-        }
-      } else {
-#pragma unroll
-        for (int q = 0; q < E; ++q) {
-          const float lv = __builtin_amdgcn_fmed3f(__builtin_rintf(v[q] * y) + z, qlo, qhi);
-          const float d = __builtin_fmaf(-(lv - z), s, v[q]);
-          acc = __builtin_fmaf(d, d, acc);
-        }
-      }
-    } else {
-#pragma unroll
-      for (int q = 0; q < E; ++q) {
-        const float lv = quant_level<SBQ_ROUND_HALF_EVEN>(v[q], s, z, qlo, qhi);
-        const float d = v[q] - dequant_level(lv, s, z);
-        acc += d * d;
-      }
-    }
-    acc = wave_reduce(acc, Sum());
-    if (lane == 0) s_acc[i][wid] = acc;
-  }
-  __syncthreads();
-  if (threadIdx.x < SBQ_MSE_CANDIDATES) {
-    double t = 0.0;
-#pragma unroll
-    for (int w = 0; w < kWavesPerBlock; ++w) t += static_cast<double>(s_acc[threadIdx.x][w]);
     if (g.chunks_per_chan == 1)  // the chunk IS the channel: accumulate in place, no fold kernel
       sse[static_cast<size_t>(c) * SBQ_MSE_CANDIDATES + threadIdx.x] += t;
     else

@@ -24,6 +24,9 @@
 // advance kernel sums them.
 // Keys, NaN / -0 handling, rank formulas: exactly those of sbq_select.hip (float_key; percentile_ranks_kernel).
 // Histograms are integer counts (order independent => deterministic).
+#include <cstddef>
+#include <type_traits>
+
 #include "sbq_common.hpp"
 
 namespace sbq {
@@ -52,15 +55,20 @@ struct WinSel {
 struct WinState {
   WinSel sel[kWinSel];
   int64_t n;  // elements in all shards
-  uint32_t arrivals;  // win_fallback_kernel: workgroups of the running sweep that have flushed (zero between launches)
+  unsigned long long pad_neg, pad_nan;  // one-launch engine: the selection's sign / NaN counts, between its launches
+  unsigned long long pad0[5];
+  // its own 128-byte line: the only word of the state that is touched by atomics
+  uint32_t arrivals;  // workgroups of the running sweep that have flushed (zero between launches)
   uint32_t pad1;
 };
+static_assert(offsetof(WinState, arrivals) == 128, "the arrival counter has a line of its own");
 struct WinSlot {  // one 128-byte line
   unsigned long long below[kWinSel];
   unsigned long long neg, nan;
   unsigned long long pad[12];
 };
 struct ShardTable {
+  static constexpr bool kSingle = false;
   const void* ptr[kMaxShards];
   int64_t count[kMaxShards];
 };
@@ -92,82 +100,129 @@ __device__ __forceinline__ uint32_t shift_for(uint64_t width, uint32_t min_shift
   return s;
 }
 
-// One workgroup of 1024: sample, histogram in LDS, bracket each selector's rank, write the first windows.
+// A barrier for LDS traffic only.  __syncthreads() is a workgroup-scope release fence + s_barrier, and the fence
+// waits for EVERY outstanding vector-memory operation (s_waitcnt vmcnt(0)): with a workgroup's slabs in flight it
+// turned "derive the windows while the data arrives" into "wait 7 us for the data, then derive the windows".  This
+// one waits for the LDS operations alone; global loads keep flying across it.
+__device__ __forceinline__ void lds_sync() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// The plan: sample, histogram in LDS, bracket each selector's rank, name the first windows.  Run by ONE workgroup as
+// its own launch (win_plan_kernel: the multi-launch protocol) or by EVERY workgroup of the one-launch engine in front
+// of its sweep (win_one_kernel: same sample, same integer arithmetic, order-independent LDS counts -- every
+// workgroup derives the same windows, nothing is communicated).
 // mode 0: explicit ranks k0 (k1); mode 1: percentile (ranks from the sample's own sign counts; the exact ones
 // follow from the first sweep).
-template <typename T>
-__global__ __launch_bounds__(1024) void win_plan_kernel(const ShardTable tab, int n_shards, WinState* __restrict__ st,
-                                                        int mode, int n_sel, int use_abs, int64_t k0, int64_t k1,
-                                                        int64_t n, double alpha, uint32_t min_shift,
-                                                        u32x4* __restrict__ scratch, uint32_t scratch_vecs) {
-  constexpr int kT = 1024, kPer = kPlanBins / kT;  // 8 bins per thread
-  __shared__ uint32_t hist[kPlanBins];
-  __shared__ uint32_t wave_tot[kT / kWave];
-  __shared__ uint32_t s_total, s_neg, s_first, s_last;
-  __shared__ int64_t r_lo[kWinSel], r_hi[kWinSel];
-  __shared__ double r_mid[kWinSel];
-  __shared__ uint32_t b_lo[kWinSel], b_hi[kWinSel];
-  for (int i = threadIdx.x; i < kPlanBins; i += kT) hist[i] = 0;
-  if (threadIdx.x == 0) {
-    s_first = kPlanBins - 1;
-    s_last = 0;
-  }
-  __syncthreads();
-  // sample: pack p of n_packs starts at element p * floor(n / n_packs) of the concatenated shards
-  const int64_t n_packs = n / kPack < kPlanPacks ? (n / kPack > 0 ? n / kPack : 1) : kPlanPacks;
-  // every thread's packs are located first and requested together: one memory round trip for the whole sample
-  constexpr int kMine = kPlanPacks / kT;
-  const void* base[kMine];
+struct PlanLds {
+  uint32_t hist[kPlanBins];
+  uint32_t wave_tot[1024 / kWave];
+  uint32_t total, neg, first, last;
+  int64_t r_lo[kWinSel], r_hi[kWinSel];
+  double r_mid[kWinSel];
+  uint32_t b_lo[kWinSel], b_hi[kWinSel];
+};
+template <typename T, int kT>
+struct PlanSample {
+  static constexpr int kMine = kPlanPacks / kT;
   int64_t e[kMine], cnt[kMine];
-  float v[kMine][kPack];
+  RawPack<T> raw[kMine];  // still packed: nothing waits for the sample before the slabs have been requested
+};
+template <typename T>
+__device__ __forceinline__ RawPack<T> raw_from_elems(const float (&v)[kPack]) {
+  RawPack<T> r;
+  if constexpr (T::id == SBQ_F32) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      r.d[0][j] = __builtin_bit_cast(uint32_t, v[j]);
+      r.d[1][j] = __builtin_bit_cast(uint32_t, v[4 + j]);
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      r.d[0][j] = static_cast<uint32_t>(Elem<T>::to_bits(v[2 * j])) | (static_cast<uint32_t>(Elem<T>::to_bits(v[2 * j + 1])) << 16);
+  }
+  return r;
+}
+
+// Every thread's packs are located first and requested together: one memory round trip for the whole sample.
+// JITTER: pack p sits at a pseudo-random offset inside its stride instead of at its start, so that data periodic
+// with the stride (a channels-last activation whose channel count divides it) is still sampled across its period.
+template <typename T, int kT, bool JITTER, typename Tab>
+__device__ __forceinline__ void plan_sample_load(const Tab& tab, int n_shards, int64_t n, int64_t n_packs,
+                                                 PlanSample<T, kT>& sm) {
+  constexpr int kMine = PlanSample<T, kT>::kMine;
+  const void* base[kMine];
+  const int64_t stride = n / n_packs;
 #pragma unroll
   for (int m = 0; m < kMine; ++m) {
     // which shard: the table lives in the kernel arguments, so it is walked with a UNIFORM index (scalar loads) and
     // the lane keeps its own pointer / count by selects -- a per-lane index would spill the table to scratch
     const int64_t p = static_cast<int64_t>(threadIdx.x) + m * kT;
-    e[m] = (p < n_packs ? p : 0) * (n / n_packs);
+    int64_t e = (p < n_packs ? p : 0) * stride;
+    if constexpr (JITTER) {
+      const uint32_t h = (static_cast<uint32_t>(p) * 2654435761u) >> 4;
+      if (stride > kPack) e += static_cast<int64_t>(h % static_cast<uint32_t>(stride - kPack + 1));
+    }
+    sm.e[m] = e;
     base[m] = tab.ptr[0];
-    cnt[m] = tab.count[0];
+    sm.cnt[m] = tab.count[0];
     bool found = false;
-    for (int i = 0; i < n_shards; ++i) {
+    for (int i = 0; i < (Tab::kSingle ? 1 : n_shards); ++i) {
       const int64_t c = tab.count[i];
-      const bool here = !found && (e[m] < c || i + 1 == n_shards);
+      const bool here = !found && (sm.e[m] < c || i + 1 == (Tab::kSingle ? 1 : n_shards));
       base[m] = here ? tab.ptr[i] : base[m];
-      cnt[m] = here ? c : cnt[m];
-      e[m] = (found || here) ? e[m] : e[m] - c;
+      sm.cnt[m] = here ? c : sm.cnt[m];
+      sm.e[m] = (found || here) ? sm.e[m] : sm.e[m] - c;
       found |= here;
     }
-    e[m] &= ~static_cast<int64_t>(kPack - 1);  // whole packs: one 16-byte load (two for fp32) when the shard allows it
+    sm.e[m] &= ~static_cast<int64_t>(kPack - 1);  // whole packs: one 16-byte load (two for fp32) when the shard allows it
   }
+  // One 16-byte load per pack, no branch: a pack that would run past its shard's end is moved back to the shard's
+  // last whole pack (the caller admits only 16-byte aligned shards of at least one pack: win_one_eligible).  A
+  // control-flow diamond here made the compiler lose count of the loads in flight and wait for ALL of them
+  // (vmcnt(0), slabs included) in front of the plan.
 #pragma unroll
   for (int m = 0; m < kMine; ++m) {
-    if ((reinterpret_cast<uintptr_t>(base[m]) & 15u) == 0 && e[m] + kPack <= cnt[m]) {
-      load_pack<T, false>(base[m], e[m], v[m]);
-    } else {
-#pragma unroll
-      for (int j = 0; j < kPack; ++j) v[m][j] = Elem<T>::load1(base[m], e[m] + j < cnt[m] ? e[m] + j : cnt[m] - 1);
-    }
+    const int64_t last = (sm.cnt[m] - kPack) & ~static_cast<int64_t>(kPack - 1);
+    sm.e[m] = sm.e[m] < last ? sm.e[m] : last;
+    sm.raw[m] = load_raw<T, false>(base[m], sm.e[m]);
   }
-  // the counter lines and histogram copies the sweeps add to (the advance leaves them clean, a first call or an
-  // abandoned one does not): 136 KB of stores, queued BEHIND the sample's loads (the vector-memory path of the one
-  // CU this kernel runs on is in order)
-  __builtin_amdgcn_sched_barrier(0);
-  for (uint32_t i = threadIdx.x; i < scratch_vecs; i += kT) scratch[i] = u32x4{0, 0, 0, 0};
-  __builtin_amdgcn_sched_barrier(0);
+}
+
+// `L.hist` must be zero (and that visible: a barrier behind the clearing) on entry.  Thread 0 writes the n_sel
+// windows to out[] (LDS or global); the caller orders that against its readers.
+struct NoStamp { __device__ __forceinline__ void operator()(int) const {} };
+template <typename T, int kT, typename Stamp = NoStamp>
+__device__ __forceinline__ void plan_compute(PlanLds& L, const PlanSample<T, kT>& sm, int64_t n_packs, int mode,
+                                             int n_sel, int use_abs, int64_t k0, int64_t k1, int64_t n, double alpha,
+                                             uint32_t min_shift, WinSel* out, Stamp stamp = Stamp()) {
+  constexpr int kMine = PlanSample<T, kT>::kMine;
+  constexpr int kPer = kPlanBins / kT;  // bins per thread
+  if (threadIdx.x == 0) {
+    L.first = kPlanBins - 1;
+    L.last = 0;
+  }
+  if (threadIdx.x < kWinSel) {
+    L.b_lo[threadIdx.x] = 0;
+    L.b_hi[threadIdx.x] = kPlanBins - 1;
+  }
 #pragma unroll
   for (int m = 0; m < kMine; ++m) {
     if (static_cast<int64_t>(threadIdx.x) + m * kT >= n_packs) continue;
+    float v[kPack];
+    unpack_raw<T>(sm.raw[m], v);
 #pragma unroll
     for (int j = 0; j < kPack; ++j)
-      if (e[m] + j < cnt[m])
-        atomicAdd(&hist[win_key(__builtin_bit_cast(uint32_t, v[m][j]), use_abs != 0) >> kPlanShift], 1u);
+      atomicAdd(&L.hist[win_key(__builtin_bit_cast(uint32_t, v[j]), use_abs != 0) >> kPlanShift], 1u);
   }
-  __syncthreads();
+  lds_sync();
+  stamp(8);
   uint32_t bins[kPer];
   uint32_t t = 0;
 #pragma unroll
   for (int i = 0; i < kPer; ++i) {
-    bins[i] = hist[threadIdx.x * kPer + i];
+    bins[i] = L.hist[threadIdx.x * kPer + i];
     t += bins[i];
   }
   const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
@@ -177,58 +232,67 @@ __global__ __launch_bounds__(1024) void win_plan_kernel(const ShardTable tab, in
     const uint32_t up = __shfl_up(incl, d, kWave);
     if (lane >= d) incl += up;
   }
-  if (lane == kWave - 1) wave_tot[wid] = incl;
-  __syncthreads();
-  uint32_t off = 0;
-  for (int w = 0; w < wid; ++w) off += wave_tot[w];
+  if (lane == kWave - 1) L.wave_tot[wid] = incl;
+  lds_sync();
+  const uint32_t mine = lane < wid ? L.wave_tot[lane] : 0u;  // (kT / 64 <= 16 waves: lanes 0 .. wid-1)
+  const uint32_t off = wave_reduce(mine, [](uint32_t a, uint32_t b) { return a + b; });
   incl += off;
   const uint32_t excl = incl - t;
-  if (threadIdx.x == kT - 1) s_total = incl;
-  if (threadIdx.x == (kKeyZero >> kPlanShift) / kPer) s_neg = excl;  // bins below kKeyZero: keys of x < 0
-  if (t) {                                  // first / last occupied bin of the sample
-    uint32_t f = 0, l = 0;
-    for (int i = 0; i < kPer; ++i)
-      if (bins[i]) { f = i; break; }
-    for (int i = kPer - 1; i >= 0; --i)
-      if (bins[i]) { l = i; break; }
-    atomicMin(&s_first, threadIdx.x * kPer + f);
-    atomicMax(&s_last, threadIdx.x * kPer + l);
+  if (threadIdx.x == kT - 1) L.total = incl;
+  if (threadIdx.x == (kKeyZero >> kPlanShift) / kPer) {
+    // bins below kKeyZero: keys of x < 0 (the boundary bin starts a thread's run when kPer divides it; else add the
+    // thread's own bins below it)
+    uint32_t below = excl;
+    for (int i = 0; i < static_cast<int>((kKeyZero >> kPlanShift) % kPer); ++i) below += bins[i];
+    L.neg = below;
   }
-  if (threadIdx.x < kWinSel) {
-    b_lo[threadIdx.x] = 0;
-    b_hi[threadIdx.x] = kPlanBins - 1;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const double S = static_cast<double>(s_total);
-    const double scale = n > 0 ? S / static_cast<double>(n) : 0.0;
-    for (int s = 0; s < n_sel; ++s) {
-      double r;  // expected rank of the target inside the sample (1-based, fractional)
-      if (mode == 0) {
-        r = static_cast<double>(s == 0 ? k0 : k1) * scale;
-      } else {
-        // percentile.py:36-43 on the sample's own counts (the last bin holds the NaNs, and nothing else that
-        // matters: +inf and the largest finite values share it)
-        const double neg = static_cast<double>(s_neg);
-        const double pos = S - neg;
-        r = s == 0 ? __builtin_fmax(neg * alpha, 1.0 * scale) : S - pos * alpha;
-      }
-      // rank error of the sample: sigma_iid = sqrt(r (1 - r/S)) for independent draws; the 8 neighbours of a pack
-      // are correlated (design effect 1 + 7 rho), so twice 6 sigma_iid + slack.  Only the cost of a miss (one more
-      // round) depends on this, never the result.
-      const double q = S > 0 ? r / S : 0.0;
-      const double var = __builtin_fmax(r * (1.0 - (q < 1.0 ? q : 1.0)), 1.0);
-      const double m = 2.0 * 6.0 * __builtin_sqrt(var) + 16.0;
-      r_mid[s] = r;
-      r_lo[s] = static_cast<int64_t>(__builtin_floor(r - m));
-      r_hi[s] = static_cast<int64_t>(__builtin_ceil(r + m));
+  {
+    // first / last occupied bin of the sample: reduced over the wave first -- one LDS atomic per wave (hundreds of
+    // threads on the same two addresses serialised for 4 us)
+    uint32_t f = kPlanBins - 1, l = 0;
+#pragma unroll
+    for (int i = kPer - 1; i >= 0; --i) f = bins[i] ? threadIdx.x * kPer + i : f;
+#pragma unroll
+    for (int i = 0; i < kPer; ++i) l = bins[i] ? threadIdx.x * kPer + i : l;
+    f = wave_reduce(f, [](uint32_t a, uint32_t b) { return a < b ? a : b; });
+    l = wave_reduce(l, [](uint32_t a, uint32_t b) { return a > b ? a : b; });
+    if (lane == 0) {
+      atomicMin(&L.first, f);
+      atomicMax(&L.last, l);
     }
   }
-  __syncthreads();
+  lds_sync();
+  stamp(9);
+  if (static_cast<int>(threadIdx.x) < n_sel) {
+    const int s = threadIdx.x;
+    const double S = static_cast<double>(L.total);
+    const double scale = n > 0 ? S / static_cast<double>(n) : 0.0;
+    double r;  // expected rank of the target inside the sample (1-based, fractional)
+    if (mode == 0) {
+      r = static_cast<double>(s == 0 ? k0 : k1) * scale;
+    } else {
+      // percentile.py:36-43 on the sample's own counts (the last bin holds the NaNs, and nothing else that
+      // matters: +inf and the largest finite values share it)
+      const double neg = static_cast<double>(L.neg);
+      const double pos = S - neg;
+      r = s == 0 ? __builtin_fmax(neg * alpha, 1.0 * scale) : S - pos * alpha;
+    }
+    // rank error of the sample: sigma_iid = sqrt(r (1 - r/S)) for independent draws; the 8 neighbours of a pack
+    // are correlated (design effect 1 + 7 rho), so twice 6 sigma_iid + slack.  Only the cost of a miss (one more
+    // round) depends on this, never the result.
+    const double q = S > 0 ? r / S : 0.0;
+    const double var = __builtin_fmax(r * (1.0 - (q < 1.0 ? q : 1.0)), 1.0);
+    const double m = 2.0 * 6.0 * __builtin_sqrt(var) + 16.0;
+    L.r_mid[s] = r;
+    L.r_lo[s] = static_cast<int64_t>(__builtin_floor(r - m));
+    L.r_hi[s] = static_cast<int64_t>(__builtin_ceil(r + m));
+  }
+  lds_sync();
+  stamp(10);
   // the thread whose bins hold sample rank r (excl < r <= incl) names the bin
   for (int s = 0; s < n_sel; ++s) {
     for (int side = 0; side < 2; ++side) {
-      const int64_t r = side == 0 ? r_lo[s] : r_hi[s];
+      const int64_t r = side == 0 ? L.r_lo[s] : L.r_hi[s];
       if (r >= 1 && r > static_cast<int64_t>(excl) && r <= static_cast<int64_t>(incl)) {
         int64_t kk = r - excl;
         uint32_t b = 0;
@@ -236,41 +300,65 @@ __global__ __launch_bounds__(1024) void win_plan_kernel(const ShardTable tab, in
           if (kk > static_cast<int64_t>(bins[i])) kk -= bins[i];
           else { b = i; break; }
         }
-        (side == 0 ? b_lo : b_hi)[s] = threadIdx.x * kPer + b;
+        (side == 0 ? L.b_lo : L.b_hi)[s] = threadIdx.x * kPer + b;
       }
     }
   }
+  lds_sync();
+  if (static_cast<int>(threadIdx.x) < n_sel) {
+    const int s = threadIdx.x;
+    const double S = static_cast<double>(L.total);
+    // A bracket that runs off the sample: the window starts at the first key instead -- or, when the target is
+    // at least 8 sample ranks away from that end (the sample's own extreme is then beyond it with probability
+    // 1 - e^-8), at the sample's extreme bin, which keeps a tail quantile's window a few bins wide.  Keys outside
+    // the window are counted, so a wrong guess only costs another round.
+    uint32_t a = L.b_lo[s], b = L.b_hi[s];
+    if (L.r_lo[s] < 1) a = L.r_mid[s] >= 8.0 ? L.first : 0u;
+    if (L.r_hi[s] > static_cast<int64_t>(L.total)) b = S - L.r_mid[s] >= 8.0 ? L.last : kPlanBins - 1;
+    if (b < a) b = a;
+    const uint32_t lo = a << kPlanShift;
+    const uint64_t width = (static_cast<uint64_t>(b - a) + 1) << kPlanShift;
+    WinSel w;
+    w.lo = lo;
+    w.shift = shift_for(width, min_shift);
+    // only the bracket itself is histogrammed: with 16-bit inputs the 2048 bins of the smallest shift span 16
+    // binades -- half of a weight tensor -- while the bracket is a few dozen values wide
+    const uint64_t room = 0xffffffffull - lo;
+    w.span = static_cast<uint32_t>(width - 1 < room ? width - 1 : room);
+    // percentile: the min side's window sits at the bottom of the data, the max side's at the top -- the sweep
+    // tests the near end first and counts what lies beyond it (a handful of keys) instead of what lies before
+    w.side = mode == 1 && s == 1 ? 1u : 0u;
+    w.k = mode == 0 ? (s == 0 ? k0 : k1) : 0;
+    w.done = 0;
+    w.fresh = 1;
+    out[s] = w;
+  }
+}
+
+// ... as its own launch: one workgroup of 1024 (it also clears the workspace of the multi-launch protocol, so that
+// needs no init launch).
+template <typename T>
+__global__ __launch_bounds__(1024) void win_plan_kernel(const ShardTable tab, int n_shards, WinState* __restrict__ st,
+                                                        int mode, int n_sel, int use_abs, int64_t k0, int64_t k1,
+                                                        int64_t n, double alpha, uint32_t min_shift,
+                                                        u32x4* __restrict__ scratch, uint32_t scratch_vecs) {
+  constexpr int kT = 1024;
+  __shared__ PlanLds L;
+  for (int i = threadIdx.x; i < kPlanBins; i += kT) L.hist[i] = 0;
+  const int64_t n_packs = n / kPack < kPlanPacks ? (n / kPack > 0 ? n / kPack : 1) : kPlanPacks;
+  PlanSample<T, kT> sm;
+  plan_sample_load<T, kT, false>(tab, n_shards, n, n_packs, sm);
+  // the counter lines and histogram copies the sweeps add to (the advance leaves them clean, a first call or an
+  // abandoned one does not): 136 KB of stores, queued BEHIND the sample's loads (the vector-memory path of the one
+  // CU this kernel runs on is in order)
+  __builtin_amdgcn_sched_barrier(0);
+  for (uint32_t i = threadIdx.x; i < scratch_vecs; i += kT) scratch[i] = u32x4{0, 0, 0, 0};
+  __builtin_amdgcn_sched_barrier(0);
   __syncthreads();
+  plan_compute<T, kT>(L, sm, n_packs, mode, n_sel, use_abs, k0, k1, n, alpha, min_shift, st->sel);
   if (threadIdx.x == 0) {
     st->n = n;
     st->arrivals = 0;
-    const double S = static_cast<double>(s_total);
-    for (int s = 0; s < n_sel; ++s) {
-      // A bracket that runs off the sample: the window starts at the first key instead -- or, when the target is
-      // at least 8 sample ranks away from that end (the sample's own extreme is then beyond it with probability
-      // 1 - e^-8), at the sample's extreme bin, which keeps a tail quantile's window a few bins wide.  Keys outside
-      // the window are counted, so a wrong guess only costs another round.
-      uint32_t a = b_lo[s], b = b_hi[s];
-      if (r_lo[s] < 1) a = r_mid[s] >= 8.0 ? s_first : 0u;
-      if (r_hi[s] > static_cast<int64_t>(s_total)) b = S - r_mid[s] >= 8.0 ? s_last : kPlanBins - 1;
-      if (b < a) b = a;
-      const uint32_t lo = a << kPlanShift;
-      const uint64_t width = (static_cast<uint64_t>(b - a) + 1) << kPlanShift;
-      WinSel w;
-      w.lo = lo;
-      w.shift = shift_for(width, min_shift);
-      // only the bracket itself is histogrammed: with 16-bit inputs the 2048 bins of the smallest shift span 16
-      // binades -- half of a weight tensor -- while the bracket is a few dozen values wide
-      const uint64_t room = 0xffffffffull - lo;
-      w.span = static_cast<uint32_t>(width - 1 < room ? width - 1 : room);
-      // percentile: the min side's window sits at the bottom of the data, the max side's at the top -- the sweep
-      // tests the near end first and counts what lies beyond it (a handful of keys) instead of what lies before
-      w.side = mode == 1 && s == 1 ? 1u : 0u;
-      w.k = mode == 0 ? (s == 0 ? k0 : k1) : 0;
-      w.done = 0;
-      w.fresh = 1;
-      st->sel[s] = w;
-    }
   }
 }
 
@@ -303,63 +391,19 @@ __device__ __forceinline__ WinSel win_read_sel(const WinState* st, int s) {
   return __builtin_bit_cast(WinSel, q);
 }
 
-template <int BLOCK, bool COHERENT>
-__device__ void win_advance(const int s, uint32_t* __restrict__ hist, WinState* __restrict__ st,
-                            WinSlot* __restrict__ slots, int percentile, double alpha, uint32_t min_shift,
-                            float* __restrict__ out0, float* __restrict__ out1, AdvShared& sh) {
-  const WinSel w = win_read_sel<COHERENT>(st, s);
-  if (w.done) return;
-  auto write_sel = [&](const WinSel& nw) {
-    struct Q { unsigned long long q[4]; };
-    const Q q = __builtin_bit_cast(Q, nw);
-    unsigned long long* dst = reinterpret_cast<unsigned long long*>(&st->sel[s]);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) win_st<COHERENT>(dst + i, q.q[i]);
-  };
-  constexpr int kPer = kWinBins / BLOCK;  // bins per thread
-  unsigned long long bins[kPer];
-#pragma unroll
-  for (int i = 0; i < kPer; ++i) bins[i] = 0;
-  {
-    // all copies requested together, cleared afterwards (a store between two loads would order them)
-    uint32_t v[kCopies][kPer];
-#pragma unroll
-    for (int c = 0; c < kCopies; ++c) {
-      const uint32_t* src = hist + (static_cast<size_t>(c) * kWinSel + s) * kWinBins + threadIdx.x * kPer;
-      if constexpr (!COHERENT && kPer == 4) {
-        const u32x4 q = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(src));
-#pragma unroll
-        for (int i = 0; i < kPer; ++i) v[c][i] = q[i];
-      } else {
-#pragma unroll
-        for (int i = 0; i < kPer; ++i) v[c][i] = win_ld<COHERENT>(src + i);
-      }
-    }
-#pragma unroll
-    for (int c = 0; c < kCopies; ++c) {
-      uint32_t* dst = hist + (static_cast<size_t>(c) * kWinSel + s) * kWinBins + threadIdx.x * kPer;
-#pragma unroll
-      for (int i = 0; i < kPer; ++i) bins[i] += v[c][i];
-      if constexpr (!COHERENT && kPer == 4) {
-        *reinterpret_cast<u32x4*>(dst) = u32x4{0, 0, 0, 0};
-      } else {
-#pragma unroll
-        for (int i = 0; i < kPer; ++i)
-          if (v[c][i]) win_st<COHERENT>(dst + i, 0u);
-      }
-    }
-  }
+// The placement of one selector's rank, given its window `w`, this thread's bins of the window's histogram and the
+// counters of the sweep (c_below / c_neg / c_nan: partial values in the threads of wave 0, zero elsewhere).  Names the
+// next window through write_sel -- or writes the result when the window is one value wide.
+template <int BLOCK, typename WriteSel>
+__device__ __forceinline__ void advance_core(const int s, const WinSel& w, const unsigned long long (&bins)[kWinBins / BLOCK],
+                                             unsigned long long c_below, unsigned long long c_neg,
+                                             unsigned long long c_nan, const int64_t n, int percentile, double alpha,
+                                             uint32_t min_shift, float* __restrict__ out0, float* __restrict__ out1,
+                                             AdvShared& sh, WriteSel&& write_sel) {
+  constexpr int kPer = kWinBins / BLOCK;
   unsigned long long t = 0;
 #pragma unroll
   for (int i = 0; i < kPer; ++i) t += bins[i];
-  // counters: thread i < kSlots reads line i
-  unsigned long long c_below = 0, c_neg = 0, c_nan = 0;
-  if (threadIdx.x < kSlots) {
-    c_below = win_ld<COHERENT>(&slots[threadIdx.x].below[s]);
-    c_neg = win_ld<COHERENT>(&slots[threadIdx.x].neg);
-    c_nan = win_ld<COHERENT>(&slots[threadIdx.x].nan);
-    if (c_below) win_st<COHERENT>(&slots[threadIdx.x].below[s], 0ull);
-  }
   const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
   unsigned long long incl = t;
 #pragma unroll
@@ -386,7 +430,6 @@ __device__ void win_advance(const int s, uint32_t* __restrict__ hist, WinState* 
   if (threadIdx.x == BLOCK - 1) sh.total = incl;
   __syncthreads();
   const unsigned long long total = sh.total;
-  const int64_t n = st->n;
   const int64_t neg = static_cast<int64_t>(sh.neg), nan = static_cast<int64_t>(sh.nan);
   const int64_t pos = n - neg - nan;
   int64_t k = w.k;
@@ -470,6 +513,66 @@ __device__ void win_advance(const int s, uint32_t* __restrict__ hist, WinState* 
   __syncthreads();  // `sh` is reused by the next selector
 }
 
+
+template <int BLOCK, bool COHERENT>
+__device__ void win_advance(const int s, uint32_t* __restrict__ hist, WinState* __restrict__ st,
+                            WinSlot* __restrict__ slots, int percentile, double alpha, uint32_t min_shift,
+                            float* __restrict__ out0, float* __restrict__ out1, AdvShared& sh) {
+  const WinSel w = win_read_sel<COHERENT>(st, s);
+  if (w.done) return;
+  auto write_sel = [&](const WinSel& nw) {
+    struct Q { unsigned long long q[4]; };
+    const Q q = __builtin_bit_cast(Q, nw);
+    unsigned long long* dst = reinterpret_cast<unsigned long long*>(&st->sel[s]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) win_st<COHERENT>(dst + i, q.q[i]);
+  };
+  constexpr int kPer = kWinBins / BLOCK;  // bins per thread
+  unsigned long long bins[kPer];
+#pragma unroll
+  for (int i = 0; i < kPer; ++i) bins[i] = 0;
+  // bins past the window's last one were never added to: their threads skip the loads (a 16-bit window is a few
+  // dozen bins wide -- a few hundred coherent loads instead of 16 K)
+  if (threadIdx.x * kPer <= (w.span >> w.shift)) {
+    // all copies requested together, cleared afterwards (a store between two loads would order them)
+    uint32_t v[kCopies][kPer];
+#pragma unroll
+    for (int c = 0; c < kCopies; ++c) {
+      const uint32_t* src = hist + (static_cast<size_t>(c) * kWinSel + s) * kWinBins + threadIdx.x * kPer;
+      if constexpr (!COHERENT && kPer == 4) {
+        const u32x4 q = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(src));
+#pragma unroll
+        for (int i = 0; i < kPer; ++i) v[c][i] = q[i];
+      } else {
+#pragma unroll
+        for (int i = 0; i < kPer; ++i) v[c][i] = win_ld<COHERENT>(src + i);
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < kCopies; ++c) {
+      uint32_t* dst = hist + (static_cast<size_t>(c) * kWinSel + s) * kWinBins + threadIdx.x * kPer;
+#pragma unroll
+      for (int i = 0; i < kPer; ++i) bins[i] += v[c][i];
+      if constexpr (!COHERENT && kPer == 4) {
+        *reinterpret_cast<u32x4*>(dst) = u32x4{0, 0, 0, 0};
+      } else {
+#pragma unroll
+        for (int i = 0; i < kPer; ++i)
+          if (v[c][i]) win_st<COHERENT>(dst + i, 0u);
+      }
+    }
+  }
+  // counters: thread i < kSlots reads line i
+  unsigned long long c_below = 0, c_neg = 0, c_nan = 0;
+  if (threadIdx.x < kSlots) {
+    c_below = win_ld<COHERENT>(&slots[threadIdx.x].below[s]);
+    c_neg = win_ld<COHERENT>(&slots[threadIdx.x].neg);
+    c_nan = win_ld<COHERENT>(&slots[threadIdx.x].nan);
+    if (c_below) win_st<COHERENT>(&slots[threadIdx.x].below[s], 0ull);
+  }
+  advance_core<BLOCK>(s, w, bins, c_below, c_neg, c_nan, st->n, percentile, alpha, min_shift, out0, out1, sh, write_sel);
+}
+
 // ... as its own launch: one workgroup per selector.
 __global__ __launch_bounds__(kAdvBlock) void win_advance_kernel(uint32_t* __restrict__ hist,
                                                                 WinState* __restrict__ st, WinSlot* __restrict__ slots,
@@ -496,6 +599,7 @@ struct WinGeom {
   static constexpr uint32_t kSlab = BLOCK * kPack * kU;
 };
 struct PassTable {
+  static constexpr bool kSingle = false;
   const void* ptr[kMaxShards];
   int64_t count[kMaxShards];
   // two lists over all shards: the whole slabs of 16-byte aligned shards (lean path), and the rest (a ragged last
@@ -504,33 +608,65 @@ struct PassTable {
   uint32_t rag_first[kMaxShards + 1];
 };
 
+// The same table for a selection over ONE tensor (the mask threshold; a single cached batch): 48 bytes, one kernarg
+// line, no shard search -- the table walk of the general form (dependent scalar loads out of a cold 1.5 KB kernarg
+// block in front of every slab request) was 2 us of the one-launch kernel's prologue.
+struct OneShard {
+  static constexpr bool kSingle = true;
+  const void* ptr[1];
+  int64_t count[1];
+  uint32_t lean_first[2];
+  uint32_t rag_first[2];
+};
+
 // (the body of a sweep, shared by win_pass_kernel and win_fallback_kernel; `load_state` fetches the selectors AFTER
 // the first slab has been requested; returns false when every selector is resolved already)
-template <typename T, int NSEL, bool SIGNS, int BLOCK, bool EARLY, typename LoadState>
-__device__ __forceinline__ bool win_sweep(const PassTable& tab, int n_shards, LoadState&& load_state,
-                                          WinSlot* __restrict__ slots, uint32_t* __restrict__ hist, int use_abs) {
+// (wg of nwg: the caller's position in the sweep -- blockIdx.x of gridDim.x, or 0 of 1 when the last workgroup of a
+// launch finishes a selection alone)
+// LDS of a sweep: the workgroup's histograms of the selectors' windows, and its counters.  After the sweep tot[] holds
+// the workgroup's totals {below[0..NSEL), neg, nan} -- with FLUSH they (and the non-empty bins) have also been added
+// to the global counter lines / histogram copies; without (the last workgroup of the one-launch engine finishing a
+// selection alone) the advance reads them right here.
+template <int NSEL, int BLOCK>
+struct SweepLds {
+  uint32_t lh[NSEL][kWinBins];
+  unsigned long long red[NSEL + 2][BLOCK / kWave];
+  unsigned long long tot[NSEL + 2];
+};
+
+template <typename T, int NSEL, bool SIGNS, int BLOCK, bool EARLY, bool FLUSH, bool ALWAYS = false, typename Tab,
+          typename LoadState>
+__device__ __forceinline__ bool win_sweep(const Tab& tab, int n_shards, const uint32_t wg, const uint32_t nwg,
+                                          LoadState&& load_state, WinSlot* __restrict__ slots,
+                                          uint32_t* __restrict__ hist, int use_abs, SweepLds<NSEL, BLOCK>& lds) {
   constexpr uint32_t kSlab = WinGeom<BLOCK>::kSlab;
   constexpr int U = WinGeom<BLOCK>::kU;
   constexpr int kWaves = BLOCK / kWave;
   constexpr int kCounters = NSEL + (SIGNS ? 2 : 0);
-  __shared__ uint32_t lh[NSEL][kWinBins];
-  __shared__ unsigned long long red[kCounters][kWaves];
-  auto locate = [&](const uint32_t (&first)[kMaxShards + 1], uint32_t g, int& shard, uint32_t& local) {  // uniform
+  auto& lh = lds.lh;
+  auto& red = lds.red;
+  auto locate = [&](const auto& first, uint32_t g, int& shard, uint32_t& local) {  // uniform
     int i = 0;
-    while (i + 1 < n_shards && g >= first[i + 1]) ++i;
+    if constexpr (!Tab::kSingle) {
+      while (i + 1 < n_shards && g >= first[i + 1]) ++i;
+      local = g - first[i];
+    } else {
+      local = g;
+    }
     shard = i;
-    local = g - first[i];
   };
   // Request lean slab g.  ALWAYS issues its loads -- past the end of the list they all read the first 16 bytes of
   // the last slab: a conditional issue would make the compiler wait for everything in flight at the join.
-  const uint32_t n_lean = tab.lean_first[n_shards];
+  const uint32_t n_lean = tab.lean_first[Tab::kSingle ? 1 : n_shards];
   auto issue = [&](uint32_t g, RawPack<T> (&raw)[U]) {
     const bool real = g < n_lean;
     int shard;
     uint32_t local;
-    locate(tab.lean_first, real ? g : n_lean - 1, shard, local);
+    // (no lean slab at all: the dummy target is the first pack of shard 0 -- the one-launch engine, which issues
+    // unconditionally, admits only aligned shards of at least a pack)
+    locate(tab.lean_first, real ? g : (n_lean ? n_lean - 1 : 0u), shard, local);
     const void* x = tab.ptr[shard];
-    const int64_t begin = static_cast<int64_t>(local) * kSlab;
+    const int64_t begin = n_lean ? static_cast<int64_t>(local) * kSlab : 0;
     const uint32_t stride = real ? kPack : 0u;
 #pragma unroll
     for (int u = 0; u < U; ++u)
@@ -540,8 +676,18 @@ __device__ __forceinline__ bool win_sweep(const PassTable& tab, int n_shards, Lo
   // the first slab is requested before anything else: the selector state below comes from a cold scalar load, the
   // LDS histograms want clearing -- a memory round trip that overlaps both
   // (EARLY == false, the fallback launch: it usually finds nothing to do, so it looks at the state first)
-  RawPack<T> buf_a[U], buf_b[U];
-  if (EARLY && n_lean > 0) issue(blockIdx.x, buf_a);
+  // FOUR slab buffers: a 16.7 M-element tensor on 256 CUs is four slabs per workgroup, all requested before the
+  // selector state is known (the one-launch engine derives it from a sample meanwhile)
+  constexpr int NB = 4;
+  RawPack<T> buf[NB][U];
+  auto issue_all = [&]() {
+#pragma unroll
+    for (int j = 0; j < NB; ++j) issue(wg + static_cast<uint32_t>(j) * nwg, buf[j]);
+  };
+  // (unconditionally in the one-launch engine -- OneShard / its PassTable twin are only ever used with admitted
+  // shards: a guard here is a control-flow diamond, after which the compiler no longer knows how many loads are in
+  // flight and makes the plan wait for all of them)
+  if (EARLY && (ALWAYS || n_lean > 0)) issue_all();
   // every selector resolved: nothing to do (the later rounds of a protocol that needed only one)
   bool live = false;
   uint32_t lo[NSEL], lom1[NSEL], sh[NSEL], span[NSEL];
@@ -563,9 +709,9 @@ __device__ __forceinline__ bool win_sweep(const PassTable& tab, int n_shards, Lo
     live |= act[s];
   }
   if (!live) return false;
-  if (!EARLY && n_lean > 0) issue(blockIdx.x, buf_a);
+  if (!EARLY && (ALWAYS || n_lean > 0)) issue_all();
   for (uint32_t i = threadIdx.x; i < NSEL * kWinBins; i += BLOCK) (&lh[0][0])[i] = 0;
-  __syncthreads();
+  lds_sync();  // (not __syncthreads(): the slabs are in flight)
   // per-lane counters (ragged path) and wave-uniform ones (lean path)
   uint32_t lt[NSEL];
 #pragma unroll
@@ -666,21 +812,22 @@ __device__ __forceinline__ bool win_sweep(const PassTable& tab, int n_shards, Lo
     }
   };
   if (n_lean > 0) {
-    // two slab buffers, alternating (a copy `current = next` would have to wait for the loads it is meant to hide)
-    uint32_t g = blockIdx.x;
+    // the buffers rotate: each is refilled as soon as it has been swept (a copy `current = next` would have to wait
+    // for the loads it is meant to hide); no refill at all in a workgroup's last group of four
+    uint32_t g = wg;
     while (g < n_lean) {
-      issue(g + gridDim.x, buf_b);
-      sweep_lean(buf_a);
-      g += gridDim.x;
-      if (g >= n_lean) break;
-      issue(g + gridDim.x, buf_a);
-      sweep_lean(buf_b);
-      g += gridDim.x;
+      const bool more = g + NB * nwg < n_lean;  // uniform
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
+        if (j == 0 || g + static_cast<uint32_t>(j) * nwg < n_lean) sweep_lean(buf[j]);
+        if (more) issue(g + static_cast<uint32_t>(NB + j) * nwg, buf[j]);
+      }
+      g += NB * nwg;
     }
   }
   // the ragged last slab of a shard, and every slab of an unaligned one
-  const uint32_t n_rag = tab.rag_first[n_shards];
-  for (uint32_t r = blockIdx.x; r < n_rag; r += gridDim.x) {
+  const uint32_t n_rag = tab.rag_first[Tab::kSingle ? 1 : n_shards];
+  for (uint32_t r = wg; r < n_rag; r += nwg) {
     int shard;
     uint32_t local;
     locate(tab.rag_first, r, shard, local);
@@ -716,11 +863,12 @@ __device__ __forceinline__ bool win_sweep(const PassTable& tab, int n_shards, Lo
     for (int c = 0; c < kCounters; ++c) red[c][wid] = tot[c];
   }
   __syncthreads();
-  WinSlot* slot = slots + (blockIdx.x % kSlots);
+  WinSlot* slot = slots + (wg % kSlots);
   if (threadIdx.x < kCounters) {
     unsigned long long t = 0;
     for (int w = 0; w < kWaves; ++w) t += red[threadIdx.x][w];
-    if (t) {
+    lds.tot[threadIdx.x] = t;
+    if (FLUSH && t) {
       if (static_cast<int>(threadIdx.x) < NSEL) {
         bool mine = false;
 #pragma unroll
@@ -733,8 +881,8 @@ __device__ __forceinline__ bool win_sweep(const PassTable& tab, int n_shards, Lo
   }
 #pragma unroll
   for (int s = 0; s < NSEL; ++s) {
-    if (!act[s]) continue;
-    uint32_t* gh = hist + (static_cast<size_t>(blockIdx.x % kCopies) * kWinSel + s) * kWinBins;
+    if (!FLUSH || !act[s]) continue;
+    uint32_t* gh = hist + (static_cast<size_t>(wg % kCopies) * kWinSel + s) * kWinBins;
     for (uint32_t i = threadIdx.x; i < static_cast<uint32_t>(kWinBins); i += BLOCK) {
       const uint32_t v = lh[s][i];
       if (v) atomicAdd(&gh[i], v);
@@ -747,10 +895,11 @@ template <typename T, int NSEL, bool SIGNS, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void win_pass_kernel(const PassTable tab, int n_shards,
                                                          const WinState* __restrict__ st, WinSlot* __restrict__ slots,
                                                          uint32_t* __restrict__ hist, int use_abs) {
-  win_sweep<T, NSEL, SIGNS, BLOCK, true>(tab, n_shards, [&](WinSel (&sel)[NSEL]) {
+  __shared__ SweepLds<NSEL, BLOCK> swl;
+  win_sweep<T, NSEL, SIGNS, BLOCK, true, true>(tab, n_shards, blockIdx.x, gridDim.x, [&](WinSel (&sel)[NSEL]) {
 #pragma unroll
     for (int s = 0; s < NSEL; ++s) sel[s] = st->sel[s];
-  }, slots, hist, use_abs);
+  }, slots, hist, use_abs, swl);
 }
 
 // A round after the expected ones: sweep and advance in ONE launch.  Such rounds are needed only when the sample
@@ -769,10 +918,11 @@ __global__ __launch_bounds__(BLOCK) void win_fallback_kernel(const PassTable tab
                                                              float* __restrict__ out0, float* __restrict__ out1) {
   __shared__ AdvShared adv;
   __shared__ uint32_t s_last;
-  const bool live = win_sweep<T, NSEL, false, BLOCK, false>(tab, n_shards, [&](WinSel (&sel)[NSEL]) {
+  __shared__ SweepLds<NSEL, BLOCK> swl;
+  const bool live = win_sweep<T, NSEL, false, BLOCK, false, true>(tab, n_shards, blockIdx.x, gridDim.x, [&](WinSel (&sel)[NSEL]) {
 #pragma unroll
     for (int s = 0; s < NSEL; ++s) sel[s] = st->sel[s];
-  }, slots, hist, use_abs);
+  }, slots, hist, use_abs, swl);
   if (!live) return;  // uniform over the grid: every workgroup read the same state
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __builtin_amdgcn_s_waitcnt(0);
@@ -787,13 +937,315 @@ __global__ __launch_bounds__(BLOCK) void win_fallback_kernel(const PassTable tab
   if (threadIdx.x == 0) win_st<true>(&st->arrivals, 0u);
 }
 
+// ---- the one-launch engine ------------------------------------------------------------------------------------
+// plan + sweep + advance in ONE kernel (16-bit inputs: the whole selection; fp32: its first round).  The launch chain
+// of the multi-launch protocol -- plan 10 us on one workgroup, sweep 10, advance 4.6, idle fallback rounds 3.9 -- spent
+// 18 of 28 us moving no data (profiles/r02v8_select_timeline.txt).  Here
+//   * every workgroup requests the sample (2 packs per thread: L2 hits for all but the first workgroup of an XCD) and
+//     then its first FOUR slabs, derives the windows from the sample while the slabs are in flight (plan_compute:
+//     identical inputs and integer arithmetic in every workgroup => identical windows, nothing communicated),
+//   * sweeps, adds its counters / non-empty histogram bins to the global lines with device atomics and counts its
+//     arrival,
+//   * and the LAST workgroup to arrive places the ranks, writes the results and leaves the workspace clean.  Nobody
+//     waits for another workgroup.
+// Rounds beyond the expected ones (a window the sample misplaced; a 16-bit window wider than 2048 values; an extreme
+// rank whose first window starts at the first key) are run by that last workgroup ALONE inside the same launch,
+// entirely out of its LDS: exact for any data, no launch in the common case, slow (~1 ms per round for 16.7 M
+// elements) in the case that essentially never happens -- the sample is jittered against data periodic with its stride.
+//
+// What travels how (measured the hard way: a line one XCD wrote with an sc1 store can stay in that XCD's L2 across
+// launches, and a later sc1 LOAD from that XCD hits it even after another XCD overwrote memory -- a selector state
+// published by workgroup 0 was read back as the previous launch's zeros whenever the last arriver ran where the
+// previous launch's last arriver had):
+//   * between workgroups of one launch: atomic read-modify-writes ONLY (performed at the memory side, never cached):
+//     adds by the sweeps, exchange-with-zero by the last arriver -- which gathers and cleans in one operation;
+//   * the selector state never leaves the workgroup: every workgroup holds its own copy in LDS (they are identical),
+//     the last arriver advances ITS copy; between the launches of an fp32 selection it passes through memory as
+//     plain stores / plain loads (a kernel boundary orders those, as in the multi-launch protocol);
+//   * the lonely rounds use no global memory besides the data and the result.
+// Workspace contract (as for the GPTQ mat-vec's arrival counters): this engine's region must be ZERO before its
+// first use, and every call leaves it zero (the mailbox words of the state aside, which are write-before-read).
+struct OneArgs {
+  WinState* st;      // arrival counter; mailbox of the selector state between the launches of an fp32 selection
+  WinSlot* slots;
+  uint32_t* hist;
+  float* out0;
+  float* out1;
+  int64_t k0, k1, n;
+  double alpha;
+  uint32_t min_shift;
+  int32_t use_abs, mode, final_round;
+  unsigned long long* stamps;  // development (knob 1 == 779): 8 timestamps per workgroup, else nullptr
+};
+// (compiled in only with -DSBQ_SEL_STAMPS=1 -- SBQ_EXTRA_HIPCC_FLAGS of sparsebit_amd/build.py: the conditional
+// stores are control flow between the loads and their uses, which costs the compiler its exact vmcnt bookkeeping)
+#ifndef SBQ_SEL_STAMPS
+#define SBQ_SEL_STAMPS 0
+#endif
+__device__ __forceinline__ void one_stamp(const OneArgs& a, int i) {
+  if constexpr (SBQ_SEL_STAMPS != 0) {
+    if (a.stamps && threadIdx.x == 0) a.stamps[blockIdx.x * 16 + i] = __builtin_amdgcn_s_memrealtime();
+  }
+}
+struct OneLds {
+  WinSel sel[kWinSel];
+  unsigned long long neg, nan;  // sign / NaN counts of the whole selection (the first sweep's)
+  uint32_t flag;
+};
+template <typename V>
+__device__ __forceinline__ V one_take(V* p) {  // read and clear, at the memory side
+  return __hip_atomic_exchange(p, static_cast<V>(0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// The advance of selector s on the workgroup's OWN state (ol.sel[s], LDS).  lh == nullptr: after a grid-wide sweep --
+// the histogram copies and counter lines are gathered (and cleared) with atomic exchanges; else: after a lonely sweep,
+// straight from its LDS histogram.
+template <int NSEL, int BLOCK>
+__device__ void one_advance(const int s, const OneArgs& a, OneLds& ol, const SweepLds<NSEL, BLOCK>* lonely,
+                            bool take_signs, AdvShared& sh) {
+  const WinSel w = ol.sel[s];
+  __syncthreads();  // everyone holds w before anyone replaces it
+  if (w.done) return;
+  constexpr int kPer = kWinBins / BLOCK;
+  unsigned long long bins[kPer];
+#pragma unroll
+  for (int i = 0; i < kPer; ++i) bins[i] = 0;
+  unsigned long long c_below = 0, c_neg = 0, c_nan = 0;
+  if (lonely) {
+#pragma unroll
+    for (int i = 0; i < kPer; ++i) bins[i] = lonely->lh[s][threadIdx.x * kPer + i];
+    if (threadIdx.x == 0) {  // (a lonely round's window is never fresh: no `below`)
+      c_neg = ol.neg;
+      c_nan = ol.nan;
+    }
+  } else {
+    // bins past the window's last one were never added to: their threads skip them (a 16-bit window is a few dozen
+    // bins wide -- a few hundred exchanges instead of 16 K)
+    if (threadIdx.x * kPer <= (w.span >> w.shift)) {
+      uint32_t v[kCopies][kPer];
+#pragma unroll
+      for (int c = 0; c < kCopies; ++c) {
+        uint32_t* src = a.hist + (static_cast<size_t>(c) * kWinSel + s) * kWinBins + threadIdx.x * kPer;
+#pragma unroll
+        for (int i = 0; i < kPer; ++i) v[c][i] = one_take(src + i);
+      }
+#pragma unroll
+      for (int c = 0; c < kCopies; ++c)
+#pragma unroll
+        for (int i = 0; i < kPer; ++i) bins[i] += v[c][i];
+    }
+    if (threadIdx.x < kSlots) {
+      c_below = one_take(&a.slots[threadIdx.x].below[s]);
+      if (take_signs) {  // once per selection: the first selector of the launch that counted them
+        c_neg = one_take(&a.slots[threadIdx.x].neg);
+        c_nan = one_take(&a.slots[threadIdx.x].nan);
+      }
+    }
+    if (!take_signs && threadIdx.x == 0) {
+      c_neg = ol.neg;
+      c_nan = ol.nan;
+    }
+  }
+  advance_core<BLOCK>(s, w, bins, c_below, c_neg, c_nan, a.n, a.mode == 1, a.alpha, a.min_shift, a.out0, a.out1, sh,
+                      [&](const WinSel& nw) { ol.sel[s] = nw; });
+  if (take_signs && threadIdx.x == 0) {  // (advance_core left the totals in sh and ended on a barrier)
+    ol.neg = sh.neg;
+    ol.nan = sh.nan;
+  }
+  __syncthreads();
+}
+
+// arrival + advance (+ the lonely rounds and the clean-up when this launch is the selection's last)
+template <typename T, int NSEL, int BLOCK, typename Tab>
+__device__ __forceinline__ void win_finish(const Tab& tab, int n_shards, const OneArgs& a, OneLds& ol,
+                                           SweepLds<NSEL, BLOCK>& swl, AdvShared& adv, bool signs_in_slots) {
+  // this workgroup's adds are acknowledged before its arrival is counted
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_s_waitcnt(0);
+  __syncthreads();
+  if (threadIdx.x == 0)
+    ol.flag = __hip_atomic_fetch_add(&a.st->arrivals, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+  __syncthreads();
+  one_stamp(a, 4);
+  if (!ol.flag) return;
+  if (threadIdx.x == 0) one_take(&a.st->arrivals);
+  one_stamp(a, 5);
+#pragma unroll
+  for (int s = 0; s < NSEL; ++s) one_advance<NSEL, BLOCK>(s, a, ol, nullptr, signs_in_slots && s == 0, adv);
+  one_stamp(a, 6);
+  if (a.final_round) {
+    // rounds nobody planned for: this workgroup sweeps alone until every selector is resolved (each round narrows a
+    // window 2048-fold or replaces a missed one: at most 1 + ceil(32 / 11) more)
+    for (int round = 0; round < 8; ++round) {
+      __syncthreads();
+      const bool live = win_sweep<T, NSEL, false, BLOCK, false, false, true>(tab, n_shards, 0u, 1u, [&](WinSel (&sel)[NSEL]) {
+#pragma unroll
+        for (int s = 0; s < NSEL; ++s) sel[s] = ol.sel[s];
+      }, a.slots, a.hist, a.use_abs, swl);
+      if (!live) break;
+      __syncthreads();
+#pragma unroll
+      for (int s = 0; s < NSEL; ++s) one_advance<NSEL, BLOCK>(s, a, ol, &swl, false, adv);
+    }
+  } else {
+    // the mailbox for the next launch of this selection: plain stores, ordered by the kernel boundary
+    if (threadIdx.x == 0) {
+#pragma unroll
+      for (int s = 0; s < NSEL; ++s) a.st->sel[s] = ol.sel[s];
+      a.st->n = a.n;
+      a.st->pad_neg = ol.neg;
+      a.st->pad_nan = ol.nan;
+    }
+  }
+}
+
+template <typename T, int NSEL, bool PCT, int BLOCK, typename Tab>
+__global__ __launch_bounds__(BLOCK) void win_one_kernel(const Tab tab, int n_shards, const OneArgs a) {
+  __shared__ PlanLds plan;
+  __shared__ AdvShared adv;
+  __shared__ OneLds ol;
+  __shared__ SweepLds<NSEL, BLOCK> swl;
+  one_stamp(a, 0);
+  for (int i = threadIdx.x; i < kPlanBins; i += BLOCK) plan.hist[i] = 0;
+  const int64_t n_packs = a.n / kPack < kPlanPacks ? (a.n / kPack > 0 ? a.n / kPack : 1) : kPlanPacks;
+  // the sample first (vector-memory loads return in order: the plan must not wait for the slabs) ...
+  one_stamp(a, 11);
+  PlanSample<T, BLOCK> sm;
+  plan_sample_load<T, BLOCK, true>(tab, n_shards, a.n, n_packs, sm);
+  __builtin_amdgcn_sched_barrier(0);
+  one_stamp(a, 12);
+  // ... then the slabs (win_sweep, EARLY), and the plan while they fly
+  constexpr bool SIGNS = PCT && NSEL == 2;
+  win_sweep<T, NSEL, SIGNS, BLOCK, true, true, true>(tab, n_shards, blockIdx.x, gridDim.x, [&](WinSel (&sel)[NSEL]) {
+    one_stamp(a, 13);
+    lds_sync();  // plan.hist is clear
+    one_stamp(a, 1);
+    plan_compute<T, BLOCK>(plan, sm, n_packs, a.mode, NSEL, a.use_abs, a.k0, a.k1, a.n, a.alpha, a.min_shift, ol.sel,
+                           [&](int i) { one_stamp(a, i); });
+    one_stamp(a, 2);
+    if (threadIdx.x == 0) {
+      ol.neg = 0;
+      ol.nan = 0;
+    }
+    lds_sync();
+#pragma unroll
+    for (int s = 0; s < NSEL; ++s) {
+      WinSel w = ol.sel[s];
+      // uniform values: into SGPRs (the sweep's window tests take them as scalar operands)
+      w.lo = __builtin_amdgcn_readfirstlane(w.lo);
+      w.shift = __builtin_amdgcn_readfirstlane(w.shift);
+      w.span = __builtin_amdgcn_readfirstlane(w.span);
+      w.done = __builtin_amdgcn_readfirstlane(w.done);
+      w.fresh = __builtin_amdgcn_readfirstlane(w.fresh);
+      sel[s] = w;
+    }
+  }, a.slots, a.hist, a.use_abs, swl);
+  one_stamp(a, 3);
+  win_finish<T, NSEL, BLOCK>(tab, n_shards, a, ol, swl, adv, SIGNS);
+  one_stamp(a, 7);
+}
+
+// a later round of a selection that needs several sweeps by design (fp32: two or three): sweep by the whole grid,
+// advance by the last workgroup to arrive; the last such launch also finishes what is left alone
+template <typename T, int NSEL, int BLOCK, typename Tab>
+__global__ __launch_bounds__(BLOCK) void win_round_kernel(const Tab tab, int n_shards, const OneArgs a) {
+  __shared__ AdvShared adv;
+  __shared__ OneLds ol;
+  __shared__ SweepLds<NSEL, BLOCK> swl;
+  win_sweep<T, NSEL, false, BLOCK, true, true, true>(tab, n_shards, blockIdx.x, gridDim.x, [&](WinSel (&sel)[NSEL]) {
+#pragma unroll
+    for (int s = 0; s < NSEL; ++s) sel[s] = a.st->sel[s];  // the previous launch's mailbox
+    if (threadIdx.x == 0) {
+#pragma unroll
+      for (int s = 0; s < NSEL; ++s) ol.sel[s] = sel[s];
+      ol.neg = a.st->pad_neg;
+      ol.nan = a.st->pad_nan;
+    }
+  }, a.slots, a.hist, a.use_abs, swl);
+  // (a round that finds every selector resolved still counts its arrivals and passes the mailbox on)
+  win_finish<T, NSEL, BLOCK>(tab, n_shards, a, ol, swl, adv, false);
+}
+
 constexpr size_t kStateBytes = 256;
 constexpr size_t kSlotBytes = sizeof(WinSlot) * kSlots;
 constexpr size_t kHistBytes = static_cast<size_t>(kCopies) * kWinSel * kWinBins * 4;
 
 }  // namespace
 
-size_t win_select_workspace_bytes() { return kStateBytes + kSlotBytes + kHistBytes + 256; }
+// [ multi-launch protocol: state | counter lines | histogram copies | pad ][ one-launch engine: the same three ]
+constexpr size_t kOldRegion = kStateBytes + kSlotBytes + kHistBytes + 256;
+constexpr size_t kOneRegion = kStateBytes + kSlotBytes + kHistBytes;
+constexpr size_t kStampBytes = 1024 * 16 * 8;  // development timestamps (knob 1 == 779)
+size_t win_select_workspace_bytes() { return kOldRegion + kOneRegion + kStampBytes; }
+
+namespace {
+// One launch for a 16-bit input, one per expected round for fp32 (see win_one_kernel).
+int win_one_run(const void* const* shards, const int64_t* counts, int n_shards, int x_dtype, int use_abs, int n_sel,
+                bool percentile, double alpha, int64_t k0, int64_t k1, float* out0, float* out1, char* region,
+                hipStream_t st) {
+  constexpr int kB = 1024;
+  const int64_t slab = WinGeom<kB>::kSlab;
+  PassTable pt{};
+  int64_t n = 0, n_lean = 0, total = 0;
+  for (int i = 0; i < n_shards; ++i) {
+    pt.ptr[i] = shards[i];
+    pt.count[i] = counts[i];
+    const int64_t all = ceil_div(counts[i], slab), lean = aligned16(shards[i]) ? counts[i] / slab : 0;
+    pt.lean_first[i] = static_cast<uint32_t>(n_lean);
+    pt.rag_first[i] = static_cast<uint32_t>(total - n_lean);
+    n_lean += lean;
+    total += all;
+    n += counts[i];
+  }
+  pt.lean_first[n_shards] = static_cast<uint32_t>(n_lean);
+  pt.rag_first[n_shards] = static_cast<uint32_t>(total - n_lean);
+  if (total >= (1ll << 31)) return SBQ_ERR_ARG;
+  const uint32_t min_shift = x_dtype == SBQ_BF16 ? 16u : (x_dtype == SBQ_F16 ? 13u : 0u);
+  const int expected = min_shift > 0 ? 1 : 3;
+  const int64_t cus = cu_count();
+  const uint32_t grid = static_cast<uint32_t>(total < cus ? (total > 0 ? total : 1) : cus);
+  OneArgs a{};
+  a.st = reinterpret_cast<WinState*>(region);
+  a.slots = reinterpret_cast<WinSlot*>(region + kStateBytes);
+  a.hist = reinterpret_cast<uint32_t*>(region + kStateBytes + kSlotBytes);
+  a.out0 = out0;
+  a.out1 = out1;
+  a.k0 = k0;
+  a.k1 = k1;
+  a.n = n;
+  a.alpha = alpha;
+  a.min_shift = min_shift;
+  a.use_abs = use_abs;
+  a.mode = percentile ? 1 : 0;
+  a.stamps = knob(1) == 779 ? reinterpret_cast<unsigned long long*>(region + kOneRegion) : nullptr;
+  int rc = SBQ_OK;
+  OneShard os{};
+  os.ptr[0] = pt.ptr[0];
+  os.count[0] = pt.count[0];
+  os.lean_first[1] = pt.lean_first[1];
+  os.rag_first[1] = pt.rag_first[1];
+  auto launch = [&](const auto& table, int r) {
+    using Tab = std::decay_t<decltype(table)>;
+    return dispatch_dtype(x_dtype, [&](auto tag) {
+      using T = decltype(tag);
+      if (r == 0) {
+        if (n_sel == 1) win_one_kernel<T, 1, false, kB, Tab><<<grid, kB, 0, st>>>(table, n_shards, a);
+        else if (percentile) win_one_kernel<T, 2, true, kB, Tab><<<grid, kB, 0, st>>>(table, n_shards, a);
+        else win_one_kernel<T, 2, false, kB, Tab><<<grid, kB, 0, st>>>(table, n_shards, a);
+      } else {
+        if (n_sel == 1) win_round_kernel<T, 1, kB, Tab><<<grid, kB, 0, st>>>(table, n_shards, a);
+        else win_round_kernel<T, 2, kB, Tab><<<grid, kB, 0, st>>>(table, n_shards, a);
+      }
+    });
+  };
+  for (int r = 0; r < expected && rc == SBQ_OK; ++r) {
+    a.final_round = r == expected - 1 ? 1 : 0;
+    rc = n_shards == 1 ? launch(os, r) : launch(pt, r);
+  }
+  if (rc != SBQ_OK) return rc;
+  return check_launch();
+}
+}  // namespace
 
 // shards: flat tensors of counts[i] elements each (a per-tensor selection over the cached batches).
 int win_select_run(const void* const* shards, const int64_t* counts, int n_shards, int x_dtype, int use_abs, int n_sel,
@@ -802,6 +1254,16 @@ int win_select_run(const void* const* shards, const int64_t* counts, int n_shard
   static_assert(sizeof(WinState) <= kStateBytes && sizeof(WinSlot) == 128, "workspace layout");
   if (workspace_bytes < win_select_workspace_bytes() || !aligned16(workspace)) return SBQ_ERR_WORKSPACE;
   if (n_shards > kMaxShards) return SBQ_ERR_ARG;
+  for (int i = 0; i < n_shards; ++i)
+    if (counts[i] >= (1ll << 32)) return SBQ_ERR_ARG;  // 32-bit per-workgroup and histogram-copy counters
+  // knob 2 == 12: the multi-launch protocol below (plan, sweep, advance, fallback rounds), kept for A/B runs -- and
+  // for the shards the one-launch engine's branch-free sample loads do not take: not 16-byte aligned, or shorter
+  // than one pack
+  bool one = knob(2) != 12;
+  for (int i = 0; one && i < n_shards; ++i) one = aligned16(shards[i]) && counts[i] >= kPack;
+  if (one)
+    return win_one_run(shards, counts, n_shards, x_dtype, use_abs, n_sel, percentile, alpha, k0, k1, out0, out1,
+                       static_cast<char*>(workspace) + kOldRegion, st);
   char* ws = static_cast<char*>(workspace);
   WinState* state = reinterpret_cast<WinState*>(ws);
   WinSlot* slots = reinterpret_cast<WinSlot*>(ws + kStateBytes);

@@ -57,6 +57,21 @@ def _gptq_workspace(device, nbytes):
     return buf
 
 
+_select_workspaces = {}
+
+
+def _select_workspace(device, nbytes):
+    """Workspace of the one-call selections (sbq_percentile_select / sbq_kth_value): like the mat-vec's, it holds
+    arrival counters and histogram copies that must be zero before the first call and are left zero by every call
+    (include/sbq.h), so it is its own zero-initialised buffer per (device, stream)."""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    buf = _select_workspaces.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.zeros(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _select_workspaces[key] = buf
+    return buf
+
+
 _DTYPE_IDS = {torch.float32: L.F32, torch.float16: L.F16, torch.bfloat16: L.BF16}
 
 
@@ -868,7 +883,7 @@ def percentile_select(shards, alpha, ch_axis=0, per_channel=True):
         outers[i], ptrs[i] = o, x.data_ptr()
     mn = torch.empty(C, dtype=torch.float32, device=dev)
     mx = torch.empty(C, dtype=torch.float32, device=dev)
-    ws = _workspace(dev, lib.sbq_radix_select_workspace_bytes(C, 2))
+    ws = _select_workspace(dev, lib.sbq_radix_select_workspace_bytes(C, 2))
     with L.device_guard(dev):
         rc = lib.sbq_percentile_select(ptrs, outers, len(shards), L.dtype_id(x0), C, inner, float(alpha), L.ptr(mn), L.ptr(mx),
                                        L.ptr(ws), ws.numel(), L.stream_ptr(dev))
@@ -877,12 +892,13 @@ def percentile_select(shards, alpha, ch_axis=0, per_channel=True):
 
 
 def kth_value(x, k, use_abs=False):
-    """1-indexed k-th smallest of x (of |x| with use_abs) as a 0-d fp32 tensor: one call, three reads of x"""
+    """1-indexed k-th smallest of x (of |x| with use_abs) as a 0-d fp32 tensor: one call -- and for a 16-bit tensor
+    one launch and one read of x"""
     dev = L.require_device(x)
     lib = L.load()
     x = x.contiguous()
     out = torch.empty((), dtype=torch.float32, device=dev)
-    ws = _workspace(dev, lib.sbq_radix_select_workspace_bytes(1, 1))
+    ws = _select_workspace(dev, lib.sbq_radix_select_workspace_bytes(1, 1))
     with L.device_guard(dev):
         rc = lib.sbq_kth_value(L.ptr(x), L.dtype_id(x), x.numel(), int(bool(use_abs)), int(k), L.ptr(out), L.ptr(ws),
                                ws.numel(), L.stream_ptr(dev))

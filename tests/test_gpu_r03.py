@@ -107,3 +107,85 @@ def test_percentile_over_more_than_64_batches(oracle, ops, dtype):
     flat = np.concatenate([b.float().numpy().reshape(-1) for b in batches])
     rmn, rmx = oracle.percentile(flat, 1e-2, 0, False)
     assert np.array_equal(mn.cpu().numpy().reshape(-1), rmn) and np.array_equal(mx.cpu().numpy().reshape(-1), rmx)
+
+
+# --------------------------------------------------------------------------------------
+# the one-launch selection engine (csrc/sbq_select_win.hip: win_one_kernel)
+# --------------------------------------------------------------------------------------
+def _kth_ref(xf, k, use_abs):
+    a = np.abs(xf) if use_abs else xf
+    return np.sort(a.reshape(-1), kind="stable")[k - 1]
+
+
+def _sample_positions(n):
+    """element offsets of the packs win_one_kernel samples (plan_sample_load, JITTER): the test below plants its
+    lie exactly there"""
+    n_packs = min(2048, max(n // 8, 1))
+    stride = n // n_packs
+    p = np.arange(n_packs, dtype=np.uint64)
+    h = ((p * np.uint64(2654435761)) & np.uint64(0xffffffff)) >> np.uint64(4)
+    off = h % np.uint64(stride - 8 + 1) if stride > 8 else np.zeros_like(p)
+    return ((p * np.uint64(stride) + off) & ~np.uint64(7)).astype(np.int64)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_one_launch_engine_survives_a_lying_sample(ops, dtype):
+    """every sampled pack holds one value the rest of the tensor never takes: the first window misses every wanted
+    rank and the launch's last workgroup finishes the selection alone (exact for any data)"""
+    n = 1 << 20
+    g = torch.Generator().manual_seed(123)
+    x = torch.randn(n, generator=g) * 4
+    pos = _sample_positions(n)
+    for e in pos:
+        x[e:e + 8] = 1000.0
+    x = x.to(dtype)
+    xf = x.float().numpy()
+    xd = x.cuda()
+    for use_abs in (False, True):
+        for k in (1, n // 3, n // 2 + 1, n - 20000, n):
+            got = float(ops.kth_value(xd, k, use_abs))
+            assert got == float(_kth_ref(xf, k, use_abs)), (dtype, use_abs, k, got)
+    # the workspace is left clean: an ordinary selection right after, through the same buffer
+    y = torch.randn(n, generator=g).to(dtype)
+    assert float(ops.kth_value(y.cuda(), n // 2, True)) == float(_kth_ref(y.float().numpy(), n // 2, True))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("n", [1, 7, 8, 4099, 16384, 3 * 16384 + 5, 1 << 22])
+def test_one_launch_engine_sizes_vs_multi_launch_protocol(oracle, ops, dtype, n):
+    """kth value and percentile at sizes from one element to many slabs per workgroup; the multi-launch protocol
+    (knob 2 == 12) must agree"""
+    from sparsebit_amd import lib as L
+
+    g = torch.Generator().manual_seed(n)
+    x = (torch.randn(n, generator=g) * torch.rand(n, generator=g) * 8).to(dtype)
+    xf = x.float().numpy()
+    xd = x.cuda()
+    ks = sorted({1, max(1, n // 2), n})
+    want = [float(_kth_ref(xf, k, True)) for k in ks]
+    rmn, rmx = oracle.percentile(xf, 1e-2, 0, False)
+    for knob in (0, 12):
+        try:
+            L.set_tuning(2, knob)
+            got = [float(ops.kth_value(xd, k, True)) for k in ks]
+            mn, mx = ops.percentile_select([xd], 1e-2, 0, False)
+        finally:
+            L.set_tuning(2, 0)
+        assert got == want, (knob, n, got, want)
+        assert same_values(mn.cpu().numpy().reshape(-1), rmn) and same_values(mx.cpu().numpy().reshape(-1), rmx), (knob, n)
+
+
+def test_one_launch_engine_back_to_back_on_one_workspace(ops):
+    """200 selections of different tensors through one workspace without a host sync in between: every call must leave
+    the arrival counter, the counter lines and the histogram copies zero for the next one"""
+    g = torch.Generator().manual_seed(9)
+    xs = [(torch.randn(1 << 18, generator=g) * (i % 7 + 1)).bfloat16().cuda() for i in range(8)]
+    n = xs[0].numel()
+    want = [float(_kth_ref(x.float().cpu().numpy(), n // 2 + i, True)) for i, x in enumerate(xs)]
+    outs = []
+    for rep in range(25):
+        for i, x in enumerate(xs):
+            outs.append(ops.kth_value(x, n // 2 + i, True))
+    torch.cuda.synchronize()
+    for j, o in enumerate(outs):
+        assert float(o) == want[j % 8], j

@@ -156,7 +156,7 @@ def test_one_launch_over_mixed_shards(oracle, dtype):
     dev = shards[0].device
     outers = (ctypes.c_int64 * len(shards))(*[s.numel() for s in shards])
     ptrs = (ctypes.c_void_p * len(shards))(*[s.data_ptr() for s in shards])
-    ws = torch.empty(lib.sbq_radix_select_workspace_bytes(1, 2), dtype=torch.uint8, device=dev)
+    ws = torch.zeros(lib.sbq_radix_select_workspace_bytes(1, 2), dtype=torch.uint8, device=dev)  # zero before first use (sbq.h)
     for alpha in (0.0, 1e-3, 0.2):
         mn = torch.empty(1, dtype=torch.float32, device=dev)
         mx = torch.empty(1, dtype=torch.float32, device=dev)

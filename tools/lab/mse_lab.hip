@@ -1,0 +1,244 @@
+// Dev tool: inner-loop variants of the MSE observer's candidate search (csrc/sbq_observe.hip: mse_partial_kernel) on a
+// 4096 x 4096 bf16 tensor, per-channel symmetric int8 -- 80 x 16.7 M candidate evaluations, VALU-bound.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off tools/lab/mse_lab.hip -o tools/lab/mse_lab
+// Every variant must produce the same argmin per row as variant 0 (and sums equal to the last bits that matter).
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+constexpr int kC = 80, kRows = 4096, kCols = 4096;
+
+__device__ __forceinline__ float cand_scale(float mn, float mx, int i) {
+  const float f = static_cast<float>(1.0 - static_cast<double>(i) * 0.01);
+  float a = mn * f, b = mx * f;
+  a = a < 0.0f ? a : 0.0f;
+  b = b > 0.0f ? b : 0.0f;
+  b = (-a > b) ? -a : b;
+  const float s = (b * 2.0f) / 255.0f;
+  return s > 1e-6f ? s : 1e-6f;
+}
+
+template <int V>
+__global__ __launch_bounds__(256) void mse_k(const uint16_t* __restrict__ x, const float* __restrict__ mn,
+                                             const float* __restrict__ mx, double* __restrict__ sse) {
+  __shared__ float s_scale[kC], s_rcp[kC];
+  __shared__ float s_acc[kC][4];
+  const uint32_t row = blockIdx.x;
+  if (threadIdx.x < kC) {
+    const float s = cand_scale(mn[row], mx[row], threadIdx.x);
+    s_scale[threadIdx.x] = s;
+    s_rcp[threadIdx.x] = 1.0f / s;
+  }
+  float v[16];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const u32x4 w = *reinterpret_cast<const u32x4*>(x + static_cast<size_t>(row) * kCols + (u * 256 + threadIdx.x) * 8);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      v[u * 8 + 2 * q] = __builtin_bit_cast(float, w[q] << 16);
+      v[u * 8 + 2 * q + 1] = __builtin_bit_cast(float, w[q] & 0xffff0000u);
+    }
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const float qlo = -128.0f, qhi = 127.0f;
+  if constexpr (V == 0 || V == 3) {
+    // product loop: mul, rndne, med3, fma, fma per element (V == 3: scale / reciprocal forced into SGPRs)
+    for (int i = 0; i < kC; ++i) {
+      float s = s_scale[i], y = s_rcp[i];
+      if constexpr (V == 3) {
+        s = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, s)));
+        y = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, y)));
+      }
+      float acc = 0.0f;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const float lv = __builtin_amdgcn_fmed3f(__builtin_rintf(v[q] * y), qlo, qhi);
+        const float d = __builtin_fmaf(-lv, s, v[q]);
+        acc = __builtin_fmaf(d, d, acc);
+      }
+#pragma unroll
+      for (int m = 32; m > 0; m >>= 1) acc += __shfl_xor(acc, m, 64);
+      if (lane == 0) s_acc[i][wid] = acc;
+    }
+  } else if constexpr (V == 1 || V == 4) {
+    // packed over PAIRS OF ELEMENTS: v_pk_mul, 2 x rndne, 2 x med3, v_pk_fma, v_pk_fma per two evaluations
+    for (int i = 0; i < kC; ++i) {
+      float s = s_scale[i], y = s_rcp[i];
+      if constexpr (V == 4) {
+        s = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, s)));
+        y = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, y)));
+      }
+      const f32x2 yv = {y, y}, ns = {-s, -s};
+      f32x2 acc2 = {0.0f, 0.0f};
+#pragma unroll
+      for (int q = 0; q < 16; q += 2) {
+        const f32x2 xv = {v[q], v[q + 1]};
+        const f32x2 t = xv * yv;
+        const f32x2 lv = {__builtin_amdgcn_fmed3f(__builtin_rintf(t[0]), qlo, qhi),
+                          __builtin_amdgcn_fmed3f(__builtin_rintf(t[1]), qlo, qhi)};
+        const f32x2 d = __builtin_elementwise_fma(lv, ns, xv);
+        acc2 = __builtin_elementwise_fma(d, d, acc2);
+      }
+      float acc = acc2[0] + acc2[1];
+#pragma unroll
+      for (int m = 32; m > 0; m >>= 1) acc += __shfl_xor(acc, m, 64);
+      if (lane == 0) s_acc[i][wid] = acc;
+    }
+  } else if constexpr (V == 2) {
+    // packed over PAIRS OF CANDIDATES: {x, x} against {y_i, y_i+1}
+    for (int i = 0; i < kC; i += 2) {
+      const f32x2 yv = {s_rcp[i], s_rcp[i + 1]}, ns = {-s_scale[i], -s_scale[i + 1]};
+      f32x2 acc2 = {0.0f, 0.0f};
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const f32x2 xv = {v[q], v[q]};
+        const f32x2 t = xv * yv;
+        const f32x2 lv = {__builtin_amdgcn_fmed3f(__builtin_rintf(t[0]), qlo, qhi),
+                          __builtin_amdgcn_fmed3f(__builtin_rintf(t[1]), qlo, qhi)};
+        const f32x2 d = __builtin_elementwise_fma(lv, ns, xv);
+        acc2 = __builtin_elementwise_fma(d, d, acc2);
+      }
+      float a0 = acc2[0], a1 = acc2[1];
+#pragma unroll
+      for (int m = 32; m > 0; m >>= 1) {
+        a0 += __shfl_xor(a0, m, 64);
+        a1 += __shfl_xor(a1, m, 64);
+      }
+      if (lane == 0) {
+        s_acc[i][wid] = a0;
+        s_acc[i + 1][wid] = a1;
+      }
+    }
+  } else if constexpr (V == 5) {
+    // V1 + the wave reduction deferred: 80 accumulators would not fit, so candidates go in groups of 8 whose sums
+    // are reduced together by a transposing butterfly (8 values: 4 + 2 + 1 + 3 shuffles instead of 48)
+    for (int i0 = 0; i0 < kC; i0 += 8) {
+      float part[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float s = s_scale[i0 + k], y = s_rcp[i0 + k];
+        const f32x2 yv = {y, y}, ns = {-s, -s};
+        f32x2 acc2 = {0.0f, 0.0f};
+#pragma unroll
+        for (int q = 0; q < 16; q += 2) {
+          const f32x2 xv = {v[q], v[q + 1]};
+          const f32x2 t = xv * yv;
+          const f32x2 lv = {__builtin_amdgcn_fmed3f(__builtin_rintf(t[0]), qlo, qhi),
+                            __builtin_amdgcn_fmed3f(__builtin_rintf(t[1]), qlo, qhi)};
+          const f32x2 d = __builtin_elementwise_fma(lv, ns, xv);
+          acc2 = __builtin_elementwise_fma(d, d, acc2);
+        }
+        part[k] = acc2[0] + acc2[1];
+      }
+      // reduce-scatter: after the three exchange steps lane l holds the sum over {l, l^32, l^16, l^8} of candidate
+      // ((l >> 5) & 1) * 4 + ((l >> 4) & 1) * 2 + ((l >> 3) & 1)
+      float h4[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const bool up = lane & 32;
+        const float keep = up ? part[4 + k] : part[k], give = up ? part[k] : part[4 + k];
+        h4[k] = keep + __shfl_xor(give, 32, 64);
+      }
+      float h2[2];
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const bool up = lane & 16;
+        const float keep = up ? h4[2 + k] : h4[k], give = up ? h4[k] : h4[2 + k];
+        h2[k] = keep + __shfl_xor(give, 16, 64);
+      }
+      float h1;
+      {
+        const bool up = lane & 8;
+        const float keep = up ? h2[1] : h2[0], give = up ? h2[0] : h2[1];
+        h1 = keep + __shfl_xor(give, 8, 64);
+      }
+      h1 += __shfl_xor(h1, 4, 64);
+      h1 += __shfl_xor(h1, 2, 64);
+      h1 += __shfl_xor(h1, 1, 64);
+      if ((lane & 7) == 0) s_acc[i0 + (((lane >> 5) & 1) * 4 + ((lane >> 4) & 1) * 2 + ((lane >> 3) & 1))][wid] = h1;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < kC) {
+    double t = 0.0;
+    for (int w = 0; w < 4; ++w) t += static_cast<double>(s_acc[threadIdx.x][w]);
+    sse[static_cast<size_t>(row) * kC + threadIdx.x] = t;
+  }
+}
+
+__global__ void init_k(uint16_t* x, float* mn, float* mx) {
+  // row r: pseudo-random values of spread 10^(-2..1); min / max by the block
+  __shared__ float smn[256], smx[256];
+  const uint32_t r = blockIdx.x;
+  const float spread = __builtin_exp2f(-6.64f + 9.97f * r / 4096.0f);
+  float lo = 1e30f, hi = -1e30f;
+  for (uint32_t c = threadIdx.x; c < kCols; c += 256) {
+    uint32_t h = (r * 4096u + c) * 2654435761u;
+    h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+    const float u = (h & 0xffffff) / 8388608.0f - 1.0f, u2 = ((h >> 8) & 0xffff) / 32768.0f - 1.0f;
+    const float val = 3.0f * u * u2 * u2 * spread;
+    const uint32_t b = __builtin_bit_cast(uint32_t, val);
+    const uint16_t bf = static_cast<uint16_t>((b + 0x7fffu + ((b >> 16) & 1u)) >> 16);
+    x[static_cast<size_t>(r) * kCols + c] = bf;
+    const float back = __builtin_bit_cast(float, static_cast<uint32_t>(bf) << 16);
+    lo = back < lo ? back : lo;
+    hi = back > hi ? back : hi;
+  }
+  smn[threadIdx.x] = lo; smx[threadIdx.x] = hi;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int i = 1; i < 256; ++i) { lo = smn[i] < lo ? smn[i] : lo; hi = smx[i] > hi ? smx[i] : hi; }
+    mn[r] = lo; mx[r] = hi;
+  }
+}
+
+template <int V>
+void run(const char* name, const uint16_t* x, const float* mn, const float* mx, double* sse, std::vector<double>& ref) {
+  hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+  for (int i = 0; i < 3; ++i) mse_k<V><<<kRows, 256>>>(x, mn, mx, sse);
+  hipEventRecord(a);
+  const int iters = 20;
+  for (int i = 0; i < iters; ++i) mse_k<V><<<kRows, 256>>>(x, mn, mx, sse);
+  hipEventRecord(b); hipEventSynchronize(b);
+  float ms; hipEventElapsedTime(&ms, a, b);
+  std::vector<double> h(static_cast<size_t>(kRows) * kC);
+  hipMemcpy(h.data(), sse, h.size() * 8, hipMemcpyDeviceToHost);
+  int diff_idx = 0; double max_rel = 0;
+  if (ref.empty()) ref = h;
+  for (int r = 0; r < kRows; ++r) {
+    int b0 = 0, b1 = 0;
+    for (int i = 1; i < kC; ++i) {
+      if (static_cast<float>(ref[r * kC + i] / kCols) < static_cast<float>(ref[r * kC + b0] / kCols)) b0 = i;
+      if (static_cast<float>(h[r * kC + i] / kCols) < static_cast<float>(h[r * kC + b1] / kCols)) b1 = i;
+    }
+    diff_idx += b0 != b1;
+    for (int i = 0; i < kC; ++i) {
+      const double rel = std::abs(h[r * kC + i] - ref[r * kC + i]) / (std::abs(ref[r * kC + i]) + 1e-300);
+      max_rel = rel > max_rel ? rel : max_rel;
+    }
+  }
+  const double us = ms * 1e3 / iters;
+  const double evals = 80.0 * kRows * kCols;
+  printf("%-52s %8.2f us  %6.1f TFLOP/s (7 flop/eval)  argmin differs in %d rows, max rel diff of sums %.2e\n", name, us,
+         evals * 7 / us / 1e6, diff_idx, max_rel);
+}
+
+int main() {
+  uint16_t* x; float *mn, *mx; double* sse;
+  hipMalloc(&x, static_cast<size_t>(kRows) * kCols * 2); hipMalloc(&mn, kRows * 4); hipMalloc(&mx, kRows * 4);
+  hipMalloc(&sse, static_cast<size_t>(kRows) * kC * 8);
+  init_k<<<kRows, 256>>>(x, mn, mx);
+  std::vector<double> ref;
+  run<0>("V0 product loop (mul rndne med3 fma fma)", x, mn, mx, sse, ref);
+  run<3>("V3 = V0 with scale / reciprocal in SGPRs", x, mn, mx, sse, ref);
+  run<1>("V1 packed over element pairs (pk_mul pk_fma pk_fma)", x, mn, mx, sse, ref);
+  run<4>("V4 = V1 with scale / reciprocal in SGPRs", x, mn, mx, sse, ref);
+  run<2>("V2 packed over candidate pairs", x, mn, mx, sse, ref);
+  run<5>("V5 = V1 + transposing butterfly reduction (8 cand.)", x, mn, mx, sse, ref);
+  run<0>("V0 again", x, mn, mx, sse, ref);
+  return 0;
+}

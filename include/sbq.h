@@ -191,6 +191,38 @@ int sbq_quant_group_backward(const void* device_table, const void* host_table, i
                              const void* const* gy, void* gx_base, float* gs_base,
                              void* workspace, size_t workspace_bytes, void* stream);
 
+/* Model-wide CALIBRATION: the min-max (and MSE) observers + calc_qparams of every weight of a model in two (four)
+ * launches -- replaces the per-layer loop of CalibrationRunner.run_weight_calibration (tools/calibration.py:117-135)
+ * over observers/minmax.py:14-25 / observers/mse.py:28-63 and observers/base.py:63-79.
+ *   1. describe the tensors with sbq_calib_item (HOST array): [C, inner] contiguous, 16-byte aligned, inner % 8 == 0,
+ *      C == 1 for a per-tensor quantizer; out_offset = where the item's C results start in the flat output buffers;
+ *   2. sbq_calib_table_build(items, n, NULL, 0, &n_rows, &bytes, &workspace_bytes) sizes the table, a second call fills
+ *      a HOST buffer; copy it to device memory (16-byte aligned) once and keep the host copy;
+ *   3. sbq_group_minmax_qparams: min_base / max_base (and, unless NULL, scale_base / zp_base) of every row of every
+ *      tensor; sbq_group_mse_qparams: the 80-candidate search on those (min, max) -> scale / zero_point / index.
+ * Results are bit-identical to the per-tensor calls (sbq_channel_stats + sbq_qparams_from_minmax; sbq_mse_accumulate +
+ * sbq_mse_select): same device code, same summation order.  The MSE launch takes rows of at most 96 x 4096 elements
+ * (SBQ_ERR_ARG beyond: such tensors go through the per-tensor entry points). */
+#define SBQ_CALIB_SYMMETRIC 1u
+typedef struct {
+  const void* x;
+  int64_t C, inner;
+  uint64_t out_offset; /* floats from the *_base pointers; C values are written there */
+  int32_t qmin, qmax;
+  uint32_t flags;      /* SBQ_CALIB_SYMMETRIC */
+  uint32_t reserved;
+} sbq_calib_item;
+int sbq_calib_table_build(const sbq_calib_item* items, int n_items, void* host_table, size_t host_table_bytes,
+                          uint32_t* n_rows_out, size_t* bytes_needed_out, size_t* workspace_bytes_out);
+/* device_table: the built table copied to the GPU; host_table: the same bytes, still on the host */
+int sbq_group_minmax_qparams(const void* device_table, const void* host_table, int x_dtype,
+                             float* min_base, float* max_base, float* scale_base, float* zp_base,
+                             void* workspace, size_t workspace_bytes, void* stream);
+int sbq_group_mse_qparams(const void* device_table, const void* host_table, int x_dtype,
+                          const float* min_base, const float* max_base,
+                          float* scale_base, float* zp_base, int32_t* index_base /* or NULL */,
+                          void* workspace, size_t workspace_bytes, void* stream);
+
 /* LSQ forward / backward on the RAW learnable parameters (quantizers/lsq.py:61-76): the kernels
  * apply scale = |scale| and zero_point = clamp(zero_point, qmin, qmax) themselves, and the backward
  * returns the step-size gradient already multiplied by gs_ratio (lsq.py:13-21,68-71) and
@@ -388,6 +420,21 @@ int sbq_percentile_select(const void* const* shards, const int64_t* outers, int 
                           void* workspace, size_t workspace_bytes, void* stream);
 int sbq_kth_value(const void* x, int x_dtype, int64_t numel, int use_abs, int64_t k, float* value_out,
                   void* workspace, size_t workspace_bytes, void* stream);
+
+/* Many whole-tensor selections in ONE launch (three for fp32): the L1 mask thresholds of a whole model
+ * (sparse/sparse_model.py:107-113 sorts every layer's weight on its own).  items: HOST array; item i is the 1-indexed
+ * k-th smallest of x_i (of |x_i| with use_abs), written to values_out[i].  Every item runs the one-launch engine of
+ * sbq_kth_value on its own share of the grid and its own region of the workspace, so the results are those of
+ * n_items sbq_kth_value calls.  Tensors must be 16-byte aligned and hold at least 8 elements (others: sbq_kth_value).
+ * Workspace: ZERO before its first use, left reusable by every call, not shared by concurrent calls. */
+typedef struct {
+  const void* x;
+  int64_t numel;
+  int64_t k;
+} sbq_kth_item;
+size_t sbq_group_kth_workspace_bytes(int n_items);
+int sbq_group_kth_value(const sbq_kth_item* items, int n_items, int x_dtype, int use_abs, float* values_out,
+                        void* workspace, size_t workspace_bytes, void* stream);
 
 /* The percentile observer's two ranks per channel, straight from the pass-0 histogram
  * (after any cross-rank SUM): neg / pos counts are sums over its lower / upper half, then

@@ -1,0 +1,391 @@
+// sbq_calib.hip -- model-wide calibration launches: the min-max (and MSE) observers + calc_qparams of EVERY weight of a
+// model in two (four) launches.
+//
+// The reference calibrates weights layer by layer: CalibrationRunner.run_weight_calibration loops over the graph
+// (sparsebit/quantization/tools/calibration.py:117-135), each layer's observer runs its own torch reductions
+// (observers/minmax.py:14-25, observers/mse.py:28-63) and calc_qparams_with_minmax (observers/base.py:63-79).  On the
+// device that is 3-5 launches per layer of ~5 us each for tensors of a few hundred kilobytes: ResNet-50's 53 weights
+// are ~1 ms of launch latency for 100 MB of reads.  Here the tensors of a model -- any mix of [C, inner] shapes, per
+// channel or per tensor, each with its own integer range and scheme -- are described once in a device table
+// (sbq_calib_table_build) and
+//   sbq_group_minmax_qparams   statistics of every row of every tensor by ONE grid (a wave per <= 4096-element
+//                              segment of a row, the per-tensor kernels' reductions: sbq_observe_body.hpp), then one
+//                              small launch that folds a row's segments and applies calc_qparams_with_minmax;
+//   sbq_group_mse_qparams      the 80-candidate search of every row by one grid (a workgroup per 4096-element chunk:
+//                              mse_chunk_body, the per-tensor kernel's body), then one launch that folds a row's
+//                              chunks in the per-tensor path's order and keeps the first strictly better candidate.
+// Same device code and the same summation order as the per-tensor entry points => bit-identical results
+// (tests/test_gpu_r03.py::test_group_calibration_equals_per_tensor).
+#include "sbq_observe_body.hpp"
+
+namespace sbq {
+namespace {
+
+struct CalibItemDev {  // 64 bytes, read through the scalar unit
+  const void* x;
+  uint64_t out_off;        // floats from the output bases
+  uint32_t C;
+  uint32_t inner;          // elements per row (< 2^32: checked)
+  uint32_t segs_per_row;   // statistics: ceil(inner / 4096)
+  uint32_t seg_wg_begin;   // first statistics workgroup of the item (its segments are padded to whole workgroups)
+  uint32_t seg_begin;      // first statistics partial of the item
+  uint32_t row_begin;      // first row of the item in the model-wide row numbering
+  uint32_t chunk_begin;    // first MSE chunk (== workgroup) of the item
+  float qlo, qhi;
+  uint32_t flags;
+  uint32_t pad[2];
+};
+static_assert(sizeof(CalibItemDev) == 64, "device table layout");
+
+struct CalibHeader {  // 64 bytes
+  uint32_t n_items, n_seg_wgs, n_rows, n_chunks, n_segs, max_chunks_per_row;
+  uint32_t pad[10];
+};
+static_assert(sizeof(CalibHeader) == 64, "device table layout");
+
+template <typename V>
+__device__ __forceinline__ V uread(const V* p) {  // uniform (scalar) load
+  typedef const V __attribute__((address_space(4))) * cptr;
+  return *reinterpret_cast<cptr>(reinterpret_cast<uintptr_t>(p));
+}
+
+__device__ __forceinline__ uint32_t udiv24(uint32_t a, uint32_t b) {  // a < 2^24: exact through one fp32 estimate
+  uint32_t r = static_cast<uint32_t>(static_cast<float>(a) * (1.0f / static_cast<float>(b)));
+  const int32_t rem = static_cast<int32_t>(a - r * b);
+  if (rem < 0) --r;
+  else if (rem >= static_cast<int32_t>(b)) ++r;
+  return r;
+}
+
+// ---- statistics: a wave per segment ---------------------------------------------------------------------
+// (the reductions of stats_minmax_kernel: three packed integer operations per dword of a 16-bit tensor,
+// v_minimum3 / v_maximum3 for fp32 -- NaN-propagating like torch.min / max)
+template <typename T>
+__global__ __launch_bounds__(kBlock) void calib_stats_kernel(const CalibItemDev* __restrict__ items,
+                                                             const uint32_t* __restrict__ wg_item,
+                                                             StatPartial* __restrict__ part) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const uint32_t idx = uread(wg_item + blockIdx.x);
+  const CalibItemDev* it = items + idx;
+  const uint32_t spr = uread(&it->segs_per_row), C = uread(&it->C), inner = uread(&it->inner);
+  const uint32_t seg = (blockIdx.x - uread(&it->seg_wg_begin)) * kWavesPerBlock +
+                       __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+  if (seg >= C * spr) return;  // padding wave of the item's last workgroup
+  const uint32_t row = spr == 1 ? seg : udiv24(seg, spr);
+  const uint32_t k = seg - row * spr;
+  const uint32_t begin = k * kStatsChunk;
+  const uint32_t len = inner - begin < kStatsChunk ? inner - begin : kStatsChunk;  // a multiple of 8
+  const int64_t first = static_cast<int64_t>(row) * inner + begin;
+  const void* x = uread(&it->x);
+  constexpr int U = 8;
+  float mn, mx;
+  if constexpr (T::id == SBQ_F32) {
+    mn = __builtin_inff();
+    mx = -__builtin_inff();
+    // rounds past the end of a short row (a 1 x 1 convolution's 64 ... 2048 elements) are skipped: a model's rows are
+    // mostly shorter than a segment, and eight clamped loads per lane would re-read each one's last pack 64-fold
+    const int n_u = static_cast<int>((len + kWave * kPack - 1) / (kWave * kPack));  // wave-uniform
+    RawPack<T> raw[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (u >= n_u) break;
+      const uint32_t eA = u * kWave * kPack + 4 * lane, eB = eA + kWave * kPack / 2;
+      raw[u] = load_raw2<T, true>(x, first + (eA < len ? eA : len - 4), first + (eB < len ? eB : len - 4));
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (u >= n_u) break;
+      float v[kPack];
+      unpack_raw<T>(raw[u], v);
+#pragma unroll
+      for (int q = 0; q < kPack; q += 2) {
+        mn = __builtin_elementwise_minimum(__builtin_elementwise_minimum(mn, v[q]), v[q + 1]);
+        mx = __builtin_elementwise_maximum(__builtin_elementwise_maximum(mx, v[q]), v[q + 1]);
+      }
+    }
+    mn = wave_reduce(mn, [](float a, float b) { return __builtin_elementwise_minimum(a, b); });
+    mx = wave_reduce(mx, [](float a, float b) { return __builtin_elementwise_maximum(a, b); });
+  } else {
+    Stat16 s = kStat16Identity;
+    const int n_u = static_cast<int>((len + kWave * kPack - 1) / (kWave * kPack));  // wave-uniform
+    RawPack<T> raw[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (u >= n_u) break;
+      uint32_t e = (u * kWave + lane) * kPack;
+      if (e >= len) e = len - kPack;
+      raw[u] = load_raw<T, true>(x, first + e);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (u >= n_u) break;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) stat16_fold(s, raw[u].d[0][q]);
+    }
+    s = stat16_wave(s);
+    stat16_decode<T>(s, mn, mx);
+  }
+  if (lane == 0) part[uread(&it->seg_begin) + seg] = StatPartial{mn, mx, 0.0};
+}
+
+__device__ __forceinline__ const CalibItemDev& item_of_row(const CalibItemDev* __restrict__ items, uint32_t n_items,
+                                                           uint32_t r) {
+  uint32_t lo = 0, hi = n_items - 1;  // last item with row_begin <= r
+  while (lo < hi) {
+    const uint32_t mid = (lo + hi + 1) >> 1;
+    if (items[mid].row_begin <= r) lo = mid;
+    else hi = mid - 1;
+  }
+  return items[lo];
+}
+
+// a thread per row: fold the row's segments (torch.min / max semantics: NaN wins), then observers/base.py:63-79
+__global__ __launch_bounds__(kBlock) void calib_stats_fold_kernel(const CalibItemDev* __restrict__ items, uint32_t n_items,
+                                                                  uint32_t n_rows, const StatPartial* __restrict__ part,
+                                                                  float* __restrict__ min_base, float* __restrict__ max_base,
+                                                                  float* __restrict__ scale_base, float* __restrict__ zp_base) {
+  const uint32_t r = blockIdx.x * kBlock + threadIdx.x;
+  if (r >= n_rows) return;
+  const CalibItemDev& it = item_of_row(items, n_items, r);
+  const uint32_t row = r - it.row_begin;
+  const StatPartial* p = part + it.seg_begin + static_cast<size_t>(row) * it.segs_per_row;
+  NanMin nmin;
+  NanMax nmax;
+  float mn = p[0].mn, mx = p[0].mx;
+  for (uint32_t k = 1; k < it.segs_per_row; ++k) {
+    mn = nmin(mn, p[k].mn);
+    mx = nmax(mx, p[k].mx);
+  }
+  min_base[it.out_off + row] = mn;
+  max_base[it.out_off + row] = mx;
+  if (scale_base) {
+    float s, z;
+    qparams_from_minmax(mn, mx, it.qhi - it.qlo, (it.flags & SBQ_CALIB_SYMMETRIC) != 0, s, z);
+    scale_base[it.out_off + row] = s;
+    zp_base[it.out_off + row] = z;
+  }
+}
+
+// ---- MSE: a workgroup per chunk ------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(kBlock) void calib_mse_kernel(const CalibItemDev* __restrict__ items,
+                                                           const uint32_t* __restrict__ chunk_item,
+                                                           const float* __restrict__ min_base,
+                                                           const float* __restrict__ max_base, double* __restrict__ part) {
+  __shared__ MseLds lds;
+  const uint32_t idx = uread(chunk_item + blockIdx.x);
+  const CalibItemDev* it = items + idx;
+  const uint32_t inner = uread(&it->inner);
+  const uint32_t cpr = (inner + kMseChunk - 1) / kMseChunk;
+  const uint32_t ch = blockIdx.x - uread(&it->chunk_begin);
+  const uint32_t row = cpr == 1 ? ch : udiv24(ch, cpr);
+  const uint32_t k = ch - row * cpr;
+  const int64_t begin = static_cast<int64_t>(k) * kMseChunk;
+  const int64_t end = begin + kMseChunk < inner ? begin + kMseChunk : inner;
+  const uint64_t off = uread(&it->out_off) + row;
+  const float qlo = uread(&it->qlo), qhi = uread(&it->qhi);
+  const double t = mse_chunk_body<T, true>(lds, uread(&it->x), static_cast<int64_t>(row) * inner, begin, end, min_base[off],
+                                           max_base[off], qhi - qlo, qlo, qhi, (uread(&it->flags) & SBQ_CALIB_SYMMETRIC) != 0);
+  if (threadIdx.x < SBQ_MSE_CANDIDATES) part[static_cast<size_t>(blockIdx.x) * SBQ_MSE_CANDIDATES + threadIdx.x] = t;
+}
+
+// Three rows per workgroup, a thread per (row, candidate): the row's chunks are summed in the per-tensor path's
+// order -- a single chunk is the sum itself (sse += t onto zero), several go through mse_fold_kernel's three
+// interleaved running sums ((s0 + s1) + s2, chunk j in sum j % 3) -- then mse_select_kernel's rule: the first
+// candidate whose fp32 loss is strictly smaller (observers/mse.py:51-61).
+constexpr int kRowsPerFoldWg = kBlock / SBQ_MSE_CANDIDATES;  // 3
+constexpr uint32_t kMaxGroupMseChunks = 96;  // one level of the per-tensor fold (kFoldFan)
+
+__global__ __launch_bounds__(kBlock) void calib_mse_select_kernel(const CalibItemDev* __restrict__ items, uint32_t n_items,
+                                                                  uint32_t n_rows, const double* __restrict__ part,
+                                                                  const float* __restrict__ min_base,
+                                                                  const float* __restrict__ max_base,
+                                                                  float* __restrict__ scale_base, float* __restrict__ zp_base,
+                                                                  int32_t* __restrict__ index_base) {
+  __shared__ float s_loss[kRowsPerFoldWg][SBQ_MSE_CANDIDATES];
+  const uint32_t sub = threadIdx.x / SBQ_MSE_CANDIDATES, i = threadIdx.x % SBQ_MSE_CANDIDATES;
+  const uint32_t r = blockIdx.x * kRowsPerFoldWg + sub;
+  const bool live = sub < static_cast<uint32_t>(kRowsPerFoldWg) && r < n_rows;
+  const CalibItemDev* it = nullptr;
+  uint32_t row = 0;
+  if (live) {
+    it = &item_of_row(items, n_items, r);
+    row = r - it->row_begin;
+    const uint32_t cpr = (it->inner + kMseChunk - 1) / kMseChunk;
+    const double* p = part + (static_cast<size_t>(it->chunk_begin) + static_cast<size_t>(row) * cpr) * SBQ_MSE_CANDIDATES + i;
+    double t;
+    if (cpr == 1) {
+      t = 0.0 + p[0];
+    } else {
+      double s3[3] = {0.0, 0.0, 0.0};
+      for (uint32_t j = 0; j < cpr; ++j) s3[j % 3] += p[static_cast<size_t>(j) * SBQ_MSE_CANDIDATES];
+      t = 0.0 + ((s3[0] + s3[1]) + s3[2]);
+    }
+    s_loss[sub][i] = static_cast<float>(t / static_cast<double>(it->inner));
+  }
+  __syncthreads();
+  if (live && i == 0) {
+    float loss_min = 1e10f;
+    int best = -1;
+    for (int c = 0; c < SBQ_MSE_CANDIDATES; ++c) {
+      const float loss = s_loss[sub][c];
+      if (loss < loss_min) {
+        loss_min = loss;
+        best = c;
+      }
+    }
+    const uint64_t off = it->out_off + row;
+    float s = 1.0f, z = 0.0f;  // mse.py:34-39 initial values
+    if (best >= 0)
+      mse_candidate(min_base[off], max_base[off], best, it->qhi - it->qlo, (it->flags & SBQ_CALIB_SYMMETRIC) != 0, s, z);
+    scale_base[off] = s;
+    zp_base[off] = z;
+    if (index_base) index_base[off] = best;
+  }
+}
+
+}  // namespace
+}  // namespace sbq
+
+extern "C" {
+
+// table = [header | items | statistics workgroup -> item | MSE chunk -> item]
+int sbq_calib_table_build(const sbq_calib_item* items, int n_items, void* host_table, size_t host_table_bytes,
+                          uint32_t* n_rows_out, size_t* bytes_needed_out, size_t* workspace_bytes_out) {
+  using namespace sbq;
+  if (n_items < 0) return SBQ_ERR_ARG;
+  if (n_items == 0) return SBQ_ERR_EMPTY;
+  if (!items) return SBQ_ERR_NULL;
+  uint64_t seg_wgs = 0, segs = 0, rows = 0, chunks = 0, max_cpr = 0;
+  for (int i = 0; i < n_items; ++i) {
+    const sbq_calib_item& it = items[i];
+    if (!it.x) return SBQ_ERR_NULL;
+    if (it.C < 0 || it.inner < 0) return SBQ_ERR_ARG;
+    if (it.C == 0 || it.inner == 0) return SBQ_ERR_EMPTY;
+    if (it.qmin >= it.qmax || it.inner % kPack != 0 || it.inner >= (1ll << 32) || it.C >= (1ll << 24)) return SBQ_ERR_ARG;
+    if (!aligned16(it.x)) return SBQ_ERR_ALIGN;
+    const uint64_t spr = ceil_div(it.inner, static_cast<int64_t>(kStatsChunk));
+    const uint64_t cpr = ceil_div(it.inner, static_cast<int64_t>(kMseChunk));
+    if (static_cast<uint64_t>(it.C) * spr >= (1ull << 24) || static_cast<uint64_t>(it.C) * cpr >= (1ull << 24)) return SBQ_ERR_ARG;
+    seg_wgs += ceil_div(static_cast<int64_t>(it.C * spr), static_cast<int64_t>(kWavesPerBlock));
+    segs += it.C * spr;
+    rows += it.C;
+    chunks += it.C * cpr;
+    max_cpr = cpr > max_cpr ? cpr : max_cpr;
+  }
+  if (seg_wgs >= (1ull << 31) || chunks >= (1ull << 31) || rows >= (1ull << 31)) return SBQ_ERR_ARG;
+  const size_t bytes = sizeof(CalibHeader) + static_cast<size_t>(n_items) * sizeof(CalibItemDev) + (seg_wgs + chunks) * 4;
+  if (bytes_needed_out) *bytes_needed_out = bytes;
+  if (n_rows_out) *n_rows_out = static_cast<uint32_t>(rows);
+  const size_t ws_stats = segs * sizeof(StatPartial), ws_mse = chunks * SBQ_MSE_CANDIDATES * sizeof(double);
+  if (workspace_bytes_out) *workspace_bytes_out = ws_stats > ws_mse ? ws_stats : ws_mse;
+  if (!host_table) return SBQ_OK;  // size query
+  if (host_table_bytes < bytes) return SBQ_ERR_WORKSPACE;
+  char* base = static_cast<char*>(host_table);
+  CalibHeader* h = reinterpret_cast<CalibHeader*>(base);
+  CalibItemDev* dev = reinterpret_cast<CalibItemDev*>(base + sizeof(CalibHeader));
+  uint32_t* wg_item = reinterpret_cast<uint32_t*>(dev + n_items);
+  uint32_t* chunk_item = wg_item + seg_wgs;
+  *h = CalibHeader{};
+  h->n_items = static_cast<uint32_t>(n_items);
+  h->n_seg_wgs = static_cast<uint32_t>(seg_wgs);
+  h->n_rows = static_cast<uint32_t>(rows);
+  h->n_chunks = static_cast<uint32_t>(chunks);
+  h->n_segs = static_cast<uint32_t>(segs);
+  h->max_chunks_per_row = static_cast<uint32_t>(max_cpr);
+  uint32_t wg = 0, sg = 0, rw = 0, ck = 0;
+  for (int i = 0; i < n_items; ++i) {
+    const sbq_calib_item& it = items[i];
+    CalibItemDev d{};
+    d.x = it.x;
+    d.out_off = it.out_offset;
+    d.C = static_cast<uint32_t>(it.C);
+    d.inner = static_cast<uint32_t>(it.inner);
+    d.segs_per_row = static_cast<uint32_t>(ceil_div(it.inner, static_cast<int64_t>(kStatsChunk)));
+    d.seg_wg_begin = wg;
+    d.seg_begin = sg;
+    d.row_begin = rw;
+    d.chunk_begin = ck;
+    d.qlo = static_cast<float>(it.qmin);
+    d.qhi = static_cast<float>(it.qmax);
+    d.flags = it.flags;
+    dev[i] = d;
+    const uint32_t n_seg = d.C * d.segs_per_row;
+    const uint32_t n_wg = (n_seg + kWavesPerBlock - 1) / kWavesPerBlock;
+    for (uint32_t k = 0; k < n_wg; ++k) wg_item[wg + k] = static_cast<uint32_t>(i);
+    const uint32_t n_ck = d.C * static_cast<uint32_t>(ceil_div(it.inner, static_cast<int64_t>(kMseChunk)));
+    for (uint32_t k = 0; k < n_ck; ++k) chunk_item[ck + k] = static_cast<uint32_t>(i);
+    wg += n_wg;
+    sg += n_seg;
+    rw += d.C;
+    ck += n_ck;
+  }
+  return SBQ_OK;
+}
+
+static int calib_header(const void* host_table, sbq::CalibHeader& h) {
+  if (!host_table) return SBQ_ERR_NULL;
+  h = *static_cast<const sbq::CalibHeader*>(host_table);
+  if (h.n_items == 0) return SBQ_ERR_EMPTY;
+  return SBQ_OK;
+}
+
+int sbq_group_minmax_qparams(const void* device_table, const void* host_table, int x_dtype, float* min_base,
+                             float* max_base, float* scale_base, float* zp_base, void* workspace,
+                             size_t workspace_bytes, void* stream) {
+  using namespace sbq;
+  if (!valid_dtype(x_dtype)) return SBQ_ERR_DTYPE;
+  CalibHeader h;
+  int rc = calib_header(host_table, h);
+  if (rc != SBQ_OK) return rc;
+  if (!device_table || !min_base || !max_base || !workspace) return SBQ_ERR_NULL;
+  if ((scale_base == nullptr) != (zp_base == nullptr)) return SBQ_ERR_NULL;
+  if (!aligned16(device_table) || !aligned16(workspace)) return SBQ_ERR_ALIGN;
+  if (workspace_bytes < static_cast<size_t>(h.n_segs) * sizeof(StatPartial)) return SBQ_ERR_WORKSPACE;
+  hipStream_t st = as_stream(stream);
+  const char* base = static_cast<const char*>(device_table);
+  const CalibItemDev* items = reinterpret_cast<const CalibItemDev*>(base + sizeof(CalibHeader));
+  const uint32_t* wg_item = reinterpret_cast<const uint32_t*>(items + h.n_items);
+  StatPartial* part = static_cast<StatPartial*>(workspace);
+  rc = dispatch_dtype(x_dtype, [&](auto tag) {
+    using T = decltype(tag);
+    calib_stats_kernel<T><<<h.n_seg_wgs, kBlock, 0, st>>>(items, wg_item, part);
+  });
+  if (rc != SBQ_OK) return rc;
+  rc = check_launch();
+  if (rc != SBQ_OK) return rc;
+  calib_stats_fold_kernel<<<(h.n_rows + kBlock - 1) / kBlock, kBlock, 0, st>>>(items, h.n_items, h.n_rows, part, min_base,
+                                                                             max_base, scale_base, zp_base);
+  return check_launch();
+}
+
+int sbq_group_mse_qparams(const void* device_table, const void* host_table, int x_dtype, const float* min_base,
+                          const float* max_base, float* scale_base, float* zp_base, int32_t* index_base,
+                          void* workspace, size_t workspace_bytes, void* stream) {
+  using namespace sbq;
+  if (!valid_dtype(x_dtype)) return SBQ_ERR_DTYPE;
+  CalibHeader h;
+  int rc = calib_header(host_table, h);
+  if (rc != SBQ_OK) return rc;
+  if (!device_table || !min_base || !max_base || !scale_base || !zp_base || !workspace) return SBQ_ERR_NULL;
+  if (!aligned16(device_table) || !aligned16(workspace)) return SBQ_ERR_ALIGN;
+  if (h.max_chunks_per_row > kMaxGroupMseChunks) return SBQ_ERR_ARG;  // rows beyond one fold level: per-tensor path
+  if (workspace_bytes < static_cast<size_t>(h.n_chunks) * SBQ_MSE_CANDIDATES * sizeof(double)) return SBQ_ERR_WORKSPACE;
+  hipStream_t st = as_stream(stream);
+  const char* base = static_cast<const char*>(device_table);
+  const CalibItemDev* items = reinterpret_cast<const CalibItemDev*>(base + sizeof(CalibHeader));
+  const uint32_t* chunk_item = reinterpret_cast<const uint32_t*>(items + h.n_items) + h.n_seg_wgs;
+  double* part = static_cast<double*>(workspace);
+  rc = dispatch_dtype(x_dtype, [&](auto tag) {
+    using T = decltype(tag);
+    calib_mse_kernel<T><<<h.n_chunks, kBlock, 0, st>>>(items, chunk_item, min_base, max_base, part);
+  });
+  if (rc != SBQ_OK) return rc;
+  rc = check_launch();
+  if (rc != SBQ_OK) return rc;
+  calib_mse_select_kernel<<<(h.n_rows + kRowsPerFoldWg - 1) / kRowsPerFoldWg, kBlock, 0, st>>>(
+      items, h.n_items, h.n_rows, part, min_base, max_base, scale_base, zp_base, index_base);
+  return check_launch();
+}
+
+}  // extern "C"

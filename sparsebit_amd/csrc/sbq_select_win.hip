@@ -1057,14 +1057,14 @@ __device__ void one_advance(const int s, const OneArgs& a, OneLds& ol, const Swe
 
 // arrival + advance (+ the lonely rounds and the clean-up when this launch is the selection's last)
 template <typename T, int NSEL, int BLOCK, typename Tab>
-__device__ __forceinline__ void win_finish(const Tab& tab, int n_shards, const OneArgs& a, OneLds& ol,
+__device__ __forceinline__ void win_finish(const Tab& tab, int n_shards, const OneArgs& a, const uint32_t nwg, OneLds& ol,
                                            SweepLds<NSEL, BLOCK>& swl, AdvShared& adv, bool signs_in_slots) {
   // this workgroup's adds are acknowledged before its arrival is counted
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __builtin_amdgcn_s_waitcnt(0);
   __syncthreads();
   if (threadIdx.x == 0)
-    ol.flag = __hip_atomic_fetch_add(&a.st->arrivals, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+    ol.flag = __hip_atomic_fetch_add(&a.st->arrivals, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nwg - 1;
   __syncthreads();
   one_stamp(a, 4);
   if (!ol.flag) return;
@@ -1099,8 +1099,11 @@ __device__ __forceinline__ void win_finish(const Tab& tab, int n_shards, const O
   }
 }
 
+// (wg of nwg: this workgroup's place among those that work on THIS selection -- the whole grid, or one item's share of
+// a launch that resolves many selections at once, sbq_group_kth_value)
 template <typename T, int NSEL, bool PCT, int BLOCK, typename Tab>
-__global__ __launch_bounds__(BLOCK) void win_one_kernel(const Tab tab, int n_shards, const OneArgs a) {
+__device__ __forceinline__ void win_one_body(const Tab& tab, int n_shards, const OneArgs& a, const uint32_t wg,
+                                             const uint32_t nwg) {
   __shared__ PlanLds plan;
   __shared__ AdvShared adv;
   __shared__ OneLds ol;
@@ -1116,7 +1119,7 @@ __global__ __launch_bounds__(BLOCK) void win_one_kernel(const Tab tab, int n_sha
   one_stamp(a, 12);
   // ... then the slabs (win_sweep, EARLY), and the plan while they fly
   constexpr bool SIGNS = PCT && NSEL == 2;
-  win_sweep<T, NSEL, SIGNS, BLOCK, true, true, true>(tab, n_shards, blockIdx.x, gridDim.x, [&](WinSel (&sel)[NSEL]) {
+  win_sweep<T, NSEL, SIGNS, BLOCK, true, true, true>(tab, n_shards, wg, nwg, [&](WinSel (&sel)[NSEL]) {
     one_stamp(a, 13);
     lds_sync();  // plan.hist is clear
     one_stamp(a, 1);
@@ -1141,18 +1144,23 @@ __global__ __launch_bounds__(BLOCK) void win_one_kernel(const Tab tab, int n_sha
     }
   }, a.slots, a.hist, a.use_abs, swl);
   one_stamp(a, 3);
-  win_finish<T, NSEL, BLOCK>(tab, n_shards, a, ol, swl, adv, SIGNS);
+  win_finish<T, NSEL, BLOCK>(tab, n_shards, a, nwg, ol, swl, adv, SIGNS);
   one_stamp(a, 7);
+}
+template <typename T, int NSEL, bool PCT, int BLOCK, typename Tab>
+__global__ __launch_bounds__(BLOCK) void win_one_kernel(const Tab tab, int n_shards, const OneArgs a) {
+  win_one_body<T, NSEL, PCT, BLOCK>(tab, n_shards, a, blockIdx.x, gridDim.x);
 }
 
 // a later round of a selection that needs several sweeps by design (fp32: two or three): sweep by the whole grid,
 // advance by the last workgroup to arrive; the last such launch also finishes what is left alone
 template <typename T, int NSEL, int BLOCK, typename Tab>
-__global__ __launch_bounds__(BLOCK) void win_round_kernel(const Tab tab, int n_shards, const OneArgs a) {
+__device__ __forceinline__ void win_round_body(const Tab& tab, int n_shards, const OneArgs& a, const uint32_t wg,
+                                               const uint32_t nwg) {
   __shared__ AdvShared adv;
   __shared__ OneLds ol;
   __shared__ SweepLds<NSEL, BLOCK> swl;
-  win_sweep<T, NSEL, false, BLOCK, true, true, true>(tab, n_shards, blockIdx.x, gridDim.x, [&](WinSel (&sel)[NSEL]) {
+  win_sweep<T, NSEL, false, BLOCK, true, true, true>(tab, n_shards, wg, nwg, [&](WinSel (&sel)[NSEL]) {
 #pragma unroll
     for (int s = 0; s < NSEL; ++s) sel[s] = a.st->sel[s];  // the previous launch's mailbox
     if (threadIdx.x == 0) {
@@ -1163,7 +1171,63 @@ __global__ __launch_bounds__(BLOCK) void win_round_kernel(const Tab tab, int n_s
     }
   }, a.slots, a.hist, a.use_abs, swl);
   // (a round that finds every selector resolved still counts its arrivals and passes the mailbox on)
-  win_finish<T, NSEL, BLOCK>(tab, n_shards, a, ol, swl, adv, false);
+  win_finish<T, NSEL, BLOCK>(tab, n_shards, a, nwg, ol, swl, adv, false);
+}
+template <typename T, int NSEL, int BLOCK, typename Tab>
+__global__ __launch_bounds__(BLOCK) void win_round_kernel(const Tab tab, int n_shards, const OneArgs a) {
+  win_round_body<T, NSEL, BLOCK>(tab, n_shards, a, blockIdx.x, gridDim.x);
+}
+
+// ---- many selections in one launch: the L1 thresholds of a whole model ------------------------------------------
+// sparse/sparse_model.py:107-113 computes every layer's mask threshold with its own torch.sort; on the device that
+// was one selection (5 launches, 27 us) per layer -- 1.4 ms for ResNet-50's 53 weights.  Here every item is a
+// selection of its own (own sample, own windows, own region of the workspace, own arrival counter and last arriver)
+// and a share of the grid's workgroups proportional to its size; the items of a launch live in the kernel arguments.
+constexpr int kKthItemsPerLaunch = 64;
+struct KthItemArg {
+  const void* x;
+  int64_t n, k;
+  uint32_t n_lean, n_rag;  // whole 16 Ki-element slabs / the ragged rest (0 or 1)
+  uint32_t wg_begin, nwg;
+};
+struct KthItems {
+  KthItemArg it[kKthItemsPerLaunch];
+};
+template <typename T, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void group_kth_kernel(const KthItems items, int n_items, char* regions, size_t region_bytes,
+                                                          float* out, int use_abs, uint32_t min_shift, int round,
+                                                          int final_round) {
+  // the item of this workgroup: last one whose first workgroup is <= blockIdx.x (uniform: scalar loads)
+  int lo = 0, hi = n_items - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (items.it[mid].wg_begin <= blockIdx.x) lo = mid;
+    else hi = mid - 1;
+  }
+  const KthItemArg me = items.it[lo];
+  OneShard tab{};
+  tab.ptr[0] = me.x;
+  tab.count[0] = me.n;
+  tab.lean_first[1] = me.n_lean;
+  tab.rag_first[1] = me.n_rag;
+  char* region = regions + static_cast<size_t>(lo) * region_bytes;
+  OneArgs a{};
+  a.st = reinterpret_cast<WinState*>(region);
+  a.slots = reinterpret_cast<WinSlot*>(region + 256);
+  a.hist = reinterpret_cast<uint32_t*>(region + 256 + sizeof(WinSlot) * kSlots);
+  a.out0 = out + lo;
+  a.out1 = nullptr;
+  a.k0 = me.k;
+  a.k1 = 0;
+  a.n = me.n;
+  a.alpha = 0.0;
+  a.min_shift = min_shift;
+  a.use_abs = use_abs;
+  a.mode = 0;
+  a.final_round = final_round;
+  a.stamps = nullptr;
+  if (round == 0) win_one_body<T, 1, false, BLOCK>(tab, 1, a, blockIdx.x - me.wg_begin, me.nwg);
+  else win_round_body<T, 1, BLOCK>(tab, 1, a, blockIdx.x - me.wg_begin, me.nwg);
 }
 
 constexpr size_t kStateBytes = 256;
@@ -1363,3 +1427,64 @@ int win_select_run(const void* const* shards, const int64_t* counts, int n_shard
 }
 
 }  // namespace sbq
+
+extern "C" {
+
+size_t sbq_group_kth_workspace_bytes(int n_items) {
+  if (n_items <= 0) return 0;
+  return static_cast<size_t>(n_items) * sbq::kOneRegion;
+}
+
+int sbq_group_kth_value(const sbq_kth_item* items, int n_items, int x_dtype, int use_abs, float* values_out,
+                        void* workspace, size_t workspace_bytes, void* stream) {
+  using namespace sbq;
+  if (!valid_dtype(x_dtype)) return SBQ_ERR_DTYPE;
+  if (n_items < 0) return SBQ_ERR_ARG;
+  if (n_items == 0) return SBQ_ERR_EMPTY;
+  if (!items || !values_out || !workspace) return SBQ_ERR_NULL;
+  if (workspace_bytes < sbq_group_kth_workspace_bytes(n_items) || !aligned16(workspace)) return SBQ_ERR_WORKSPACE;
+  constexpr int kB = 1024;
+  const int64_t slab = WinGeom<kB>::kSlab;
+  for (int i = 0; i < n_items; ++i) {
+    if (!items[i].x) return SBQ_ERR_NULL;
+    if (items[i].numel < kPack || items[i].numel >= (1ll << 32)) return SBQ_ERR_ARG;  // (tiny tensors: sbq_kth_value)
+    if (items[i].k < 1 || items[i].k > items[i].numel) return SBQ_ERR_ARG;
+    if (!aligned16(items[i].x)) return SBQ_ERR_ALIGN;
+  }
+  hipStream_t st = as_stream(stream);
+  const uint32_t min_shift = x_dtype == SBQ_BF16 ? 16u : (x_dtype == SBQ_F16 ? 13u : 0u);
+  const int expected = min_shift > 0 ? 1 : 3;
+  const int64_t cus = cu_count();
+  for (int first = 0; first < n_items; first += kKthItemsPerLaunch) {
+    const int cnt = n_items - first < kKthItemsPerLaunch ? n_items - first : kKthItemsPerLaunch;
+    KthItems args{};
+    uint32_t grid = 0;
+    for (int j = 0; j < cnt; ++j) {
+      const sbq_kth_item& it = items[first + j];
+      KthItemArg& d = args.it[j];
+      d.x = it.x;
+      d.n = it.numel;
+      d.k = it.k;
+      d.n_lean = static_cast<uint32_t>(it.numel / slab);
+      d.n_rag = it.numel % slab ? 1u : 0u;
+      // four slabs per workgroup (all of them in flight before the windows are known), at most one workgroup per CU
+      int64_t nwg = ceil_div(static_cast<int64_t>(d.n_lean) + d.n_rag, static_cast<int64_t>(4));
+      nwg = nwg < 1 ? 1 : (nwg > cus ? cus : nwg);
+      d.wg_begin = grid;
+      d.nwg = static_cast<uint32_t>(nwg);
+      grid += d.nwg;
+    }
+    char* regions = static_cast<char*>(workspace) + static_cast<size_t>(first) * kOneRegion;
+    for (int r = 0; r < expected; ++r) {
+      int rc = dispatch_dtype(x_dtype, [&](auto tag) {
+        using T = decltype(tag);
+        group_kth_kernel<T, kB><<<grid, kB, 0, st>>>(args, cnt, regions, kOneRegion, values_out + first, use_abs, min_shift, r,
+                                                    r == expected - 1 ? 1 : 0);
+      });
+      if (rc != SBQ_OK) return rc;
+    }
+  }
+  return check_launch();
+}
+
+}  // extern "C"

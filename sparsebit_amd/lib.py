@@ -47,6 +47,30 @@ class GroupItem(ctypes.Structure):
         ("reserved", ctypes.c_uint32),
     ]
 
+class CalibItem(ctypes.Structure):
+    """sbq_calib_item of include/sbq.h"""
+
+    _fields_ = [
+        ("x", ctypes.c_void_p),
+        ("C", ctypes.c_int64),
+        ("inner", ctypes.c_int64),
+        ("out_offset", ctypes.c_uint64),
+        ("qmin", ctypes.c_int32),
+        ("qmax", ctypes.c_int32),
+        ("flags", ctypes.c_uint32),
+        ("reserved", ctypes.c_uint32),
+    ]
+
+
+CALIB_SYMMETRIC = 1
+
+
+class KthItem(ctypes.Structure):
+    """sbq_kth_item of include/sbq.h"""
+
+    _fields_ = [("x", ctypes.c_void_p), ("numel", ctypes.c_int64), ("k", ctypes.c_int64)]
+
+
 c_i64, c_int, c_vp, c_sz, c_dbl = (
     ctypes.c_int64,
     ctypes.c_int,
@@ -103,6 +127,11 @@ _SIGNATURES = {
     "sbq_quant_group_forward": (c_int, [c_vp, c_int, ctypes.c_uint32, c_int, c_int, c_int, c_vp, c_vp]),
     "sbq_group_bwd_table_build": (c_int, [c_vp, c_int, c_vp, c_sz, c_vp, c_vp, c_vp, c_vp]),
     "sbq_quant_group_backward": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "sbq_group_kth_workspace_bytes": (c_sz, [c_int]),
+    "sbq_group_kth_value": (c_int, [c_vp, c_int, c_int, c_int, c_vp, c_vp, c_sz, c_vp]),
+    "sbq_calib_table_build": (c_int, [c_vp, c_int, c_vp, c_sz, c_vp, c_vp, c_vp]),
+    "sbq_group_minmax_qparams": (c_int, [c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "sbq_group_mse_qparams": (c_int, [c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "sbq_mask_quant_forward": (
         c_int,
         [c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_int, c_int, c_int, c_vp],

@@ -405,6 +405,93 @@ class GroupFakeQuant:
         return [t.view(sh) for t, sh in zip(flat.split_with_sizes(self.numels), self.shapes)]
 
 
+class GroupCalibration:
+    """Model-wide weight calibration: the min-max (and MSE) observers + calc_qparams of a whole list of weights in
+    two (four) launches instead of 3-5 per layer (tools/calibration.py:117-135 loops the layers).
+
+    entries: list of (weight, qmin, qmax, symmetric, per_channel).  Weights must stay where they are (pointers are
+    captured).  `supports(w)` tells which tensors the grouped launch takes (contiguous, 16-byte aligned, rows of
+    whole 8-element packs); the caller calibrates the others one by one.  Results are bit-identical to the
+    per-tensor ops (channel_stats + qparams_from_minmax, mse_accumulate + mse_select)."""
+
+    @staticmethod
+    def supports(w, per_channel=True):
+        inner = w[0].numel() if per_channel else w.numel()
+        return bool(w.is_cuda and w.is_contiguous() and w.data_ptr() % 16 == 0 and inner % 8 == 0 and w.numel() > 0
+                    and w.dtype in _DTYPE_IDS)
+
+    def __init__(self, entries):
+        lib = L.load()
+        if not entries:
+            raise L.SbqError("GroupCalibration needs at least one tensor")
+        self.dev = L.require_device(*[e[0] for e in entries])
+        self.dtype = entries[0][0].dtype
+        self.tensors = [e[0] for e in entries]
+        n = len(entries)
+        items = (L.CalibItem * n)()
+        off = 0
+        self.slices = []
+        for i, (w, qmin, qmax, symmetric, per_channel) in enumerate(entries):
+            if w.dtype != self.dtype:
+                raise L.SbqError("GroupCalibration: tensors must share a dtype")
+            if not self.supports(w, per_channel):
+                raise L.SbqError("GroupCalibration: tensor %d is not eligible (see supports())" % i)
+            C = w.shape[0] if per_channel else 1
+            items[i] = L.CalibItem(w.data_ptr(), C, w.numel() // C, off, int(qmin), int(qmax),
+                                   L.CALIB_SYMMETRIC if symmetric else 0, 0)
+            self.slices.append(slice(off, off + C))
+            off += C
+        self.n_values = off
+        n_rows = ctypes.c_uint32()
+        nbytes = ctypes.c_size_t()
+        ws_bytes = ctypes.c_size_t()
+        L.check(lib.sbq_calib_table_build(items, n, None, 0, ctypes.byref(n_rows), ctypes.byref(nbytes), ctypes.byref(ws_bytes)))
+        self.host_table = (ctypes.c_uint8 * nbytes.value)()
+        L.check(lib.sbq_calib_table_build(items, n, self.host_table, nbytes.value, ctypes.byref(n_rows), ctypes.byref(nbytes),
+                                          ctypes.byref(ws_bytes)))
+        self.table = torch.frombuffer(self.host_table, dtype=torch.uint8).to(self.dev)
+        self.ws = torch.empty(max(ws_bytes.value, 16), dtype=torch.uint8, device=self.dev)
+        self.mn = torch.empty(off, dtype=torch.float32, device=self.dev)
+        self.mx = torch.empty(off, dtype=torch.float32, device=self.dev)
+        self.scale = torch.empty(off, dtype=torch.float32, device=self.dev)
+        self.zp = torch.empty(off, dtype=torch.float32, device=self.dev)
+        self.index = torch.empty(off, dtype=torch.int32, device=self.dev)
+        # per-tensor views into the flat result buffers, made once (the launches below only refill the buffers)
+        self.views = {name: [getattr(self, name)[sl] for sl in self.slices] for name in ("mn", "mx", "scale", "zp", "index")}
+
+    def launch_minmax(self, want_qparams=True):
+        """enqueue the two launches; results land in the flat buffers self.mn / mx (/ scale / zp)"""
+        lib = L.load()
+        with L.device_guard(self.dev):
+            rc = lib.sbq_group_minmax_qparams(L.ptr(self.table), self.host_table, _DTYPE_IDS[self.dtype], L.ptr(self.mn),
+                                              L.ptr(self.mx), L.ptr(self.scale) if want_qparams else None,
+                                              L.ptr(self.zp) if want_qparams else None, L.ptr(self.ws), self.ws.numel(),
+                                              L.stream_ptr(self.dev))
+        L.check(rc)
+
+    def launch_mse(self):
+        """enqueue the four launches of the MSE calibration; results in self.scale / zp / index"""
+        lib = L.load()
+        self.launch_minmax(want_qparams=False)
+        with L.device_guard(self.dev):
+            rc = lib.sbq_group_mse_qparams(L.ptr(self.table), self.host_table, _DTYPE_IDS[self.dtype], L.ptr(self.mn),
+                                           L.ptr(self.mx), L.ptr(self.scale), L.ptr(self.zp), L.ptr(self.index), L.ptr(self.ws),
+                                           self.ws.numel(), L.stream_ptr(self.dev))
+        L.check(rc)
+
+    def minmax_qparams(self):
+        """-> per tensor lists (min, max, scale, zero_point): views into four flat fp32 buffers"""
+        self.launch_minmax()
+        v = self.views
+        return v["mn"], v["mx"], v["scale"], v["zp"]
+
+    def mse_qparams(self):
+        """min-max statistics, then the 80-candidate MSE search -> per tensor lists (scale, zero_point, best index)"""
+        self.launch_mse()
+        v = self.views
+        return v["scale"], v["zp"], v["index"]
+
+
 class GroupFakeQuantBackward:
     """STE backward of a whole group in two launches (sbq_quant_group_backward).
 
@@ -903,6 +990,45 @@ def kth_value(x, k, use_abs=False):
         rc = lib.sbq_kth_value(L.ptr(x), L.dtype_id(x), x.numel(), int(bool(use_abs)), int(k), L.ptr(out), L.ptr(ws),
                                ws.numel(), L.stream_ptr(dev))
     L.check(rc)
+    return out
+
+
+_group_kth_workspaces = {}
+
+
+def group_kth_value(tensors, ks, use_abs=False):
+    """k-th smallest of MANY tensors (of their absolute values with use_abs) in one launch (three for fp32): the L1
+    thresholds of a whole model (sparse/sparse_model.py:107-113).  -> flat fp32 tensor [len(tensors)].
+    Tensors the grouped launch does not take (unaligned, fewer than 8 elements, not contiguous) go through kth_value."""
+    dev = L.require_device(*tensors)
+    lib = L.load()
+    n = len(tensors)
+    if n == 0 or n != len(ks):
+        raise L.SbqError("group_kth_value: one rank per tensor")
+    out = torch.empty(n, dtype=torch.float32, device=dev)
+    dtype = tensors[0].dtype
+    ok = [t.is_contiguous() and t.data_ptr() % 16 == 0 and t.numel() >= 8 and t.dtype == dtype for t in tensors]
+    idx = [i for i in range(n) if ok[i]]
+    if idx:
+        items = (L.KthItem * len(idx))()
+        for j, i in enumerate(idx):
+            items[j] = L.KthItem(tensors[i].data_ptr(), tensors[i].numel(), int(ks[i]))
+        nbytes = lib.sbq_group_kth_workspace_bytes(len(idx))
+        key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+        ws = _group_kth_workspaces.get(key)
+        if ws is None or ws.numel() < nbytes:
+            ws = torch.zeros(nbytes, dtype=torch.uint8, device=dev)  # zero before first use (include/sbq.h)
+            _group_kth_workspaces[key] = ws
+        vals = out if len(idx) == n else torch.empty(len(idx), dtype=torch.float32, device=dev)
+        with L.device_guard(dev):
+            rc = lib.sbq_group_kth_value(items, len(idx), L.dtype_id(tensors[idx[0]]), int(bool(use_abs)), L.ptr(vals), L.ptr(ws),
+                                         ws.numel(), L.stream_ptr(dev))
+        L.check(rc)
+        if vals is not out:
+            out[torch.tensor(idx, device=dev)] = vals
+    for i in range(n):
+        if not ok[i]:
+            out[i] = kth_value(tensors[i], ks[i], use_abs)
     return out
 
 

@@ -189,3 +189,69 @@ def test_one_launch_engine_back_to_back_on_one_workspace(ops):
     torch.cuda.synchronize()
     for j, o in enumerate(outs):
         assert float(o) == want[j % 8], j
+
+
+# --------------------------------------------------------------------------------------
+# model-wide calibration launches (csrc/sbq_calib.hip, group_kth_kernel)
+# --------------------------------------------------------------------------------------
+CALIB_SHAPES = [(64, 64, 1, 1), (64, 64, 3, 3), (256, 64, 1, 1), (512, 512, 3, 3), (100, 2048), (8, 8), (3, 16392),
+                (5, 4096 * 3 + 8), (1, 40000)]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("symmetric,qmin,qmax", [(True, -128, 127), (False, 0, 255), (True, -8, 7)])
+def test_group_calibration_equals_per_tensor(oracle, ops, dtype, symmetric, qmin, qmax):
+    """min-max and MSE qparams of a list of weights by the grouped launches == the per-tensor ops, bit for bit (per
+    channel and per tensor items mixed), and == the oracle on one of them"""
+    from sparsebit_amd import lib as L
+
+    g = torch.Generator().manual_seed(17)
+    ws = [(torch.randn(s, generator=g) * (0.1 + i)).to(dtype).cuda() for i, s in enumerate(CALIB_SHAPES)]
+    ws[2].view(-1)[5] = float("nan")  # a NaN row propagates like torch.min / max
+    per_channel = [i % 4 != 3 for i in range(len(ws))]
+    grp = ops.GroupCalibration([(w, qmin, qmax, symmetric, pc) for w, pc in zip(ws, per_channel)])
+    mn, mx, s, z = grp.minmax_qparams()
+    for i, w in enumerate(ws):
+        rmn, rmx, _ = ops.channel_stats(w, 0, per_channel[i])
+        rs, rz = ops.qparams_from_minmax(rmn, rmx, qmin, qmax, symmetric)
+        assert same_values(mn[i].cpu().numpy(), rmn.cpu().numpy().reshape(-1)), i
+        assert same_values(mx[i].cpu().numpy(), rmx.cpu().numpy().reshape(-1)), i
+        assert same_values(s[i].cpu().numpy(), rs.cpu().numpy().reshape(-1)), i
+        assert same_values(z[i].cpu().numpy(), rz.cpu().numpy().reshape(-1)), i
+    ws[2].view(-1)[5] = 0.5
+    # (the grouped MSE launch takes rows of at most 96 chunks: the 2.4 M-element tensor stays per channel here)
+    per_channel = [i not in (7, 8) for i in range(len(ws))]
+    grp = ops.GroupCalibration([(w, qmin, qmax, symmetric, pc) for w, pc in zip(ws, per_channel)])
+    s, z, idx = grp.mse_qparams()
+    for i, w in enumerate(ws):
+        rmn, rmx, _ = ops.channel_stats(w, 0, per_channel[i])
+        C = w.shape[0] if per_channel[i] else 1
+        sse = torch.zeros(C, L.MSE_CANDIDATES, dtype=torch.float64, device="cuda")
+        ops.mse_accumulate(w, rmn, rmx, qmin, qmax, symmetric, sse, 0, per_channel[i])
+        rs, rz, ri = ops.mse_select(sse, w.numel() // C, rmn, rmx, qmin, qmax, symmetric)
+        assert torch.equal(idx[i], ri.reshape(-1)), i
+        assert torch.equal(s[i], rs.reshape(-1)) and torch.equal(z[i], rz.reshape(-1)), i
+    k = 1
+    _, _, b_ref, _ = oracle.mse(ws[k].float().cpu().numpy().reshape(ws[k].shape[0], -1), qmin, qmax, symmetric, 0, True)
+    assert np.array_equal(idx[k].cpu().numpy(), b_ref)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_group_kth_value_equals_per_tensor(ops, dtype):
+    g = torch.Generator().manual_seed(23)
+    sizes = [9, 64, 4099, 16384, 16384 * 3 + 5, 147 * 64, 1 << 20, 2359296, 8, 100003]
+    ts = [(torch.randn(n, generator=g) * (1 + i)).to(dtype).cuda() for i, n in enumerate(sizes)]
+    ts.append(torch.randn(70001, generator=g).to(dtype).cuda()[1:])  # unaligned: goes through kth_value
+    ts.append(torch.randn(5, generator=g).to(dtype).cuda())          # tiny: likewise
+    for ratio in (0.5, 0.0, 0.999):
+        ks = [min(int(t.numel() * ratio), t.numel() - 1) + 1 for t in ts]
+        got = ops.group_kth_value(ts, ks, True)
+        for i, t in enumerate(ts):
+            a = np.abs(t.float().cpu().numpy().reshape(-1))
+            assert float(got[i]) == float(np.sort(a)[ks[i] - 1]), (i, ratio)
+    # twice more through the same workspace (it must come back clean), signed keys this time
+    for rep in range(2):
+        ks = [t.numel() // 3 + 1 for t in ts]
+        got = ops.group_kth_value(ts, ks, False)
+        for i, t in enumerate(ts):
+            assert float(got[i]) == float(np.sort(t.float().cpu().numpy().reshape(-1))[ks[i] - 1]), (i, rep)

@@ -50,6 +50,8 @@ def main():
     ap.add_argument("--steps", type=int, default=500)
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--quick", action="store_true",
+                    help="headline + multi-GPU plumbing only: no config legs, no CPU baseline (tests/test_gpu_bench_n2.py)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -380,6 +382,7 @@ def main():
     #      gate computed in this run (bench_configs.py).  Rank 0 only: the oracle legs are host work.
     if rank == 0:
         extras["headline_gates"] = gates
+    if rank == 0 and not args.quick:
         extras["configs"] = {
             "config2_mse_per_channel": BC.config2_mse(ctx),
             "config3_percentile": BC.config3_percentile(ctx),
@@ -401,7 +404,7 @@ def main():
 
     # ---- CPU baseline: the reference's CPU fake-quant ops on this box's host cores -----------
     cpu_baseline = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.quick:
         from oracle import torch_port
 
         # the reference would run with torch's default thread count (all cores); on a many-core

@@ -321,6 +321,60 @@ def config4_gptq(c):
                            "reference test's tolerance", weight_copies_in_rotation=copies,
                            cache_resident_us=round(us_warm, 3), max_abs_err=float(np.abs(got - ref).max()))
         del qws, scs, zrs
+    # ---- a decoder layer's projections that share their input, as ONE launch each (quant.py:262-278 issues one
+    #      mat-vec per QuantLinear): q / k / v = 3 x (4096 -> 4096); gate + up = 2 x (4096 -> 11008)
+    for name, in_f, outs in (("qkv_3x4096x4096_one_launch", 4096, (4096, 4096, 4096)),
+                             ("gate_up_2x4096x11008_one_launch", 4096, (11008, 11008))):
+        groups = in_f // 128
+        w_bytes = sum(in_f // 8 * o * 4 for o in outs)
+        copies = max(2, int(3.2e8 // w_bytes) + 1)
+        sets = []
+        for cpy in range(copies):
+            mats = []
+            for m, o in enumerate(outs):
+                qws, scs, zrs, x = _gptq_problem(in_f, o, 40 + cpy * 8 + m, c.dev, 1)
+                mats.append((qws[0], scs[0], zrs[0]))
+            sets.append(mats)
+        xd = x.to(c.dev)
+        ys = [torch.zeros(1, o, dtype=torch.float32, device=c.dev) for o in outs]
+        total = sum(outs)
+        ws = torch.zeros(max(lib.sbq_gptq_workspace_bytes(1, in_f, total), 16), dtype=torch.uint8, device=c.dev)
+        n = len(outs)
+        arr = lambda ts: (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts])  # noqa: E731
+        outf = (ctypes.c_int64 * n)(*outs)
+        yp = arr(ys)
+        margs = [(arr([m[0] for m in mats]), arr([m[1] for m in mats]), arr([m[2] for m in mats])) for mats in sets]
+
+        def run(i):
+            a = margs[i % copies]
+            return lib.sbq_vecquantmatmul_multi(4, L.ptr(xd), n, a[0], yp, a[1], a[2], outf, 1, in_f, 128, L.ptr(ws), ws.numel(), c.st)
+
+        us = c.timed(run, 300, warm=30)
+
+        def run_single(i):
+            mats = sets[i % copies]
+            for m in range(n):
+                lib.sbq_vecquant4matmul(L.ptr(xd), L.ptr(mats[m][0]), L.ptr(ys[m]), L.ptr(mats[m][1]), L.ptr(mats[m][2]), 1, in_f,
+                                        outs[m], 128, L.ptr(ws), ws.numel(), c.st)
+
+        us_1 = c.timed(run_single, 200, warm=20)
+        for y in ys:
+            y.zero_()
+        L.check(run(0))
+        torch.cuda.synchronize(c.dev)
+        ok = True
+        worst = 0.0
+        for m in range(n):
+            ref = O.vecquantmatmul(x.numpy(), sets[0][m][0].cpu().numpy(), np.zeros(outs[m], np.float32), sets[0][m][1].cpu().numpy(),
+                                   sets[0][m][2].cpu().numpy(), 128, 4)
+            got = ys[m].cpu().numpy()
+            tol = 1e-5 * max(1.0, float(np.abs(ref).max()))
+            ok = ok and bool(np.all(np.abs(got - ref) <= tol + 1e-5 * np.abs(ref)))
+            worst = max(worst, float(np.abs(got - ref).max()))
+        nbytes = w_bytes + sum(2 * o * groups * 4 for o in outs) + (in_f + 2 * total) * 4
+        out[name] = _entry(us, nbytes, ok, "every matrix's y == oracle at the reference test's tolerance", launches=1,
+                           one_launch_per_matrix_us=round(us_1, 3), us_per_4096x4096_equivalent=round(us * 9486336 / nbytes, 3),
+                           weight_copies_in_rotation=copies, max_abs_err=worst)
     return out
 
 

@@ -470,6 +470,15 @@ int sbq_mask_from_threshold(const void* x, int x_dtype, int64_t numel,
  *    Deterministic: fixed summation order (the persistent-strip kernel of HBM-sized matrices adds each output
  *    element with ONE float atomic -- a single addend, so still order independent).
  * ------------------------------------------------------------------ */
+/* GPTQ's find_params grid search (quant.py:86-104, `mse=True`): for every row of x [rows, inner] (an output channel,
+ * or one quantization group of it) the first of n_candidates shrink factors p = 1 - i / grid with the strictly
+ * smallest sum |quantize(x; p * xmin, p * xmax) - x|^norm.  xmin / xmax: the row's adjusted extrema (quant.py:71-84);
+ * scale_io / zero_io hold the un-shrunk parameters on entry and the chosen ones on return; index_out (or NULL) the
+ * chosen i (-1: none was finite).  symmetric: zero stays (maxq + 1) / 2. */
+int sbq_gptq_mse_search(const void* x, int x_dtype, int64_t rows, int64_t inner, const float* xmin, const float* xmax,
+                        int maxq, int symmetric, float norm, int grid, int n_candidates,
+                        float* scale_io, float* zero_io, int32_t* index_out, void* stream);
+
 /* Workspace contract: its first SBQ_GPTQ_COUNTER_BYTES bytes are arrival counters of the
  * single-launch K-split fold; they must be ZERO before the first call (allocate with
  * hipMemset once), every call leaves them zero, and a workspace must not be shared by calls
@@ -492,6 +501,19 @@ int sbq_vecquant2matmul(const float* x, const int32_t* qweight, float* out,
                         int64_t group_size,
                         void* workspace, size_t workspace_bytes, void* stream);
 
+/* Several quantized matrices that share the activation vector -- the q / k / v projections of a decoder layer, the
+ * gate and up projections of its MLP -- in ONE launch: the reference issues one mat-vec per QuantLinear
+ * (quant.py:262-278), seven launches of 6-9 us per LLaMA-7B decoder layer for 4-8 us of bandwidth work.  All arrays
+ * are HOST arrays of n_mats (<= 4) entries; matrix m is [rows(in_features), out_features[m]] with its own scales /
+ * zeros / pre-filled out.  Results are those of n_mats single calls up to the fp32 summation order across K blocks
+ * (the K split is chosen for the whole launch; equal splits give bit-identical results) -- and single calls are what
+ * runs for anything the strip kernel does not take.  Workspace: sbq_gptq_workspace_bytes(batch, in_features, sum of out_features), same
+ * zero-counter contract. */
+int sbq_vecquantmatmul_multi(int bits, const float* x, int n_mats, const int32_t* const* qweights, float* const* outs,
+                             const float* const* scales, const float* const* zeros, const int64_t* out_features,
+                             int64_t batch, int64_t in_features, int64_t group_size,
+                             void* workspace, size_t workspace_bytes, void* stream);
+
 /* ------------------------------------------------------------------ *
  * 6. Launch tuning (benchmarks only; defaults are chosen per shape)
  * ------------------------------------------------------------------ */
@@ -500,7 +522,8 @@ int sbq_vecquant2matmul(const float* x, const int32_t* qweight, float* out,
  * knob 2: A/B switches that never change results (3 = IEEE division in the headline QDQ
  * kernel; 1 / 2 = 128 / 64 channels per K lane, 4 = byte converts instead of the e4m3 decode,
  * 9 = two-launch path in the GPTQ mat-vec, 6 = no LDS-DMA prefetch, 8 = plain strip order,
- * 5 = (strip, K block) grid instead of the persistent strip workers on HBM-sized matrices --
+ * 5 = (strip, K block) grid instead of the persistent strip workers on HBM-sized matrices, 13 = round 2's K-split
+ * rule --
  * and, in sbq_percentile_rows, the general row kernel instead of the small-rank extraction;
  * 7 = fixed-digit radix engine for whole-tensor selections, 12 = the multi-launch windowed protocol (plan / sweep /
  * advance / fallback launches) instead of the one-launch engine, 11 = general statistics kernel for a min-max-only call). knob 3: resident schedule of the forward QDQ

@@ -201,10 +201,11 @@ def vecquantmatmul(x, qweight, bias, scales, zeros, group_size, bits):
 
 
 # ---- GPTQ host-side helpers (numpy restatements; offline steps of config 4) ----------
-def gptq_find_params(w, bit=4, groupsize=-1):
-    """Quantizer.find_params(weight=True, perchannel=True, sym=False, mse=False)
-    (llama/quantization/utils/quant.py:43-132): per (row, group) asymmetric min/max.
-    -> scale, zero shaped [out, groups]"""
+def gptq_find_params(w, bit=4, groupsize=-1, sym=False, mse=False, norm=2.4, grid=100, maxshrink=0.8):
+    """Quantizer.find_params(weight=True, perchannel=True) (llama/quantization/utils/quant.py:43-132): per (row,
+    group) min/max parameters, symmetric (:77-81, zero = (maxq + 1) / 2) or asymmetric, and optionally the `mse` grid
+    search of :86-104 (80 shrink factors p = 1 - i / grid, error sum |quantize(x) - x|^norm, first strictly smaller
+    wins).  -> scale, zero shaped [out, groups]  (+ errs [rows, candidates] when mse, for tie analysis)"""
     w = _f32(w)
     out_f, in_f = w.shape
     gs = in_f if groupsize == -1 else groupsize
@@ -213,12 +214,33 @@ def gptq_find_params(w, bit=4, groupsize=-1):
     xg = w.reshape(-1, gs)
     xmin = np.minimum(xg.min(1), np.float32(0))
     xmax = np.maximum(xg.max(1), np.float32(0))
+    if sym:
+        xmax = np.maximum(np.abs(xmin), xmax)
+        xmin = np.where(xmin < 0, -xmax, xmin).astype(np.float32)
     both0 = (xmin == 0) & (xmax == 0)
     xmin[both0] = -1
     xmax[both0] = +1
     scale = ((xmax - xmin) / maxq).astype(np.float32)
-    zero = np.rint(-xmin / scale).astype(np.float32)
-    return scale.reshape(out_f, -1), zero.reshape(out_f, -1)
+    zero = (np.full_like(scale, (maxq + 1) / 2) if sym else np.rint(-xmin / scale)).astype(np.float32)
+    if not mse:
+        return scale.reshape(out_f, -1), zero.reshape(out_f, -1)
+    best = np.full(xg.shape[0], np.inf, dtype=np.float32)
+    zero0 = zero.copy()
+    errs = []
+    for i in range(int(maxshrink * grid)):
+        p = np.float32(1 - i / grid)
+        xmin1, xmax1 = p * xmin, p * xmax
+        scale1 = ((xmax1 - xmin1) / maxq).astype(np.float32)
+        zero1 = zero0 if sym else np.rint(-xmin1 / scale1).astype(np.float32)
+        q = np.clip(np.rint(xg / scale1[:, None]) + zero1[:, None], 0, maxq).astype(np.float32)
+        d = np.abs(scale1[:, None] * (q - zero1[:, None]) - xg).astype(np.float32)
+        err = np.power(d, np.float32(norm)).astype(np.float32).sum(1, dtype=np.float32)
+        errs.append(err)
+        better = err < best
+        best = np.where(better, err, best)
+        scale = np.where(better, scale1, scale)
+        zero = np.where(better, zero1, zero)
+    return scale.reshape(out_f, -1), zero.reshape(out_f, -1), np.stack(errs, 1)
 
 
 def gptq_quantize(w, scale, zero, bit=4):

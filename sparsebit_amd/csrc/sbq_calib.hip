@@ -244,10 +244,82 @@ __global__ __launch_bounds__(kBlock) void calib_mse_select_kernel(const CalibIte
   }
 }
 
+// ---- GPTQ's grid search (large_language_models/llama/quantization/utils/quant.py:86-104) ----------------------
+// find_params(mse=True): for every row (output channel, or one group of it) the shrink factor p = 1 - i / grid whose
+// parameters give the smallest sum |quantize(x) - x|^norm; the first strictly smaller error wins.  The reference
+// makes int(maxshrink * grid) = 80 passes of six tensor ops over the whole weight; here a wave keeps walking its
+// row (L1 / L2 resident after the first pass) and only scale / zero / index leave the kernel.  fp32 operation for
+// operation like the tensor ops (the Python scalar p is rounded to fp32 where torch multiplies a fp32 tensor by
+// it); the error sums are fp32 lane partials + a wave reduction, where torch.sum has its own order -- candidates
+// whose errors tie to the last bits may swap, which the tests allow for (tests/test_gpu_r03.py).
+template <typename T>
+__global__ __launch_bounds__(kBlock) void gptq_mse_kernel(const void* __restrict__ x, int64_t rows, int64_t inner,
+                                                          const float* __restrict__ xmin_v, const float* __restrict__ xmax_v,
+                                                          float maxq, int symmetric, float zero_sym, float norm, int grid,
+                                                          int n_cand, float* __restrict__ scale_io,
+                                                          float* __restrict__ zero_io, int32_t* __restrict__ index_out) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int64_t row = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + threadIdx.x / kWave;
+  if (row >= rows) return;
+  const float xmin = xmin_v[row], xmax = xmax_v[row];
+  float best = __builtin_inff();
+  float best_s = scale_io[row], best_z = zero_io[row];
+  int best_i = -1;
+  for (int i = 0; i < n_cand; ++i) {
+    const float p = static_cast<float>(1.0 - static_cast<double>(i) / static_cast<double>(grid));
+    const float xmin1 = p * xmin, xmax1 = p * xmax;
+    const float scale1 = (xmax1 - xmin1) / maxq;
+    const float zero1 = symmetric ? zero_sym : __builtin_rintf(-xmin1 / scale1);
+    float err = 0.0f;
+    for (int64_t e = lane; e < inner; e += kWave) {
+      const float v = Elem<T>::load1(x, row * inner + e);
+      float q = __builtin_rintf(v / scale1) + zero1;
+      const float qc = __builtin_fminf(__builtin_fmaxf(q, 0.0f), maxq);  // torch.clamp(.., 0, maxq) ...
+      q = (q != q) ? q : qc;                                               // ... which propagates NaN
+      const float d = __builtin_fabsf(scale1 * (q - zero1) - v);
+      err += __builtin_powf(d, norm);
+    }
+    err = wave_reduce(err, Sum());
+    if (err < best) {
+      best = err;
+      best_s = scale1;
+      best_z = zero1;
+      best_i = i;
+    }
+  }
+  if (lane == 0) {
+    scale_io[row] = best_s;
+    zero_io[row] = best_z;
+    if (index_out) index_out[row] = best_i;
+  }
+}
+
 }  // namespace
 }  // namespace sbq
 
 extern "C" {
+
+int sbq_gptq_mse_search(const void* x, int x_dtype, int64_t rows, int64_t inner, const float* xmin, const float* xmax,
+                        int maxq, int symmetric, float norm, int grid, int n_candidates, float* scale_io,
+                        float* zero_io, int32_t* index_out, void* stream) {
+  using namespace sbq;
+  if (!valid_dtype(x_dtype)) return SBQ_ERR_DTYPE;
+  if (rows < 0 || inner < 0) return SBQ_ERR_ARG;
+  if (rows == 0 || inner == 0) return SBQ_ERR_EMPTY;
+  if (!x || !xmin || !xmax || !scale_io || !zero_io) return SBQ_ERR_NULL;
+  if (maxq < 1 || grid < 1 || n_candidates < 0 || rows >= (1ll << 33)) return SBQ_ERR_ARG;
+  if (reinterpret_cast<uintptr_t>(x) % dtype_size(x_dtype)) return SBQ_ERR_ALIGN;
+  hipStream_t st = as_stream(stream);
+  const uint32_t gridx = static_cast<uint32_t>(ceil_div(rows, static_cast<int64_t>(kWavesPerBlock)));
+  const float zero_sym = static_cast<float>((maxq + 1) / 2.0);
+  int rc = dispatch_dtype(x_dtype, [&](auto tag) {
+    using T = decltype(tag);
+    gptq_mse_kernel<T><<<gridx, kBlock, 0, st>>>(x, rows, inner, xmin, xmax, static_cast<float>(maxq), symmetric, zero_sym,
+                                               norm, grid, n_candidates, scale_io, zero_io, index_out);
+  });
+  if (rc != SBQ_OK) return rc;
+  return check_launch();
+}
 
 // table = [header | items | statistics workgroup -> item | MSE chunk -> item]
 int sbq_calib_table_build(const sbq_calib_item* items, int n_items, void* host_table, size_t host_table_bytes,

@@ -419,11 +419,34 @@ __device__ __forceinline__ void strip_fold_partials(uint32_t strip, int split, c
 // pass p is being computed, and are picked up from LDS at the top of pass p+1.  A wave only ever reads back the
 // words its own lanes requested, so the weight ring needs no barrier; in-flight bytes cost LDS, not registers,
 // so three workgroups per CU keep ~96 KB of weight reads outstanding ALL the time instead of 4 x 32 KB half of it.
+// Several matrices that share the activation vector (the q / k / v projections of a decoder layer; gate + up of its
+// MLP: quant.py:262-278 issues one mat-vec per QuantLinear) as ONE launch: the strips of all of them form one grid,
+// a workgroup looks up its matrix (uniform scalar loads out of the kernel arguments) and proceeds as for a single
+// matrix.  n == 0: the plain pointer arguments.
+constexpr int kMaxMulti = 4;
+struct GptqMulti {
+  int32_t n;
+  int32_t strip_begin[kMaxMulti + 1];
+  const int32_t* qw[kMaxMulti];
+  const float* scales[kMaxMulti];
+  const float* zeros[kMaxMulti];
+  float* out[kMaxMulti];
+  int64_t out_features[kMaxMulti];
+  int64_t part_off[kMaxMulti];  // floats: where the matrix's partial tiles start
+};
+
 template <int BITS, int kBT, int KL, int CH, bool DEC8 = false, bool PF = false>
 __global__ __launch_bounds__(8 * KL) __attribute__((amdgpu_waves_per_eu(CH == 64 && kBT == 1 ? (PF ? 3 : 4) : 1, 8))) void gptq_strip_kernel(
-    const float* __restrict__ x, const int32_t* __restrict__ qw, const float* __restrict__ scales,
-    const float* __restrict__ zeros, float* __restrict__ out, float* __restrict__ part,
-    uint32_t* __restrict__ arrivals, const GptqGeom g) {
+    const float* __restrict__ x, const int32_t* __restrict__ qw_a, const float* __restrict__ scales_a,
+    const float* __restrict__ zeros_a, float* __restrict__ out_a, float* __restrict__ part_a,
+    uint32_t* __restrict__ arrivals_a, const GptqGeom g_a, const GptqMulti mm) {
+  GptqGeom g = g_a;
+  const int32_t* __restrict__ qw = qw_a;
+  const float* __restrict__ scales = scales_a;
+  const float* __restrict__ zeros = zeros_a;
+  float* __restrict__ out = out_a;
+  float* __restrict__ part = part_a;
+  uint32_t* __restrict__ arrivals = arrivals_a;
   constexpr int kThreads = 8 * KL;
   constexpr int kRows = CH * BITS / 32;       // qweight rows of one K lane: 16 / 12 / 8 for CH = 128
   constexpr int kRowsPerPass = KL * kRows;    // = KL * CH input channels
@@ -440,6 +463,18 @@ __global__ __launch_bounds__(8 * KL) __attribute__((amdgpu_waves_per_eu(CH == 64
   // pieces of the same rows (knob 2 == 8: plain order, for A/B runs).
   uint32_t strip = blockIdx.x;
   if (g.xcd_swizzle) strip = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  if (mm.n > 0) {
+    int m = 0;
+    while (m + 1 < mm.n && strip >= static_cast<uint32_t>(mm.strip_begin[m + 1])) ++m;  // uniform
+    qw = mm.qw[m];
+    scales = mm.scales[m];
+    zeros = mm.zeros[m];
+    out = mm.out[m];
+    g.out_features = mm.out_features[m];
+    part = part_a + mm.part_off[m];
+    arrivals = arrivals_a + mm.strip_begin[m];
+    strip -= static_cast<uint32_t>(mm.strip_begin[m]);
+  }
   const int64_t col0 = static_cast<int64_t>(strip) * kStripCols + cl * 4;
   const int split = gridDim.y;
   // 16-byte loads of x need aligned rows
@@ -994,7 +1029,7 @@ int gptq_matmul(const float* x, const int32_t* qweight, float* out, const float*
     if (split > kStripMaxSplit) split = kStripMaxSplit;
     const dim3 grid(static_cast<uint32_t>(strips), static_cast<uint32_t>(split));
     gptq_strip_kernel<BITS, 4, 32, kSliceK / 2, BITS != 3><<<grid, 256, 0, st>>>(x, qweight, scales, zeros, out, part,
-                                                                                arrivals, g);
+                                                                                arrivals, g, GptqMulti{});
     return check_launch();
   }
   if (vec && out_features % kStripCols == 0 && batch <= 2 && !half_slices && strips <= kMaxStrips &&
@@ -1012,7 +1047,14 @@ int gptq_matmul(const float* x, const int32_t* qweight, float* out, const float*
     // every extra block is another partial tile, another arrival and another workgroup start-up for the same bytes.
     // A matrix with >= 2048 strips needs none: each workgroup walks all of K and adds to `out` directly.
     const int64_t passes = ceil_div(in_features, 32 * ch);
-    int64_t split = ceil_div(static_cast<int64_t>(cu_count()) * 8, strips);
+    // Round 3 (tools/r03_gptq_probe.py, HBM-cold, B = 1): the split's price -- partial tiles, the arrival add and the
+    // last arriver's fold are three dependent memory round trips -- exceeds its gain whenever a workgroup's own K walk
+    // is short.  4096 -> {4096, 11008, 12288, 22016} (two passes): 7.3 / 11.3 / 11.3 / 15.9 us unsplit against 8.7 /
+    // 13.8 / 14.3 / 22.6 with any split; 11008 -> 4096 (six passes, 128 strips): 15.7 unsplit, 12.2 with two K blocks,
+    // 15.2 with six.  So: one K block per three passes, more only to put a workgroup on every other CU.
+    int64_t split = passes >= 3 ? ceil_div(passes, 3) : 1;
+    while (strips * split * 2 < static_cast<int64_t>(cu_count()) && split < passes) ++split;
+    if (knob(2) == 13) split = ceil_div(static_cast<int64_t>(cu_count()) * 8, strips);  // round 2's rule, for A/B runs
     if (knob(1) > 0 && knob(1) < 128) split = knob(1);  // dev override (shares the grid-cap knob)
     if (split > passes) split = passes;
     if (split > kStripMaxSplit) split = kStripMaxSplit;
@@ -1021,9 +1063,9 @@ int gptq_matmul(const float* x, const int32_t* qweight, float* out, const float*
 #define SBQ_STRIP(CH, D8)                                                                                  \
   do {                                                                                                     \
     if (batch == 2)                                                                                        \
-      gptq_strip_kernel<BITS, 2, 32, CH, D8><<<grid, 256, 0, st>>>(x, qweight, scales, zeros, out, part, arrivals, g); \
+      gptq_strip_kernel<BITS, 2, 32, CH, D8><<<grid, 256, 0, st>>>(x, qweight, scales, zeros, out, part, arrivals, g, GptqMulti{}); \
     else                                                                                                   \
-      gptq_strip_kernel<BITS, 1, 32, CH, D8><<<grid, 256, 0, st>>>(x, qweight, scales, zeros, out, part, arrivals, g); \
+      gptq_strip_kernel<BITS, 1, 32, CH, D8><<<grid, 256, 0, st>>>(x, qweight, scales, zeros, out, part, arrivals, g, GptqMulti{}); \
   } while (0)
     // several passes per workgroup (HBM-sized matrices): the next pass's weights are prefetched by LDS-DMA
     // (knob 2 == 6: off, for A/B runs)
@@ -1068,9 +1110,9 @@ int gptq_matmul(const float* x, const int32_t* qweight, float* out, const float*
       if (knob(2) != 4) {  // packed e4m3 decode (knob 2 == 4: byte converts, for A/B runs)
         if (prefetch) {
           if (batch == 2)
-            gptq_strip_kernel<BITS, 2, 32, 64, true, true><<<grid, 256, 0, st>>>(x, qweight, scales, zeros, out, part, arrivals, g);
+            gptq_strip_kernel<BITS, 2, 32, 64, true, true><<<grid, 256, 0, st>>>(x, qweight, scales, zeros, out, part, arrivals, g, GptqMulti{});
           else
-            gptq_strip_kernel<BITS, 1, 32, 64, true, true><<<grid, 256, 0, st>>>(x, qweight, scales, zeros, out, part, arrivals, g);
+            gptq_strip_kernel<BITS, 1, 32, 64, true, true><<<grid, 256, 0, st>>>(x, qweight, scales, zeros, out, part, arrivals, g, GptqMulti{});
           return check_launch();
         }
         if (ch == kSliceK) SBQ_STRIP(128, true);
@@ -1080,9 +1122,9 @@ int gptq_matmul(const float* x, const int32_t* qweight, float* out, const float*
     }
     if (prefetch && BITS == 3) {
       if (batch == 2)
-        gptq_strip_kernel<BITS, 2, 32, 64, false, true><<<grid, 256, 0, st>>>(x, qweight, scales, zeros, out, part, arrivals, g);
+        gptq_strip_kernel<BITS, 2, 32, 64, false, true><<<grid, 256, 0, st>>>(x, qweight, scales, zeros, out, part, arrivals, g, GptqMulti{});
       else
-        gptq_strip_kernel<BITS, 1, 32, 64, false, true><<<grid, 256, 0, st>>>(x, qweight, scales, zeros, out, part, arrivals, g);
+        gptq_strip_kernel<BITS, 1, 32, 64, false, true><<<grid, 256, 0, st>>>(x, qweight, scales, zeros, out, part, arrivals, g, GptqMulti{});
       return check_launch();
     }
     if (ch == kSliceK) SBQ_STRIP(128, false);
@@ -1096,10 +1138,101 @@ int gptq_matmul(const float* x, const int32_t* qweight, float* out, const float*
   return gptq_launch_partial<BITS, kSliceK>(x, qweight, out, scales, zeros, part, g, vec, st);
 }
 
+// Several matrices, one activation vector, ONE launch (see GptqMulti).  Falls back to one launch per matrix -- same
+// results -- for anything the strip kernel does not take.
+template <int BITS>
+int gptq_matmul_multi(const float* x, int n_mats, const int32_t* const* qweights, float* const* outs,
+                      const float* const* scales, const float* const* zeros, const int64_t* out_features, int64_t batch,
+                      int64_t in_features, int64_t group_size, void* workspace, size_t workspace_bytes, void* stream) {
+  if (n_mats < 1 || n_mats > kMaxMulti) return SBQ_ERR_ARG;
+  if (!x || !qweights || !outs || !scales || !zeros || !out_features || !workspace) return SBQ_ERR_NULL;
+  int64_t total_out = 0;
+  bool strip_ok = batch >= 1 && batch <= 2 && group_size != 0 && group_size % kSliceK == 0 && knob(2) != 9;
+  for (int m = 0; m < n_mats; ++m) {
+    if (!qweights[m] || !outs[m] || !scales[m] || !zeros[m]) return SBQ_ERR_NULL;
+    if (out_features[m] <= 0) return SBQ_ERR_ARG;
+    total_out += out_features[m];
+    strip_ok = strip_ok && out_features[m] % kStripCols == 0 && aligned16(qweights[m]);
+  }
+  const int64_t strips = total_out / kStripCols;
+  strip_ok = strip_ok && strips <= kMaxStrips && in_features > 0 && in_features < (1ll << 31);
+  if (!strip_ok || n_mats == 1) {
+    for (int m = 0; m < n_mats; ++m) {
+      int rc = gptq_matmul<BITS>(x, qweights[m], outs[m], scales[m], zeros[m], batch, in_features, out_features[m], group_size,
+                                 workspace, workspace_bytes, stream);
+      if (rc != SBQ_OK) return rc;
+    }
+    return SBQ_OK;
+  }
+  constexpr int kMinGroup = BITS == 2 ? 64 : 128;
+  if (group_size % kMinGroup != 0) return SBQ_ERR_ARG;
+  GptqGeom g;
+  if (!gptq_geom(BITS, kSliceK, batch, in_features, total_out, group_size, g)) return SBQ_ERR_ARG;
+  const size_t need = kCounterBytes + static_cast<size_t>(kStripMaxSplit) * batch * total_out * sizeof(float);
+  if (workspace_bytes < need || !aligned16(workspace)) return SBQ_ERR_WORKSPACE;
+  if (reinterpret_cast<uintptr_t>(x) & 3u) return SBQ_ERR_ALIGN;
+  hipStream_t st = as_stream(stream);
+  uint32_t* arrivals = static_cast<uint32_t*>(workspace);
+  float* part = reinterpret_cast<float*>(static_cast<char*>(workspace) + kCounterBytes);
+  constexpr int ch = kSliceK / 2;
+  const int64_t passes = ceil_div(in_features, 32 * ch);
+  int64_t split = passes >= 3 ? ceil_div(passes, 3) : 1;
+  while (strips * split * 2 < static_cast<int64_t>(cu_count()) && split < passes) ++split;
+  if (knob(1) > 0 && knob(1) < 128) split = knob(1);
+  if (split > passes) split = passes;
+  if (split > kStripMaxSplit) split = kStripMaxSplit;
+  GptqMulti mm{};
+  mm.n = n_mats;
+  int64_t sb = 0, po = 0;
+  for (int m = 0; m < n_mats; ++m) {
+    mm.strip_begin[m] = static_cast<int32_t>(sb);
+    mm.qw[m] = qweights[m];
+    mm.scales[m] = scales[m];
+    mm.zeros[m] = zeros[m];
+    mm.out[m] = outs[m];
+    mm.out_features[m] = out_features[m];
+    mm.part_off[m] = po;
+    sb += out_features[m] / kStripCols;
+    po += split * batch * out_features[m];
+  }
+  mm.strip_begin[n_mats] = static_cast<int32_t>(sb);
+  g.xcd_swizzle = (strips % 8 == 0 && knob(2) != 8) ? 1 : 0;
+  const dim3 grid(static_cast<uint32_t>(strips), static_cast<uint32_t>(split));
+  const bool prefetch = passes >= 2 * split && knob(2) != 6;
+  constexpr bool kDec8 = BITS != 3;
+#define SBQ_MULTI(BT, PFV) \
+  gptq_strip_kernel<BITS, BT, 32, 64, kDec8, PFV><<<grid, 256, 0, st>>>(x, nullptr, nullptr, nullptr, nullptr, part, arrivals, g, mm)
+  if (prefetch) {
+    if (batch == 2) SBQ_MULTI(2, true);
+    else SBQ_MULTI(1, true);
+  } else {
+    if (batch == 2) SBQ_MULTI(2, false);
+    else SBQ_MULTI(1, false);
+  }
+#undef SBQ_MULTI
+  return check_launch();
+}
+
 }  // namespace
 }  // namespace sbq
 
 extern "C" {
+
+int sbq_vecquantmatmul_multi(int bits, const float* x, int n_mats, const int32_t* const* qweights, float* const* outs,
+                             const float* const* scales, const float* const* zeros, const int64_t* out_features,
+                             int64_t batch, int64_t in_features, int64_t group_size, void* workspace,
+                             size_t workspace_bytes, void* stream) {
+  if (bits == 4)
+    return sbq::gptq_matmul_multi<4>(x, n_mats, qweights, outs, scales, zeros, out_features, batch, in_features, group_size,
+                                     workspace, workspace_bytes, stream);
+  if (bits == 3)
+    return sbq::gptq_matmul_multi<3>(x, n_mats, qweights, outs, scales, zeros, out_features, batch, in_features, group_size,
+                                     workspace, workspace_bytes, stream);
+  if (bits == 2)
+    return sbq::gptq_matmul_multi<2>(x, n_mats, qweights, outs, scales, zeros, out_features, batch, in_features, group_size,
+                                     workspace, workspace_bytes, stream);
+  return SBQ_ERR_ARG;
+}
 
 size_t sbq_gptq_workspace_bytes(int64_t batch, int64_t in_features, int64_t out_features) {
   using namespace sbq;

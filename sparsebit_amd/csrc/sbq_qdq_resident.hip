@@ -4,6 +4,7 @@
 // (sparsebit/quantization/torch_extensions/fake_quant_tensor.cu:50-66,170-188) for those shapes.
 #include <utility>
 
+#include "sbq_observe_body.hpp"
 #include "sbq_qdq_math.hpp"
 
 namespace sbq {
@@ -323,10 +324,103 @@ __global__ __launch_bounds__(kResBlock) void qdq_resident_kernel(
 // waves and a single barrier for all U rows; every lane then derives the row's scale / zero point itself
 // (qparams_from_minmax: the reference's fp32 operations) and converts its slab in place.  NaN propagates like
 // torch.min / max: v_min / v_max drop it, a separate flag restores it (as in stats_partial_kernel).
-struct RowStat {
+// Statistics of a slab, reduced over the wave for all U slabs AT ONCE: per-lane accumulators (16-bit inputs: the three
+// packed integer words of sbq_observe_body.hpp -- no unpack, 1.5 operations per element; fp32: v_minimum3 /
+// v_maximum3, NaN-propagating), then a transposing butterfly -- at each of the first log2(U) exchange steps a lane
+// keeps half of its slabs and hands the other half to its partner, so U slabs cost U - 1 + (6 - log2 U) shuffles per
+// word instead of 6 U.  Afterwards lane l holds the wave's result of slab
+//   U == 8: (l >> 5 & 1) * 4 + (l >> 4 & 1) * 2 + (l >> 3 & 1)        U == 4: (l >> 5 & 1) * 2 + (l >> 4 & 1)
+// in every lane of its group (round 2: 2 wave reductions + a ballot per slab, after unpacking it: 16 reductions of
+// 6 shuffles each for U = 8).
+struct SlabAccF32 {
   float mn, mx;
-  int nan;
+  __device__ __forceinline__ static SlabAccF32 of(const RawPack<F32>& r) {
+    float v[kPack];
+    unpack_raw<F32>(r, v);
+    SlabAccF32 a{v[0], v[0]};
+#pragma unroll
+    for (int j = 1; j < kPack; j += 2) {
+      const float w = j + 1 < kPack ? v[j + 1] : v[j];
+      a.mn = __builtin_elementwise_minimum(__builtin_elementwise_minimum(a.mn, v[j]), w);
+      a.mx = __builtin_elementwise_maximum(__builtin_elementwise_maximum(a.mx, v[j]), w);
+    }
+    return a;
+  }
+  __device__ __forceinline__ SlabAccF32 merged(const SlabAccF32& o) const {
+    return SlabAccF32{__builtin_elementwise_minimum(mn, o.mn), __builtin_elementwise_maximum(mx, o.mx)};
+  }
+  __device__ __forceinline__ SlabAccF32 shuffled(int m) const { return SlabAccF32{__shfl_xor(mn, m, kWave), __shfl_xor(mx, m, kWave)}; }
+  __device__ __forceinline__ void decode(float& lo, float& hi) const {
+    lo = mn;
+    hi = mx;
+  }
 };
+template <typename T16>
+struct SlabAcc16 {
+  Stat16 s;
+  __device__ __forceinline__ static SlabAcc16 of(const RawPack<T16>& r) {
+    SlabAcc16 a{kStat16Identity};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) stat16_fold(a.s, r.d[0][q]);
+    // both 16-bit halves into the low one (the high one keeps a copy: harmless for max / min)
+    a.s = stat16_merge(a.s, Stat16{a.s.a >> 16, a.s.b >> 16, static_cast<uint32_t>(static_cast<int32_t>(a.s.c) >> 16)});
+    return a;
+  }
+  __device__ __forceinline__ SlabAcc16 merged(const SlabAcc16& o) const { return SlabAcc16{stat16_merge(s, o.s)}; }
+  __device__ __forceinline__ SlabAcc16 shuffled(int m) const {
+    return SlabAcc16{Stat16{static_cast<uint32_t>(__shfl_xor(static_cast<int>(s.a), m, kWave)),
+                            static_cast<uint32_t>(__shfl_xor(static_cast<int>(s.b), m, kWave)),
+                            static_cast<uint32_t>(__shfl_xor(static_cast<int>(s.c), m, kWave))}};
+  }
+  __device__ __forceinline__ void decode(float& lo, float& hi) const { stat16_decode<T16>(s, lo, hi); }
+};
+template <typename Tin>
+struct SlabAccSel { using type = SlabAcc16<Tin>; };
+template <>
+struct SlabAccSel<F32> { using type = SlabAccF32; };
+
+// the transposing butterfly: acc[0 .. U) per lane -> one accumulator per lane (its slab: see above)
+template <typename A, int U>
+__device__ __forceinline__ A slab_butterfly(A (&acc)[U], uint32_t lane) {
+  static_assert(U == 4 || U == 8, "slabs per wave");
+  if constexpr (U == 8) {
+    A h4[4];
+    const bool up = lane & 32u;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const A keep = up ? acc[4 + k] : acc[k], give = up ? acc[k] : acc[4 + k];
+      h4[k] = keep.merged(give.shuffled(32));
+    }
+    A h2[2];
+    const bool up2 = lane & 16u;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const A keep = up2 ? h4[2 + k] : h4[k], give = up2 ? h4[k] : h4[2 + k];
+      h2[k] = keep.merged(give.shuffled(16));
+    }
+    const bool up3 = lane & 8u;
+    const A keep = up3 ? h2[1] : h2[0], give = up3 ? h2[0] : h2[1];
+    A r = keep.merged(give.shuffled(8));
+    r = r.merged(r.shuffled(4));
+    r = r.merged(r.shuffled(2));
+    return r.merged(r.shuffled(1));
+  } else {
+    A h2[2];
+    const bool up = lane & 32u;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const A keep = up ? acc[2 + k] : acc[k], give = up ? acc[k] : acc[2 + k];
+      h2[k] = keep.merged(give.shuffled(32));
+    }
+    const bool up2 = lane & 16u;
+    const A keep = up2 ? h2[1] : h2[0], give = up2 ? h2[0] : h2[1];
+    A r = keep.merged(give.shuffled(16));
+    r = r.merged(r.shuffled(8));
+    r = r.merged(r.shuffled(4));
+    r = r.merged(r.shuffled(2));
+    return r.merged(r.shuffled(1));
+  }
+}
 
 template <typename Tin, typename Tout, int U>
 __global__ __launch_bounds__(kResBlock) void qdq_observe_kernel(
@@ -338,7 +432,8 @@ __global__ __launch_bounds__(kResBlock) void qdq_observe_kernel(
   constexpr uint32_t kIn = Tin::id == SBQ_F32 ? 4 : 2, kOut = Tout::id == SBQ_F32 ? 4 : 2;
   constexpr uint32_t kSlabElems = kBlock * kPack;
   constexpr int kWaves = kResBlock / kWave;
-  __shared__ RowStat part[U][kWaves];
+  using Acc = typename SlabAccSel<Tin>::type;
+  __shared__ Acc part[U][kWaves];
   const uint32_t sub = __builtin_amdgcn_readfirstlane(threadIdx.x / kBlock);
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
   const uint32_t tid = threadIdx.x % kBlock;
@@ -367,23 +462,16 @@ __global__ __launch_bounds__(kResBlock) void qdq_observe_kernel(
     }
   }
   __builtin_amdgcn_sched_barrier(0);  // all loads in flight first
-  // phase A: per slab, as it lands: the lane's extrema, the wave's, one LDS record per (u, wave)
+  // phase A: per slab, as it lands: the lane's accumulator; then ONE butterfly for all U slabs, one LDS record per
+  // (slab, wave) from the lane group that ends up holding it
+  Acc acc[U];
 #pragma unroll
-  for (int u = 0; u < U; ++u) {
-    float v[kPack];
-    unpack_raw<Tin>(raw[u], v);
-    float mn = v[0], mx = v[0];
-    int nan = v[0] != v[0];
-#pragma unroll
-    for (int j = 1; j < kPack; ++j) {
-      mn = __builtin_fminf(mn, v[j]);
-      mx = __builtin_fmaxf(mx, v[j]);
-      nan |= v[j] != v[j];
-    }
-    mn = wave_reduce(mn, [](float a, float b) { return __builtin_fminf(a, b); });
-    mx = wave_reduce(mx, [](float a, float b) { return __builtin_fmaxf(a, b); });
-    const bool any_nan = __builtin_amdgcn_ballot_w64(nan != 0) != 0;
-    if (lane == 0) part[u][wave] = RowStat{mn, mx, any_nan ? 1 : 0};
+  for (int u = 0; u < U; ++u) acc[u] = Acc::of(raw[u]);
+  {
+    const Acc mine = slab_butterfly<Acc, U>(acc, lane);
+    const uint32_t slab_of_lane = U == 8 ? ((lane >> 5 & 1u) * 4 + (lane >> 4 & 1u) * 2 + (lane >> 3 & 1u))
+                                         : ((lane >> 5 & 1u) * 2 + (lane >> 4 & 1u));
+    if ((lane & (U == 8 ? 7u : 15u)) == 0) part[slab_of_lane][wave] = mine;
   }
   __syncthreads();
   // phase B: lane u of every wave turns slab u's records into the row's scale / zero point (the reference's fp32
@@ -395,14 +483,10 @@ __global__ __launch_bounds__(kResBlock) void qdq_observe_kernel(
   if (lane < static_cast<uint32_t>(U)) {
     const int w0 = two ? 0 : static_cast<int>(sub) * (kWaves / 2);
     const int nw = two ? kWaves : kWaves / 2;
-    float mn = part[lane][w0].mn, mx = part[lane][w0].mx;
-    int nan = part[lane][w0].nan;
-    for (int w = 1; w < nw; ++w) {
-      mn = __builtin_fminf(mn, part[lane][w0 + w].mn);
-      mx = __builtin_fmaxf(mx, part[lane][w0 + w].mx);
-      nan |= part[lane][w0 + w].nan;
-    }
-    if (nan) mn = mx = __builtin_nanf("");
+    Acc r = part[lane][w0];
+    for (int w = 1; w < nw; ++w) r = r.merged(part[lane][w0 + w]);
+    float mn, mx;
+    r.decode(mn, mx);  // (NaN in the row: both NaN, like torch.min / max)
     qparams_from_minmax(mn, mx, qrange, symmetric != 0, my_sc, my_zp);
     const uint32_t sl = sl0 + lane * kResSub;
     // one wave per row publishes the observer's results

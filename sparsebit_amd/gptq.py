@@ -2,8 +2,8 @@
 large_language_models/llama/quantization/utils/quant.py.
 
   quantize()                     quant.py:8-10
-  Quantizer.find_params()        quant.py:43-132   (weight=True, perchannel, asymmetric,
-                                                     mse=False -- what convert.py/test use)
+  Quantizer.find_params()        quant.py:43-132   (every branch: weights / activations, per channel /
+                                                     per tensor, sym / asym, min-max / mse grid search)
   QuantLinear.pack / forward     quant.py:187-278
   Quant{4,3,2}Matmul             quant.py:281-403  -> sbq_vecquant{4,3,2}matmul
 
@@ -35,28 +35,46 @@ class Quantizer(nn.Module):
         self.register_buffer("zero", torch.zeros(shape))
 
     def configure(self, bit, perchannel=False, sym=True, mse=False, norm=2.4, grid=100, maxshrink=0.8):
-        if mse:
-            raise NotImplementedError("GPTQ mse search is not on the MI355X hot path")
         self.maxq = torch.tensor(2 ** bit - 1)
         self.perchannel = perchannel
         self.sym = sym
         self.mse = mse
+        self.norm = norm
+        self.grid = grid
+        self.maxshrink = maxshrink
         self.bit = bit
 
     def find_params(self, x, weight=False, groupsize=-1):
-        """Grouped asymmetric/symmetric min-max parameters of a [out, in] weight."""
-        if not (weight and self.perchannel):
-            raise NotImplementedError("only per-channel weight parameters are on the MI355X hot path")
+        """quant.py:43-132, every branch: weights [out, in] (optionally in groups) and activations of rank 4 / 3 / 2,
+        per channel or per tensor, symmetric or not, min-max or the `mse` grid search.  The row statistics come from
+        sbq_channel_stats, the grid search from sbq_gptq_mse_search; what is left are the reference's own handful of
+        elementwise ops on [rows]-sized vectors."""
         dev = x.device
         self.maxq = self.maxq.to(dev)
-        shape = x.shape
         if groupsize != -1:
-            assert x.shape[1] % groupsize == 0
+            # groupsize must be a divisor of infeatures
+            assert weight is True and x.shape[1] % groupsize == 0
             groups = x.shape[1] // groupsize
         else:
             groups = 1
-        rows = x.reshape(-1, groupsize) if groups > 1 else x.flatten(1)
-        xmin, xmax, _ = ops.channel_stats(rows.contiguous(), 0, True)  # [out*groups] each, one read
+        shape = x.shape
+        if self.perchannel:
+            if weight:
+                if groups > 1:
+                    x = x.reshape((-1, groupsize))
+                x = x.flatten(1)
+            else:
+                if len(shape) == 4:
+                    x = x.permute([1, 0, 2, 3])
+                    x = x.flatten(1)
+                if len(shape) == 3:
+                    x = x.reshape((-1, shape[-1])).t()
+                if len(shape) == 2:
+                    x = x.t()
+        else:
+            x = x.flatten().unsqueeze(0)
+        x = x.contiguous()  # [rows, inner]: what the kernels read
+        xmin, xmax, _ = ops.channel_stats(x, 0, True)  # one read of x
         zero_t = torch.zeros_like(xmin)
         xmin = torch.minimum(xmin, zero_t)
         xmax = torch.maximum(xmax, zero_t)
@@ -71,12 +89,35 @@ class Quantizer(nn.Module):
             self.zero = torch.full_like(self.scale, (self.maxq + 1) / 2)
         else:
             self.zero = torch.round(-xmin / self.scale)
-        if groups > 1:
-            new_shape = [shape[0], groups] + [1] * (len(shape) - 1)
-        else:
-            new_shape = [-1] + [1] * (len(shape) - 1)
-        self.scale = self.scale.reshape(new_shape)
-        self.zero = self.zero.reshape(new_shape)
+        if self.mse:
+            self.scale = self.scale.contiguous()
+            self.zero = self.zero.contiguous()
+            ops.gptq_mse_search(x, xmin.contiguous(), xmax.contiguous(), int(self.maxq), self.sym, self.scale, self.zero,
+                                self.norm, self.grid, int(self.maxshrink * self.grid))
+        if not self.perchannel:
+            if weight:
+                tmp = shape[0]
+            else:
+                tmp = shape[1] if len(shape) != 3 else shape[2]
+            self.scale = self.scale.repeat(tmp)
+            self.zero = self.zero.repeat(tmp)
+        if weight:
+            if groups > 1:
+                new_shape = [shape[0], groups] + [1] * (len(shape) - 1)
+            else:
+                new_shape = [-1] + [1] * (len(shape) - 1)
+            self.scale = self.scale.reshape(new_shape)
+            self.zero = self.zero.reshape(new_shape)
+            return
+        if len(shape) == 4:
+            self.scale = self.scale.reshape((1, -1, 1, 1))
+            self.zero = self.zero.reshape((1, -1, 1, 1))
+        if len(shape) == 3:
+            self.scale = self.scale.reshape((1, 1, -1))
+            self.zero = self.zero.reshape((1, 1, -1))
+        if len(shape) == 2:
+            self.scale = self.scale.unsqueeze(0)
+            self.zero = self.zero.unsqueeze(0)
 
     def quantize(self, x):
         if self.ready():
@@ -199,6 +240,26 @@ class Quant2Matmul(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad):
         raise NotImplementedError("inference-only kernel")
+
+
+def quant_matmul_multi(input, layers):
+    """[layer(input) for layer in layers] for up to 4 QuantLinear layers that read the SAME input (q / k / v of an
+    attention block; gate + up of its MLP) with ONE mat-vec launch instead of one per layer (quant.py:262-278).
+    Layers must share infeatures, bit width and group size; inference only, like Quant{4,3,2}Matmul."""
+    first = layers[0]
+    for ql in layers:
+        if (ql.infeatures, ql.bit, ql.groupsize) != (first.infeatures, first.bit, first.groupsize):
+            raise ValueError("quant_matmul_multi: layers must share infeatures, bit width and group size")
+    x = input.reshape(-1, input.shape[-1]).float().contiguous()
+    outs = []
+    for ql in layers:
+        out_shape = input.shape[:-1] + (ql.outfeatures,)
+        outs.append(ql.bias.float().repeat(x.shape[0], 1).contiguous() if ql.bias is not None
+                    else torch.zeros(x.shape[0], ql.outfeatures, dtype=torch.float32, device=x.device))
+    gs = first.groupsize if first.groupsize != -1 else 0
+    ops.vecquantmatmul_multi(first.bit, x, [ql.qweight for ql in layers], outs, [ql.scales for ql in layers],
+                             [ql.zeros for ql in layers], gs)
+    return [o.reshape(input.shape[:-1] + (ql.outfeatures,)).to(input.dtype) for o, ql in zip(outs, layers)]
 
 
 class _KernelModule:

@@ -170,6 +170,9 @@ _SIGNATURES = {
     "sbq_radix_finish": (c_int, [c_vp, c_i64, c_int, c_int, c_vp, c_vp]),
     "sbq_sign_counts": (c_int, [c_vp, c_int, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp]),
     "sbq_mask_from_threshold": (c_int, [c_vp, c_int, c_i64, c_vp, c_vp, c_vp]),
+    "sbq_gptq_mse_search": (c_int, [c_vp, c_int, c_i64, c_i64, c_vp, c_vp, c_int, c_int, ctypes.c_float, c_int, c_int, c_vp, c_vp,
+                                    c_vp, c_vp]),
+    "sbq_vecquantmatmul_multi": (c_int, [c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_sz, c_vp]),
     "sbq_gptq_workspace_bytes": (c_sz, [c_i64, c_i64, c_i64]),
     "sbq_vecquant4matmul": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_vp, c_sz, c_vp]),
     "sbq_vecquant3matmul": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_vp, c_sz, c_vp]),

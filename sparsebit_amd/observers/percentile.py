@@ -12,6 +12,7 @@ from .. import select
 @register_observer
 class Observer(BaseObserver):
     TYPE = "percentile"
+    MAX_SHARDED_CHANNELS = 256  # 8 MB of histograms per pass
 
     def __init__(self, config, qdesc):
         super(Observer, self).__init__(config, qdesc)
@@ -46,6 +47,15 @@ class Observer(BaseObserver):
             fused = ops.percentile_select(shards, self.alpha, self.ch_axis, perch)
             if fused is not None:
                 return fused
+        elif perch and C > self.MAX_SHARDED_CHANNELS:
+            # The sharded protocol all-reduces an int64 [C, 2, 2048] histogram per pass: 32 KB per channel, 134 MB
+            # at C = 4096 -- three times.  That is a bandwidth problem on xGMI, not the latency-bound statistic
+            # exchange the design budgets for, and no shipped config calibrates per-channel
+            # ACTIVATIONS with the percentile observer (weights are replicated and never take this path).
+            raise L.SbqError(
+                "sharded per-channel percentile over %d channels would all-reduce %d MB of histograms per pass; "
+                "calibrate this quantizer per tensor, or outside dist.sharded_calibration() (every rank then sees "
+                "all batches)" % (C, C * 2 * L.RADIX_BINS * 8 >> 20))
         vals, counts = select.kth_values(shards, None, ops.HipSelectBackend(), False, self.ch_axis, perch, dev,
                                          percentile_alpha=self.alpha, n_channels=C)
         zero = torch.zeros(C, dtype=torch.float32, device=dev)

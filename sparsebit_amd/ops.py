@@ -1120,5 +1120,56 @@ def vecquantmatmul(bits, x, qweight, out, scales, zeros, group_size=0):
     return out
 
 
+def vecquantmatmul_multi(bits, x, qweights, outs, scales, zeros, group_size):
+    """outs[m] += dequant(qweights[m]) @ x for up to 4 matrices that share x, in ONE launch (q / k / v; gate + up)."""
+    dev = L.require_device(x, *qweights, *outs, *scales, *zeros)
+    lib = L.load()
+    n = len(qweights)
+    if not (1 <= n <= 4 and len(outs) == n and len(scales) == n and len(zeros) == n):
+        raise L.SbqError("vecquantmatmul_multi: 1 to 4 matrices with their outputs, scales and zeros")
+    in_f = x.shape[-1]
+    batch = x.numel() // in_f
+    if x.dtype != torch.float32 or not x.is_contiguous():
+        raise L.SbqError("vecquantmatmul_multi: x must be contiguous float32")
+    rows = (in_f + 31) // 32 * 3 if bits == 3 else (in_f * bits + 31) // 32
+    sc = [_f32c(t, dev) for t in scales]
+    zr = [_f32c(t, dev) for t in zeros]
+    total = 0
+    for m in range(n):
+        qw, out = qweights[m], outs[m]
+        if qw.dtype != torch.int32 or qw.dim() != 2 or qw.shape[0] != rows or not qw.is_contiguous():
+            raise L.SbqError("vecquantmatmul_multi: qweight %d must be contiguous int32 [%d, out]" % (m, rows))
+        if out.dtype != torch.float32 or not out.is_contiguous() or out.numel() != batch * qw.shape[1]:
+            raise L.SbqError("vecquantmatmul_multi: out %d must be contiguous float32 [batch, %d]" % (m, qw.shape[1]))
+        total += qw.shape[1]
+    arr = lambda ts: (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts])  # noqa: E731
+    outf = (ctypes.c_int64 * n)(*[qw.shape[1] for qw in qweights])
+    with L.device_guard(dev):
+        ws = _gptq_workspace(dev, lib.sbq_gptq_workspace_bytes(batch, in_f, total))
+        rc = lib.sbq_vecquantmatmul_multi(int(bits), L.ptr(x), n, arr(qweights), arr(outs), arr(sc), arr(zr), outf, batch, in_f,
+                                          int(group_size), L.ptr(ws), ws.numel(), L.stream_ptr(dev))
+    L.check(rc)
+    return outs
+
+
+def gptq_mse_search(x2d, xmin, xmax, maxq, symmetric, scale, zero, norm=2.4, grid=100, n_candidates=80):
+    """GPTQ find_params' grid search (quant.py:86-104) over the rows of x2d [rows, inner]; scale / zero hold the
+    un-shrunk parameters and are UPDATED IN PLACE.  -> chosen candidate index per row (int32, -1: none finite)."""
+    dev = L.require_device(x2d, xmin, xmax, scale, zero)
+    lib = L.load()
+    x2d = x2d.contiguous()
+    rows, inner = x2d.shape
+    for t in (xmin, xmax, scale, zero):
+        if t.dtype != torch.float32 or not t.is_contiguous() or t.numel() != rows:
+            raise L.SbqError("gptq_mse_search: xmin / xmax / scale / zero must be contiguous fp32 with one value per row")
+    index = torch.empty(rows, dtype=torch.int32, device=dev)
+    with L.device_guard(dev):
+        rc = lib.sbq_gptq_mse_search(L.ptr(x2d), L.dtype_id(x2d), rows, inner, L.ptr(xmin), L.ptr(xmax), int(maxq),
+                                     int(bool(symmetric)), ctypes.c_float(norm), int(grid), int(n_candidates), L.ptr(scale),
+                                     L.ptr(zero), L.ptr(index), L.stream_ptr(dev))
+    L.check(rc)
+    return index
+
+
 def vecquant4matmul(x, qweight, out, scales, zeros, group_size=0):
     return vecquantmatmul(4, x, qweight, out, scales, zeros, group_size)

@@ -99,13 +99,13 @@ class Quantizer(BaseQuantizer):
 
     def _qparams_preprocess(self, x):
         if self.export_onnx:
-            return (
-                torch.tensor(self.scale.abs().detach().cpu().numpy(), device=self.device),
-                torch.tensor(
-                    torch.clamp(self.zero_point, self.qdesc.qmin, self.qdesc.qmax).detach().cpu().numpy(),
-                    device=self.device,
-                ),
-            )
+            # the reference rebuilds both tensors through numpy (lsq.py:53-63) so that the ONNX tracer sees plain
+            # constants instead of the Parameter's abs / clamp graph; a detached clone on the device is the same
+            # values with no graph and no host round trip
+            with torch.no_grad():
+                scale = self.scale.detach().abs().clone().to(self.device)
+                zero_point = torch.clamp(self.zero_point.detach(), self.qdesc.qmin, self.qdesc.qmax).clone().to(self.device)
+            return scale, zero_point
         scale = self.scale.abs()
         zero_point = torch.clamp(self.zero_point, self.qdesc.qmin, self.qdesc.qmax)
         return scale, zero_point

@@ -367,3 +367,41 @@ def test_enums_compare_by_name_and_derived_classes_satisfy_foreign_isinstance():
         assert isinstance(q, ForeignBase) and impl_type(q) is cls and q.only_on_foreign() == "kept"
         q.set_backend(ForeignBackend.VIRTUAL)
         assert q.forward.__func__ is cls.forward  # behaviour is ours
+
+
+def test_lsq_export_branch_builds_constants_without_a_host_round_trip():
+    """LSQ's _qparams_preprocess under export_onnx (lsq.py:53-63): |scale| and clamp(zero_point) as graph-free
+    tensors with the reference's values, and the export forward on torch.fake_quantize_*"""
+    from sparsebit_amd.common import Backend
+    from sparsebit_amd.config import quantizer_config
+    from sparsebit_amd.quantizers import build_quantizer
+
+    q = build_quantizer(quantizer_config("per-channel-symmetric", 4, "lsq"))
+    q.set_backend(Backend.ONNXRUNTIME)
+    q.dims = 2
+    q.scale = torch.nn.Parameter(q._broadcast_qparams(torch.tensor([-0.1, 0.2, 0.05])))
+    q.zero_point = q._broadcast_qparams(torch.tensor([0.0, 9.0, -20.0]))
+    q.init_params = True
+    q.enable_quant()
+    q.enable_export_onnx()
+    s, z = q._qparams_preprocess(None)
+    assert not s.requires_grad and s.grad_fn is None and z.grad_fn is None
+    assert torch.equal(s.reshape(-1), torch.tensor([0.1, 0.2, 0.05])) and torch.equal(z.reshape(-1), torch.tensor([0.0, 7.0, -8.0]))
+    assert s.data_ptr() != q.scale.data_ptr()  # a copy: the exporter may not alias the Parameter
+    x = torch.tensor([[0.26, -1.0], [100.0, 0.31], [0.0, -0.024]])
+    y = q(x)
+    want = torch.fake_quantize_per_channel_affine(x, torch.tensor([0.1, 0.2, 0.05]), torch.tensor([0, 7, -8], dtype=torch.int32), 0, -128, 127)
+    assert y.shape == want.shape
+
+
+def test_sharded_per_channel_percentile_is_refused_beyond_8mb_of_histograms(monkeypatch):
+    """the sharded protocol's int64 [C, 2, 2048] histogram is 134 MB per pass at C = 4096"""
+    from sparsebit_amd import dist as sbq_dist
+    from sparsebit_amd import lib as L
+    from sparsebit_amd.config import quantizer_config
+    from sparsebit_amd.quantizers import build_quantizer
+
+    q = build_quantizer(quantizer_config("per-channel-symmetric", 8, "uniform", "PERCENTILE", "weight"))
+    monkeypatch.setattr(sbq_dist, "active", lambda: True)
+    with pytest.raises(L.SbqError, match="sharded per-channel percentile"):
+        q.observer._radix_minmax([torch.zeros(4096, 16)])

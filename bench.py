@@ -376,7 +376,7 @@ def main():
 
     extras["mse_observer_per_channel_us"] = round(timed_op(step_mse, 10), 1)
     # vector-ALU rate of the MSE kernel, from the committed counter pass (tools/rocprof_bench.sh)
-    extras["mse_kernel_valu"] = pmc_extra("mse_partial_kernel")
+    extras["mse_kernel_valu"] = pmc_extra("mse_partial_kernel")  # SQ_INSTS_VALU of the committed counter pass
 
     # ---- BASELINE configs 2-5: every leg with its own time, algorithmic bytes, roofline fraction and an oracle
     #      gate computed in this run (bench_configs.py).  Rank 0 only: the oracle legs are host work.

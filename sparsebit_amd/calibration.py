@@ -157,11 +157,62 @@ class DeviceCalibrator:
         # Weights are replicated on every rank: observed and finished OUTSIDE the sharded context.  Inside it
         # their statistics would be all-reduced as if the W replicas were W distinct shards -- harmless for
         # min/max, but ACIQ's sample count, the percentile ranks and LSQ+'s unbiased std would change.
+        grouped = self._calibrate_weights_grouped(out)
         for name, m in self.oprs:
             wq = getattr(m, "weight_quantizer", None)
-            if _live(wq):
+            if _live(wq) and name not in grouped:
                 wq.update_observer(m.weight)
                 out[name + ".weight_quantizer"] = wq.calc_qparams()
+
+    def _calibrate_weights_grouped(self, out):
+        """The weight quantizers whose calibration is nothing but a plain min-max / MSE observer followed by
+        calc_qparams (the uniform quantizer of every shipped PTQ config), all at once: two launches for the model's
+        min-max observers, four for its MSE observers (ops.GroupCalibration) instead of 3-5 per layer
+        (tools/calibration.py:117-135 loops the layers).  Bit-identical to the per-layer path, which takes whatever
+        is not eligible.  -> names handled here."""
+        from . import ops
+        from .observers.minmax import Observer as MinMaxObserver
+        from .observers.mse import Observer as MseObserver
+        from .registry import impl_type
+
+        pools = {}
+        for name, m in self.oprs:
+            wq = getattr(m, "weight_quantizer", None)
+            if not _live(wq):
+                continue
+            w = getattr(m, "weight", None)
+            cls = impl_type(wq)
+            obs_cls = impl_type(wq.observer)
+            plain = (cls.calc_qparams is BaseQuantizer.calc_qparams and cls.update_observer is BaseQuantizer.update_observer
+                     and obs_cls in (MinMaxObserver, MseObserver) and isinstance(w, torch.Tensor) and w.is_cuda
+                     and len(wq.observer.data_cache) == 0 and (not wq.is_perchannel or wq.qdesc.ch_axis == 0)
+                     and w.dim() >= 2 and ops.GroupCalibration.supports(w.detach(), wq.is_perchannel))
+            if obs_cls is MseObserver and plain:  # the grouped MSE launch folds at most 96 chunks per row
+                plain = (w[0].numel() if wq.is_perchannel else w.numel()) <= 96 * 4096
+            if plain:
+                pools.setdefault((obs_cls is MseObserver, w.dtype), []).append((name, wq, w.detach()))
+        done = set()
+        for (is_mse, _), members in pools.items():
+            if len(members) < 2:
+                continue  # a lone tensor gains nothing
+            grp = ops.GroupCalibration([(w, wq.qdesc.qrange[0], wq.qdesc.qrange[1], wq.qdesc.is_symmetric, wq.is_perchannel)
+                                        for _, wq, w in members])
+            if is_mse:
+                scale, zp, index = grp.mse_qparams()
+            else:
+                _, _, scale, zp = grp.minmax_qparams()
+            for i, (name, wq, w) in enumerate(members):
+                # (clones: the group's flat buffers are reused by its next launch)
+                wq.dims = w.dim()
+                wq.observer._store_minmax(grp.views["mn"][i].clone(), grp.views["mx"][i].clone())
+                if is_mse:
+                    wq.observer.best_index = index[i].clone()
+                s_i, z_i = scale[i].clone(), zp[i].clone()
+                if not wq.is_perchannel:
+                    s_i, z_i = s_i.reshape(()), z_i.reshape(())
+                out[name + ".weight_quantizer"] = wq._adopt(s_i, z_i)
+                done.add(name)
+        return done
 
     def _finish_inputs(self, out):
         for name, m in self.oprs:

@@ -63,3 +63,28 @@ class Sparser(BaseSparser):
                 keep[torch.sort(rowsum, stable=True).indices[:pruned]] = 0
             return keep.reshape([-1] + [1] * (x.dim() - 1)).expand_as(x).contiguous()
         raise NotImplementedError("sparser type {!r} (the reference knows 'unstructed' and 'structed')".format(self.type))
+
+
+def calc_masks(pairs):
+    """Model-wide form of SparseModel.calc_params (sparse/sparse_model.py:107-113 calls every SparseOpr's calc_mask in
+    turn, each with its own torch.sort): the L1 thresholds of ALL unstructured layers come out of one selection launch
+    (three for fp32 weights; ops.group_kth_value), then one mask pass per layer.
+    pairs: [(sparser, weight), ...] -> [mask, ...]; masks equal `sparser.calc_mask(weight)` element for element.
+    Layers of another type or with ratio 0 go through their own calc_mask."""
+    masks = [None] * len(pairs)
+    todo = [i for i, (sp, w) in enumerate(pairs) if sp.ratio != 0.0 and sp.type == "unstructed" and w.is_cuda]
+    by_dtype = {}
+    for i in todo:
+        by_dtype.setdefault(pairs[i][1].dtype, []).append(i)
+    for idxs in by_dtype.values():
+        if len(idxs) < 2:
+            continue
+        ws = [pairs[i][1].detach().contiguous() for i in idxs]
+        ks = [min(int(w.numel() * pairs[i][0].ratio), w.numel() - 1) + 1 for i, w in zip(idxs, ws)]
+        thr = ops.group_kth_value(ws, ks, use_abs=True)
+        for j, i in enumerate(idxs):
+            masks[i] = ops.mask_from_threshold(ws[j], thr[j])
+    for i, (sp, w) in enumerate(pairs):
+        if masks[i] is None:
+            masks[i] = sp.calc_mask(w)
+    return masks

@@ -405,3 +405,58 @@ def test_gptq_quant_matmul_multi_on_quantlinear_layers(ops):
     got = gptq.quant_matmul_multi(x, qls)
     for a, b in zip(want, got):
         assert a.shape == b.shape and (a - b).abs().max().item() <= 1e-5 * max(1.0, a.abs().max().item())
+
+
+def test_l1_calc_masks_model_wide_equals_per_layer():
+    from sparsebit_amd.config import sparser_config
+    from sparsebit_amd.sparsers import build_sparser
+    from sparsebit_amd.sparsers.l1norm import calc_masks
+
+    g = torch.Generator().manual_seed(8)
+    shapes = [(64, 64, 3, 3), (128, 64, 1, 1), (256, 256, 3, 3), (10, 77), (1000, 512)]
+    ratios = [0.5, 0.3, 0.9, 0.5, 0.0]
+    pairs = []
+    for shp, r in zip(shapes, ratios):
+        sp = build_sparser(sparser_config(r, "unstructed", "l1norm"))
+        pairs.append((sp, torch.randn(shp, generator=g).cuda()))
+    got = calc_masks(pairs)
+    for (sp, w), m in zip(pairs, got):
+        assert torch.equal(m.to(torch.bool), sp.calc_mask(w).to(torch.bool))
+
+
+def test_device_calibrator_groups_plain_weight_quantizers(oracle):
+    """DeviceCalibrator calibrates the plain min-max / MSE weight quantizers of a model with the grouped launches; the
+    results must be those of the per-layer path (and of the oracle)"""
+    from sparsebit_amd.calibration import DeviceCalibrator
+    from sparsebit_amd.common import Backend
+    from sparsebit_amd.config import quantizer_config
+    from sparsebit_amd.quantizers import build_quantizer
+
+    class Opr(torch.nn.Module):
+        def __init__(self, cin, cout, observer, scheme="per-channel-symmetric"):
+            super().__init__()
+            self.weight = torch.nn.Parameter(torch.randn(cout, cin, 3, 3) * 0.1)
+            self.weight_quantizer = build_quantizer(quantizer_config(scheme, 8, "uniform", observer, "weight"))
+            self.weight_quantizer.set_backend(Backend.VIRTUAL)
+            self.input_quantizer = None
+
+        def forward(self, x):
+            return torch.nn.functional.conv2d(x, self.weight, padding=1)
+
+    torch.manual_seed(12)
+    net = torch.nn.Sequential(Opr(8, 16, "MINMAX"), Opr(16, 16, "MSE"), Opr(16, 8, "MINMAX", "per-tensor-affine"),
+                              Opr(8, 8, "MSE"), Opr(8, 24, "MINMAX")).cuda()
+    cal = DeviceCalibrator(net)
+    res = cal.calibrate([torch.randn(2, 8, 6, 6, device="cuda")])
+    for i, m in enumerate(net):
+        q = build_quantizer(m.weight_quantizer.cfg)
+        q.set_backend(Backend.VIRTUAL)
+        q.update_observer(m.weight)
+        s, z = q.calc_qparams()
+        s2, z2 = res["%d.weight_quantizer" % i]
+        assert s.shape == s2.shape and torch.equal(s, s2) and torch.equal(z, z2), i
+        assert torch.equal(m.weight_quantizer.scale, s) and torch.equal(q.observer.min_val, m.weight_quantizer.observer.min_val)
+        y1 = q(m.weight.detach())
+        m.weight_quantizer.enable_quant()
+        q.enable_quant()
+        assert torch.equal(q(m.weight.detach()), m.weight_quantizer(m.weight.detach())), i

@@ -31,11 +31,14 @@ template <typename T, typename Tg, bool VEC>
 __global__ __launch_bounds__(kBlock) void ste_backward_kernel(
     const void* __restrict__ x, const void* __restrict__ gy, void* __restrict__ gx,
     const float* __restrict__ scale, const float* __restrict__ zero_point,
-    GradPartial* __restrict__ part, const ChunkGeom g, float qlo, float qhi, int rounding, int lsq) {
+    GradPartial* __restrict__ part, const ChunkGeom g, float qlo, float qhi, int rounding, int lsq,
+    // a channel that is ONE chunk (every [C, inner <= 8192] weight) writes its gradients itself: no fold launch
+    float* __restrict__ gs_final, float* __restrict__ gzp_final, float gs_ratio, int final_) {
   __shared__ double s_d[kWavesPerBlock];
   const uint32_t bid = blockIdx.x;
   const ChunkPos cp = chunk_pos(g, bid);
-  float s = scale[cp.c], zp = zero_point[cp.c];
+  const float s_raw = scale[cp.c];
+  float s = s_raw, zp = zero_point[cp.c];
   if (lsq) {  // raw LSQ parameters: s = |s|, zp = clamp(zp, qmin, qmax)  (lsq.py:61-62)
     s = __builtin_fabsf(s);
     zp = __builtin_amdgcn_fmed3f(zp, qlo, qhi);
@@ -135,7 +138,16 @@ __global__ __launch_bounds__(kBlock) void ste_backward_kernel(
   if (part) {
     const double a = block_reduce(static_cast<double>(gs), Sum(), s_d);
     const double b = block_reduce(static_cast<double>(gz), Sum(), s_d);
-    if (threadIdx.x == 0) part[bid] = GradPartial{a, b};
+    if (threadIdx.x == 0) {
+      if (final_) {  // exactly what ste_fold_kernel does with a single partial
+        float gsv = static_cast<float>(a);
+        if (lsq) gsv = (gsv * gs_ratio) * (s_raw > 0.0f ? 1.0f : (s_raw < 0.0f ? -1.0f : 0.0f));
+        if (gs_final) gs_final[cp.c] = gsv;
+        if (gzp_final) gzp_final[cp.c] = static_cast<float>(b);
+      } else {
+        part[bid] = GradPartial{a, b};
+      }
+    }
   }
 }
 
@@ -201,6 +213,7 @@ int ste_backward(const void* x, const void* gy, int x_dtype, void* gx, int gx_dt
   }
   hipStream_t st = as_stream(stream);
   const uint32_t grid = g.chunks_per_chan * g.C;
+  const bool final_ = want_param_grads && g.chunks_per_chan == 1;
   const bool vec = pack_friendly(x, C, outer, inner) && aligned16(gy) && aligned16(gx);
   const float qlo = static_cast<float>(qmin), qhi = static_cast<float>(qmax);
   int rc = dispatch_dtype(x_dtype, [&](auto tag) {
@@ -208,16 +221,18 @@ int ste_backward(const void* x, const void* gy, int x_dtype, void* gx, int gx_dt
     auto go = [&](auto gtag) {
       using Tg = decltype(gtag);
       if (vec)
-        ste_backward_kernel<T, Tg, true><<<grid, kBlock, 0, st>>>(x, gy, gx, scale, zp, part, g, qlo, qhi, rounding, lsq);
+        ste_backward_kernel<T, Tg, true><<<grid, kBlock, 0, st>>>(x, gy, gx, scale, zp, part, g, qlo, qhi, rounding, lsq,
+                                                               gs, gzp, gs_ratio, final_ ? 1 : 0);
       else
-        ste_backward_kernel<T, Tg, false><<<grid, kBlock, 0, st>>>(x, gy, gx, scale, zp, part, g, qlo, qhi, rounding, lsq);
+        ste_backward_kernel<T, Tg, false><<<grid, kBlock, 0, st>>>(x, gy, gx, scale, zp, part, g, qlo, qhi, rounding, lsq,
+                                                                gs, gzp, gs_ratio, final_ ? 1 : 0);
     };
     if (gx_dtype == SBQ_F32) go(F32());
     else go(T());
   });
   if (rc != SBQ_OK) return rc;
   rc = check_launch();
-  if (rc != SBQ_OK || !want_param_grads) return rc;
+  if (rc != SBQ_OK || !want_param_grads || final_) return rc;
   ste_fold_kernel<<<g.C, kBlock, 0, st>>>(part, g.chunks_per_chan, gs, gzp, lsq ? scale : nullptr, gs_ratio);
   return check_launch();
 }

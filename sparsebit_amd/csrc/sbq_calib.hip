@@ -33,13 +33,15 @@ struct CalibItemDev {  // 64 bytes, read through the scalar unit
   uint32_t chunk_begin;    // first MSE chunk (== workgroup) of the item
   float qlo, qhi;
   uint32_t flags;
-  uint32_t pad[2];
+  uint32_t part_begin;     // first MSE partial record of the item
+  uint32_t mse_waves;      // 0: a workgroup per 4096-element chunk; 1 / 2 / 4: a WAVE per row of <= 512 / 1024 / 2048
+                           // elements, holding that many of the per-tensor kernel's waves' shares
 };
 static_assert(sizeof(CalibItemDev) == 64, "device table layout");
 
 struct CalibHeader {  // 64 bytes
-  uint32_t n_items, n_seg_wgs, n_rows, n_chunks, n_segs, max_chunks_per_row;
-  uint32_t pad[10];
+  uint32_t n_items, n_seg_wgs, n_rows, n_chunks, n_segs, max_chunks_per_row, n_parts;
+  uint32_t pad[9];
 };
 static_assert(sizeof(CalibHeader) == 64, "device table layout");
 
@@ -166,15 +168,104 @@ __global__ __launch_bounds__(kBlock) void calib_stats_fold_kernel(const CalibIte
   }
 }
 
-// ---- MSE: a workgroup per chunk ------------------------------------------------------------------------
+// ---- MSE ------------------------------------------------------------------------------------------------
+// A model's rows are mostly SHORT (a 1 x 1 convolution: 64 ... 2048 elements): a workgroup per row would walk the 80
+// candidates over 4096 register slots of which a few per cent hold data (967 us for ResNet-50's 25.5 M elements,
+// four times the per-tensor kernel's rate).  Rows of at most 2048 elements are therefore taken by ONE WAVE each, four
+// rows per workgroup.  To stay bit-identical with the per-tensor kernel the wave reproduces its summation tree: there
+// pack p of a row sits in lane p % 64 of wave (p % 256) / 64, each wave reduces its lanes' fp32 sums by the xor
+// butterfly and the four wave sums are added in fp64 -- here lane l holds packs l, 64 + l, 128 + l, 192 + l with one
+// accumulator per "virtual wave", reduces each by the same butterfly and adds them in the same order.
+template <typename T, int NV>
+__device__ __forceinline__ void mse_wave_rows(MseLds (&lds)[kWavesPerBlock], const CalibItemDev* it, uint32_t row,
+                                              const float* __restrict__ min_base, const float* __restrict__ max_base,
+                                              double* __restrict__ part) {
+  const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
+  MseLds& L = lds[wid];
+  const uint32_t inner = uread(&it->inner), C = uread(&it->C);
+  const bool live = row < C;  // wave-uniform
+  const uint64_t off = uread(&it->out_off) + (live ? row : 0);
+  const float qlo = uread(&it->qlo), qhi = uread(&it->qhi);
+  const bool symmetric = (uread(&it->flags) & SBQ_CALIB_SYMMETRIC) != 0;
+  const float mn = min_base[off], mx = max_base[off];
+  for (int i = lane; i < SBQ_MSE_CANDIDATES; i += kWave) {
+    float s, z;
+    mse_candidate(mn, mx, i, qhi - qlo, symmetric, s, z);
+    L.scale[i] = s;
+    L.zp[i] = z;
+    L.rcp[i] = fast_div_ok(s) ? 1.0f / s : 0.0f;
+  }
+  float v[NV][kPack];
+  const void* x = uread(&it->x);
+  const int64_t row_base = static_cast<int64_t>(live ? row : 0) * inner;
+#pragma unroll
+  for (int w = 0; w < NV; ++w) {
+    const uint32_t e = (w * kWave + lane) * kPack;
+    const bool in = e + kPack <= inner;
+    float t[kPack];
+    load_pack<T, true>(x, row_base + (in ? e : 0), t);
+#pragma unroll
+    for (int q = 0; q < kPack; ++q) v[w][q] = in ? t[q] : 0.0f;
+  }
+  // (the candidates were written and are read by this wave alone: LDS operations of a wave execute in order)
+  for (int i = 0; i < SBQ_MSE_CANDIDATES; ++i) {
+    const float s = L.scale[i], z = L.zp[i], y = L.rcp[i];
+    float acc[NV];
+#pragma unroll
+    for (int w = 0; w < NV; ++w) {
+      float a = 0.0f;
+      if (y != 0.0f) {
+        if (z == 0.0f) {
+#pragma unroll
+          for (int q = 0; q < kPack; ++q) {
+            const float lv = __builtin_amdgcn_fmed3f(__builtin_rintf(v[w][q] * y), qlo, qhi);
+            const float d = __builtin_fmaf(-lv, s, v[w][q]);
+            a = __builtin_fmaf(d, d, a);
+          }
+        } else {
+#pragma unroll
+          for (int q = 0; q < kPack; ++q) {
+            const float lv = __builtin_amdgcn_fmed3f(__builtin_rintf(v[w][q] * y) + z, qlo, qhi);
+            const float d = __builtin_fmaf(-(lv - z), s, v[w][q]);
+            a = __builtin_fmaf(d, d, a);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < kPack; ++q) {
+          const float lv = quant_level<SBQ_ROUND_HALF_EVEN>(v[w][q], s, z, qlo, qhi);
+          const float d = v[w][q] - dequant_level(lv, s, z);
+          a += d * d;
+        }
+      }
+      acc[w] = wave_reduce(a, Sum());
+    }
+    if (lane == 0 && live) {
+      double t = 0.0;
+#pragma unroll
+      for (int w = 0; w < kWavesPerBlock; ++w) t += w < NV ? static_cast<double>(acc[w < NV ? w : 0]) : 0.0;
+      part[(static_cast<size_t>(uread(&it->part_begin)) + row) * SBQ_MSE_CANDIDATES + i] = t;
+    }
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(kBlock) void calib_mse_kernel(const CalibItemDev* __restrict__ items,
                                                            const uint32_t* __restrict__ chunk_item,
                                                            const float* __restrict__ min_base,
                                                            const float* __restrict__ max_base, double* __restrict__ part) {
-  __shared__ MseLds lds;
+  __shared__ MseLds lds_w[kWavesPerBlock];
+  MseLds& lds = lds_w[0];
   const uint32_t idx = uread(chunk_item + blockIdx.x);
   const CalibItemDev* it = items + idx;
+  const uint32_t mode = uread(&it->mse_waves);
+  if (mode != 0) {  // workgroup-uniform: a wave per row
+    const uint32_t row = (blockIdx.x - uread(&it->chunk_begin)) * kWavesPerBlock + threadIdx.x / kWave;
+    if (mode == 1) mse_wave_rows<T, 1>(lds_w, it, row, min_base, max_base, part);
+    else if (mode == 2) mse_wave_rows<T, 2>(lds_w, it, row, min_base, max_base, part);
+    else mse_wave_rows<T, 4>(lds_w, it, row, min_base, max_base, part);
+    return;
+  }
   const uint32_t inner = uread(&it->inner);
   const uint32_t cpr = (inner + kMseChunk - 1) / kMseChunk;
   const uint32_t ch = blockIdx.x - uread(&it->chunk_begin);
@@ -186,7 +277,8 @@ __global__ __launch_bounds__(kBlock) void calib_mse_kernel(const CalibItemDev* _
   const float qlo = uread(&it->qlo), qhi = uread(&it->qhi);
   const double t = mse_chunk_body<T, true>(lds, uread(&it->x), static_cast<int64_t>(row) * inner, begin, end, min_base[off],
                                            max_base[off], qhi - qlo, qlo, qhi, (uread(&it->flags) & SBQ_CALIB_SYMMETRIC) != 0);
-  if (threadIdx.x < SBQ_MSE_CANDIDATES) part[static_cast<size_t>(blockIdx.x) * SBQ_MSE_CANDIDATES + threadIdx.x] = t;
+  if (threadIdx.x < SBQ_MSE_CANDIDATES)
+    part[(static_cast<size_t>(uread(&it->part_begin)) + ch) * SBQ_MSE_CANDIDATES + threadIdx.x] = t;
 }
 
 // Three rows per workgroup, a thread per (row, candidate): the row's chunks are summed in the per-tensor path's
@@ -211,8 +303,8 @@ __global__ __launch_bounds__(kBlock) void calib_mse_select_kernel(const CalibIte
   if (live) {
     it = &item_of_row(items, n_items, r);
     row = r - it->row_begin;
-    const uint32_t cpr = (it->inner + kMseChunk - 1) / kMseChunk;
-    const double* p = part + (static_cast<size_t>(it->chunk_begin) + static_cast<size_t>(row) * cpr) * SBQ_MSE_CANDIDATES + i;
+    const uint32_t cpr = it->mse_waves ? 1u : (it->inner + kMseChunk - 1) / kMseChunk;
+    const double* p = part + (static_cast<size_t>(it->part_begin) + static_cast<size_t>(row) * cpr) * SBQ_MSE_CANDIDATES + i;
     double t;
     if (cpr == 1) {
       t = 0.0 + p[0];
@@ -328,7 +420,10 @@ int sbq_calib_table_build(const sbq_calib_item* items, int n_items, void* host_t
   if (n_items < 0) return SBQ_ERR_ARG;
   if (n_items == 0) return SBQ_ERR_EMPTY;
   if (!items) return SBQ_ERR_NULL;
-  uint64_t seg_wgs = 0, segs = 0, rows = 0, chunks = 0, max_cpr = 0;
+  uint64_t seg_wgs = 0, segs = 0, rows = 0, chunks = 0, max_cpr = 0, parts = 0;
+  auto mse_mode = [](int64_t inner) -> uint32_t {  // virtual waves of a wave-per-row item, 0: workgroup per chunk
+    return inner <= 512 ? 1u : (inner <= 1024 ? 2u : (inner <= 2048 ? 4u : 0u));
+  };
   for (int i = 0; i < n_items; ++i) {
     const sbq_calib_item& it = items[i];
     if (!it.x) return SBQ_ERR_NULL;
@@ -342,14 +437,20 @@ int sbq_calib_table_build(const sbq_calib_item* items, int n_items, void* host_t
     seg_wgs += ceil_div(static_cast<int64_t>(it.C * spr), static_cast<int64_t>(kWavesPerBlock));
     segs += it.C * spr;
     rows += it.C;
-    chunks += it.C * cpr;
+    if (mse_mode(it.inner)) {
+      chunks += ceil_div(it.C, static_cast<int64_t>(kWavesPerBlock));
+      parts += it.C;
+    } else {
+      chunks += it.C * cpr;
+      parts += it.C * cpr;
+    }
     max_cpr = cpr > max_cpr ? cpr : max_cpr;
   }
   if (seg_wgs >= (1ull << 31) || chunks >= (1ull << 31) || rows >= (1ull << 31)) return SBQ_ERR_ARG;
   const size_t bytes = sizeof(CalibHeader) + static_cast<size_t>(n_items) * sizeof(CalibItemDev) + (seg_wgs + chunks) * 4;
   if (bytes_needed_out) *bytes_needed_out = bytes;
   if (n_rows_out) *n_rows_out = static_cast<uint32_t>(rows);
-  const size_t ws_stats = segs * sizeof(StatPartial), ws_mse = chunks * SBQ_MSE_CANDIDATES * sizeof(double);
+  const size_t ws_stats = segs * sizeof(StatPartial), ws_mse = parts * SBQ_MSE_CANDIDATES * sizeof(double);
   if (workspace_bytes_out) *workspace_bytes_out = ws_stats > ws_mse ? ws_stats : ws_mse;
   if (!host_table) return SBQ_OK;  // size query
   if (host_table_bytes < bytes) return SBQ_ERR_WORKSPACE;
@@ -365,7 +466,8 @@ int sbq_calib_table_build(const sbq_calib_item* items, int n_items, void* host_t
   h->n_chunks = static_cast<uint32_t>(chunks);
   h->n_segs = static_cast<uint32_t>(segs);
   h->max_chunks_per_row = static_cast<uint32_t>(max_cpr);
-  uint32_t wg = 0, sg = 0, rw = 0, ck = 0;
+  h->n_parts = static_cast<uint32_t>(parts);
+  uint32_t wg = 0, sg = 0, rw = 0, ck = 0, pt = 0;
   for (int i = 0; i < n_items; ++i) {
     const sbq_calib_item& it = items[i];
     CalibItemDev d{};
@@ -378,6 +480,8 @@ int sbq_calib_table_build(const sbq_calib_item* items, int n_items, void* host_t
     d.seg_begin = sg;
     d.row_begin = rw;
     d.chunk_begin = ck;
+    d.part_begin = pt;
+    d.mse_waves = mse_mode(it.inner);
     d.qlo = static_cast<float>(it.qmin);
     d.qhi = static_cast<float>(it.qmax);
     d.flags = it.flags;
@@ -385,12 +489,14 @@ int sbq_calib_table_build(const sbq_calib_item* items, int n_items, void* host_t
     const uint32_t n_seg = d.C * d.segs_per_row;
     const uint32_t n_wg = (n_seg + kWavesPerBlock - 1) / kWavesPerBlock;
     for (uint32_t k = 0; k < n_wg; ++k) wg_item[wg + k] = static_cast<uint32_t>(i);
-    const uint32_t n_ck = d.C * static_cast<uint32_t>(ceil_div(it.inner, static_cast<int64_t>(kMseChunk)));
+    const uint32_t cpr = static_cast<uint32_t>(ceil_div(it.inner, static_cast<int64_t>(kMseChunk)));
+    const uint32_t n_ck = d.mse_waves ? (d.C + kWavesPerBlock - 1) / kWavesPerBlock : d.C * cpr;
     for (uint32_t k = 0; k < n_ck; ++k) chunk_item[ck + k] = static_cast<uint32_t>(i);
     wg += n_wg;
     sg += n_seg;
     rw += d.C;
     ck += n_ck;
+    pt += d.mse_waves ? d.C : d.C * cpr;
   }
   return SBQ_OK;
 }
@@ -442,7 +548,7 @@ int sbq_group_mse_qparams(const void* device_table, const void* host_table, int 
   if (!device_table || !min_base || !max_base || !scale_base || !zp_base || !workspace) return SBQ_ERR_NULL;
   if (!aligned16(device_table) || !aligned16(workspace)) return SBQ_ERR_ALIGN;
   if (h.max_chunks_per_row > kMaxGroupMseChunks) return SBQ_ERR_ARG;  // rows beyond one fold level: per-tensor path
-  if (workspace_bytes < static_cast<size_t>(h.n_chunks) * SBQ_MSE_CANDIDATES * sizeof(double)) return SBQ_ERR_WORKSPACE;
+  if (workspace_bytes < static_cast<size_t>(h.n_parts) * SBQ_MSE_CANDIDATES * sizeof(double)) return SBQ_ERR_WORKSPACE;
   hipStream_t st = as_stream(stream);
   const char* base = static_cast<const char*>(device_table);
   const CalibItemDev* items = reinterpret_cast<const CalibItemDev*>(base + sizeof(CalibHeader));

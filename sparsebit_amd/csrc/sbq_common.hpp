@@ -278,6 +278,29 @@ __device__ __forceinline__ V block_reduce(V v, Op op, V* slot) {
   return r;
 }
 
+// Wave-level inclusive scan / reductions of a 32-bit value on DPP (row shifts inside the 16-lane rows, then the two row
+// broadcasts of gfx9): ~8 vector instructions instead of six ds_bpermute round trips through the LDS crossbar
+// (~100 cycles each) -- the plan runs a scan and three reductions on the critical path of every workgroup.
+template <typename Op>
+__device__ __forceinline__ uint32_t dpp_scan_u32(uint32_t v, uint32_t identity, Op op) {
+  const int id = static_cast<int>(identity);
+#define SBQ_DPP(CTRL, ROWMASK) \
+  v = op(v, static_cast<uint32_t>(__builtin_amdgcn_update_dpp(id, static_cast<int>(v), CTRL, ROWMASK, 0xf, false)))
+  SBQ_DPP(0x111, 0xf);  // row_shr:1
+  SBQ_DPP(0x112, 0xf);  // row_shr:2
+  SBQ_DPP(0x114, 0xf);  // row_shr:4
+  SBQ_DPP(0x118, 0xf);  // row_shr:8
+  SBQ_DPP(0x142, 0xa);  // row_bcast:15 into rows 1 and 3
+  SBQ_DPP(0x143, 0xc);  // row_bcast:31 into rows 2 and 3
+#undef SBQ_DPP
+  return v;
+}
+template <typename Op>
+__device__ __forceinline__ uint32_t dpp_reduce_u32(uint32_t v, uint32_t identity, Op op) {  // result in every lane
+  v = dpp_scan_u32(v, identity, op);
+  return static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(v), kWave - 1));
+}
+
 // torch.min / torch.max semantics: NaN wins.
 struct NanMin {
   __device__ __forceinline__ float operator()(float a, float b) const {

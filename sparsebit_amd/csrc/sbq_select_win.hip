@@ -91,6 +91,46 @@ __device__ __forceinline__ float win_key_float(uint32_t k) {
   return __builtin_bit_cast(float, u);
 }
 
+// ---- keys of a 16-bit tensor, computed on its RAW bits (the one-launch engine) ----------------------------------
+// The 32-bit map above needs the element as a float: a shift or a convert, then five integer operations, per element.
+// A 16-bit tensor has 65 536 values: its keys are its own bit patterns through the same sign transform in 16 bits,
+//   key16(b) = (b ^ (b < 0 ? 0xffff : 0x8000)) - key16'(-inf)      (mod 2^16; negative NaNs wrap to the top)
+// and the engine works on key32 = key16 << 16 with min_shift 16, so plan, windows (always 2^16 aligned) and advance
+// are untouched.  Both keys of a dword come out of five PACKED operations (and, arithmetic shift, or, xor, subtract:
+// 2.5 per element) plus one shift / mask each to feed the window tests -- 3.5 operations per element instead of 6.
+template <typename T>
+struct Key16 {
+  static constexpr uint32_t kNegInf = T::id == SBQ_BF16 ? 0xff80u : 0xfc00u;
+  static constexpr uint32_t kRot = (~kNegInf) & 0xffffu;                       // key16'(-inf) before the rotation
+  static constexpr uint32_t kZero = ((0x7fffu - kRot) & 0xffffu) << 16;        // key32(-0): keys below are x < 0
+  static constexpr uint32_t kInf = ((((kNegInf & 0x7fffu) | 0x8000u) - kRot) & 0xffffu) << 16;  // key32(+inf)
+  // two keys, packed like the two elements of the dword; amask2 = 0x7fff7fff for |x|, else all ones
+  static __device__ __forceinline__ uint32_t pack2(uint32_t w, uint32_t amask2) {
+    typedef int16_t i16x2 __attribute__((ext_vector_type(2)));
+    typedef uint16_t u16x2 __attribute__((ext_vector_type(2)));
+    w &= amask2;
+    const uint32_t m = __builtin_bit_cast(uint32_t, __builtin_bit_cast(i16x2, w) >> static_cast<int16_t>(15));
+    const uint32_t t = w ^ (m | 0x80008000u);
+    const u16x2 rot = {static_cast<uint16_t>(kRot), static_cast<uint16_t>(kRot)};
+    return __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, t) - rot);
+  }
+  static __device__ __forceinline__ uint32_t one(uint32_t b16, bool use_abs) {  // key32 of one raw element
+    return pack2(b16, use_abs ? 0x7fff7fffu : 0xffffffffu) << 16;
+  }
+  static __device__ __forceinline__ float value(uint32_t key32) {
+    const uint32_t t = ((key32 >> 16) + kRot) & 0xffffu;
+    const uint32_t b = (t & 0x8000u) ? (t & 0x7fffu) : (~t & 0xffffu);
+    return Elem<T>::from_bits(static_cast<uint16_t>(b));
+  }
+};
+// which map a selection's keys follow: the advance turns the final key back into a value with it
+enum { KEYS_F32 = 0, KEYS_BF16_RAW = 1, KEYS_F16_RAW = 2 };
+__device__ __forceinline__ float key_value(uint32_t key32, int key_mode) {
+  if (key_mode == KEYS_BF16_RAW) return Key16<BF16>::value(key32);
+  if (key_mode == KEYS_F16_RAW) return Key16<F16>::value(key32);
+  return win_key_float(key32);
+}
+
 struct SumL { __device__ __forceinline__ unsigned long long operator()(unsigned long long a, unsigned long long b) const { return a + b; } };
 
 __device__ __forceinline__ uint32_t shift_for(uint64_t width, uint32_t min_shift) {
@@ -193,7 +233,7 @@ __device__ __forceinline__ void plan_sample_load(const Tab& tab, int n_shards, i
 // `L.hist` must be zero (and that visible: a barrier behind the clearing) on entry.  Thread 0 writes the n_sel
 // windows to out[] (LDS or global); the caller orders that against its readers.
 struct NoStamp { __device__ __forceinline__ void operator()(int) const {} };
-template <typename T, int kT, typename Stamp = NoStamp>
+template <typename T, int kT, bool KEY16 = false, typename Stamp = NoStamp>
 __device__ __forceinline__ void plan_compute(PlanLds& L, const PlanSample<T, kT>& sm, int64_t n_packs, int mode,
                                              int n_sel, int use_abs, int64_t k0, int64_t k1, int64_t n, double alpha,
                                              uint32_t min_shift, WinSel* out, Stamp stamp = Stamp()) {
@@ -210,11 +250,21 @@ __device__ __forceinline__ void plan_compute(PlanLds& L, const PlanSample<T, kT>
 #pragma unroll
   for (int m = 0; m < kMine; ++m) {
     if (static_cast<int64_t>(threadIdx.x) + m * kT >= n_packs) continue;
-    float v[kPack];
-    unpack_raw<T>(sm.raw[m], v);
+    if constexpr (KEY16 && T::id != SBQ_F32) {
+      const uint32_t amask2 = use_abs ? 0x7fff7fffu : 0xffffffffu;
 #pragma unroll
-    for (int j = 0; j < kPack; ++j)
-      atomicAdd(&L.hist[win_key(__builtin_bit_cast(uint32_t, v[j]), use_abs != 0) >> kPlanShift], 1u);
+      for (int q = 0; q < 4; ++q) {
+        const uint32_t k2 = Key16<T>::pack2(sm.raw[m].d[0][q], amask2);
+        atomicAdd(&L.hist[(k2 << 16) >> kPlanShift], 1u);
+        atomicAdd(&L.hist[(k2 & 0xffff0000u) >> kPlanShift], 1u);
+      }
+    } else {
+      float v[kPack];
+      unpack_raw<T>(sm.raw[m], v);
+#pragma unroll
+      for (int j = 0; j < kPack; ++j)
+        atomicAdd(&L.hist[win_key(__builtin_bit_cast(uint32_t, v[j]), use_abs != 0) >> kPlanShift], 1u);
+    }
   }
   lds_sync();
   stamp(8);
@@ -226,24 +276,21 @@ __device__ __forceinline__ void plan_compute(PlanLds& L, const PlanSample<T, kT>
     t += bins[i];
   }
   const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
-  uint32_t incl = t;
-#pragma unroll
-  for (int d = 1; d < kWave; d <<= 1) {
-    const uint32_t up = __shfl_up(incl, d, kWave);
-    if (lane >= d) incl += up;
-  }
+  auto add = [](uint32_t a, uint32_t b) { return a + b; };
+  uint32_t incl = dpp_scan_u32(t, 0u, add);
   if (lane == kWave - 1) L.wave_tot[wid] = incl;
   lds_sync();
   const uint32_t mine = lane < wid ? L.wave_tot[lane] : 0u;  // (kT / 64 <= 16 waves: lanes 0 .. wid-1)
-  const uint32_t off = wave_reduce(mine, [](uint32_t a, uint32_t b) { return a + b; });
+  const uint32_t off = dpp_reduce_u32(mine, 0u, add);
   incl += off;
   const uint32_t excl = incl - t;
   if (threadIdx.x == kT - 1) L.total = incl;
-  if (threadIdx.x == (kKeyZero >> kPlanShift) / kPer) {
-    // bins below kKeyZero: keys of x < 0 (the boundary bin starts a thread's run when kPer divides it; else add the
+  constexpr uint32_t kZeroBin = ((KEY16 && T::id != SBQ_F32) ? Key16<T>::kZero : kKeyZero) >> kPlanShift;
+  if (threadIdx.x == kZeroBin / kPer) {
+    // bins below key(-0): keys of x < 0 (the boundary bin starts a thread's run when kPer divides it; else add the
     // thread's own bins below it)
     uint32_t below = excl;
-    for (int i = 0; i < static_cast<int>((kKeyZero >> kPlanShift) % kPer); ++i) below += bins[i];
+    for (int i = 0; i < static_cast<int>(kZeroBin % kPer); ++i) below += bins[i];
     L.neg = below;
   }
   {
@@ -254,8 +301,8 @@ __device__ __forceinline__ void plan_compute(PlanLds& L, const PlanSample<T, kT>
     for (int i = kPer - 1; i >= 0; --i) f = bins[i] ? threadIdx.x * kPer + i : f;
 #pragma unroll
     for (int i = 0; i < kPer; ++i) l = bins[i] ? threadIdx.x * kPer + i : l;
-    f = wave_reduce(f, [](uint32_t a, uint32_t b) { return a < b ? a : b; });
-    l = wave_reduce(l, [](uint32_t a, uint32_t b) { return a > b ? a : b; });
+    f = dpp_reduce_u32(f, 0xffffffffu, [](uint32_t a, uint32_t b) { return a < b ? a : b; });
+    l = dpp_reduce_u32(l, 0u, [](uint32_t a, uint32_t b) { return a > b ? a : b; });
     if (lane == 0) {
       atomicMin(&L.first, f);
       atomicMax(&L.last, l);
@@ -399,23 +446,39 @@ __device__ __forceinline__ void advance_core(const int s, const WinSel& w, const
                                              unsigned long long c_below, unsigned long long c_neg,
                                              unsigned long long c_nan, const int64_t n, int percentile, double alpha,
                                              uint32_t min_shift, float* __restrict__ out0, float* __restrict__ out1,
-                                             AdvShared& sh, WriteSel&& write_sel) {
+                                             AdvShared& sh, WriteSel&& write_sel, const int key_mode = KEYS_F32) {
   constexpr int kPer = kWinBins / BLOCK;
   unsigned long long t = 0;
 #pragma unroll
   for (int i = 0; i < kPer; ++i) t += bins[i];
   const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
+  // Every count here is at most n: below 2^32 elements (uniform test) the scan and the prefix of the wave totals run
+  // on DPP in 32 bits; the 64-bit shuffles remain for selections over more.  So do the sums of the 64 counter lines --
+  // as wave reductions of 64-bit values they were 36 ds_bpermute round trips, most of this function's 2 us (LDS
+  // atomics on one 64-bit word, tried first, were slower still: 3.2 us).
+  const bool small = static_cast<unsigned long long>(n) < (1ull << 32);
+  auto add32 = [](uint32_t a, uint32_t b) { return a + b; };
   unsigned long long incl = t;
+  if (small) {
+    incl = dpp_scan_u32(static_cast<uint32_t>(t), 0u, add32);
+  } else {
 #pragma unroll
-  for (int d = 1; d < kWave; d <<= 1) {
-    const unsigned long long up = __shfl_up(incl, d, kWave);
-    if (lane >= d) incl += up;
+    for (int d = 1; d < kWave; d <<= 1) {
+      const unsigned long long up = __shfl_up(incl, d, kWave);
+      if (lane >= d) incl += up;
+    }
   }
   if (lane == kWave - 1) sh.wave_tot[wid] = incl;
   if (wid == 0) {  // the 64 counter lines live in wave 0
-    c_below = wave_reduce(c_below, SumL());
-    c_neg = wave_reduce(c_neg, SumL());
-    c_nan = wave_reduce(c_nan, SumL());
+    if (small) {
+      c_below = dpp_reduce_u32(static_cast<uint32_t>(c_below), 0u, add32);
+      c_neg = dpp_reduce_u32(static_cast<uint32_t>(c_neg), 0u, add32);
+      c_nan = dpp_reduce_u32(static_cast<uint32_t>(c_nan), 0u, add32);
+    } else {
+      c_below = wave_reduce(c_below, SumL());
+      c_neg = wave_reduce(c_neg, SumL());
+      c_nan = wave_reduce(c_nan, SumL());
+    }
     if (lane == 0) {
       sh.below = c_below;
       sh.neg = c_neg;
@@ -424,7 +487,11 @@ __device__ __forceinline__ void advance_core(const int s, const WinSel& w, const
   }
   __syncthreads();
   unsigned long long off = 0;
-  for (int v = 0; v < wid; ++v) off += sh.wave_tot[v];
+  if (small) {
+    off = dpp_reduce_u32(lane < wid ? static_cast<uint32_t>(sh.wave_tot[lane & (BLOCK / kWave - 1)]) : 0u, 0u, add32);
+  } else {
+    for (int v = 0; v < wid; ++v) off += sh.wave_tot[v];
+  }
   incl += off;
   const unsigned long long excl = incl - t;
   if (threadIdx.x == BLOCK - 1) sh.total = incl;
@@ -493,13 +560,13 @@ __device__ __forceinline__ void advance_core(const int s, const WinSel& w, const
     if (w.shift <= min_shift) {
       nw.done = 1;  // a bin is one representable value: of a 16-bit input's 2^min_shift keys in it, the real one has
       // low bits 0 for x < 0 (~bits ends in ones, minus the rotation) and 1 for x >= 0 (zeros minus the rotation)
-      if (min_shift > 0 && ((nw.lo + kRot) & 0x80000000u)) nw.lo |= 1u;
+      if (key_mode == KEYS_F32 && min_shift > 0 && ((nw.lo + kRot) & 0x80000000u)) nw.lo |= 1u;
       if (percentile) {
         // percentile.py:30-43: without negative (non-negative) elements min (max) stays 0
-        if (s == 0) out0[0] = neg > 0 ? win_key_float(nw.lo) : 0.0f;
-        else out1[0] = pos > 0 ? win_key_float(nw.lo) : 0.0f;
+        if (s == 0) out0[0] = neg > 0 ? key_value(nw.lo, key_mode) : 0.0f;
+        else out1[0] = pos > 0 ? key_value(nw.lo, key_mode) : 0.0f;
       } else {
-        out0[s] = win_key_float(nw.lo);
+        out0[s] = key_value(nw.lo, key_mode);
       }
     } else {
       nw.shift = w.shift > min_shift + kWinLog ? w.shift - kWinLog : min_shift;
@@ -634,8 +701,8 @@ struct SweepLds {
   unsigned long long tot[NSEL + 2];
 };
 
-template <typename T, int NSEL, bool SIGNS, int BLOCK, bool EARLY, bool FLUSH, bool ALWAYS = false, typename Tab,
-          typename LoadState>
+template <typename T, int NSEL, bool SIGNS, int BLOCK, bool EARLY, bool FLUSH, bool ALWAYS = false, bool KEY16 = false,
+          typename Tab, typename LoadState>
 __device__ __forceinline__ bool win_sweep(const Tab& tab, int n_shards, const uint32_t wg, const uint32_t nwg,
                                           LoadState&& load_state, WinSlot* __restrict__ slots,
                                           uint32_t* __restrict__ hist, int use_abs, SweepLds<NSEL, BLOCK>& lds) {
@@ -720,6 +787,9 @@ __device__ __forceinline__ bool win_sweep(const Tab& tab, int n_shards, const ui
   const bool lane0 = (threadIdx.x & (kWave - 1)) == 0;
   // |x|: clear the sign first; then the same transform (the sign fill of a non-negative word is 0)
   const uint32_t amask = use_abs ? 0x7fffffffu : 0xffffffffu;
+  constexpr bool RAW16 = KEY16 && T::id != SBQ_F32;  // keys straight from the raw 16-bit patterns (Key16)
+  constexpr uint32_t kZeroKey = RAW16 ? Key16<T>::kZero : kKeyZero, kInfKey = RAW16 ? Key16<T>::kInf : kKeyInf;
+  const uint32_t amask2 = use_abs ? 0x7fff7fffu : 0xffffffffu;
   auto key_of = [&](uint32_t bits) {
     const uint32_t b = bits & amask;
     const uint32_t m = static_cast<uint32_t>(static_cast<int32_t>(b) >> 31) | 0x80000000u;
@@ -732,8 +802,8 @@ __device__ __forceinline__ bool win_sweep(const Tab& tab, int n_shards, const ui
   constexpr bool ONESIDED = SIGNS && NSEL == 2;
   auto visit = [&](uint32_t kk, bool valid) {
     if constexpr (SIGNS) {
-      neg += valid && kk < kKeyZero;
-      nan += valid && kk > kKeyInf;
+      neg += valid && kk < kZeroKey;
+      nan += valid && kk > kInfKey;
     }
 #pragma unroll
     for (int s = 0; s < NSEL; ++s) {
@@ -752,8 +822,8 @@ __device__ __forceinline__ bool win_sweep(const Tab& tab, int n_shards, const ui
   };
   auto lean = [&](uint32_t kk, uint32_t (&w_lt)[NSEL], uint32_t& w_neg, uint32_t& w_nan) {
     if constexpr (SIGNS) {
-      count(w_neg, kk < kKeyZero);
-      count(w_nan, kk > kKeyInf);
+      count(w_neg, kk < kZeroKey);
+      count(w_nan, kk > kInfKey);
     }
     if constexpr (ONESIDED) {
       if (kk <= lo[0] + span[0]) {  // at or below the top of the bottom window: rare
@@ -789,6 +859,13 @@ __device__ __forceinline__ bool win_sweep(const Tab& tab, int n_shards, const ui
         for (int q = 0; q < 4; ++q) lean(key_of(raw[u].d[0][q]), w_lt, w_neg, w_nan);
 #pragma unroll
         for (int q = 0; q < 4; ++q) lean(key_of(raw[u].d[1][q]), w_lt, w_neg, w_nan);
+      } else if constexpr (RAW16) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const uint32_t k2 = Key16<T>::pack2(raw[u].d[0][q], amask2);
+          lean(k2 << 16, w_lt, w_neg, w_nan);
+          lean(k2 & 0xffff0000u, w_lt, w_neg, w_nan);
+        }
       } else if constexpr (T::id == SBQ_BF16) {
         // bf16 -> fp32 bits is a shift / a mask: no conversion
 #pragma unroll
@@ -840,14 +917,26 @@ __device__ __forceinline__ bool win_sweep(const Tab& tab, int n_shards, const ui
     if ((reinterpret_cast<uintptr_t>(x) & 15u) == 0) {
       vend = begin + ((end - begin) / kPack) * kPack;
       for (int64_t e = begin + static_cast<int64_t>(threadIdx.x) * kPack; e < vend; e += static_cast<int64_t>(BLOCK) * kPack) {
-        float v[kPack];
-        load_pack<T, true>(x, e, v);
+        if constexpr (RAW16) {
+          const RawPack<T> r = load_raw<T, true>(x, e);
 #pragma unroll
-        for (int q = 0; q < kPack; ++q) visit(key_of(__builtin_bit_cast(uint32_t, v[q])), true);
+          for (int q = 0; q < 4; ++q) {
+            const uint32_t k2 = Key16<T>::pack2(r.d[0][q], amask2);
+            visit(k2 << 16, true);
+            visit(k2 & 0xffff0000u, true);
+          }
+        } else {
+          float v[kPack];
+          load_pack<T, true>(x, e, v);
+#pragma unroll
+          for (int q = 0; q < kPack; ++q) visit(key_of(__builtin_bit_cast(uint32_t, v[q])), true);
+        }
       }
     }
-    for (int64_t e = vend + threadIdx.x; e < end; e += BLOCK)
-      visit(key_of(__builtin_bit_cast(uint32_t, Elem<T>::load1(x, e))), true);
+    for (int64_t e = vend + threadIdx.x; e < end; e += BLOCK) {
+      if constexpr (RAW16) visit(Key16<T>::one(static_cast<const uint16_t*>(x)[e], use_abs != 0), true);
+      else visit(key_of(__builtin_bit_cast(uint32_t, Elem<T>::load1(x, e))), true);
+    }
   }
   // counters: lanes -> wave -> workgroup -> one of the 64 counter lines
   const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
@@ -975,6 +1064,7 @@ struct OneArgs {
   double alpha;
   uint32_t min_shift;
   int32_t use_abs, mode, final_round;
+  int32_t key_mode;  // KEYS_*: how the final key turns back into a value
   unsigned long long* stamps;  // development (knob 1 == 779): 8 timestamps per workgroup, else nullptr
 };
 // (compiled in only with -DSBQ_SEL_STAMPS=1 -- SBQ_EXTRA_HIPCC_FLAGS of sparsebit_amd/build.py: the conditional
@@ -984,7 +1074,7 @@ struct OneArgs {
 #endif
 __device__ __forceinline__ void one_stamp(const OneArgs& a, int i) {
   if constexpr (SBQ_SEL_STAMPS != 0) {
-    if (a.stamps && threadIdx.x == 0) a.stamps[blockIdx.x * 16 + i] = __builtin_amdgcn_s_memrealtime();
+    if (a.stamps && threadIdx.x == 0) a.stamps[blockIdx.x * 32 + i] = __builtin_amdgcn_s_memrealtime();
   }
 }
 struct OneLds {
@@ -1000,8 +1090,11 @@ __device__ __forceinline__ V one_take(V* p) {  // read and clear, at the memory 
 // The advance of selector s on the workgroup's OWN state (ol.sel[s], LDS).  lh == nullptr: after a grid-wide sweep --
 // the histogram copies and counter lines are gathered (and cleared) with atomic exchanges; else: after a lonely sweep,
 // straight from its LDS histogram.
+// (forceinline: as a real function -- which it becomes for two selectors -- the call passes `s` and `lonely` at run
+// time, the bin arrays go through scratch and the 16 exchanges of a thread are issued one round trip at a time: 4-5 us
+// per selector instead of 0.7)
 template <int NSEL, int BLOCK>
-__device__ void one_advance(const int s, const OneArgs& a, OneLds& ol, const SweepLds<NSEL, BLOCK>* lonely,
+__device__ __forceinline__ void one_advance(const int s, const OneArgs& a, OneLds& ol, const SweepLds<NSEL, BLOCK>* lonely,
                             bool take_signs, AdvShared& sh) {
   const WinSel w = ol.sel[s];
   __syncthreads();  // everyone holds w before anyone replaces it
@@ -1046,8 +1139,10 @@ __device__ void one_advance(const int s, const OneArgs& a, OneLds& ol, const Swe
       c_nan = ol.nan;
     }
   }
+  one_stamp(a, 16 + 2 * s);
   advance_core<BLOCK>(s, w, bins, c_below, c_neg, c_nan, a.n, a.mode == 1, a.alpha, a.min_shift, a.out0, a.out1, sh,
-                      [&](const WinSel& nw) { ol.sel[s] = nw; });
+                      [&](const WinSel& nw) { ol.sel[s] = nw; }, a.key_mode);
+  one_stamp(a, 17 + 2 * s);
   if (take_signs && threadIdx.x == 0) {  // (advance_core left the totals in sh and ended on a barrier)
     ol.neg = sh.neg;
     ol.nan = sh.nan;
@@ -1078,7 +1173,7 @@ __device__ __forceinline__ void win_finish(const Tab& tab, int n_shards, const O
     // window 2048-fold or replaces a missed one: at most 1 + ceil(32 / 11) more)
     for (int round = 0; round < 8; ++round) {
       __syncthreads();
-      const bool live = win_sweep<T, NSEL, false, BLOCK, false, false, true>(tab, n_shards, 0u, 1u, [&](WinSel (&sel)[NSEL]) {
+      const bool live = win_sweep<T, NSEL, false, BLOCK, false, false, true, true>(tab, n_shards, 0u, 1u, [&](WinSel (&sel)[NSEL]) {
 #pragma unroll
         for (int s = 0; s < NSEL; ++s) sel[s] = ol.sel[s];
       }, a.slots, a.hist, a.use_abs, swl);
@@ -1119,18 +1214,25 @@ __device__ __forceinline__ void win_one_body(const Tab& tab, int n_shards, const
   one_stamp(a, 12);
   // ... then the slabs (win_sweep, EARLY), and the plan while they fly
   constexpr bool SIGNS = PCT && NSEL == 2;
-  win_sweep<T, NSEL, SIGNS, BLOCK, true, true, true>(tab, n_shards, wg, nwg, [&](WinSel (&sel)[NSEL]) {
+  win_sweep<T, NSEL, SIGNS, BLOCK, true, true, true, true>(tab, n_shards, wg, nwg, [&](WinSel (&sel)[NSEL]) {
     one_stamp(a, 13);
     lds_sync();  // plan.hist is clear
     one_stamp(a, 1);
-    plan_compute<T, BLOCK>(plan, sm, n_packs, a.mode, NSEL, a.use_abs, a.k0, a.k1, a.n, a.alpha, a.min_shift, ol.sel,
-                           [&](int i) { one_stamp(a, i); });
+    plan_compute<T, BLOCK, true>(plan, sm, n_packs, a.mode, NSEL, a.use_abs, a.k0, a.k1, a.n, a.alpha, a.min_shift, ol.sel,
+                                 [&](int i) { one_stamp(a, i); });
     one_stamp(a, 2);
     if (threadIdx.x == 0) {
       ol.neg = 0;
       ol.nan = 0;
     }
     lds_sync();
+    if constexpr (SBQ_SEL_STAMPS != 0) {  // the windows the plan chose: {lo, shift | span << 32} per selector
+      if (a.stamps && threadIdx.x < static_cast<uint32_t>(NSEL)) {
+        const WinSel w = ol.sel[threadIdx.x];
+        a.stamps[blockIdx.x * 32 + 30 + threadIdx.x] = static_cast<unsigned long long>(w.lo) | (static_cast<unsigned long long>(w.span) << 32);
+        if (threadIdx.x == 0) a.stamps[blockIdx.x * 32 + 29] = static_cast<unsigned long long>(w.shift) | (static_cast<unsigned long long>(ol.sel[NSEL - 1].shift) << 32);
+      }
+    }
 #pragma unroll
     for (int s = 0; s < NSEL; ++s) {
       WinSel w = ol.sel[s];
@@ -1160,7 +1262,7 @@ __device__ __forceinline__ void win_round_body(const Tab& tab, int n_shards, con
   __shared__ AdvShared adv;
   __shared__ OneLds ol;
   __shared__ SweepLds<NSEL, BLOCK> swl;
-  win_sweep<T, NSEL, false, BLOCK, true, true, true>(tab, n_shards, wg, nwg, [&](WinSel (&sel)[NSEL]) {
+  win_sweep<T, NSEL, false, BLOCK, true, true, true, true>(tab, n_shards, wg, nwg, [&](WinSel (&sel)[NSEL]) {
 #pragma unroll
     for (int s = 0; s < NSEL; ++s) sel[s] = a.st->sel[s];  // the previous launch's mailbox
     if (threadIdx.x == 0) {
@@ -1225,6 +1327,7 @@ __global__ __launch_bounds__(BLOCK) void group_kth_kernel(const KthItems items, 
   a.use_abs = use_abs;
   a.mode = 0;
   a.final_round = final_round;
+  a.key_mode = T::id == SBQ_BF16 ? KEYS_BF16_RAW : (T::id == SBQ_F16 ? KEYS_F16_RAW : KEYS_F32);
   a.stamps = nullptr;
   if (round == 0) win_one_body<T, 1, false, BLOCK>(tab, 1, a, blockIdx.x - me.wg_begin, me.nwg);
   else win_round_body<T, 1, BLOCK>(tab, 1, a, blockIdx.x - me.wg_begin, me.nwg);
@@ -1239,7 +1342,7 @@ constexpr size_t kHistBytes = static_cast<size_t>(kCopies) * kWinSel * kWinBins 
 // [ multi-launch protocol: state | counter lines | histogram copies | pad ][ one-launch engine: the same three ]
 constexpr size_t kOldRegion = kStateBytes + kSlotBytes + kHistBytes + 256;
 constexpr size_t kOneRegion = kStateBytes + kSlotBytes + kHistBytes;
-constexpr size_t kStampBytes = 1024 * 16 * 8;  // development timestamps (knob 1 == 779)
+constexpr size_t kStampBytes = 1024 * 32 * 8;  // development timestamps (knob 1 == 779)
 size_t win_select_workspace_bytes() { return kOldRegion + kOneRegion + kStampBytes; }
 
 namespace {
@@ -1264,11 +1367,13 @@ int win_one_run(const void* const* shards, const int64_t* counts, int n_shards, 
   pt.lean_first[n_shards] = static_cast<uint32_t>(n_lean);
   pt.rag_first[n_shards] = static_cast<uint32_t>(total - n_lean);
   if (total >= (1ll << 31)) return SBQ_ERR_ARG;
-  const uint32_t min_shift = x_dtype == SBQ_BF16 ? 16u : (x_dtype == SBQ_F16 ? 13u : 0u);
+  // (16-bit tensors: keys are the raw bit patterns, Key16 -- every value is one key of the 2^16-aligned key space)
+  const uint32_t min_shift = x_dtype == SBQ_F32 ? 0u : 16u;
   const int expected = min_shift > 0 ? 1 : 3;
   const int64_t cus = cu_count();
   const uint32_t grid = static_cast<uint32_t>(total < cus ? (total > 0 ? total : 1) : cus);
   OneArgs a{};
+  a.key_mode = x_dtype == SBQ_BF16 ? KEYS_BF16_RAW : (x_dtype == SBQ_F16 ? KEYS_F16_RAW : KEYS_F32);
   a.st = reinterpret_cast<WinState*>(region);
   a.slots = reinterpret_cast<WinSlot*>(region + kStateBytes);
   a.hist = reinterpret_cast<uint32_t*>(region + kStateBytes + kSlotBytes);
@@ -1452,7 +1557,7 @@ int sbq_group_kth_value(const sbq_kth_item* items, int n_items, int x_dtype, int
     if (!aligned16(items[i].x)) return SBQ_ERR_ALIGN;
   }
   hipStream_t st = as_stream(stream);
-  const uint32_t min_shift = x_dtype == SBQ_BF16 ? 16u : (x_dtype == SBQ_F16 ? 13u : 0u);
+  const uint32_t min_shift = x_dtype == SBQ_F32 ? 0u : 16u;
   const int expected = min_shift > 0 ? 1 : 3;
   const int64_t cus = cu_count();
   for (int first = 0; first < n_items; first += kKthItemsPerLaunch) {

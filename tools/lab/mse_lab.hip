@@ -3,6 +3,8 @@
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off tools/lab/mse_lab.hip -o tools/lab/mse_lab
 // Every variant must produce the same argmin per row as variant 0 (and sums equal to the last bits that matter).
 #include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -113,6 +115,50 @@ __global__ __launch_bounds__(256) void mse_k(const uint16_t* __restrict__ x, con
         s_acc[i + 1][wid] = a1;
       }
     }
+  } else if constexpr (V == 6) {
+    // product loop with TWO accumulators (even / odd elements): halves the dependent fma chain per candidate
+    for (int i = 0; i < kC; ++i) {
+      const float s = s_scale[i], y = s_rcp[i];
+      float a0 = 0.0f, a1 = 0.0f;
+#pragma unroll
+      for (int q = 0; q < 16; q += 2) {
+        const float l0 = __builtin_amdgcn_fmed3f(__builtin_rintf(v[q] * y), qlo, qhi);
+        const float l1 = __builtin_amdgcn_fmed3f(__builtin_rintf(v[q + 1] * y), qlo, qhi);
+        const float d0 = __builtin_fmaf(-l0, s, v[q]);
+        const float d1 = __builtin_fmaf(-l1, s, v[q + 1]);
+        a0 = __builtin_fmaf(d0, d0, a0);
+        a1 = __builtin_fmaf(d1, d1, a1);
+      }
+      float acc = a0 + a1;
+#pragma unroll
+      for (int m = 32; m > 0; m >>= 1) acc += __shfl_xor(acc, m, 64);
+      if (lane == 0) s_acc[i][wid] = acc;
+    }
+  } else if constexpr (V == 7) {
+    // two candidates per pass over the registers, scalar ops, four accumulators: x * y_i and x * y_i+1 share the load
+    // of x from the register file and give the scheduler two independent chains
+    for (int i = 0; i < kC; i += 2) {
+      const float s0 = s_scale[i], y0 = s_rcp[i], s1 = s_scale[i + 1], y1 = s_rcp[i + 1];
+      float a0 = 0.0f, a1 = 0.0f;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const float l0 = __builtin_amdgcn_fmed3f(__builtin_rintf(v[q] * y0), qlo, qhi);
+        const float l1 = __builtin_amdgcn_fmed3f(__builtin_rintf(v[q] * y1), qlo, qhi);
+        const float d0 = __builtin_fmaf(-l0, s0, v[q]);
+        const float d1 = __builtin_fmaf(-l1, s1, v[q]);
+        a0 = __builtin_fmaf(d0, d0, a0);
+        a1 = __builtin_fmaf(d1, d1, a1);
+      }
+#pragma unroll
+      for (int m = 32; m > 0; m >>= 1) {
+        a0 += __shfl_xor(a0, m, 64);
+        a1 += __shfl_xor(a1, m, 64);
+      }
+      if (lane == 0) {
+        s_acc[i][wid] = a0;
+        s_acc[i + 1][wid] = a1;
+      }
+    }
   } else if constexpr (V == 5) {
     // V1 + the wave reduction deferred: 80 accumulators would not fit, so candidates go in groups of 8 whose sums
     // are reduced together by a transposing butterfly (8 values: 4 + 2 + 1 + 3 shuffles instead of 48)
@@ -197,17 +243,27 @@ __global__ void init_k(uint16_t* x, float* mn, float* mx) {
 }
 
 template <int V>
-void run(const char* name, const uint16_t* x, const float* mn, const float* mx, double* sse, std::vector<double>& ref) {
-  hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
-  for (int i = 0; i < 3; ++i) mse_k<V><<<kRows, 256>>>(x, mn, mx, sse);
-  hipEventRecord(a);
-  const int iters = 20;
+double time_once(const uint16_t* x, const float* mn, const float* mx, double* sse, int iters) {
+  hipEvent_t a, b;
+  (void)hipEventCreate(&a);
+  (void)hipEventCreate(&b);
+  mse_k<V><<<kRows, 256>>>(x, mn, mx, sse);
+  (void)hipEventRecord(a);
   for (int i = 0; i < iters; ++i) mse_k<V><<<kRows, 256>>>(x, mn, mx, sse);
-  hipEventRecord(b); hipEventSynchronize(b);
-  float ms; hipEventElapsedTime(&ms, a, b);
+  (void)hipEventRecord(b);
+  (void)hipEventSynchronize(b);
+  float ms;
+  (void)hipEventElapsedTime(&ms, a, b);
+  return ms * 1e3 / iters;
+}
+
+template <int V>
+void check(const char* name, double us, const uint16_t* x, const float* mn, const float* mx, double* sse, std::vector<double>& ref) {
+  mse_k<V><<<kRows, 256>>>(x, mn, mx, sse);
   std::vector<double> h(static_cast<size_t>(kRows) * kC);
-  hipMemcpy(h.data(), sse, h.size() * 8, hipMemcpyDeviceToHost);
-  int diff_idx = 0; double max_rel = 0;
+  (void)hipMemcpy(h.data(), sse, h.size() * 8, hipMemcpyDeviceToHost);
+  int diff_idx = 0;
+  double max_rel = 0;
   if (ref.empty()) ref = h;
   for (int r = 0; r < kRows; ++r) {
     int b0 = 0, b1 = 0;
@@ -221,24 +277,42 @@ void run(const char* name, const uint16_t* x, const float* mn, const float* mx, 
       max_rel = rel > max_rel ? rel : max_rel;
     }
   }
-  const double us = ms * 1e3 / iters;
   const double evals = 80.0 * kRows * kCols;
-  printf("%-52s %8.2f us  %6.1f TFLOP/s (7 flop/eval)  argmin differs in %d rows, max rel diff of sums %.2e\n", name, us,
+  printf("%-56s %8.2f us  %6.1f TFLOP/s (7 flop/eval)  argmin differs in %d rows, max rel diff of sums %.2e\n", name, us,
          evals * 7 / us / 1e6, diff_idx, max_rel);
 }
 
 int main() {
-  uint16_t* x; float *mn, *mx; double* sse;
-  hipMalloc(&x, static_cast<size_t>(kRows) * kCols * 2); hipMalloc(&mn, kRows * 4); hipMalloc(&mx, kRows * 4);
-  hipMalloc(&sse, static_cast<size_t>(kRows) * kC * 8);
+  uint16_t* x;
+  float *mn, *mx;
+  double* sse;
+  (void)hipMalloc(&x, static_cast<size_t>(kRows) * kCols * 2);
+  (void)hipMalloc(&mn, kRows * 4);
+  (void)hipMalloc(&mx, kRows * 4);
+  (void)hipMalloc(&sse, static_cast<size_t>(kRows) * kC * 8);
   init_k<<<kRows, 256>>>(x, mn, mx);
+  // clocks settle first (the first variant of an earlier version of this lab read 164 us, the same kernel 137 us a second later)
+  for (int i = 0; i < 40; ++i) time_once<0>(x, mn, mx, sse, 50);
+  double best[8];
+  for (int v = 0; v < 8; ++v) best[v] = 1e30;
+  for (int round = 0; round < 5; ++round) {
+    best[0] = std::min(best[0], time_once<0>(x, mn, mx, sse, 30));
+    best[1] = std::min(best[1], time_once<1>(x, mn, mx, sse, 30));
+    best[2] = std::min(best[2], time_once<2>(x, mn, mx, sse, 30));
+    best[3] = std::min(best[3], time_once<3>(x, mn, mx, sse, 30));
+    best[4] = std::min(best[4], time_once<4>(x, mn, mx, sse, 30));
+    best[5] = std::min(best[5], time_once<5>(x, mn, mx, sse, 30));
+    best[6] = std::min(best[6], time_once<6>(x, mn, mx, sse, 30));
+    best[7] = std::min(best[7], time_once<7>(x, mn, mx, sse, 30));
+  }
   std::vector<double> ref;
-  run<0>("V0 product loop (mul rndne med3 fma fma)", x, mn, mx, sse, ref);
-  run<3>("V3 = V0 with scale / reciprocal in SGPRs", x, mn, mx, sse, ref);
-  run<1>("V1 packed over element pairs (pk_mul pk_fma pk_fma)", x, mn, mx, sse, ref);
-  run<4>("V4 = V1 with scale / reciprocal in SGPRs", x, mn, mx, sse, ref);
-  run<2>("V2 packed over candidate pairs", x, mn, mx, sse, ref);
-  run<5>("V5 = V1 + transposing butterfly reduction (8 cand.)", x, mn, mx, sse, ref);
-  run<0>("V0 again", x, mn, mx, sse, ref);
+  check<0>("V0 product loop (mul rndne med3 fma fma)", best[0], x, mn, mx, sse, ref);
+  check<3>("V3 = V0 with scale / reciprocal in SGPRs", best[3], x, mn, mx, sse, ref);
+  check<6>("V6 = V0 with two accumulators", best[6], x, mn, mx, sse, ref);
+  check<7>("V7 two candidates per pass, scalar ops", best[7], x, mn, mx, sse, ref);
+  check<1>("V1 packed over element pairs (pk_mul pk_fma pk_fma)", best[1], x, mn, mx, sse, ref);
+  check<4>("V4 = V1 with scale / reciprocal in SGPRs", best[4], x, mn, mx, sse, ref);
+  check<2>("V2 packed over candidate pairs", best[2], x, mn, mx, sse, ref);
+  check<5>("V5 = V1 + transposing butterfly reduction (8 cand.)", best[5], x, mn, mx, sse, ref);
   return 0;
 }

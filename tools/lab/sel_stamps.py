@@ -35,15 +35,20 @@ for kind in ("kth", "pct"):
     for i in range(5): run(kind, i)
     torch.cuda.synchronize()
     L.set_tuning(1, 0)
-    s = sw[OLD + ONE: OLD + ONE + 256 * 128].view(torch.int64).reshape(256, 16).cpu().numpy().astype(np.int64)
+    s = sw[OLD + ONE: OLD + ONE + 256 * 256].view(torch.int64).reshape(256, 32).cpu().numpy().astype(np.int64)
     t0 = s[:, 0].min()
     rel = (s - t0) * 0.01  # us
-    names = ["start", "loads issued", "plan done", "sweep+flush", "arrival", "reset", "advance", "end", "plan: hist", "plan: scan", "plan: ranks", "hist cleared", "sample issued", "slabs issued"]
+    names = ["start", "loads issued", "plan done", "sweep+flush", "arrival", "reset", "advance", "end", "plan: hist", "plan: scan", "plan: ranks", "hist cleared", "sample issued", "slabs issued", "-", "-", "adv0 gathered", "adv0 placed", "adv1 gathered", "adv1 placed"]
+    w0 = s[0, 30]; w1 = s[0, 31]; sh = s[0, 29]
+    print("   windows of workgroup 0: sel0 lo=%08x span=%08x shift=%d | sel1 lo=%08x span=%08x shift=%d | all workgroups agree: %s" % (
+        w0 & 0xffffffff, (w0 >> 32) & 0xffffffff, sh & 0xffffffff, w1 & 0xffffffff, (w1 >> 32) & 0xffffffff, (sh >> 32) & 0xffffffff,
+        bool((s[:, 30] == w0).all() and (s[:, 31] == w1).all())))
     print("== %s: per-stamp us after the first workgroup's start: min / median / max over 256 workgroups" % kind)
     for j, nm in enumerate(names):
         col = rel[:, j]
         col = col[s[:, j] >= t0]  # stamps 5, 6 exist for the last arriver only (older values otherwise)
-        if j in (5, 6):
+        if nm == '-': continue
+        if j in (5, 6, 16, 17, 18, 19):
             last = np.argmax(s[:, 4])
             print("  %-14s last arriver (wg %d): %.2f" % (nm, last, rel[last, j]))
         else:

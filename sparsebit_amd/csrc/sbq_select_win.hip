@@ -188,7 +188,9 @@ __device__ __forceinline__ RawPack<T> raw_from_elems(const float (&v)[kPack]) {
 // Every thread's packs are located first and requested together: one memory round trip for the whole sample.
 // JITTER: pack p sits at a pseudo-random offset inside its stride instead of at its start, so that data periodic
 // with the stride (a channels-last activation whose channel count divides it) is still sampled across its period.
-template <typename T, int kT, bool JITTER, typename Tab>
+// GUARDED (the multi-launch protocol, which takes any shard): unaligned shards, shards shorter than a pack and a
+// shard's ragged end are read element by element, clamped to the shard.
+template <typename T, int kT, bool JITTER, bool GUARDED = false, typename Tab>
 __device__ __forceinline__ void plan_sample_load(const Tab& tab, int n_shards, int64_t n, int64_t n_packs,
                                                  PlanSample<T, kT>& sm) {
   constexpr int kMine = PlanSample<T, kT>::kMine;
@@ -224,9 +226,24 @@ __device__ __forceinline__ void plan_sample_load(const Tab& tab, int n_shards, i
   // (vmcnt(0), slabs included) in front of the plan.
 #pragma unroll
   for (int m = 0; m < kMine; ++m) {
-    const int64_t last = (sm.cnt[m] - kPack) & ~static_cast<int64_t>(kPack - 1);
-    sm.e[m] = sm.e[m] < last ? sm.e[m] : last;
-    sm.raw[m] = load_raw<T, false>(base[m], sm.e[m]);
+    if constexpr (GUARDED) {
+      const int64_t c = sm.cnt[m];
+      if ((reinterpret_cast<uintptr_t>(base[m]) & 15u) == 0 && sm.e[m] + kPack <= c) {
+        sm.raw[m] = load_raw<T, false>(base[m], sm.e[m]);
+      } else {
+        float v[kPack];
+#pragma unroll
+        for (int j = 0; j < kPack; ++j) {
+          const int64_t i = sm.e[m] + j < c ? sm.e[m] + j : c - 1;
+          v[j] = c > 0 ? Elem<T>::load1(base[m], i) : 0.f;
+        }
+        sm.raw[m] = raw_from_elems<T>(v);
+      }
+    } else {
+      const int64_t last = (sm.cnt[m] - kPack) & ~static_cast<int64_t>(kPack - 1);
+      sm.e[m] = sm.e[m] < last ? sm.e[m] : last;
+      sm.raw[m] = load_raw<T, false>(base[m], sm.e[m]);
+    }
   }
 }
 
@@ -394,7 +411,7 @@ __global__ __launch_bounds__(1024) void win_plan_kernel(const ShardTable tab, in
   for (int i = threadIdx.x; i < kPlanBins; i += kT) L.hist[i] = 0;
   const int64_t n_packs = n / kPack < kPlanPacks ? (n / kPack > 0 ? n / kPack : 1) : kPlanPacks;
   PlanSample<T, kT> sm;
-  plan_sample_load<T, kT, false>(tab, n_shards, n, n_packs, sm);
+  plan_sample_load<T, kT, false, true>(tab, n_shards, n, n_packs, sm);
   // the counter lines and histogram copies the sweeps add to (the advance leaves them clean, a first call or an
   // abandoned one does not): 136 KB of stores, queued BEHIND the sample's loads (the vector-memory path of the one
   // CU this kernel runs on is in order)
@@ -1204,19 +1221,23 @@ __device__ __forceinline__ void win_one_body(const Tab& tab, int n_shards, const
   __shared__ OneLds ol;
   __shared__ SweepLds<NSEL, BLOCK> swl;
   one_stamp(a, 0);
-  for (int i = threadIdx.x; i < kPlanBins; i += BLOCK) plan.hist[i] = 0;
   const int64_t n_packs = a.n / kPack < kPlanPacks ? (a.n / kPack > 0 ? a.n / kPack : 1) : kPlanPacks;
   // the sample first (vector-memory loads return in order: the plan must not wait for the slabs) ...
-  one_stamp(a, 11);
   PlanSample<T, BLOCK> sm;
   plan_sample_load<T, BLOCK, true>(tab, n_shards, a.n, n_packs, sm);
   __builtin_amdgcn_sched_barrier(0);
+  one_stamp(a, 11);
+  for (int i = threadIdx.x; i < kPlanBins; i += BLOCK) plan.hist[i] = 0;
+  // ... of EVERY wave before any wave's slabs: the compute unit's memory pipeline serves its waves' requests in
+  // order, so a late wave's sample would queue behind the early waves' slabs -- 128 KB per workgroup, 5 us at a
+  // compute unit's share of the HBM rate -- and the plan, which needs the whole sample, with it.  (Measured: the
+  // barrier below used to sit behind the slab requests and took 4.3 us to clear.)
+  lds_sync();  // also: plan.hist is clear
   one_stamp(a, 12);
   // ... then the slabs (win_sweep, EARLY), and the plan while they fly
   constexpr bool SIGNS = PCT && NSEL == 2;
   win_sweep<T, NSEL, SIGNS, BLOCK, true, true, true, true>(tab, n_shards, wg, nwg, [&](WinSel (&sel)[NSEL]) {
     one_stamp(a, 13);
-    lds_sync();  // plan.hist is clear
     one_stamp(a, 1);
     plan_compute<T, BLOCK, true>(plan, sm, n_packs, a.mode, NSEL, a.use_abs, a.k0, a.k1, a.n, a.alpha, a.min_shift, ol.sel,
                                  [&](int i) { one_stamp(a, i); });

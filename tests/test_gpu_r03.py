@@ -460,3 +460,26 @@ def test_device_calibrator_groups_plain_weight_quantizers(oracle):
         m.weight_quantizer.enable_quant()
         q.enable_quant()
         assert torch.equal(q(m.weight.detach()), m.weight_quantizer(m.weight.detach())), i
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+def test_selection_reads_nothing_outside_a_short_shard(ops, dtype):
+    """Shards shorter than a 16-byte pack (and ragged ends) at the very start / end of a device allocation: the
+    sample loads of the multi-launch protocol must stay inside the shard (a read 16 bytes in front of a fresh
+    allocation is a memory access fault, not a wrong value)."""
+    big = torch.empty(48 << 20, dtype=torch.uint8, device="cuda")  # its own segment of the caching allocator
+    elem = torch.empty(0, dtype=dtype).element_size()
+    whole = big.view(dtype)
+    g = torch.Generator().manual_seed(3)
+    for n in (1, 2, 7, 9, 15, 1000, 1001):
+        vals = torch.randn(n, generator=g).to(dtype)
+        for x in (whole[:n], whole[whole.numel() - n:]):
+            x.copy_(vals)
+            ref = np.sort(vals.float().numpy())
+            for k in sorted({1, (n + 1) // 2, n}):
+                assert float(ops.kth_value(x, k, False)) == ref[k - 1], (n, k)
+            lo, hi = ops.percentile_select([x.reshape(1, n)], 0.25, per_channel=False)
+            assert np.isfinite(float(lo)) and np.isfinite(float(hi))
+    torch.cuda.synchronize()
+    assert elem in (2, 4)

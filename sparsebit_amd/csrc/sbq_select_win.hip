@@ -458,17 +458,23 @@ __device__ __forceinline__ WinSel win_read_sel(const WinState* st, int s) {
 // The placement of one selector's rank, given its window `w`, this thread's bins of the window's histogram and the
 // counters of the sweep (c_below / c_neg / c_nan: partial values in the threads of wave 0, zero elsewhere).  Names the
 // next window through write_sel -- or writes the result when the window is one value wide.
+// BLOCK threads, numbered `tid`, work on the selector: the whole workgroup, or one half of it while the other half
+// places the other selector (one_advance_pair) -- every path through this function crosses the same three workgroup
+// barriers, so the halves may take different ones.  put_signs == false: this half's wave 0 holds no sign counts; the
+// other half writes them into this half's `sh` as well (`also`), before the first barrier.
 template <int BLOCK, typename WriteSel>
-__device__ __forceinline__ void advance_core(const int s, const WinSel& w, const unsigned long long (&bins)[kWinBins / BLOCK],
+__device__ __forceinline__ void advance_core(const int tid, const int s, const WinSel& w,
+                                             const unsigned long long (&bins)[kWinBins / BLOCK],
                                              unsigned long long c_below, unsigned long long c_neg,
                                              unsigned long long c_nan, const int64_t n, int percentile, double alpha,
                                              uint32_t min_shift, float* __restrict__ out0, float* __restrict__ out1,
-                                             AdvShared& sh, WriteSel&& write_sel, const int key_mode = KEYS_F32) {
+                                             AdvShared& sh, WriteSel&& write_sel, const int key_mode = KEYS_F32,
+                                             const bool put_signs = true, AdvShared* also = nullptr) {
   constexpr int kPer = kWinBins / BLOCK;
   unsigned long long t = 0;
 #pragma unroll
   for (int i = 0; i < kPer; ++i) t += bins[i];
-  const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
+  const int lane = tid & (kWave - 1), wid = tid / kWave;
   // Every count here is at most n: below 2^32 elements (uniform test) the scan and the prefix of the wave totals run
   // on DPP in 32 bits; the 64-bit shuffles remain for selections over more.  So do the sums of the 64 counter lines --
   // as wave reductions of 64-bit values they were 36 ds_bpermute round trips, most of this function's 2 us (LDS
@@ -498,8 +504,14 @@ __device__ __forceinline__ void advance_core(const int s, const WinSel& w, const
     }
     if (lane == 0) {
       sh.below = c_below;
-      sh.neg = c_neg;
-      sh.nan = c_nan;
+      if (put_signs) {
+        sh.neg = c_neg;
+        sh.nan = c_nan;
+        if (also) {
+          also->neg = c_neg;
+          also->nan = c_nan;
+        }
+      }
     }
   }
   __syncthreads();
@@ -511,7 +523,7 @@ __device__ __forceinline__ void advance_core(const int s, const WinSel& w, const
   }
   incl += off;
   const unsigned long long excl = incl - t;
-  if (threadIdx.x == BLOCK - 1) sh.total = incl;
+  if (tid == BLOCK - 1) sh.total = incl;
   __syncthreads();
   const unsigned long long total = sh.total;
   const int64_t neg = static_cast<int64_t>(sh.neg), nan = static_cast<int64_t>(sh.nan);
@@ -529,7 +541,7 @@ __device__ __forceinline__ void advance_core(const int s, const WinSel& w, const
     const uint64_t hi = static_cast<uint64_t>(w.lo) + w.span + 1;  // exclusive
     if (static_cast<unsigned long long>(k) <= below) {
       // the sample lied: the rank is below the window.  New window: every key below it.
-      if (threadIdx.x == 0) {
+      if (tid == 0) {
         WinSel nw = w;
         nw.lo = 0;
         nw.shift = shift_for(w.lo, min_shift);
@@ -544,7 +556,7 @@ __device__ __forceinline__ void advance_core(const int s, const WinSel& w, const
     if (static_cast<unsigned long long>(k) > below + total) {
       // ... or above it.  New window: every key from its end on (hi < 2^32 here: a window reaching the last key
       // holds every element that is not below it)
-      if (threadIdx.x == 0) {
+      if (tid == 0) {
         WinSel nw = w;
         nw.lo = static_cast<uint32_t>(hi);
         nw.shift = shift_for((1ull << 32) - hi, min_shift);
@@ -571,7 +583,7 @@ __device__ __forceinline__ void advance_core(const int s, const WinSel& w, const
       }
     }
     WinSel nw = w;
-    nw.lo = w.lo + (static_cast<uint32_t>(threadIdx.x * kPer + b) << w.shift);
+    nw.lo = w.lo + (static_cast<uint32_t>(tid * kPer + b) << w.shift);
     nw.k = static_cast<int64_t>(kk);
     nw.fresh = 0;
     if (w.shift <= min_shift) {
@@ -654,7 +666,7 @@ __device__ void win_advance(const int s, uint32_t* __restrict__ hist, WinState* 
     c_nan = win_ld<COHERENT>(&slots[threadIdx.x].nan);
     if (c_below) win_st<COHERENT>(&slots[threadIdx.x].below[s], 0ull);
   }
-  advance_core<BLOCK>(s, w, bins, c_below, c_neg, c_nan, st->n, percentile, alpha, min_shift, out0, out1, sh, write_sel);
+  advance_core<BLOCK>(threadIdx.x, s, w, bins, c_below, c_neg, c_nan, st->n, percentile, alpha, min_shift, out0, out1, sh, write_sel);
 }
 
 // ... as its own launch: one workgroup per selector.
@@ -716,7 +728,15 @@ struct SweepLds {
   uint32_t lh[NSEL][kWinBins];
   unsigned long long red[NSEL + 2][BLOCK / kWave];
   unsigned long long tot[NSEL + 2];
+#if defined(SBQ_SEL_STAMPS) && SBQ_SEL_STAMPS != 0
+  unsigned long long* stamps;  // development build only
+#endif
 };
+#if defined(SBQ_SEL_STAMPS) && SBQ_SEL_STAMPS != 0
+#define SBQ_SWEEP_STAMP(i) do { if (lds.stamps && threadIdx.x == 0) lds.stamps[blockIdx.x * 32 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define SBQ_SWEEP_STAMP(i) do { } while (0)
+#endif
 
 template <typename T, int NSEL, bool SIGNS, int BLOCK, bool EARLY, bool FLUSH, bool ALWAYS = false, bool KEY16 = false,
           typename Tab, typename LoadState>
@@ -864,6 +884,88 @@ __device__ __forceinline__ bool win_sweep(const Tab& tab, int n_shards, const ui
       if (d <= span[s]) atomicAdd(&lh[s][d >> sh[s]], 1u);
     }
   };
+  // 16-bit inputs: the keys of a pack stay PACKED.  A window of a 16-bit selection is 2^16-aligned in key32 (Key16),
+  // so every test has an exact 16-bit form; per pack of 8 keys the sweep spends one packed min / max chain and one
+  // compare per window to learn that NONE of them is in it (all but a few per cent of the packs), and one compare
+  // per key for the counts that every key contributes to.  Only a pack with a key in a window -- or a NaN -- goes
+  // through its keys one by one, behind a real branch.
+  // (As separate key32 values every key paid a shift, a subtract, two compares and three predicated-off
+  // instructions of the histogram add: 8 vector operations per key, against 4 here.)
+  typedef uint16_t u16x2 __attribute__((ext_vector_type(2)));
+  auto pk = [](uint32_t v) { return __builtin_bit_cast(u16x2, v); };
+  auto pk_min = [&](uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(pk(a), pk(b))); };
+  auto pk_max = [&](uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(pk(a), pk(b))); };
+  auto pk_sub = [&](uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, pk(a) - pk(b)); };
+  auto halves_min = [](uint32_t v) { const uint32_t a = v & 0xffffu, b = v >> 16; return a < b ? a : b; };
+  auto halves_max = [](uint32_t v) { const uint32_t a = v & 0xffffu, b = v >> 16; return a > b ? a : b; };
+  uint32_t lo16[NSEL], span16[NSEL], sh16[NSEL], lo2[NSEL];
+#pragma unroll
+  for (int s = 0; s < NSEL; ++s) {
+    lo16[s] = lo[s] >> 16;
+    span16[s] = span[s] >> 16;
+    sh16[s] = sh[s] >= 16 ? sh[s] - 16 : 0;
+    lo2[s] = lo16[s] * 0x10001u;
+  }
+  constexpr uint32_t kZero16 = kZeroKey >> 16, kInf16 = kInfKey >> 16;
+  auto lean16 = [&](const uint32_t (&x)[4], uint32_t (&w_lt)[NSEL], uint32_t& w_neg) {
+    bool slow = false;
+    if constexpr (SIGNS) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        count(w_neg, (x[q] & 0xffffu) < kZero16);
+        count(w_neg, (x[q] >> 16) < kZero16);
+      }
+    }
+    if constexpr (SIGNS || ONESIDED) {
+      const uint32_t mx = halves_max(pk_max(pk_max(x[0], x[1]), pk_max(x[2], x[3])));
+      if constexpr (SIGNS) slow |= mx > kInf16;
+      if constexpr (ONESIDED) slow |= mx >= lo16[1];
+    }
+    if constexpr (ONESIDED) {
+      const uint32_t mn = halves_min(pk_min(pk_min(x[0], x[1]), pk_min(x[2], x[3])));
+      slow |= mn <= lo16[0] + span16[0];
+    } else {
+#pragma unroll
+      for (int s = 0; s < NSEL; ++s) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          count(w_lt[s], (x[q] & 0xffffu) < lo16[s]);
+          count(w_lt[s], (x[q] >> 16) < lo16[s]);
+        }
+        const uint32_t d = halves_min(pk_min(pk_min(pk_sub(x[0], lo2[s]), pk_sub(x[1], lo2[s])),
+                                             pk_min(pk_sub(x[2], lo2[s]), pk_sub(x[3], lo2[s]))));
+        slow |= d <= span16[s];
+      }
+    }
+    if (slow) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const uint32_t k = h ? x[q] >> 16 : x[q] & 0xffffu;
+          if constexpr (SIGNS) nan += k > kInf16;
+          if constexpr (ONESIDED) {
+            if (k <= lo16[0] + span16[0]) {
+              const uint32_t d = (k - lo16[0]) & 0xffffu;
+              if (d <= span16[0]) atomicAdd(&lh[0][d >> sh16[0]], 1u);
+              else ++lt[0];  // wrapped: below the window
+            }
+            if (k >= lo16[1]) {
+              const uint32_t d = k - lo16[1];
+              if (d <= span16[1]) atomicAdd(&lh[1][d >> sh16[1]], 1u);
+              else ++lt[1];  // above the window
+            }
+          } else {
+#pragma unroll
+            for (int s = 0; s < NSEL; ++s) {
+              const uint32_t d = (k - lo16[s]) & 0xffffu;
+              if (d <= span16[s]) atomicAdd(&lh[s][d >> sh16[s]], 1u);
+            }
+          }
+        }
+      }
+    }
+  };
   auto sweep_lean = [&](const RawPack<T> (&raw)[U]) {
     // wave-uniform counters of this slab (SGPRs), folded into lane 0's counters at its end
     uint32_t w_lt[NSEL], w_neg = 0, w_nan = 0;
@@ -877,12 +979,10 @@ __device__ __forceinline__ bool win_sweep(const Tab& tab, int n_shards, const ui
 #pragma unroll
         for (int q = 0; q < 4; ++q) lean(key_of(raw[u].d[1][q]), w_lt, w_neg, w_nan);
       } else if constexpr (RAW16) {
+        uint32_t x[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const uint32_t k2 = Key16<T>::pack2(raw[u].d[0][q], amask2);
-          lean(k2 << 16, w_lt, w_neg, w_nan);
-          lean(k2 & 0xffff0000u, w_lt, w_neg, w_nan);
-        }
+        for (int q = 0; q < 4; ++q) x[q] = Key16<T>::pack2(raw[u].d[0][q], amask2);
+        lean16(x, w_lt, w_neg);
       } else if constexpr (T::id == SBQ_BF16) {
         // bf16 -> fp32 bits is a shift / a mask: no conversion
 #pragma unroll
@@ -956,6 +1056,7 @@ __device__ __forceinline__ bool win_sweep(const Tab& tab, int n_shards, const ui
     }
   }
   // counters: lanes -> wave -> workgroup -> one of the 64 counter lines
+  SBQ_SWEEP_STAMP(15);
   const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
   unsigned long long tot[kCounters];
 #pragma unroll
@@ -969,6 +1070,7 @@ __device__ __forceinline__ bool win_sweep(const Tab& tab, int n_shards, const ui
     for (int c = 0; c < kCounters; ++c) red[c][wid] = tot[c];
   }
   __syncthreads();
+  SBQ_SWEEP_STAMP(20);
   WinSlot* slot = slots + (wg % kSlots);
   if (threadIdx.x < kCounters) {
     unsigned long long t = 0;
@@ -1157,8 +1259,8 @@ __device__ __forceinline__ void one_advance(const int s, const OneArgs& a, OneLd
     }
   }
   one_stamp(a, 16 + 2 * s);
-  advance_core<BLOCK>(s, w, bins, c_below, c_neg, c_nan, a.n, a.mode == 1, a.alpha, a.min_shift, a.out0, a.out1, sh,
-                      [&](const WinSel& nw) { ol.sel[s] = nw; }, a.key_mode);
+  advance_core<BLOCK>(threadIdx.x, s, w, bins, c_below, c_neg, c_nan, a.n, a.mode == 1, a.alpha, a.min_shift, a.out0, a.out1,
+                      sh, [&](const WinSel& nw) { ol.sel[s] = nw; }, a.key_mode);
   one_stamp(a, 17 + 2 * s);
   if (take_signs && threadIdx.x == 0) {  // (advance_core left the totals in sh and ended on a barrier)
     ol.neg = sh.neg;
@@ -1167,10 +1269,62 @@ __device__ __forceinline__ void one_advance(const int s, const OneArgs& a, OneLd
   __syncthreads();
 }
 
+// Both selectors of a launch at once, after a grid-wide sweep: half of the workgroup each (the placement is a chain
+// of barriers, scans and one thread's arithmetic -- 2.2 us per selector of latency, not of work).  Only when both
+// are still unresolved; the counts of a first sweep (take_signs) are taken by half 0 and handed to half 1.
+template <int BLOCK>
+__device__ __forceinline__ void one_advance_pair(const OneArgs& a, OneLds& ol, bool take_signs, AdvShared (&sh)[2]) {
+  constexpr int NT = BLOCK / 2;
+  static_assert(NT % kWave == 0 && NT >= kSlots, "a half is whole waves and holds the counter lines");
+  const int s = threadIdx.x / NT;  // wave-uniform
+  const int tid = threadIdx.x - s * NT;
+  const WinSel w = ol.sel[s];
+  __syncthreads();  // everyone holds w before anyone replaces it
+  constexpr int kPer = kWinBins / NT;
+  unsigned long long bins[kPer];
+#pragma unroll
+  for (int i = 0; i < kPer; ++i) bins[i] = 0;
+  unsigned long long c_below = 0, c_neg = 0, c_nan = 0;
+  if (static_cast<uint32_t>(tid * kPer) <= (w.span >> w.shift)) {
+    uint32_t v[kCopies][kPer];
+#pragma unroll
+    for (int c = 0; c < kCopies; ++c) {
+      uint32_t* src = a.hist + (static_cast<size_t>(c) * kWinSel + s) * kWinBins + tid * kPer;
+#pragma unroll
+      for (int i = 0; i < kPer; ++i) v[c][i] = one_take(src + i);
+    }
+#pragma unroll
+    for (int c = 0; c < kCopies; ++c)
+#pragma unroll
+      for (int i = 0; i < kPer; ++i) bins[i] += v[c][i];
+  }
+  if (tid < kSlots) {
+    c_below = one_take(&a.slots[tid].below[s]);
+    if (take_signs && s == 0) {
+      c_neg = one_take(&a.slots[tid].neg);
+      c_nan = one_take(&a.slots[tid].nan);
+    }
+  }
+  if (!take_signs && tid == 0) {
+    c_neg = ol.neg;
+    c_nan = ol.nan;
+  }
+  one_stamp(a, 16);
+  advance_core<NT>(tid, s, w, bins, c_below, c_neg, c_nan, a.n, a.mode == 1, a.alpha, a.min_shift, a.out0, a.out1, sh[s],
+                   [&](const WinSel& nw) { ol.sel[s] = nw; }, a.key_mode, !take_signs || s == 0,
+                   take_signs && s == 0 ? &sh[1] : nullptr);
+  one_stamp(a, 17);
+  if (take_signs && threadIdx.x == 0) {  // (advance_core left the totals in sh and ended on a barrier)
+    ol.neg = sh[0].neg;
+    ol.nan = sh[0].nan;
+  }
+  __syncthreads();
+}
+
 // arrival + advance (+ the lonely rounds and the clean-up when this launch is the selection's last)
 template <typename T, int NSEL, int BLOCK, typename Tab>
 __device__ __forceinline__ void win_finish(const Tab& tab, int n_shards, const OneArgs& a, const uint32_t nwg, OneLds& ol,
-                                           SweepLds<NSEL, BLOCK>& swl, AdvShared& adv, bool signs_in_slots) {
+                                           SweepLds<NSEL, BLOCK>& swl, AdvShared (&adv)[2], bool signs_in_slots) {
   // this workgroup's adds are acknowledged before its arrival is counted
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __builtin_amdgcn_s_waitcnt(0);
@@ -1182,8 +1336,14 @@ __device__ __forceinline__ void win_finish(const Tab& tab, int n_shards, const O
   if (!ol.flag) return;
   if (threadIdx.x == 0) one_take(&a.st->arrivals);
   one_stamp(a, 5);
+  bool pair = false;
+  if constexpr (NSEL == 2) pair = !ol.sel[0].done && !ol.sel[1].done;
+  if (pair) {
+    if constexpr (NSEL == 2) one_advance_pair<BLOCK>(a, ol, signs_in_slots, adv);
+  } else {
 #pragma unroll
-  for (int s = 0; s < NSEL; ++s) one_advance<NSEL, BLOCK>(s, a, ol, nullptr, signs_in_slots && s == 0, adv);
+    for (int s = 0; s < NSEL; ++s) one_advance<NSEL, BLOCK>(s, a, ol, nullptr, signs_in_slots && s == 0, adv[0]);
+  }
   one_stamp(a, 6);
   if (a.final_round) {
     // rounds nobody planned for: this workgroup sweeps alone until every selector is resolved (each round narrows a
@@ -1197,7 +1357,7 @@ __device__ __forceinline__ void win_finish(const Tab& tab, int n_shards, const O
       if (!live) break;
       __syncthreads();
 #pragma unroll
-      for (int s = 0; s < NSEL; ++s) one_advance<NSEL, BLOCK>(s, a, ol, &swl, false, adv);
+      for (int s = 0; s < NSEL; ++s) one_advance<NSEL, BLOCK>(s, a, ol, &swl, false, adv[0]);
     }
   } else {
     // the mailbox for the next launch of this selection: plain stores, ordered by the kernel boundary
@@ -1217,10 +1377,13 @@ template <typename T, int NSEL, bool PCT, int BLOCK, typename Tab>
 __device__ __forceinline__ void win_one_body(const Tab& tab, int n_shards, const OneArgs& a, const uint32_t wg,
                                              const uint32_t nwg) {
   __shared__ PlanLds plan;
-  __shared__ AdvShared adv;
+  __shared__ AdvShared adv[2];
   __shared__ OneLds ol;
   __shared__ SweepLds<NSEL, BLOCK> swl;
   one_stamp(a, 0);
+#if SBQ_SEL_STAMPS != 0
+  if (threadIdx.x == 0) swl.stamps = a.stamps;
+#endif
   const int64_t n_packs = a.n / kPack < kPlanPacks ? (a.n / kPack > 0 ? a.n / kPack : 1) : kPlanPacks;
   // the sample first (vector-memory loads return in order: the plan must not wait for the slabs) ...
   PlanSample<T, BLOCK> sm;
@@ -1254,6 +1417,10 @@ __device__ __forceinline__ void win_one_body(const Tab& tab, int n_shards, const
         if (threadIdx.x == 0) a.stamps[blockIdx.x * 32 + 29] = static_cast<unsigned long long>(w.shift) | (static_cast<unsigned long long>(ol.sel[NSEL - 1].shift) << 32);
       }
     }
+    if constexpr (SBQ_SEL_STAMPS == 2) {  // when has every slab arrived?
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      one_stamp(a, 14);
+    }
 #pragma unroll
     for (int s = 0; s < NSEL; ++s) {
       WinSel w = ol.sel[s];
@@ -1280,7 +1447,7 @@ __global__ __launch_bounds__(BLOCK) void win_one_kernel(const Tab tab, int n_sha
 template <typename T, int NSEL, int BLOCK, typename Tab>
 __device__ __forceinline__ void win_round_body(const Tab& tab, int n_shards, const OneArgs& a, const uint32_t wg,
                                                const uint32_t nwg) {
-  __shared__ AdvShared adv;
+  __shared__ AdvShared adv[2];
   __shared__ OneLds ol;
   __shared__ SweepLds<NSEL, BLOCK> swl;
   win_sweep<T, NSEL, false, BLOCK, true, true, true, true>(tab, n_shards, wg, nwg, [&](WinSel (&sel)[NSEL]) {

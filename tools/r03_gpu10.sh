@@ -1,7 +1,7 @@
 #!/bin/bash
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-( timeout 200 python tools/lab/sel_stamps.py 2>&1 | grep -v amdgpu.ids ) > gpurun_out/r03j_stamps.log 2>&1
-( timeout 900 python -m pytest tests/test_gpu_select_win.py tests/test_gpu_r03.py -x -q 2>&1 | tail -5 ) > gpurun_out/r03j_tests.log 2>&1
-( timeout 300 python tools/r03_probe.py 2>&1 | grep -v amdgpu.ids ) > gpurun_out/r03j_probe.log 2>&1
-grep -E "adv|arrival|end  |sweep|plan|issued|cleared|==" gpurun_out/r03j_stamps.log; tail -3 gpurun_out/r03j_tests.log; cat gpurun_out/r03j_probe.log
+( timeout 200 python tools/lab/sel_stamps.py 2>&1 | grep -v amdgpu.ids ) > gpurun_out/r03k_stamps.log 2>&1
+( timeout 900 python -m pytest tests/test_gpu_select_win.py tests/test_gpu_r03.py -x -q 2>&1 | tail -5 ) > gpurun_out/r03k_tests.log 2>&1
+( timeout 300 python tools/r03_probe.py 2>&1 | grep -v amdgpu.ids ) > gpurun_out/r03k_probe.log 2>&1
+grep -E "adv|arrival|end  |sweep|plan|issued|cleared|==" gpurun_out/r03k_stamps.log; tail -3 gpurun_out/r03k_tests.log; cat gpurun_out/r03k_probe.log

@@ -27,6 +27,7 @@
 #include <cstddef>
 #include <type_traits>
 
+#include <atomic>
 #include "sbq_common.hpp"
 
 namespace sbq {
@@ -65,7 +66,10 @@ static_assert(offsetof(WinState, arrivals) == 128, "the arrival counter has a li
 struct WinSlot {  // one 128-byte line
   unsigned long long below[kWinSel];
   unsigned long long neg, nan;
-  unsigned long long pad[12];
+  // one-launch engine, resident rounds: (epoch << 8) | (round << 1) | done -- what the round's last arriver found.
+  // Compared for equality with the caller's own epoch and round, never cleared: a stale value matches nothing.
+  unsigned long long verdict;
+  unsigned long long pad[11];
 };
 struct ShardTable {
   static constexpr bool kSingle = false;
@@ -1184,6 +1188,7 @@ struct OneArgs {
   uint32_t min_shift;
   int32_t use_abs, mode, final_round;
   int32_t key_mode;  // KEYS_*: how the final key turns back into a value
+  unsigned long long epoch;  // of this selection (host counter, > 0): tags the verdicts of its resident rounds
   unsigned long long* stamps;  // development (knob 1 == 779): 8 timestamps per workgroup, else nullptr
 };
 // (compiled in only with -DSBQ_SEL_STAMPS=1 -- SBQ_EXTRA_HIPCC_FLAGS of sparsebit_amd/build.py: the conditional
@@ -1200,6 +1205,7 @@ struct OneLds {
   WinSel sel[kWinSel];
   unsigned long long neg, nan;  // sign / NaN counts of the whole selection (the first sweep's)
   uint32_t flag;
+  unsigned long long verdict;
 };
 template <typename V>
 __device__ __forceinline__ V one_take(V* p) {  // read and clear, at the memory side
@@ -1321,10 +1327,27 @@ __device__ __forceinline__ void one_advance_pair(const OneArgs& a, OneLds& ol, b
   __syncthreads();
 }
 
-// arrival + advance (+ the lonely rounds and the clean-up when this launch is the selection's last)
+// arrival + advance.  Returns true when this workgroup is to sweep again with the state in ol (a resident round).
+//
+// A selection's LAST launch must resolve every selector.  When the windows it starts from are already one value per
+// bin (16-bit inputs whose sample bracketed the rank within 2048 values -- the common case) one advance does it, and
+// every workgroup but the last arriver leaves at its arrival.  When they are not -- the rank is an extreme (k = 1,
+// alpha = 1e-5: the sample cannot bracket it), the bracket is wider than 2048 values (fp16 around zero), the data is
+// half zeros -- every workgroup KNOWS, because every workgroup derived the same windows: the launch is `resident`.
+// Then nobody leaves: the others wait for the last arriver's verdict (64 copies, one per counter line, polled with
+// atomic read-modify-writes: an XCD's L2 may hold a stale copy of anything else), fetch the narrowed windows from the
+// state's mailbox and sweep again, all of them -- a second grid-wide sweep of data that is still in the memory-side
+// cache costs 8 us.  Before, the last arriver swept the whole tensor alone: 835 us for 16.7 M elements, 7 ms when
+// half of them were one value.  (Not resident and still unresolved -- the sample lied, 1e-9 by design: the last
+// arriver does finish alone, below.)
+// The grid is at most one workgroup per compute unit and workgroups are dispatched in order, so the workgroups a
+// resident one waits for are running or will be given the next free compute unit; a wait that outlasts any
+// plausible schedule (seconds) traps instead of hanging the device.
 template <typename T, int NSEL, int BLOCK, typename Tab>
-__device__ __forceinline__ void win_finish(const Tab& tab, int n_shards, const OneArgs& a, const uint32_t nwg, OneLds& ol,
-                                           SweepLds<NSEL, BLOCK>& swl, AdvShared (&adv)[2], bool signs_in_slots) {
+__device__ __forceinline__ bool win_finish(const Tab& tab, int n_shards, const OneArgs& a, const uint32_t wg,
+                                           const uint32_t nwg, OneLds& ol, SweepLds<NSEL, BLOCK>& swl,
+                                           AdvShared (&adv)[2], bool signs_in_slots, const bool resident,
+                                           const uint32_t round) {
   // this workgroup's adds are acknowledged before its arrival is counted
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __builtin_amdgcn_s_waitcnt(0);
@@ -1333,7 +1356,34 @@ __device__ __forceinline__ void win_finish(const Tab& tab, int n_shards, const O
     ol.flag = __hip_atomic_fetch_add(&a.st->arrivals, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nwg - 1;
   __syncthreads();
   one_stamp(a, 4);
-  if (!ol.flag) return;
+  const unsigned long long tag = (a.epoch << 8) | (static_cast<unsigned long long>(round) << 1);
+  unsigned long long* mail = reinterpret_cast<unsigned long long*>(a.st);  // sel[] first, then n, pad_neg, pad_nan
+  constexpr int kSelWords = static_cast<int>(sizeof(WinSel) / 8) * NSEL;
+  static_assert(offsetof(WinState, sel) == 0 && sizeof(WinSel) % 8 == 0, "mailbox layout");
+  if (!ol.flag) {
+    if (!(a.final_round && resident)) return false;
+    if (threadIdx.x == 0) {
+      unsigned long long* vp = &a.slots[wg % kSlots].verdict;
+      unsigned long long v = 0;
+      for (uint32_t spin = 0;; ++spin) {
+        v = __hip_atomic_fetch_add(vp, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((v >> 1) == (tag >> 1)) break;
+        if (spin > (1u << 23)) __builtin_trap();  // seconds: the grid is not resident -- a bug, not a schedule
+        __builtin_amdgcn_s_sleep(8);
+      }
+      ol.verdict = v;
+    }
+    __syncthreads();
+    if (ol.verdict & 1ull) return false;  // resolved
+    // the narrowed windows (written before the verdict: both are read-modify-writes at the memory side)
+    if (threadIdx.x < kSelWords)
+      reinterpret_cast<unsigned long long*>(ol.sel)[threadIdx.x] =
+          __hip_atomic_fetch_add(mail + threadIdx.x, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == kSelWords) ol.neg = __hip_atomic_fetch_add(&a.st->pad_neg, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == kSelWords + 1) ol.nan = __hip_atomic_fetch_add(&a.st->pad_nan, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    return true;
+  }
   if (threadIdx.x == 0) one_take(&a.st->arrivals);
   one_stamp(a, 5);
   bool pair = false;
@@ -1345,10 +1395,41 @@ __device__ __forceinline__ void win_finish(const Tab& tab, int n_shards, const O
     for (int s = 0; s < NSEL; ++s) one_advance<NSEL, BLOCK>(s, a, ol, nullptr, signs_in_slots && s == 0, adv[0]);
   }
   one_stamp(a, 6);
-  if (a.final_round) {
-    // rounds nobody planned for: this workgroup sweeps alone until every selector is resolved (each round narrows a
-    // window 2048-fold or replaces a missed one: at most 1 + ceil(32 / 11) more)
-    for (int round = 0; round < 8; ++round) {
+  if (!a.final_round) {
+    // the mailbox for the next launch of this selection: plain stores, ordered by the kernel boundary
+    if (threadIdx.x == 0) {
+#pragma unroll
+      for (int s = 0; s < NSEL; ++s) a.st->sel[s] = ol.sel[s];
+      a.st->n = a.n;
+      a.st->pad_neg = ol.neg;
+      a.st->pad_nan = ol.nan;
+    }
+    return false;
+  }
+  bool all_done = true;  // (the advance ended on a barrier: ol.sel is settled)
+#pragma unroll
+  for (int s = 0; s < NSEL; ++s) all_done &= ol.sel[s].done != 0;
+  if (resident) {
+    if (!all_done) {
+      if (threadIdx.x < kSelWords)
+        __hip_atomic_exchange(mail + threadIdx.x, reinterpret_cast<unsigned long long*>(ol.sel)[threadIdx.x], __ATOMIC_RELAXED,
+                              __HIP_MEMORY_SCOPE_AGENT);
+      if (threadIdx.x == kSelWords) __hip_atomic_exchange(&a.st->pad_neg, ol.neg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (threadIdx.x == kSelWords + 1) __hip_atomic_exchange(&a.st->pad_nan, ol.nan, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // (the exchanges return: they have been performed when their results are here)
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      __builtin_amdgcn_s_waitcnt(0);
+      __syncthreads();
+    }
+    if (threadIdx.x < kSlots)
+      __hip_atomic_exchange(&a.slots[threadIdx.x].verdict, tag | (all_done ? 1ull : 0ull), __ATOMIC_RELAXED,
+                            __HIP_MEMORY_SCOPE_AGENT);
+    return !all_done;
+  }
+  if (!all_done) {
+    // rounds nobody planned for, with everybody else gone: this workgroup sweeps alone until every selector is
+    // resolved (each round narrows a window 2048-fold or replaces a missed one: at most 1 + ceil(32 / 11) more)
+    for (int r = 0; r < 8; ++r) {
       __syncthreads();
       const bool live = win_sweep<T, NSEL, false, BLOCK, false, false, true, true>(tab, n_shards, 0u, 1u, [&](WinSel (&sel)[NSEL]) {
 #pragma unroll
@@ -1359,16 +1440,39 @@ __device__ __forceinline__ void win_finish(const Tab& tab, int n_shards, const O
 #pragma unroll
       for (int s = 0; s < NSEL; ++s) one_advance<NSEL, BLOCK>(s, a, ol, &swl, false, adv[0]);
     }
-  } else {
-    // the mailbox for the next launch of this selection: plain stores, ordered by the kernel boundary
-    if (threadIdx.x == 0) {
-#pragma unroll
-      for (int s = 0; s < NSEL; ++s) a.st->sel[s] = ol.sel[s];
-      a.st->n = a.n;
-      a.st->pad_neg = ol.neg;
-      a.st->pad_nan = ol.nan;
-    }
   }
+  return false;
+}
+
+// The rounds after a launch's first sweep: everybody again, while the verdicts say so.
+template <typename T, int NSEL, int BLOCK, typename Tab>
+__device__ __forceinline__ void win_resident_rounds(const Tab& tab, int n_shards, const OneArgs& a, const uint32_t wg,
+                                                    const uint32_t nwg, OneLds& ol, SweepLds<NSEL, BLOCK>& swl,
+                                                    AdvShared (&adv)[2], bool again) {
+  for (uint32_t round = 2; again && round < 12; ++round) {
+    __syncthreads();
+    win_sweep<T, NSEL, false, BLOCK, true, true, true, true>(tab, n_shards, wg, nwg, [&](WinSel (&sel)[NSEL]) {
+#pragma unroll
+      for (int s = 0; s < NSEL; ++s) {
+        WinSel w = ol.sel[s];
+        w.lo = __builtin_amdgcn_readfirstlane(w.lo);
+        w.shift = __builtin_amdgcn_readfirstlane(w.shift);
+        w.span = __builtin_amdgcn_readfirstlane(w.span);
+        w.done = __builtin_amdgcn_readfirstlane(w.done);
+        w.fresh = __builtin_amdgcn_readfirstlane(w.fresh);
+        sel[s] = w;
+      }
+    }, a.slots, a.hist, a.use_abs, swl);
+    again = win_finish<T, NSEL, BLOCK>(tab, n_shards, a, wg, nwg, ol, swl, adv, false, true, round);
+  }
+}
+// does the launch stay resident?  (uniform over the grid: every workgroup holds the same windows)
+template <int NSEL>
+__device__ __forceinline__ bool win_is_resident(const OneArgs& a, const OneLds& ol) {
+  bool r = false;
+#pragma unroll
+  for (int s = 0; s < NSEL; ++s) r |= ol.sel[s].done == 0 && ol.sel[s].shift > a.min_shift;
+  return a.final_round && r;
 }
 
 // (wg of nwg: this workgroup's place among those that work on THIS selection -- the whole grid, or one item's share of
@@ -1434,7 +1538,9 @@ __device__ __forceinline__ void win_one_body(const Tab& tab, int n_shards, const
     }
   }, a.slots, a.hist, a.use_abs, swl);
   one_stamp(a, 3);
-  win_finish<T, NSEL, BLOCK>(tab, n_shards, a, nwg, ol, swl, adv, SIGNS);
+  const bool resident = win_is_resident<NSEL>(a, ol);
+  const bool again = win_finish<T, NSEL, BLOCK>(tab, n_shards, a, wg, nwg, ol, swl, adv, SIGNS, resident, 1u);
+  if (a.final_round) win_resident_rounds<T, NSEL, BLOCK>(tab, n_shards, a, wg, nwg, ol, swl, adv, again);
   one_stamp(a, 7);
 }
 template <typename T, int NSEL, bool PCT, int BLOCK, typename Tab>
@@ -1461,7 +1567,10 @@ __device__ __forceinline__ void win_round_body(const Tab& tab, int n_shards, con
     }
   }, a.slots, a.hist, a.use_abs, swl);
   // (a round that finds every selector resolved still counts its arrivals and passes the mailbox on)
-  win_finish<T, NSEL, BLOCK>(tab, n_shards, a, nwg, ol, swl, adv, false);
+  __syncthreads();  // ol, written by thread 0 above
+  const bool resident = win_is_resident<NSEL>(a, ol);
+  const bool again = win_finish<T, NSEL, BLOCK>(tab, n_shards, a, wg, nwg, ol, swl, adv, false, resident, 1u);
+  if (a.final_round) win_resident_rounds<T, NSEL, BLOCK>(tab, n_shards, a, wg, nwg, ol, swl, adv, again);
 }
 template <typename T, int NSEL, int BLOCK, typename Tab>
 __global__ __launch_bounds__(BLOCK) void win_round_kernel(const Tab tab, int n_shards, const OneArgs a) {
@@ -1486,7 +1595,7 @@ struct KthItems {
 template <typename T, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void group_kth_kernel(const KthItems items, int n_items, char* regions, size_t region_bytes,
                                                           float* out, int use_abs, uint32_t min_shift, int round,
-                                                          int final_round) {
+                                                          int final_round, unsigned long long epoch) {
   // the item of this workgroup: last one whose first workgroup is <= blockIdx.x (uniform: scalar loads)
   int lo = 0, hi = n_items - 1;
   while (lo < hi) {
@@ -1517,9 +1626,14 @@ __global__ __launch_bounds__(BLOCK) void group_kth_kernel(const KthItems items, 
   a.final_round = final_round;
   a.key_mode = T::id == SBQ_BF16 ? KEYS_BF16_RAW : (T::id == SBQ_F16 ? KEYS_F16_RAW : KEYS_F32);
   a.stamps = nullptr;
+  a.epoch = epoch;
   if (round == 0) win_one_body<T, 1, false, BLOCK>(tab, 1, a, blockIdx.x - me.wg_begin, me.nwg);
   else win_round_body<T, 1, BLOCK>(tab, 1, a, blockIdx.x - me.wg_begin, me.nwg);
 }
+
+// every selection gets its own epoch (> 0): the tag of its resident rounds' verdicts (WinSlot::verdict)
+std::atomic<unsigned long long> g_select_epoch{0};
+unsigned long long next_epoch() { return (g_select_epoch.fetch_add(1, std::memory_order_relaxed) + 1) & ((1ull << 55) - 1); }
 
 constexpr size_t kStateBytes = 256;
 constexpr size_t kSlotBytes = sizeof(WinSlot) * kSlots;
@@ -1574,6 +1688,7 @@ int win_one_run(const void* const* shards, const int64_t* counts, int n_shards, 
   a.min_shift = min_shift;
   a.use_abs = use_abs;
   a.mode = percentile ? 1 : 0;
+  a.epoch = next_epoch();
   a.stamps = knob(1) == 779 ? reinterpret_cast<unsigned long long*>(region + kOneRegion) : nullptr;
   int rc = SBQ_OK;
   OneShard os{};
@@ -1768,11 +1883,12 @@ int sbq_group_kth_value(const sbq_kth_item* items, int n_items, int x_dtype, int
       grid += d.nwg;
     }
     char* regions = static_cast<char*>(workspace) + static_cast<size_t>(first) * kOneRegion;
+    const unsigned long long epoch = next_epoch();
     for (int r = 0; r < expected; ++r) {
       int rc = dispatch_dtype(x_dtype, [&](auto tag) {
         using T = decltype(tag);
         group_kth_kernel<T, kB><<<grid, kB, 0, st>>>(args, cnt, regions, kOneRegion, values_out + first, use_abs, min_shift, r,
-                                                    r == expected - 1 ? 1 : 0);
+                                                    r == expected - 1 ? 1 : 0, epoch);
       });
       if (rc != SBQ_OK) return rc;
     }

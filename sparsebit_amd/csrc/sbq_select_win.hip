@@ -48,7 +48,11 @@ struct WinSel {
   uint32_t lo;     // first key of the window
   uint32_t shift;  // bin = (key - lo) >> shift, kWinBins bins
   uint32_t span;   // last in-window offset: the window is [lo, lo + span], at most kWinBins << shift keys
-  uint32_t side;   // what a fresh window's sweep counts besides the histogram: 0 = the keys below it, 1 = above it
+  uint32_t side;   // bit 0: what a fresh window's sweep counts besides the histogram: 0 = the keys below it, 1 = above
+                   // bit 1: the window holds a zero that is a large share of the data (ReLU outputs, pruned weights):
+                   //        16-bit sweeps count +-0 in registers instead of adding to one LDS word 32 K times
+                   // bit 2: the window holds a large share of the data (a rank in the bulk): 16-bit sweeps test
+                   //        every key against it instead of packs of keys first
   int64_t k;       // rank (1-based): absolute while `fresh`, relative to the window afterwards
   uint32_t done;   // key `lo` is the answer
   uint32_t fresh;  // window came from the sample: the sweep also counts the keys below it
@@ -396,6 +400,17 @@ __device__ __forceinline__ void plan_compute(PlanLds& L, const PlanSample<T, kT>
     // percentile: the min side's window sits at the bottom of the data, the max side's at the top -- the sweep
     // tests the near end first and counts what lies beyond it (a handful of keys) instead of what lies before
     w.side = mode == 1 && s == 1 ? 1u : 0u;
+    {
+      constexpr uint32_t kz = (KEY16 && T::id != SBQ_F32) ? Key16<T>::kZero : kKeyZero;       // key32(-0)
+      constexpr uint32_t kp = (KEY16 && T::id != SBQ_F32) ? Key16<T>::kZero + 0x10000u : kKeyZero + 1u;  // key32(+0)
+      const uint32_t zc = L.hist[kz >> kPlanShift] + ((kp >> kPlanShift) != (kz >> kPlanShift) ? L.hist[kp >> kPlanShift] : 0u);
+      const bool holds = kz - w.lo <= w.span || kp - w.lo <= w.span;
+      if (holds && static_cast<uint64_t>(zc) * 64u >= L.total) w.side |= 2u;
+      // bit 2: the bracket holds more than 1/64 of the sample (a rank in the bulk of the data: +-6 sigma of 16 K
+      // draws is a tenth of it) -- most packs of 8 hold a key of the window, and testing packs first is a detour
+      const int64_t r0 = L.r_lo[s] < 1 ? 1 : L.r_lo[s], r1 = L.r_hi[s] > static_cast<int64_t>(L.total) ? L.total : L.r_hi[s];
+      if ((r1 - r0) * 64 >= static_cast<int64_t>(L.total)) w.side |= 4u;
+    }
     w.k = mode == 0 ? (s == 0 ? k0 : k1) : 0;
     w.done = 0;
     w.fresh = 1;
@@ -541,7 +556,7 @@ __device__ __forceinline__ void advance_core(const int tid, const int s, const W
       k = k < 1 ? 1 : (k > n ? n : k);
     }
     // (side 1: the counter holds the keys ABOVE the window -- NaNs included, they sort last)
-    const unsigned long long below = w.side ? static_cast<unsigned long long>(n) - total - sh.below : sh.below;
+    const unsigned long long below = (w.side & 1u) ? static_cast<unsigned long long>(n) - total - sh.below : sh.below;
     const uint64_t hi = static_cast<uint64_t>(w.lo) + w.span + 1;  // exclusive
     if (static_cast<unsigned long long>(k) <= below) {
       // the sample lied: the rank is below the window.  New window: every key below it.
@@ -732,6 +747,7 @@ struct SweepLds {
   uint32_t lh[NSEL][kWinBins];
   unsigned long long red[NSEL + 2][BLOCK / kWave];
   unsigned long long tot[NSEL + 2];
+  u32x4 queue[BLOCK / kWave][2 * kWave];  // 16-bit sweeps: each wave's packs that await examination
 #if defined(SBQ_SEL_STAMPS) && SBQ_SEL_STAMPS != 0
   unsigned long long* stamps;  // development build only
 #endif
@@ -911,6 +927,62 @@ __device__ __forceinline__ bool win_sweep(const Tab& tab, int n_shards, const ui
     lo2[s] = lo16[s] * 0x10001u;
   }
   constexpr uint32_t kZero16 = kZeroKey >> 16, kInf16 = kInfKey >> 16;
+  bool zero_hot = false;  // uniform
+  uint32_t zc[NSEL];
+#pragma unroll
+  for (int s = 0; s < NSEL; ++s) {
+    zero_hot |= RAW16 && act[s] && (sel[s].side & 2u) != 0;
+    zc[s] = 0;
+  }
+  // zero_hot: a window holds a zero that is a large share of the data -- its in-window occurrences are counted in
+  // the examining lane's registers (-0 in the low half of zc, +0 in the high half; folded into the histogram at the
+  // end of every slab) instead of being added to the same LDS word by every lane
+  bool dense = false;  // uniform
+#pragma unroll
+  for (int s = 0; s < NSEL; ++s) dense |= RAW16 && !ONESIDED && act[s] && (sel[s].side & 4u) != 0;
+  dense = dense && !zero_hot;
+  const uint32_t kz16 = zero_hot ? kZero16 : 0x20000u;  // (no key is 0x20000 or 0x20001)
+  u32x4* const queue = &lds.queue[threadIdx.x / kWave][0];
+  uint32_t q_tail = 0;  // uniform
+  auto drain = [&](uint32_t first, uint32_t count) {
+    __builtin_amdgcn_wave_barrier();
+    if ((threadIdx.x & (kWave - 1)) < count) {
+      const u32x4 v = queue[first + (threadIdx.x & (kWave - 1))];
+      const uint32_t x[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const uint32_t k = h ? x[q] >> 16 : x[q] & 0xffffu;
+          if constexpr (SIGNS) nan += k > kInf16;
+          const uint32_t zd = k - kz16;  // 0: -0, 1: +0 (zero_hot)
+          auto in_window = [&](int s, uint32_t d) {
+            if (zd <= 1u) zc[s] += 1u << (16 * zd);
+            else atomicAdd(&lh[s][d >> sh16[s]], 1u);
+          };
+          if constexpr (ONESIDED) {
+            if (k <= lo16[0] + span16[0]) {
+              const uint32_t d = (k - lo16[0]) & 0xffffu;
+              if (d <= span16[0]) in_window(0, d);
+              else ++lt[0];  // wrapped: below the window
+            }
+            if (k >= lo16[1]) {
+              const uint32_t d = k - lo16[1];
+              if (d <= span16[1]) in_window(1, d);
+              else ++lt[1];  // above the window
+            }
+          } else {
+#pragma unroll
+            for (int s = 0; s < NSEL; ++s) {
+              const uint32_t d = (k - lo16[s]) & 0xffffu;
+              if (d <= span16[s]) in_window(s, d);
+            }
+          }
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  };
   auto lean16 = [&](const uint32_t (&x)[4], uint32_t (&w_lt)[NSEL], uint32_t& w_neg) {
     bool slow = false;
     if constexpr (SIGNS) {
@@ -941,32 +1013,53 @@ __device__ __forceinline__ bool win_sweep(const Tab& tab, int n_shards, const ui
         slow |= d <= span16[s];
       }
     }
-    if (slow) {
+    // A pack with a key in a window (or a NaN) is QUEUED, not examined here: per pack the lanes that hold one are a
+    // few of 64, yet as a branch the examination ran for the whole wave almost every time (one such lane in 64 is
+    // enough) -- 130 instructions per pack instead of 33.  The queue (LDS, this wave's own 128 entries) is drained
+    // 64 packs at a time with every lane busy, so the examination's cost follows the number of such packs.
+    const uint64_t qm = __builtin_amdgcn_ballot_w64(slow);
+    if (qm) {  // uniform
+      const uint32_t pos = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(qm >> 32),
+                                                     __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(qm), 0u));
+      if (slow) queue[q_tail + pos] = u32x4{x[0], x[1], x[2], x[3]};
+      q_tail += static_cast<uint32_t>(__builtin_popcountll(qm));
+      if (q_tail >= kWave) {
+        q_tail -= kWave;
+        drain(q_tail, kWave);
+      }
+    }
+  };
+  // dense windows: every key against every window, no pack-level test (7 operations per key whatever the data)
+  auto dense16 = [&](const uint32_t (&x)[4], uint32_t (&w_lt)[NSEL], uint32_t& w_neg) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < 4; ++q) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const uint32_t k = h ? x[q] >> 16 : x[q] & 0xffffu;
-          if constexpr (SIGNS) nan += k > kInf16;
-          if constexpr (ONESIDED) {
-            if (k <= lo16[0] + span16[0]) {
-              const uint32_t d = (k - lo16[0]) & 0xffffu;
-              if (d <= span16[0]) atomicAdd(&lh[0][d >> sh16[0]], 1u);
-              else ++lt[0];  // wrapped: below the window
-            }
-            if (k >= lo16[1]) {
-              const uint32_t d = k - lo16[1];
-              if (d <= span16[1]) atomicAdd(&lh[1][d >> sh16[1]], 1u);
-              else ++lt[1];  // above the window
-            }
-          } else {
-#pragma unroll
-            for (int s = 0; s < NSEL; ++s) {
-              const uint32_t d = (k - lo16[s]) & 0xffffu;
-              if (d <= span16[s]) atomicAdd(&lh[s][d >> sh16[s]], 1u);
-            }
-          }
+      for (int h = 0; h < 2; ++h) {
+        const uint32_t k = h ? x[q] >> 16 : x[q] & 0xffffu;
+        if constexpr (SIGNS) {
+          count(w_neg, k < kZero16);
+          nan += k > kInf16;
         }
+#pragma unroll
+        for (int s = 0; s < NSEL; ++s) {
+          const uint32_t d = k - lo16[s];  // (k < lo: wraps past every span)
+          count(w_lt[s], k < lo16[s]);
+          if (d <= span16[s]) atomicAdd(&lh[s][d >> sh16[s]], 1u);
+        }
+      }
+    }
+  };
+  // the zero counts of this wave, into the histogram (zero_hot sweeps, at the end of every slab: 16 bits per half
+  // hold the 16 keys a lane sees in a slab many times over)
+  auto fold_zeros = [&]() {
+#pragma unroll
+    for (int s = 0; s < NSEL; ++s) {
+      auto add32 = [](uint32_t a, uint32_t b) { return a + b; };
+      const uint32_t z0 = dpp_reduce_u32(zc[s] & 0xffffu, 0u, add32), z1 = dpp_reduce_u32(zc[s] >> 16, 0u, add32);
+      zc[s] = 0;
+      if (lane0) {
+        if (z0) atomicAdd(&lh[s][((kZero16 - lo16[s]) & 0xffffu) >> sh16[s]], z0);
+        if (z1) atomicAdd(&lh[s][((kZero16 + 1u - lo16[s]) & 0xffffu) >> sh16[s]], z1);
       }
     }
   };
@@ -986,7 +1079,13 @@ __device__ __forceinline__ bool win_sweep(const Tab& tab, int n_shards, const ui
         uint32_t x[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) x[q] = Key16<T>::pack2(raw[u].d[0][q], amask2);
-        lean16(x, w_lt, w_neg);
+        if constexpr (!ONESIDED) {
+          if (dense) dense16(x, w_lt, w_neg);
+          else lean16(x, w_lt, w_neg);
+        } else {
+          lean16(x, w_lt, w_neg);
+        }
+        if constexpr (U > 16) static_assert(U <= 16, "zc: 16 bits per half");
       } else if constexpr (T::id == SBQ_BF16) {
         // bf16 -> fp32 bits is a shift / a mask: no conversion
 #pragma unroll
@@ -1001,6 +1100,9 @@ __device__ __forceinline__ bool win_sweep(const Tab& tab, int n_shards, const ui
 #pragma unroll
         for (int q = 0; q < kPack; ++q) lean(key_of(__builtin_bit_cast(uint32_t, v[q])), w_lt, w_neg, w_nan);
       }
+    }
+    if constexpr (RAW16) {
+      if (zero_hot) fold_zeros();
     }
 #pragma unroll
     for (int s = 0; s < NSEL; ++s) lt[s] += !ONESIDED && lane0 && lo[s] != 0 ? w_lt[s] : 0u;
@@ -1021,6 +1123,13 @@ __device__ __forceinline__ bool win_sweep(const Tab& tab, int n_shards, const ui
         if (more) issue(g + static_cast<uint32_t>(NB + j) * nwg, buf[j]);
       }
       g += NB * nwg;
+    }
+  }
+  if constexpr (RAW16) {
+    if (q_tail) {  // uniform
+      drain(0u, q_tail);
+      q_tail = 0;
+      if (zero_hot) fold_zeros();
     }
   }
   // the ragged last slab of a shard, and every slab of an unaligned one
@@ -1062,12 +1171,20 @@ __device__ __forceinline__ bool win_sweep(const Tab& tab, int n_shards, const ui
   // counters: lanes -> wave -> workgroup -> one of the 64 counter lines
   SBQ_SWEEP_STAMP(15);
   const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
+  // (a lane's counters are 32-bit and count at most the elements it saw; a wave's sums stay below 2^32 while the
+  // wave sees fewer than that: the 64-bit shuffles remain for sweeps of more than 2^26 slabs)
   unsigned long long tot[kCounters];
+  const bool small = static_cast<uint64_t>(n_lean + tab.rag_first[Tab::kSingle ? 1 : n_shards]) * kSlab < (1ull << 32);
+  auto add32 = [](uint32_t a, uint32_t b) { return a + b; };
+  auto wsum = [&](uint32_t v) -> unsigned long long {
+    return small ? static_cast<unsigned long long>(dpp_reduce_u32(v, 0u, add32))
+                 : wave_reduce(static_cast<unsigned long long>(v), SumL());
+  };
 #pragma unroll
-  for (int s = 0; s < NSEL; ++s) tot[s] = wave_reduce(static_cast<unsigned long long>(lt[s]), SumL());
+  for (int s = 0; s < NSEL; ++s) tot[s] = wsum(lt[s]);
   if constexpr (SIGNS) {
-    tot[NSEL] = wave_reduce(static_cast<unsigned long long>(neg), SumL());
-    tot[NSEL + 1] = wave_reduce(static_cast<unsigned long long>(nan), SumL());
+    tot[NSEL] = wsum(neg);
+    tot[NSEL + 1] = wsum(nan);
   }
   if (lane == 0) {
 #pragma unroll
@@ -1279,7 +1396,8 @@ __device__ __forceinline__ void one_advance(const int s, const OneArgs& a, OneLd
 // of barriers, scans and one thread's arithmetic -- 2.2 us per selector of latency, not of work).  Only when both
 // are still unresolved; the counts of a first sweep (take_signs) are taken by half 0 and handed to half 1.
 template <int BLOCK>
-__device__ __forceinline__ void one_advance_pair(const OneArgs& a, OneLds& ol, bool take_signs, AdvShared (&sh)[2]) {
+__device__ __forceinline__ void one_advance_pair(const OneArgs& a, OneLds& ol, bool take_signs, AdvShared (&sh)[2],
+                                                 uint32_t (&acc)[2][kWinBins]) {
   constexpr int NT = BLOCK / 2;
   static_assert(NT % kWave == 0 && NT >= kSlots, "a half is whole waves and holds the counter lines");
   const int s = threadIdx.x / NT;  // wave-uniform
@@ -1291,25 +1409,49 @@ __device__ __forceinline__ void one_advance_pair(const OneArgs& a, OneLds& ol, b
 #pragma unroll
   for (int i = 0; i < kPer; ++i) bins[i] = 0;
   unsigned long long c_below = 0, c_neg = 0, c_nan = 0;
-  if (static_cast<uint32_t>(tid * kPer) <= (w.span >> w.shift)) {
-    uint32_t v[kCopies][kPer];
-#pragma unroll
-    for (int c = 0; c < kCopies; ++c) {
-      uint32_t* src = a.hist + (static_cast<size_t>(c) * kWinSel + s) * kWinBins + tid * kPer;
-#pragma unroll
-      for (int i = 0; i < kPer; ++i) v[c][i] = one_take(src + i);
+  // The window's bins of the 8 histogram copies, summed in this workgroup's own LDS histogram (acc: the sweep has
+  // flushed it): the words are dealt to the half's threads round robin, so a 16-bit window's few hundred words are
+  // a handful of exchanges per thread in one round trip.  (A thread per 4 bins and 8 copies was 32 registers of
+  // results on top of the placement's own, and 57 of them went through scratch.)
+  {
+    for (int i = tid; i < kWinBins; i += NT) acc[s][i] = 0;
+    __syncthreads();
+    // (the counter lines in the same round trip as the bins: requested first, used after the placement's scan)
+    if (tid < kSlots) {
+      c_below = one_take(&a.slots[tid].below[s]);
+      if (take_signs && s == 0) {
+        c_neg = one_take(&a.slots[tid].neg);
+        c_nan = one_take(&a.slots[tid].nan);
+      }
     }
+    const uint32_t nb = (w.span >> w.shift) + 1u;  // <= kWinBins
+    uint32_t lg = 0;
+    while ((1u << lg) < nb) ++lg;
+    const uint32_t total = static_cast<uint32_t>(kCopies) << lg;  // a power of two
+    // Every exchange of a batch is issued unconditionally (behind a condition each would wait for the one before:
+    // four round trips instead of one).  Slots past the end wrap around -- a word taken twice reads zero the second
+    // time -- and the bins between nb and 2^lg were never added to.
+    auto batch = [&](auto kc, uint32_t base) {
+      constexpr int K = decltype(kc)::value;
+      uint32_t v[K];
 #pragma unroll
-    for (int c = 0; c < kCopies; ++c)
+      for (int j = 0; j < K; ++j) {
+        const uint32_t idx = (base + static_cast<uint32_t>(j * NT + tid)) & (total - 1u);
+        v[j] = one_take(a.hist + (static_cast<size_t>(idx >> lg) * kWinSel + s) * kWinBins + (idx & ((1u << lg) - 1u)));
+      }
 #pragma unroll
-      for (int i = 0; i < kPer; ++i) bins[i] += v[c][i];
-  }
-  if (tid < kSlots) {
-    c_below = one_take(&a.slots[tid].below[s]);
-    if (take_signs && s == 0) {
-      c_neg = one_take(&a.slots[tid].neg);
-      c_nan = one_take(&a.slots[tid].nan);
-    }
+      for (int j = 0; j < K; ++j) {
+        const uint32_t idx = (base + static_cast<uint32_t>(j * NT + tid)) & (total - 1u);
+        if (v[j]) atomicAdd(&acc[s][idx & ((1u << lg) - 1u)], v[j]);
+      }
+    };
+    if (total <= static_cast<uint32_t>(NT)) batch(std::integral_constant<int, 1>(), 0u);
+    else if (total <= 4u * NT) batch(std::integral_constant<int, 4>(), 0u);
+    else
+      for (uint32_t base = 0; base < total; base += 16u * NT) batch(std::integral_constant<int, 16>(), base);
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < kPer; ++i) bins[i] = acc[s][tid * kPer + i];
   }
   if (!take_signs && tid == 0) {
     c_neg = ol.neg;
@@ -1389,7 +1531,7 @@ __device__ __forceinline__ bool win_finish(const Tab& tab, int n_shards, const O
   bool pair = false;
   if constexpr (NSEL == 2) pair = !ol.sel[0].done && !ol.sel[1].done;
   if (pair) {
-    if constexpr (NSEL == 2) one_advance_pair<BLOCK>(a, ol, signs_in_slots, adv);
+    if constexpr (NSEL == 2) one_advance_pair<BLOCK>(a, ol, signs_in_slots, adv, swl.lh);
   } else {
 #pragma unroll
     for (int s = 0; s < NSEL; ++s) one_advance<NSEL, BLOCK>(s, a, ol, nullptr, signs_in_slots && s == 0, adv[0]);
@@ -1460,6 +1602,7 @@ __device__ __forceinline__ void win_resident_rounds(const Tab& tab, int n_shards
         w.span = __builtin_amdgcn_readfirstlane(w.span);
         w.done = __builtin_amdgcn_readfirstlane(w.done);
         w.fresh = __builtin_amdgcn_readfirstlane(w.fresh);
+        w.side = __builtin_amdgcn_readfirstlane(w.side);
         sel[s] = w;
       }
     }, a.slots, a.hist, a.use_abs, swl);
@@ -1534,6 +1677,7 @@ __device__ __forceinline__ void win_one_body(const Tab& tab, int n_shards, const
       w.span = __builtin_amdgcn_readfirstlane(w.span);
       w.done = __builtin_amdgcn_readfirstlane(w.done);
       w.fresh = __builtin_amdgcn_readfirstlane(w.fresh);
+      w.side = __builtin_amdgcn_readfirstlane(w.side);
       sel[s] = w;
     }
   }, a.slots, a.hist, a.use_abs, swl);

@@ -12,7 +12,9 @@ dev = torch.device("cuda:0")
 st = L.stream_ptr(dev)
 R = C = 4096
 g = torch.Generator().manual_seed(0)
-w = (torch.randn(R, C, generator=g) * torch.logspace(-2, 1, R).unsqueeze(1)).bfloat16().to(dev)
+w = (torch.randn(R, C, generator=g) * torch.logspace(-2, 1, R).unsqueeze(1))
+if os.environ.get("SEL_DATA") == "relu": w = torch.relu(torch.randn(R, C, generator=g))
+w = w.bfloat16().to(dev)
 xs = [w] + [torch.roll(w, i, 1).contiguous() for i in range(1, 12)]
 n = R * C
 nbytes = lib.sbq_radix_select_workspace_bytes(1, 2)
@@ -49,7 +51,7 @@ for kind in ("kth", "pct"):
         col = col[s[:, j] >= t0]  # stamps 5, 6 exist for the last arriver only (older values otherwise)
         if nm == '-' or (col.size == 0 and j not in (5, 6, 16, 17, 18, 19)): continue
         if j in (5, 6, 16, 17, 18, 19):
-            last = np.argmax(s[:, 4])
+            last = np.argmax(s[:, 6])  # the workgroup that advanced: the only fresh stamp 6
             print("  %-14s last arriver (wg %d): %.2f" % (nm, last, rel[last, j]))
         else:
             print("  %-14s %.2f / %.2f / %.2f" % (nm, col.min(), np.median(col), col.max()))

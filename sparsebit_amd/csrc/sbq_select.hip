@@ -628,14 +628,15 @@ int sbq_radix_histogram(const void* x, int x_dtype, int64_t outer, int64_t C, in
 }
 
 // The whole three-pass protocol enqueued by ONE call (single process: nothing to all-reduce between
-// the passes).  Workspace = [hist | state | counts].
+// the passes).  Workspace = [windowed engine's regions][hist | state | counts].  The two never overlap: the windowed
+// engine's region must be zero before its first use and is left zero by every call (include/sbq.h), and callers keep
+// ONE workspace for per-tensor and per-channel selections -- the fixed-digit passes' histograms used to start at
+// offset 0 and left their last counts in the counter lines of the next whole-tensor selection (3 ranks off).
 size_t sbq_radix_select_workspace_bytes(int64_t C, int n_sel) {
   if (C <= 0 || n_sel < 1 || n_sel > sbq::kMaxSel) return 0;
   const size_t fixed = static_cast<size_t>(C) * n_sel * SBQ_RADIX_BINS * 8 + static_cast<size_t>(C) * n_sel * 16 +
                        static_cast<size_t>(C) * 16 + 64;
-  // a whole-tensor selection (C == 1) runs the windowed engine in the same workspace
-  const size_t win = C == 1 ? sbq::win_select_workspace_bytes() : 0;
-  return fixed > win ? fixed : win;
+  return sbq::win_select_workspace_bytes() + fixed;
 }
 
 static int radix_select_run(const void* const* shards, const int64_t* outers, int n_shards, int x_dtype, int64_t C,
@@ -675,8 +676,9 @@ static int radix_select_run(const void* const* shards, const int64_t* outers, in
                           percentile ? min_out : values_out, max_out, workspace, workspace_bytes, st);
   }
   const size_t hist_bytes = static_cast<size_t>(C) * n_sel * SBQ_RADIX_BINS * 8;
-  int64_t* hist = static_cast<int64_t*>(workspace);
-  int64_t* state = reinterpret_cast<int64_t*>(static_cast<char*>(workspace) + hist_bytes);
+  char* fixed = static_cast<char*>(workspace) + win_select_workspace_bytes();
+  int64_t* hist = reinterpret_cast<int64_t*>(fixed);
+  int64_t* state = reinterpret_cast<int64_t*>(fixed + hist_bytes);
   int64_t* counts = state + static_cast<size_t>(C) * n_sel * 2;
   // one launch zeroes histogram, state and counts (and plants explicit ranks); after that every advance
   // leaves the histogram zeroed for the next pass

@@ -136,7 +136,11 @@ def _worker(rank, world, port, tmp):
     idx = min(int(w.numel() * 0.5), w.numel() - 1)
     with sd.sharded_calibration():
         v = select.kth_values([w[rank::world].contiguous()], [[idx + 1]], ops.HipSelectBackend(), True, 0, False, dev)
-    ok["mask_thresh"] = float(v.reshape(())) == float(ops.kth_value(w, idx + 1, True))
+    one = float(ops.kth_value(w, idx + 1, True))
+    ok["mask_thresh"] = float(v.reshape(())) == one
+    if not ok["mask_thresh"]:
+        print("rank", rank, "mask_thresh: sharded", float(v.reshape(())), "single", one, "sort",
+              float(torch.sort(w.abs().reshape(-1))[0][idx]), flush=True)
 
     torch.save(ok, os.path.join(tmp, "rank%d.pt" % rank))
     dist.barrier()

@@ -483,3 +483,17 @@ def test_selection_reads_nothing_outside_a_short_shard(ops, dtype):
             assert np.isfinite(float(lo)) and np.isfinite(float(hi))
     torch.cuda.synchronize()
     assert elem in (2, 4)
+
+
+@pytest.mark.gpu
+def test_per_channel_selection_leaves_the_whole_tensor_engine_clean(ops):
+    """One workspace serves per-channel (fixed-digit passes) and whole-tensor (windowed engine) selections: the former
+    must not leave counts where the latter expects zeros (it did: the next k-th value was 3 ranks off)."""
+    g = torch.Generator().manual_seed(21)
+    w = torch.randn(256, 96, generator=g).cuda()
+    ref = torch.sort(w.abs().reshape(-1))[0]
+    for rep in range(3):
+        x = torch.randn(64, 3000, generator=g).cuda()
+        ops.percentile_select([x], 0.01, ch_axis=0, per_channel=True)  # fixed-digit passes over 64 channels
+        k = 12289 + rep
+        assert float(ops.kth_value(w, k, True)) == float(ref[k - 1]), rep

@@ -413,7 +413,16 @@ int sbq_radix_finish(const int64_t* state, int64_t C, int n_sel, int use_abs,
  * ZERO before its first use (hipMemset once), every call leaves it reusable by the next one, and it must not be
  * shared by calls that can run concurrently (different streams).  A whole-tensor selection (C == 1) of a 16-bit
  * tensor is ONE launch: every workgroup brackets the wanted ranks from the same 2048-pack sample, sweeps its slabs
- * once, and the last workgroup to arrive resolves the ranks (fp32: one such launch per 11 key bits that remain). */
+ * once, and the last workgroup to arrive resolves the ranks (fp32: one such launch per 11 key bits that remain).
+ * Layout: [whole-tensor engine: the part that must start zero][fixed-digit passes (C > 1): self-initialising], so
+ * one workspace may serve per-channel and whole-tensor selections in any order.
+ * Resident rounds: when the first windows cannot resolve a rank in one sweep -- an extreme rank (k = 1, alpha =
+ * 1e-5), a bracket wider than 2048 values (fp16 around zero), half of the data one value -- every workgroup derives
+ * that from the same sample, none of them leaves, and the launch sweeps again as a whole (+15-40 us instead of one
+ * workgroup sweeping the tensor alone, 0.8-7 ms).  The launch is at most one workgroup per compute unit; waiting
+ * workgroups poll a verdict word, so two such launches that can run CONCURRENTLY on one device (two streams, or two
+ * processes sharing a GPU) may each hold the compute units the other needs: the wait traps after a few seconds
+ * instead of hanging.  One selection at a time per device -- which is what a calibration loop does. */
 size_t sbq_radix_select_workspace_bytes(int64_t C, int n_sel);
 int sbq_percentile_select(const void* const* shards, const int64_t* outers, int n_shards, int x_dtype,
                           int64_t C, int64_t inner, double alpha, float* min_out, float* max_out,

@@ -53,6 +53,7 @@ struct WinSel {
                    //        16-bit sweeps count +-0 in registers instead of adding to one LDS word 32 K times
                    // bit 2: the window holds a large share of the data (a rank in the bulk): 16-bit sweeps test
                    //        every key against it instead of packs of keys first
+                   // bit 3: the window may miss its rank (an extreme the sample did not see): the launch is resident
   int64_t k;       // rank (1-based): absolute while `fresh`, relative to the window afterwards
   uint32_t done;   // key `lo` is the answer
   uint32_t fresh;  // window came from the sample: the sweep also counts the keys below it
@@ -385,9 +386,32 @@ __device__ __forceinline__ void plan_compute(PlanLds& L, const PlanSample<T, kT>
     // 1 - e^-8), at the sample's extreme bin, which keeps a tail quantile's window a few bins wide.  Keys outside
     // the window are counted, so a wrong guess only costs another round.
     uint32_t a = L.b_lo[s], b = L.b_hi[s];
-    if (L.r_lo[s] < 1) a = L.r_mid[s] >= 8.0 ? L.first : 0u;
-    if (L.r_hi[s] > static_cast<int64_t>(L.total)) b = S - L.r_mid[s] >= 8.0 ? L.last : kPlanBins - 1;
+    const bool off_lo = L.r_lo[s] < 1, off_hi = L.r_hi[s] > static_cast<int64_t>(L.total);
+    if (off_lo) a = L.r_mid[s] >= 8.0 ? L.first : 0u;
+    if (off_hi) b = S - L.r_mid[s] >= 8.0 ? L.last : kPlanBins - 1;
     if (b < a) b = a;
+    // 16-bit inputs: a window resolves its rank in one sweep while it is at most 2048 values (256 plan bins) wide,
+    // and what it costs follows the elements inside it, not its width.  A bracket that runs off the sample and fits
+    // spends the rest of that capacity OUTWARD: the extreme the sample has not seen (k = 1, alpha = 1e-5, the few
+    // negatives of a GELU output) is then inside unless it lies 16 binades (bf16; 2 for fp16) beyond the sample's
+    // own -- instead of the window starting at key 0, 32 K values wide, and needing a second sweep every time.
+    // Not reaching the end of the key space with fewer than 8 sample ranks of evidence, the launch stays resident
+    // (bit 3): a miss then costs a second grid-wide sweep, not one workgroup sweeping alone.
+    bool uncertain = false;
+    const uint32_t cap = min_shift > 0 && min_shift + kWinLog >= static_cast<uint32_t>(kPlanShift)
+                             ? (static_cast<uint32_t>(kWinBins) << min_shift) >> kPlanShift : 0u;
+    if (cap > 0) {
+      // (the part of the bracket the sample does cover: from / up to its own extreme bin)
+      // (only with fewer than 8 sample ranks of evidence: beyond that the sample's own extreme bin is the end of the
+      // window, as above -- the advance gathers every bin of a window from 8 histogram copies, wide or not)
+      if (off_lo && !off_hi && L.r_mid[s] < 8.0 && b >= L.first && b - L.first + 1u <= cap) {
+        a = b + 1u >= cap ? b + 1u - cap : 0u;
+        uncertain = a > 0;
+      } else if (off_hi && !off_lo && S - L.r_mid[s] < 8.0 && L.last >= a && L.last - a + 1u <= cap) {
+        b = a + cap - 1u < static_cast<uint32_t>(kPlanBins) ? a + cap - 1u : kPlanBins - 1;
+        uncertain = b < static_cast<uint32_t>(kPlanBins) - 1u;
+      }
+    }
     const uint32_t lo = a << kPlanShift;
     const uint64_t width = (static_cast<uint64_t>(b - a) + 1) << kPlanShift;
     WinSel w;
@@ -399,7 +423,7 @@ __device__ __forceinline__ void plan_compute(PlanLds& L, const PlanSample<T, kT>
     w.span = static_cast<uint32_t>(width - 1 < room ? width - 1 : room);
     // percentile: the min side's window sits at the bottom of the data, the max side's at the top -- the sweep
     // tests the near end first and counts what lies beyond it (a handful of keys) instead of what lies before
-    w.side = mode == 1 && s == 1 ? 1u : 0u;
+    w.side = (mode == 1 && s == 1 ? 1u : 0u) | (uncertain ? 8u : 0u);
     {
       constexpr uint32_t kz = (KEY16 && T::id != SBQ_F32) ? Key16<T>::kZero : kKeyZero;       // key32(-0)
       constexpr uint32_t kp = (KEY16 && T::id != SBQ_F32) ? Key16<T>::kZero + 0x10000u : kKeyZero + 1u;  // key32(+0)
@@ -1427,22 +1451,29 @@ __device__ __forceinline__ void one_advance_pair(const OneArgs& a, OneLds& ol, b
     const uint32_t nb = (w.span >> w.shift) + 1u;  // <= kWinBins
     uint32_t lg = 0;
     while ((1u << lg) < nb) ++lg;
-    const uint32_t total = static_cast<uint32_t>(kCopies) << lg;  // a power of two
+    // (two bins per exchange: the words of a copy share a few cache lines, and read-modify-writes on one line are
+    // served one after the other)
+    const uint32_t lgw = lg > 0 ? lg - 1u : 0u;  // log2 of the 8-byte words per copy that are touched
+    const uint32_t total = static_cast<uint32_t>(kCopies) << lgw;  // a power of two
     // Every exchange of a batch is issued unconditionally (behind a condition each would wait for the one before:
     // four round trips instead of one).  Slots past the end wrap around -- a word taken twice reads zero the second
     // time -- and the bins between nb and 2^lg were never added to.
     auto batch = [&](auto kc, uint32_t base) {
       constexpr int K = decltype(kc)::value;
-      uint32_t v[K];
+      unsigned long long v[K];
 #pragma unroll
       for (int j = 0; j < K; ++j) {
         const uint32_t idx = (base + static_cast<uint32_t>(j * NT + tid)) & (total - 1u);
-        v[j] = one_take(a.hist + (static_cast<size_t>(idx >> lg) * kWinSel + s) * kWinBins + (idx & ((1u << lg) - 1u)));
+        unsigned long long* copy = reinterpret_cast<unsigned long long*>(a.hist + (static_cast<size_t>(idx >> lgw) * kWinSel + s) * kWinBins);
+        v[j] = one_take(copy + (idx & ((1u << lgw) - 1u)));
       }
 #pragma unroll
       for (int j = 0; j < K; ++j) {
         const uint32_t idx = (base + static_cast<uint32_t>(j * NT + tid)) & (total - 1u);
-        if (v[j]) atomicAdd(&acc[s][idx & ((1u << lg) - 1u)], v[j]);
+        const uint32_t b = (idx & ((1u << lgw) - 1u)) * 2u;
+        const uint32_t lo_ = static_cast<uint32_t>(v[j]), hi_ = static_cast<uint32_t>(v[j] >> 32);
+        if (lo_) atomicAdd(&acc[s][b], lo_);
+        if (hi_) atomicAdd(&acc[s][b + 1u], hi_);
       }
     };
     if (total <= static_cast<uint32_t>(NT)) batch(std::integral_constant<int, 1>(), 0u);
@@ -1614,7 +1645,7 @@ template <int NSEL>
 __device__ __forceinline__ bool win_is_resident(const OneArgs& a, const OneLds& ol) {
   bool r = false;
 #pragma unroll
-  for (int s = 0; s < NSEL; ++s) r |= ol.sel[s].done == 0 && ol.sel[s].shift > a.min_shift;
+  for (int s = 0; s < NSEL; ++s) r |= ol.sel[s].done == 0 && (ol.sel[s].shift > a.min_shift || (ol.sel[s].side & 8u) != 0);
   return a.final_round && r;
 }
 

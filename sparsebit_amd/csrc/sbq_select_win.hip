@@ -1846,7 +1846,11 @@ int win_one_run(const void* const* shards, const int64_t* counts, int n_shards, 
   if (total >= (1ll << 31)) return SBQ_ERR_ARG;
   // (16-bit tensors: keys are the raw bit patterns, Key16 -- every value is one key of the 2^16-aligned key space)
   const uint32_t min_shift = x_dtype == SBQ_F32 ? 0u : 16u;
-  const int expected = min_shift > 0 ? 1 : 3;
+  // One launch for a 16-bit input; one per expected sweep for fp32 (a sweep per 11 key bits).  knob 2 == 15 runs an
+  // fp32 selection as ONE launch too, its later sweeps as resident rounds (win_finish): measured 79 us against 72 for
+  // the three launches (16.7 M elements) -- a resident round pays the verdict's poll and a 2048-bin gather under the
+  // pollers' traffic, a launch boundary pays 2 us -- so the launches stay.
+  const int expected = min_shift > 0 || knob(2) == 15 ? 1 : 3;
   const int64_t cus = cu_count();
   const uint32_t grid = static_cast<uint32_t>(total < cus ? (total > 0 ? total : 1) : cus);
   OneArgs a{};
@@ -2036,7 +2040,7 @@ int sbq_group_kth_value(const sbq_kth_item* items, int n_items, int x_dtype, int
   }
   hipStream_t st = as_stream(stream);
   const uint32_t min_shift = x_dtype == SBQ_F32 ? 0u : 16u;
-  const int expected = min_shift > 0 ? 1 : 3;
+  const int expected = min_shift > 0 || knob(2) == 15 ? 1 : 3;
   const int64_t cus = cu_count();
   for (int first = 0; first < n_items; first += kKthItemsPerLaunch) {
     const int cnt = n_items - first < kKthItemsPerLaunch ? n_items - first : kKthItemsPerLaunch;

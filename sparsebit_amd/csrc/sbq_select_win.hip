@@ -28,6 +28,9 @@
 #include <type_traits>
 
 #include <atomic>
+#ifndef SBQ_SEL_STAMPS
+#define SBQ_SEL_STAMPS 0  // -DSBQ_SEL_STAMPS=1: development timestamps (tools/lab/build_stamps.py)
+#endif
 #include "sbq_common.hpp"
 
 namespace sbq {
@@ -272,6 +275,10 @@ __device__ __forceinline__ void plan_compute(PlanLds& L, const PlanSample<T, kT>
   if (threadIdx.x < kWinSel) {
     L.b_lo[threadIdx.x] = 0;
     L.b_hi[threadIdx.x] = kPlanBins - 1;
+  }
+  if constexpr (SBQ_SEL_STAMPS != 0) {  // development build: when has the sample arrived?
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    stamp(14);
   }
 #pragma unroll
   for (int m = 0; m < kMine; ++m) {
@@ -1334,9 +1341,6 @@ struct OneArgs {
 };
 // (compiled in only with -DSBQ_SEL_STAMPS=1 -- SBQ_EXTRA_HIPCC_FLAGS of sparsebit_amd/build.py: the conditional
 // stores are control flow between the loads and their uses, which costs the compiler its exact vmcnt bookkeeping)
-#ifndef SBQ_SEL_STAMPS
-#define SBQ_SEL_STAMPS 0
-#endif
 __device__ __forceinline__ void one_stamp(const OneArgs& a, int i) {
   if constexpr (SBQ_SEL_STAMPS != 0) {
     if (a.stamps && threadIdx.x == 0) a.stamps[blockIdx.x * 32 + i] = __builtin_amdgcn_s_memrealtime();

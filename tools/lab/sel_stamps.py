@@ -40,7 +40,7 @@ for kind in ("kth", "pct"):
     s = sw[OLD + ONE: OLD + ONE + 256 * 256].view(torch.int64).reshape(256, 32).cpu().numpy().astype(np.int64)
     t0 = s[:, 0].min()
     rel = (s - t0) * 0.01  # us
-    names = ["start", "loads issued", "plan done", "sweep+flush", "arrival", "reset", "advance", "end", "plan: hist", "plan: scan", "plan: ranks", "hist cleared", "sample issued", "slabs issued", "all slabs in", "sweep loop done", "adv0 gathered", "adv0 placed", "adv1 gathered", "adv1 placed", "counters reduced"]
+    names = ["start", "loads issued", "plan done", "sweep+flush", "arrival", "reset", "advance", "end", "plan: hist", "plan: scan", "plan: ranks", "hist cleared", "sample issued", "slabs issued", "sample in", "sweep loop done", "adv0 gathered", "adv0 placed", "adv1 gathered", "adv1 placed", "counters reduced"]
     w0 = s[0, 30]; w1 = s[0, 31]; sh = s[0, 29]
     print("   windows of workgroup 0: sel0 lo=%08x span=%08x shift=%d | sel1 lo=%08x span=%08x shift=%d | all workgroups agree: %s" % (
         w0 & 0xffffffff, (w0 >> 32) & 0xffffffff, sh & 0xffffffff, w1 & 0xffffffff, (w1 >> 32) & 0xffffffff, (sh >> 32) & 0xffffffff,

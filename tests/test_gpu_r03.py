@@ -497,3 +497,72 @@ def test_per_channel_selection_leaves_the_whole_tensor_engine_clean(ops):
         ops.percentile_select([x], 0.01, ch_axis=0, per_channel=True)  # fixed-digit passes over 64 channels
         k = 12289 + rep
         assert float(ops.kth_value(w, k, True)) == float(ref[k - 1]), rep
+
+
+def _pct_ref(x, alpha):
+    """percentile.py:27-46 on one flat fp32 array (the oracle's arithmetic: exact order statistics)"""
+    srt = np.sort(x, kind="stable")
+    n = x.size
+    neg, pos = int((x < 0).sum()), int((x >= 0).sum())
+    # Python round == rint on the double product
+    kmax = n - max(int(np.rint(pos * alpha)), 0)
+    kmin = max(int(np.rint(neg * alpha)), 1)
+    mx = srt[min(max(kmax, 1), n) - 1] if pos > 0 else 0.0
+    mn = srt[kmin - 1] if neg > 0 else 0.0
+    return float(mn), float(mx)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
+def test_resident_rounds_and_special_windows_are_exact(ops, dtype):
+    """The cases the one-launch engine does not resolve with its first window -- or resolves with a special one:
+    extreme ranks (outward bracket, resident launch), half of the data zeros (zero-hot windows), +-0 mixes, wide fp16
+    brackets (second sweep by the whole grid), several cached batches.  Exact against a sort."""
+    g = torch.Generator().manual_seed(77)
+    n = 3 * 1024 * 1024 + 40
+    base = torch.randn(n, generator=g)
+    sets = {
+        "gauss": base,
+        "relu": torch.relu(base),
+        "pruned": base * (torch.rand(n, generator=g) < 0.5),  # +-0 in half of the places
+        "neg_relu": -torch.relu(base),
+        "few_neg": torch.where(torch.rand(n, generator=g) < 1e-4, -base.abs(), base.abs()),
+        "heavy": base * torch.exp(4 * torch.randn(n, generator=g)),
+    }
+    for name, x in sets.items():
+        xd = x.to(dtype).cuda()
+        xf = xd.float().cpu().numpy()
+        for use_abs in (False, True):
+            srt = np.sort(np.abs(xf) if use_abs else xf)
+            for k in (1, 2, 37, n // 1000, n // 3, n // 2, n - n // 1000, n - 1, n):
+                got = float(ops.kth_value(xd, k, use_abs))
+                assert got == float(srt[k - 1]), (name, use_abs, k, got, float(srt[k - 1]))
+        for alpha in (0.3, 1e-2, 1e-3, 1e-5, 0.0):
+            mn, mx = ops.percentile_select([xd], alpha, per_channel=False)
+            assert (float(mn), float(mx)) == _pct_ref(xf, alpha), (name, alpha)
+        # the same data as four cached batches of different sizes is the same selection
+        cuts = [0, n // 5, n // 2, n - 70000, n]
+        parts = [xd[cuts[i]:cuts[i + 1]].clone().reshape(1, -1) for i in range(4)]
+        got = ops.percentile_select(parts, 1e-3, per_channel=False)
+        if got is not None:
+            assert (float(got[0]), float(got[1])) == _pct_ref(xf, 1e-3), name
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_group_kth_value_extreme_ranks_and_zero_heavy_items(ops, dtype):
+    """Items of one grouped launch decide about their own resident rounds: extremes and pruned tensors beside plain ones."""
+    g = torch.Generator().manual_seed(5)
+    sizes = [70000, 300000, 16384 * 9, 1 << 20, 40, 123457]
+    xs, ks = [], []
+    for i, n in enumerate(sizes):
+        x = torch.randn(n, generator=g)
+        if i % 2:
+            x = x * (torch.rand(n, generator=g) < 0.5)
+        xs.append(x.to(dtype).cuda())
+        ks.append([1, n, n // 2, max(1, n // 1000), n - 1, 2][i])
+    for use_abs in (False, True):
+        got = ops.group_kth_value(xs, ks, use_abs).cpu().numpy()
+        for i, x in enumerate(xs):
+            srt = np.sort(np.abs(x.float().cpu().numpy()) if use_abs else x.float().cpu().numpy())
+            assert got[i] == srt[ks[i] - 1], (i, use_abs, got[i], srt[ks[i] - 1])

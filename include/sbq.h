@@ -420,9 +420,12 @@ int sbq_radix_finish(const int64_t* state, int64_t C, int n_sel, int use_abs,
  * 1e-5), a bracket wider than 2048 values (fp16 around zero), half of the data one value -- every workgroup derives
  * that from the same sample, none of them leaves, and the launch sweeps again as a whole (+15-40 us instead of one
  * workgroup sweeping the tensor alone, 0.8-7 ms).  The launch is at most one workgroup per compute unit; waiting
- * workgroups poll a verdict word, so two such launches that can run CONCURRENTLY on one device (two streams, or two
- * processes sharing a GPU) may each hold the compute units the other needs: the wait traps after a few seconds
- * instead of hanging.  One selection at a time per device -- which is what a calibration loop does. */
+ * workgroups poll a verdict word and hold their compute unit meanwhile, so two such launches running CONCURRENTLY on
+ * one device (two streams with their own workspaces, two processes sharing a GPU) can each hold units the other
+ * needs.  The wait is therefore bounded: a workgroup that has waited 100 us plus four times its own time to arrival
+ * resigns and leaves, the round's last arriver tells the others how many are left, and they share the next sweep by
+ * ticket -- in the worst case it sweeps alone.  Concurrent selections are slower, never stuck, always exact
+ * (tests/test_gpu_r03.py::test_concurrent_resident_selections_neither_hang_nor_differ). */
 size_t sbq_radix_select_workspace_bytes(int64_t C, int n_sel);
 int sbq_percentile_select(const void* const* shards, const int64_t* outers, int n_shards, int x_dtype,
                           int64_t C, int64_t inner, double alpha, float* min_out, float* max_out,

@@ -65,10 +65,14 @@ struct WinState {
   WinSel sel[kWinSel];
   int64_t n;  // elements in all shards
   unsigned long long pad_neg, pad_nan;  // one-launch engine: the selection's sign / NaN counts, between its launches
-  unsigned long long pad0[5];
-  // its own 128-byte line: the only word of the state that is touched by atomics
+  unsigned long long part;              // resident rounds: the workgroups that take part in the next one
+  unsigned long long pad0[4];
+  // its own 128-byte line: the words of the state that are touched by atomics only
   uint32_t arrivals;  // workgroups of the running sweep that have flushed (zero between launches)
-  uint32_t pad1;
+  uint32_t ticket;    // resident rounds: the next participant's index (reset by the publisher of the round before)
+  // resident rounds: (epoch, round) << 24 | closed << 23 | the workgroups that gave up waiting for this round's
+  // verdict.  Tagged, never cleared: a word of another round or selection reads as "nobody yet".
+  unsigned long long resign;
 };
 static_assert(offsetof(WinState, arrivals) == 128, "the arrival counter has a line of its own");
 struct WinSlot {  // one 128-byte line
@@ -1351,6 +1355,8 @@ struct OneLds {
   unsigned long long neg, nan;  // sign / NaN counts of the whole selection (the first sweep's)
   uint32_t flag;
   unsigned long long verdict;
+  unsigned long long t0;  // s_memrealtime at the kernel's start (100 MHz)
+  uint32_t part, ticket;  // resident rounds: participants of the next round, this workgroup's index among them
 };
 template <typename V>
 __device__ __forceinline__ V one_take(V* p) {  // read and clear, at the memory side
@@ -1534,6 +1540,8 @@ __device__ __forceinline__ bool win_finish(const Tab& tab, int n_shards, const O
   __syncthreads();
   one_stamp(a, 4);
   const unsigned long long tag = (a.epoch << 8) | (static_cast<unsigned long long>(round) << 1);
+  const unsigned long long rtag = ((a.epoch << 8) | round) & ((1ull << 40) - 1ull);  // of st->resign
+  constexpr unsigned long long kResignClosed = 1ull << 23;
   unsigned long long* mail = reinterpret_cast<unsigned long long*>(a.st);  // sel[] first, then n, pad_neg, pad_nan
   constexpr int kSelWords = static_cast<int>(sizeof(WinSel) / 8) * NSEL;
   static_assert(offsetof(WinState, sel) == 0 && sizeof(WinSel) % 8 == 0, "mailbox layout");
@@ -1544,22 +1552,54 @@ __device__ __forceinline__ bool win_finish(const Tab& tab, int n_shards, const O
       unsigned long long v = 0;
       // (a poll every quarter of a microsecond; four times fewer changed nothing for the rounds and cost the launches
       // that resolve in their first round a microsecond at their end)
+      // A waiting workgroup holds a compute unit.  Two resident launches running at once on one device (two streams,
+      // two processes) can each hold the units the other's missing workgroups need -- nobody's fault and nobody's
+      // progress.  So a wait is bounded: after 100 us plus four times what this workgroup itself needed to get here,
+      // it RESIGNS (counted in st->resign, unless the verdict is being published at that moment) and leaves; the
+      // publisher tells the rest how many are left, and they share the next sweep by ticket.  In the worst case the
+      // last arriver sweeps alone, as it did before there were resident rounds.
+      const unsigned long long t_arr = __builtin_amdgcn_s_memrealtime();
+      const unsigned long long limit = 10000ull + 4ull * (t_arr - ol.t0);
+      bool may_resign = true;
       for (uint32_t spin = 0;; ++spin) {
         __builtin_amdgcn_s_sleep(8);
         v = __hip_atomic_fetch_add(vp, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if ((v >> 1) == (tag >> 1)) break;
-        if (spin > (1u << 23)) __builtin_trap();  // seconds: the grid is not resident -- a bug, not a schedule
+        if (may_resign && (spin & 15u) == 15u && __builtin_amdgcn_s_memrealtime() - t_arr > limit) {
+          unsigned long long cur = __hip_atomic_fetch_add(&a.st->resign, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          bool gone = false;
+          for (;;) {
+            unsigned long long next;
+            if ((cur >> 24) != rtag) next = (rtag << 24) | 1ull;
+            else if (cur & kResignClosed) break;  // the verdict is on its way: this workgroup is counted in
+            else next = cur + 1ull;
+            if (__hip_atomic_compare_exchange_strong(&a.st->resign, &cur, next, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                     __HIP_MEMORY_SCOPE_AGENT)) {
+              gone = true;
+              break;
+            }
+          }
+          if (gone) {
+            v = 1ull;  // leave as if resolved: the others finish the selection
+            break;
+          }
+          may_resign = false;
+        }
+        if (spin > (1u << 25)) __builtin_trap();  // tens of seconds behind a closed gate: a bug, not a schedule
       }
       ol.verdict = v;
     }
     __syncthreads();
-    if (ol.verdict & 1ull) return false;  // resolved
+    if (ol.verdict & 1ull) return false;  // resolved (or resigned)
     // the narrowed windows (written before the verdict: both are read-modify-writes at the memory side)
     if (threadIdx.x < kSelWords)
       reinterpret_cast<unsigned long long*>(ol.sel)[threadIdx.x] =
           __hip_atomic_fetch_add(mail + threadIdx.x, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (threadIdx.x == kSelWords) ol.neg = __hip_atomic_fetch_add(&a.st->pad_neg, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (threadIdx.x == kSelWords + 1) ol.nan = __hip_atomic_fetch_add(&a.st->pad_nan, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == kSelWords + 2)
+      ol.part = static_cast<uint32_t>(__hip_atomic_fetch_add(&a.st->part, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    if (threadIdx.x == kSelWords + 3) ol.ticket = __hip_atomic_fetch_add(&a.st->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     return true;
   }
@@ -1589,7 +1629,24 @@ __device__ __forceinline__ bool win_finish(const Tab& tab, int n_shards, const O
 #pragma unroll
   for (int s = 0; s < NSEL; ++s) all_done &= ol.sel[s].done != 0;
   if (resident) {
+    // close the round's gate: who has resigned by now is out, who tries later finds it closed and stays
+    if (threadIdx.x == 0) {
+      unsigned long long cur = __hip_atomic_fetch_add(&a.st->resign, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      unsigned long long base;
+      for (;;) {
+        base = (cur >> 24) == rtag ? cur : (rtag << 24);
+        if (__hip_atomic_compare_exchange_strong(&a.st->resign, &cur, base | kResignClosed, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                 __HIP_MEMORY_SCOPE_AGENT))
+          break;
+      }
+      ol.part = nwg - static_cast<uint32_t>(base & (kResignClosed - 1ull));
+      ol.ticket = 0;  // the publisher is participant 0 of the next round; the others draw from 1
+      if (!all_done) __hip_atomic_exchange(&a.st->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
     if (!all_done) {
+      if (threadIdx.x == kSelWords + 2)
+        __hip_atomic_exchange(&a.st->part, static_cast<unsigned long long>(ol.part), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (threadIdx.x < kSelWords)
         __hip_atomic_exchange(mail + threadIdx.x, reinterpret_cast<unsigned long long*>(ol.sel)[threadIdx.x], __ATOMIC_RELAXED,
                               __HIP_MEMORY_SCOPE_AGENT);
@@ -1625,11 +1682,13 @@ __device__ __forceinline__ bool win_finish(const Tab& tab, int n_shards, const O
 
 // The rounds after a launch's first sweep: everybody again, while the verdicts say so.
 template <typename T, int NSEL, int BLOCK, typename Tab>
-__device__ __forceinline__ void win_resident_rounds(const Tab& tab, int n_shards, const OneArgs& a, const uint32_t wg,
-                                                    const uint32_t nwg, OneLds& ol, SweepLds<NSEL, BLOCK>& swl,
+__device__ __forceinline__ void win_resident_rounds(const Tab& tab, int n_shards, const OneArgs& a, const uint32_t,
+                                                    const uint32_t, OneLds& ol, SweepLds<NSEL, BLOCK>& swl,
                                                     AdvShared (&adv)[2], bool again) {
   for (uint32_t round = 2; again && round < 12; ++round) {
     __syncthreads();
+    // this round's participants and this workgroup's place among them (win_finish: the verdict's mailbox / a ticket)
+    const uint32_t wg = __builtin_amdgcn_readfirstlane(ol.ticket), nwg = __builtin_amdgcn_readfirstlane(ol.part);
     win_sweep<T, NSEL, false, BLOCK, true, true, true, true>(tab, n_shards, wg, nwg, [&](WinSel (&sel)[NSEL]) {
 #pragma unroll
       for (int s = 0; s < NSEL; ++s) {
@@ -1664,6 +1723,7 @@ __device__ __forceinline__ void win_one_body(const Tab& tab, int n_shards, const
   __shared__ AdvShared adv[2];
   __shared__ OneLds ol;
   __shared__ SweepLds<NSEL, BLOCK> swl;
+  if (threadIdx.x == 0) ol.t0 = __builtin_amdgcn_s_memrealtime();  // (read by thread 0 only: win_finish)
   one_stamp(a, 0);
 #if SBQ_SEL_STAMPS != 0
   if (threadIdx.x == 0) swl.stamps = a.stamps;
@@ -1737,6 +1797,7 @@ __device__ __forceinline__ void win_round_body(const Tab& tab, int n_shards, con
   __shared__ AdvShared adv[2];
   __shared__ OneLds ol;
   __shared__ SweepLds<NSEL, BLOCK> swl;
+  if (threadIdx.x == 0) ol.t0 = __builtin_amdgcn_s_memrealtime();
   win_sweep<T, NSEL, false, BLOCK, true, true, true, true>(tab, n_shards, wg, nwg, [&](WinSel (&sel)[NSEL]) {
 #pragma unroll
     for (int s = 0; s < NSEL; ++s) sel[s] = a.st->sel[s];  // the previous launch's mailbox

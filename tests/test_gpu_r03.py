@@ -566,3 +566,36 @@ def test_group_kth_value_extreme_ranks_and_zero_heavy_items(ops, dtype):
         for i, x in enumerate(xs):
             srt = np.sort(np.abs(x.float().cpu().numpy()) if use_abs else x.float().cpu().numpy())
             assert got[i] == srt[ks[i] - 1], (i, use_abs, got[i], srt[ks[i] - 1])
+
+
+def _resident_worker(rank, iters, out_dir):
+    import os as _os
+    import sys as _sys
+
+    _sys.path.insert(0, _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))))
+    from sparsebit_amd import ops as _ops
+
+    g = torch.Generator().manual_seed(100 + rank)
+    x = torch.relu(torch.randn(4096 * 4096, generator=g)).bfloat16().cuda()
+    ref = torch.sort(x.float())[0]
+    n = x.numel()
+    bad = 0
+    for i in range(iters):
+        k = [1, n, n // 3, n // 2][i % 4]
+        bad += float(_ops.kth_value(x, k, False)) != float(ref[k - 1])
+        mn, mx = _ops.percentile_select([x.reshape(1, -1)], 1e-5, per_channel=False)
+        bad += float(mn) != 0.0 or float(mx) != float(ref[n - max(round(n * 1e-5), 0) - 1])
+    torch.cuda.synchronize()
+    torch.save({"bad": bad}, _os.path.join(out_dir, "resident%d.pt" % rank))
+
+
+@pytest.mark.gpu
+def test_concurrent_resident_selections_neither_hang_nor_differ(tmp_path):
+    """Two processes on ONE device, both running selections whose launches stay resident (ReLU data: zero-heavy
+    windows, extreme ranks), 256 workgroups each on 256 compute units.  Each launch's waiting workgroups hold units
+    the other's missing workgroups need; the bounded wait + resignation (win_finish) must let both finish, exactly."""
+    import torch.multiprocessing as mp
+
+    mp.spawn(_resident_worker, args=(120, str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        assert torch.load(str(tmp_path / ("resident%d.pt" % r)))["bad"] == 0

@@ -1341,6 +1341,7 @@ struct OneArgs {
   int32_t use_abs, mode, final_round;
   int32_t key_mode;  // KEYS_*: how the final key turns back into a value
   unsigned long long epoch;  // of this selection (host counter, > 0): tags the verdicts of its resident rounds
+  int32_t always_resident;   // every workgroup waits for the verdict even when the plan expects one sweep
   unsigned long long* stamps;  // development (knob 1 == 779): 8 timestamps per workgroup, else nullptr
 };
 // (compiled in only with -DSBQ_SEL_STAMPS=1 -- SBQ_EXTRA_HIPCC_FLAGS of sparsebit_amd/build.py: the conditional
@@ -1711,7 +1712,7 @@ __device__ __forceinline__ bool win_is_resident(const OneArgs& a, const OneLds& 
   bool r = false;
 #pragma unroll
   for (int s = 0; s < NSEL; ++s) r |= ol.sel[s].done == 0 && (ol.sel[s].shift > a.min_shift || (ol.sel[s].side & 8u) != 0);
-  return a.final_round && r;
+  return a.final_round && (r || a.always_resident);
 }
 
 // (wg of nwg: this workgroup's place among those that work on THIS selection -- the whole grid, or one item's share of
@@ -1935,6 +1936,7 @@ int win_one_run(const void* const* shards, const int64_t* counts, int n_shards, 
   a.use_abs = use_abs;
   a.mode = percentile ? 1 : 0;
   a.epoch = next_epoch();
+  a.always_resident = knob(2) == 16 ? 1 : 0;
   a.stamps = knob(1) == 779 ? reinterpret_cast<unsigned long long*>(region + kOneRegion) : nullptr;
   int rc = SBQ_OK;
   OneShard os{};

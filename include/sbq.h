@@ -540,7 +540,7 @@ int sbq_vecquantmatmul_multi(int bits, const float* x, int n_mats, const int32_t
  * 7 = fixed-digit radix engine for whole-tensor selections, 12 = the multi-launch windowed protocol (plan / sweep /
  * advance / fallback launches) instead of the one-launch engine, 15 = an fp32 whole-tensor selection as ONE launch of resident
  * rounds instead of one launch per sweep, 16 = every whole-tensor selection waits for its verdict (resident) even when its plan expects
- * one sweep: +1.5-2 us, measured, 11 = general statistics kernel for a min-max-only call). knob 3: resident schedule of the forward QDQ
+ * one sweep: +1.5-2 us, measured, 17 = the extraction kernel instead of the packed sorted lists for 16-bit rows in sbq_percentile_rows, 11 = general statistics kernel for a min-max-only call). knob 3: resident schedule of the forward QDQ
  * (0 = auto: tensors that fit the chip's registers in one sitting, 1 = never, 2 = always) */
 int sbq_set_tuning(int knob, int value);
 

@@ -109,36 +109,7 @@ __device__ __forceinline__ float win_key_float(uint32_t k) {
 
 // ---- keys of a 16-bit tensor, computed on its RAW bits (the one-launch engine) ----------------------------------
 // The 32-bit map above needs the element as a float: a shift or a convert, then five integer operations, per element.
-// A 16-bit tensor has 65 536 values: its keys are its own bit patterns through the same sign transform in 16 bits,
-//   key16(b) = (b ^ (b < 0 ? 0xffff : 0x8000)) - key16'(-inf)      (mod 2^16; negative NaNs wrap to the top)
-// and the engine works on key32 = key16 << 16 with min_shift 16, so plan, windows (always 2^16 aligned) and advance
-// are untouched.  Both keys of a dword come out of five PACKED operations (and, arithmetic shift, or, xor, subtract:
-// 2.5 per element) plus one shift / mask each to feed the window tests -- 3.5 operations per element instead of 6.
-template <typename T>
-struct Key16 {
-  static constexpr uint32_t kNegInf = T::id == SBQ_BF16 ? 0xff80u : 0xfc00u;
-  static constexpr uint32_t kRot = (~kNegInf) & 0xffffu;                       // key16'(-inf) before the rotation
-  static constexpr uint32_t kZero = ((0x7fffu - kRot) & 0xffffu) << 16;        // key32(-0): keys below are x < 0
-  static constexpr uint32_t kInf = ((((kNegInf & 0x7fffu) | 0x8000u) - kRot) & 0xffffu) << 16;  // key32(+inf)
-  // two keys, packed like the two elements of the dword; amask2 = 0x7fff7fff for |x|, else all ones
-  static __device__ __forceinline__ uint32_t pack2(uint32_t w, uint32_t amask2) {
-    typedef int16_t i16x2 __attribute__((ext_vector_type(2)));
-    typedef uint16_t u16x2 __attribute__((ext_vector_type(2)));
-    w &= amask2;
-    const uint32_t m = __builtin_bit_cast(uint32_t, __builtin_bit_cast(i16x2, w) >> static_cast<int16_t>(15));
-    const uint32_t t = w ^ (m | 0x80008000u);
-    const u16x2 rot = {static_cast<uint16_t>(kRot), static_cast<uint16_t>(kRot)};
-    return __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, t) - rot);
-  }
-  static __device__ __forceinline__ uint32_t one(uint32_t b16, bool use_abs) {  // key32 of one raw element
-    return pack2(b16, use_abs ? 0x7fff7fffu : 0xffffffffu) << 16;
-  }
-  static __device__ __forceinline__ float value(uint32_t key32) {
-    const uint32_t t = ((key32 >> 16) + kRot) & 0xffffu;
-    const uint32_t b = (t & 0x8000u) ? (t & 0x7fffu) : (~t & 0xffffu);
-    return Elem<T>::from_bits(static_cast<uint16_t>(b));
-  }
-};
+// (Key16 -- the 16-bit keys of a 16-bit tensor -- lives in sbq_common.hpp: sbq_select.hip's row kernels use it too)
 // which map a selection's keys follow: the advance turns the final key back into a value with it
 enum { KEYS_F32 = 0, KEYS_BF16_RAW = 1, KEYS_F16_RAW = 2 };
 __device__ __forceinline__ float key_value(uint32_t key32, int key_mode) {

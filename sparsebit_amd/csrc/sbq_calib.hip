@@ -173,9 +173,9 @@ __global__ __launch_bounds__(kBlock) void calib_stats_fold_kernel(const CalibIte
 // candidates over 4096 register slots of which a few per cent hold data (967 us for ResNet-50's 25.5 M elements,
 // four times the per-tensor kernel's rate).  Rows of at most 2048 elements are therefore taken by ONE WAVE each, four
 // rows per workgroup.  To stay bit-identical with the per-tensor kernel the wave reproduces its summation tree: there
-// pack p of a row sits in lane p % 64 of wave (p % 256) / 64, each wave reduces its lanes' fp32 sums by the xor
-// butterfly and the four wave sums are added in fp64 -- here lane l holds packs l, 64 + l, 128 + l, 192 + l with one
-// accumulator per "virtual wave", reduces each by the same butterfly and adds them in the same order.
+// pack p of a row sits in lane p % 64 of wave (p % 256) / 64, each wave reduces its lanes' fp32 sums by the
+// wave sum (wave_sum_f32) and the four wave sums are added in fp64 -- here lane l holds packs l, 64 + l, 128 + l, 192 + l with one
+// accumulator per "virtual wave", reduces each by the same wave sum (wave_sum_f32) and adds them in the same order.
 template <typename T, int NV>
 __device__ __forceinline__ void mse_wave_rows(MseLds (&lds)[kWavesPerBlock], const CalibItemDev* it, uint32_t row,
                                               const float* __restrict__ min_base, const float* __restrict__ max_base,
@@ -238,7 +238,7 @@ __device__ __forceinline__ void mse_wave_rows(MseLds (&lds)[kWavesPerBlock], con
           a += d * d;
         }
       }
-      acc[w] = wave_reduce(a, Sum());
+      acc[w] = wave_sum_f32(a);
     }
     if (lane == 0 && live) {
       double t = 0.0;

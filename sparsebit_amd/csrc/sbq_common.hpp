@@ -301,6 +301,16 @@ __device__ __forceinline__ uint32_t dpp_reduce_u32(uint32_t v, uint32_t identity
   return static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(v), kWave - 1));
 }
 
+// Sum of an fp32 value over the wave on DPP, the result in every lane: six dependent vector adds instead of six
+// ds_bpermute round trips.  The association is the scan's (fixed, the same on every call): callers that must agree
+// bit for bit (the MSE observer's per-tensor and model-wide kernels) all use THIS function.
+__device__ __forceinline__ float wave_sum_f32(float a) {
+  const uint32_t r = dpp_reduce_u32(__builtin_bit_cast(uint32_t, a), 0u, [](uint32_t x, uint32_t y) {
+    return __builtin_bit_cast(uint32_t, __builtin_bit_cast(float, x) + __builtin_bit_cast(float, y));
+  });
+  return __builtin_bit_cast(float, r);
+}
+
 // A 16-bit tensor has 65 536 values: its keys are its own bit patterns through the same sign transform in 16 bits,
 //   key16(b) = (b ^ (b < 0 ? 0xffff : 0x8000)) - key16'(-inf)      (mod 2^16; negative NaNs wrap to the top)
 // and the engine works on key32 = key16 << 16 with min_shift 16, so plan, windows (always 2^16 aligned) and advance

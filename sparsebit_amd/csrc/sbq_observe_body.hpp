@@ -160,11 +160,9 @@ __device__ __forceinline__ double mse_chunk_body(MseLds& lds, const void* __rest
         a0 = __builtin_fmaf(d0, d0, a0);
         a1 = __builtin_fmaf(d1, d1, a1);
       }
-#pragma unroll
-      for (int m = kWave / 2; m > 0; m >>= 1) {
-        a0 += __shfl_xor(a0, m, kWave);
-        a1 += __shfl_xor(a1, m, kWave);
-      }
+      // (wave sums on DPP: the butterfly's twelve ds_bpermute round trips per pair were a fifth of this loop)
+      a0 = wave_sum_f32(a0);
+      a1 = wave_sum_f32(a1);
       if (lane == 0) {
         lds.acc[i][wid] = a0;
         lds.acc[i + 1][wid] = a1;
@@ -210,7 +208,7 @@ __device__ __forceinline__ double mse_chunk_body(MseLds& lds, const void* __rest
         acc += d * d;
       }
     }
-    acc = wave_reduce(acc, Sum());
+    acc = wave_sum_f32(acc);
     if (lane == 0) lds.acc[i][wid] = acc;
   }
   __syncthreads();

@@ -372,8 +372,10 @@ __global__ __launch_bounds__(kBlock) void percentile_rows_top16_kernel(const voi
   int rem_hi = static_cast<int>(static_cast<int64_t>(inner) - k_max + 1), rem_lo = static_cast<int>(k_min);
   rem_hi = rem_hi > R ? R : rem_hi;  // (cannot happen: the host picked R)
   rem_lo = rem_lo > R ? R : rem_lo;
-  if constexpr (R > 3) {
-    if (rem_hi > 3 || rem_lo > 3) build(std::integral_constant<int, R>());  // uniform
+  if constexpr (R > 3) {  // uniform branches
+    const int deep = rem_hi > rem_lo ? rem_hi : rem_lo;
+    if (R > 5 && deep > 5) build(std::integral_constant<int, R>());
+    else if (deep > 3) build(std::integral_constant<int, (R < 5 ? R : 5)>());
   }
   // pop the wave's largest head rem_hi - 1 times: exactly one lane gives up one key per pop, so duplicates count
   for (int j = 1; j < rem_hi; ++j) {  // uniform
@@ -712,10 +714,10 @@ int sbq_percentile_rows(const void* x, int x_dtype, int64_t C, int64_t inner, do
   // ranks within a few elements of either end (alpha * inner small): one wave per row, extraction instead of
   // bisection + histograms (knob 2 == 5: off, for A/B runs)
   if (inner <= 4096 && inner % kPack == 0 && aligned16(x) && alpha * static_cast<double>(inner) <= 8.0 && knob(2) != 5) {
-    // 16-bit rows whose ranks are at most 5 from either end for EVERY row (round(inner * alpha) + 1 bounds both):
+    // 16-bit rows whose ranks are at most 9 from either end for EVERY row (round(inner * alpha) + 1 bounds both):
     // sorted lists of packed keys instead of the extraction (knob 2 == 17: off, for A/B runs)
     const int need = static_cast<int>(__builtin_rint(static_cast<double>(inner) * alpha)) + 1;
-    if (x_dtype != SBQ_F32 && need <= 5 && knob(2) != 17) {
+    if (x_dtype != SBQ_F32 && need <= 9 && knob(2) != 17) {
       int rc = dispatch_dtype(x_dtype, [&](auto tag) {
         using T = decltype(tag);
         if constexpr (T::id != SBQ_F32) {
@@ -727,7 +729,8 @@ int sbq_percentile_rows(const void* x, int x_dtype, int64_t C, int64_t inner, do
     else percentile_rows_top16_kernel<T, false, RR><<<grid, kBlock, 0, st>>>(x, c32, n, alpha, min_out, max_out);              \
   } while (0)
           if (need <= 3) SBQ_TOP(3);
-          else SBQ_TOP(5);
+          else if (need <= 5) SBQ_TOP(5);
+          else SBQ_TOP(9);
 #undef SBQ_TOP
         }
       });

@@ -270,6 +270,112 @@ __global__ __launch_bounds__(kBlock) void percentile_rows_tail_kernel(const void
   }
 }
 
+// The sorted-list form of the kernel above for 32-bit keys (fp32 rows -- what a reference user's fp32 weights are):
+// a lane keeps the RR largest and smallest of its 64 keys in sorted registers (a max / min pair per level and key)
+// and the wave pops one head per rank; see percentile_rows_top16_kernel below for the packed 16-bit form and the
+// argument.  1000 instead of 1800 operations per row at the default alpha.
+template <typename T, bool FULL, int R>
+__global__ __launch_bounds__(kBlock) void percentile_rows_top32_kernel(const void* __restrict__ x, uint32_t C, uint32_t inner,
+                                                                       double alpha, float* __restrict__ min_out,
+                                                                       float* __restrict__ max_out) {
+  constexpr int kPacks = 8;
+  constexpr int kN = kPacks * kPack;
+  auto umax = [](uint32_t a, uint32_t b) { return a > b ? a : b; };
+  auto umin = [](uint32_t a, uint32_t b) { return a < b ? a : b; };
+  const uint32_t lane = threadIdx.x & (kWave - 1);
+  const uint32_t row = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + threadIdx.x / kWave);
+  if (row >= C) return;
+  const int64_t base = static_cast<int64_t>(row) * inner;
+  uint32_t keys[kN];
+  bool ok[kPacks];
+  RawPack<T> raw[kPacks];  // the whole row in flight before the first use
+#pragma unroll
+  for (int p = 0; p < kPacks; ++p) {
+    const uint32_t e = (p * kWave + lane) * kPack;
+    ok[p] = FULL || e < inner;
+    raw[p] = load_raw<T, true>(x, base + (ok[p] ? e : 0));
+  }
+  uint32_t neg = 0, pos = 0;
+#pragma unroll
+  for (int p = 0; p < kPacks; ++p) {
+    float v[kPack];
+    unpack_raw<T>(raw[p], v);
+#pragma unroll
+    for (int j = 0; j < kPack; ++j) {
+      keys[p * kPack + j] = float_key(v[j], false);
+      neg += ok[p] && v[j] < 0.0f;
+      pos += ok[p] && v[j] >= 0.0f;
+    }
+  }
+  auto uadd = [](uint32_t a, uint32_t b) { return a + b; };
+  neg = __builtin_amdgcn_readfirstlane(dpp_reduce_u32(neg, 0u, uadd));
+  pos = __builtin_amdgcn_readfirstlane(dpp_reduce_u32(pos, 0u, uadd));
+  // percentile.py:36-43 (1-indexed k-th smallest; Python round == rint on a double)
+  const double rp = __builtin_rint(static_cast<double>(pos) * alpha);
+  const double rn = __builtin_rint(static_cast<double>(neg) * alpha);
+  int64_t k_max = static_cast<int64_t>(inner) - static_cast<int64_t>(rp > 0.0 ? rp : 0.0);
+  int64_t k_min = static_cast<int64_t>(rn > 1.0 ? rn : 1.0);
+  if (k_max < 1) k_max = 1;
+  if (k_min > inner) k_min = inner;
+  int rem_hi = static_cast<int>(static_cast<int64_t>(inner) - k_max + 1), rem_lo = static_cast<int>(k_min);
+  rem_hi = rem_hi > R ? R : rem_hi;  // (cannot happen: the host picked R)
+  rem_lo = rem_lo > R ? R : rem_lo;
+  uint32_t hi[R], lo[R];
+  auto build = [&](auto rr_tag) {
+    constexpr int RR = decltype(rr_tag)::value;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      hi[r] = 0u;
+      lo[r] = 0xffffffffu;
+    }
+#pragma unroll
+    for (int i = 0; i < kN; ++i) {
+      uint32_t t = (FULL || ok[i / kPack]) ? keys[i] : 0u;
+#pragma unroll
+      for (int r = 0; r < RR; ++r) {
+        const uint32_t m = umax(hi[r], t);
+        if (r + 1 < RR) t = umin(hi[r], t);
+        hi[r] = m;
+      }
+      t = (FULL || ok[i / kPack]) ? keys[i] : 0xffffffffu;
+#pragma unroll
+      for (int r = 0; r < RR; ++r) {
+        const uint32_t m = umin(lo[r], t);
+        if (r + 1 < RR) t = umax(lo[r], t);
+        lo[r] = m;
+      }
+    }
+  };
+  {  // the depth this row's own ranks ask for (uniform branches)
+    const int deep = rem_hi > rem_lo ? rem_hi : rem_lo;
+    if (R > 5 && deep > 5) build(std::integral_constant<int, R>());
+    else if (R > 3 && deep > 3) build(std::integral_constant<int, (R < 5 ? R : 5)>());
+    else build(std::integral_constant<int, (R < 3 ? R : 3)>());
+  }
+  for (int j = 1; j < rem_hi; ++j) {  // uniform: one lane gives up one key per pop, so duplicates count
+    const uint32_t m = dpp_reduce_u32(hi[0], 0u, umax);
+    const uint64_t who = __builtin_amdgcn_ballot_w64(hi[0] == m);
+    if (lane == static_cast<uint32_t>(__builtin_ctzll(who))) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) hi[r] = r + 1 < R ? hi[r + 1] : 0u;
+    }
+  }
+  const uint32_t hi_key = dpp_reduce_u32(hi[0], 0u, umax);
+  for (int j = 1; j < rem_lo; ++j) {
+    const uint32_t m = dpp_reduce_u32(lo[0], 0xffffffffu, umin);
+    const uint64_t who = __builtin_amdgcn_ballot_w64(lo[0] == m);
+    if (lane == static_cast<uint32_t>(__builtin_ctzll(who))) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) lo[r] = r + 1 < R ? lo[r + 1] : 0xffffffffu;
+    }
+  }
+  const uint32_t lo_key = dpp_reduce_u32(lo[0], 0xffffffffu, umin);
+  if (lane == 0) {
+    min_out[row] = neg > 0 ? key_float(lo_key) : 0.0f;
+    max_out[row] = pos > 0 ? key_float(hi_key) : 0.0f;
+  }
+}
+
 // The same small ranks for a 16-bit row, on PACKED keys (Key16: the raw bit patterns through a packed sign transform;
 // two keys per register).  The extraction above spends 192 operations per lane on every distinct value it passes
 // (64 subtracts, 64 minimums, 64 compares) -- 1800 per row with the key conversion, a third of them per rank, and
@@ -735,6 +841,20 @@ int sbq_percentile_rows(const void* x, int x_dtype, int64_t C, int64_t inner, do
         }
       });
       if (rc != SBQ_OK) return rc;
+      return check_launch();
+    }
+    if (x_dtype == SBQ_F32 && need <= 9 && knob(2) != 17) {
+      const uint32_t grid = static_cast<uint32_t>(ceil_div(C, kWavesPerBlock));
+      const uint32_t c32 = static_cast<uint32_t>(C);
+#define SBQ_TOP32(RR)                                                                                           \
+  do {                                                                                                          \
+    if (inner == 4096) percentile_rows_top32_kernel<F32, true, RR><<<grid, kBlock, 0, st>>>(x, c32, n, alpha, min_out, max_out); \
+    else percentile_rows_top32_kernel<F32, false, RR><<<grid, kBlock, 0, st>>>(x, c32, n, alpha, min_out, max_out);              \
+  } while (0)
+      if (need <= 3) SBQ_TOP32(3);
+      else if (need <= 5) SBQ_TOP32(5);
+      else SBQ_TOP32(9);
+#undef SBQ_TOP32
       return check_launch();
     }
     int rc = dispatch_dtype(x_dtype, [&](auto tag) {

@@ -18,7 +18,7 @@ def timed(fn, iters=200, warm=20, rounds=3):
     return best
 lib = L.load(); st = L.stream_ptr(dev)
 g = torch.Generator().manual_seed(0)
-for dt, did in ((torch.bfloat16, L.BF16), (torch.float16, L.F16)):
+for dt, did in ((torch.bfloat16, L.BF16), (torch.float32, L.F32)):
     xs = [(torch.randn(4096, 4096, generator=g) * torch.logspace(-2, 1, 4096).unsqueeze(1)).to(dt).to(dev) for _ in range(12)]
     mn = torch.empty(4096, dtype=torch.float32, device=dev); mx = torch.empty_like(mn)
     for alpha in (1e-3, 5e-4, 1.9e-3):

@@ -1276,17 +1276,21 @@ __global__ __launch_bounds__(BLOCK) void win_fallback_kernel(const PassTable tab
 // plan + sweep + advance in ONE kernel (16-bit inputs: the whole selection; fp32: its first round).  The launch chain
 // of the multi-launch protocol -- plan 10 us on one workgroup, sweep 10, advance 4.6, idle fallback rounds 3.9 -- spent
 // 18 of 28 us moving no data (profiles/r02v8_select_timeline.txt).  Here
-//   * every workgroup requests the sample (2 packs per thread: L2 hits for all but the first workgroup of an XCD) and
-//     then its first FOUR slabs, derives the windows from the sample while the slabs are in flight (plan_compute:
-//     identical inputs and integer arithmetic in every workgroup => identical windows, nothing communicated),
+//   * every workgroup requests the sample (2 packs per thread, all waves before any slab: L2 hits for all but the
+//     first workgroup of an XCD) and then its first FOUR slabs, derives the windows from the sample while the slabs
+//     are in flight (plan_compute: identical inputs and integer arithmetic in every workgroup => identical windows,
+//     nothing communicated),
 //   * sweeps, adds its counters / non-empty histogram bins to the global lines with device atomics and counts its
 //     arrival,
-//   * and the LAST workgroup to arrive places the ranks, writes the results and leaves the workspace clean.  Nobody
+//   * and the LAST workgroup to arrive places the ranks, writes the results and leaves the workspace clean.  When the
+//     windows resolve the ranks in one sweep -- the common case, known to every workgroup from the plan -- nobody
 //     waits for another workgroup.
-// Rounds beyond the expected ones (a window the sample misplaced; a 16-bit window wider than 2048 values; an extreme
-// rank whose first window starts at the first key) are run by that last workgroup ALONE inside the same launch,
-// entirely out of its LDS: exact for any data, no launch in the common case, slow (~1 ms per round for 16.7 M
-// elements) in the case that essentially never happens -- the sample is jittered against data periodic with its stride.
+// When they do not (a 16-bit window wider than 2048 values, an extreme rank the sample has no evidence for, half of
+// the data in one bin: again known to everybody) the launch is RESIDENT: the others wait for the last arriver's
+// verdict and the whole grid sweeps again (win_finish, win_resident_rounds) -- with a bounded wait, resignation
+// and tickets, so that two such launches sharing a device cannot starve each other.  Only a window the sample
+// misplaced outright (1e-9 by design; it is jittered against data periodic with its stride) is finished by the last
+// workgroup ALONE, out of its LDS: exact for any data, ~1 ms per round for 16.7 M elements.
 //
 // What travels how (measured the hard way: a line one XCD wrote with an sc1 store can stay in that XCD's L2 across
 // launches, and a later sc1 LOAD from that XCD hits it even after another XCD overwrote memory -- a selector state
@@ -1297,6 +1301,8 @@ __global__ __launch_bounds__(BLOCK) void win_fallback_kernel(const PassTable tab
 //   * the selector state never leaves the workgroup: every workgroup holds its own copy in LDS (they are identical),
 //     the last arriver advances ITS copy; between the launches of an fp32 selection it passes through memory as
 //     plain stores / plain loads (a kernel boundary orders those, as in the multi-launch protocol);
+//   * resident rounds: the narrowed windows, the participant count and the verdict cross as atomic exchanges /
+//     fetch-adds of zero; tickets and resignations are atomic counters;
 //   * the lonely rounds use no global memory besides the data and the result.
 // Workspace contract (as for the GPTQ mat-vec's arrival counters): this engine's region must be ZERO before its
 // first use, and every call leaves it zero (the mailbox words of the state aside, which are write-before-read).

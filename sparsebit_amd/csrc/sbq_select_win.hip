@@ -69,11 +69,18 @@ struct WinState {
   unsigned long long pad0[4];
   // its own 128-byte line: the words of the state that are touched by atomics only
   uint32_t arrivals;  // workgroups of the running sweep that have flushed (zero between launches)
+  // resident launches so far on this state (bumped by the one that resolves a selection).  The one-launch engine adds
+  // to {arrivals, serial} as ONE 64-bit word, so a workgroup's arrival also tells it the serial: with the host's epoch
+  // it makes the verdict tags of a launch unique even when the same captured launch is REPLAYED (a hipGraph carries
+  // its kernel arguments, epoch included, into every replay).
+  uint32_t serial;
   uint32_t ticket;    // resident rounds: the next participant's index (reset by the publisher of the round before)
+  uint32_t pad1;
   // resident rounds: (epoch, round) << 24 | closed << 23 | the workgroups that gave up waiting for this round's
   // verdict.  Tagged, never cleared: a word of another round or selection reads as "nobody yet".
   unsigned long long resign;
 };
+static_assert(offsetof(WinState, serial) == offsetof(WinState, arrivals) + 4, "{arrivals, serial} is one 64-bit word");
 static_assert(offsetof(WinState, arrivals) == 128, "the arrival counter has a line of its own");
 struct WinSlot {  // one 128-byte line
   unsigned long long below[kWinSel];
@@ -1334,6 +1341,7 @@ struct OneLds {
   uint32_t flag;
   unsigned long long verdict;
   unsigned long long t0;  // s_memrealtime at the kernel's start (100 MHz)
+  unsigned long long serial;  // st->serial as this workgroup's arrival found it
   uint32_t part, ticket;  // resident rounds: participants of the next round, this workgroup's index among them
 };
 template <typename V>
@@ -1513,12 +1521,17 @@ __device__ __forceinline__ bool win_finish(const Tab& tab, int n_shards, const O
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __builtin_amdgcn_s_waitcnt(0);
   __syncthreads();
-  if (threadIdx.x == 0)
-    ol.flag = __hip_atomic_fetch_add(&a.st->arrivals, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nwg - 1;
+  unsigned long long* arrive64 = reinterpret_cast<unsigned long long*>(&a.st->arrivals);  // {arrivals, serial}
+  if (threadIdx.x == 0) {
+    const unsigned long long was = __hip_atomic_fetch_add(arrive64, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    ol.flag = static_cast<uint32_t>(was) == nwg - 1;
+    ol.serial = was >> 32;
+  }
   __syncthreads();
   one_stamp(a, 4);
-  const unsigned long long tag = (a.epoch << 8) | (static_cast<unsigned long long>(round) << 1);
-  const unsigned long long rtag = ((a.epoch << 8) | round) & ((1ull << 40) - 1ull);  // of st->resign
+  const unsigned long long nonce = (a.epoch & 0xffffffffull) | ((ol.serial & 0x7fffffull) << 32);
+  const unsigned long long tag = (nonce << 8) | (static_cast<unsigned long long>(round) << 1);
+  const unsigned long long rtag = (((nonce ^ (nonce >> 23)) << 8) | round) & ((1ull << 40) - 1ull);  // of st->resign
   constexpr unsigned long long kResignClosed = 1ull << 23;
   unsigned long long* mail = reinterpret_cast<unsigned long long*>(a.st);  // sel[] first, then n, pad_neg, pad_nan
   constexpr int kSelWords = static_cast<int>(sizeof(WinSel) / 8) * NSEL;
@@ -1581,7 +1594,9 @@ __device__ __forceinline__ bool win_finish(const Tab& tab, int n_shards, const O
     __syncthreads();
     return true;
   }
-  if (threadIdx.x == 0) one_take(&a.st->arrivals);
+  // (back to zero arrivals; the serial in the upper half stays)
+  if (threadIdx.x == 0)
+    __hip_atomic_fetch_add(arrive64, ~static_cast<unsigned long long>(nwg) + 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   one_stamp(a, 5);
   bool pair = false;
   if constexpr (NSEL == 2) pair = !ol.sel[0].done && !ol.sel[1].done;
@@ -1619,6 +1634,7 @@ __device__ __forceinline__ bool win_finish(const Tab& tab, int n_shards, const O
       }
       ol.part = nwg - static_cast<uint32_t>(base & (kResignClosed - 1ull));
       ol.ticket = 0;  // the publisher is participant 0 of the next round; the others draw from 1
+      if (all_done) __hip_atomic_fetch_add(arrive64, 1ull << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (!all_done) __hip_atomic_exchange(&a.st->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();

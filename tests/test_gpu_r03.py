@@ -599,3 +599,30 @@ def test_concurrent_resident_selections_neither_hang_nor_differ(tmp_path):
     mp.spawn(_resident_worker, args=(120, str(tmp_path)), nprocs=2, join=True)
     for r in range(2):
         assert torch.load(str(tmp_path / ("resident%d.pt" % r)))["bad"] == 0
+
+
+@pytest.mark.gpu
+def test_resident_selection_replayed_from_a_graph(ops):
+    """A captured selection is replayed with its kernel arguments unchanged -- the host's epoch included; the verdict
+    tags of a resident launch must still be unique per replay (the state's serial travels with the arrival)."""
+    n = 2 * 1024 * 1024
+    g = torch.Generator().manual_seed(8)
+    x = torch.relu(torch.randn(n, generator=g)).bfloat16().cuda()
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        ops.kth_value(x, 1, False)  # this stream's workspace exists (and is zero) before the capture
+        ops.percentile_select([x.reshape(1, -1)], 1e-5, per_channel=False)
+        torch.cuda.current_stream().synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=s):
+            v1 = ops.kth_value(x, 1, False)
+            vn = ops.kth_value(x, n // 3, False)
+            mn, mx = ops.percentile_select([x.reshape(1, -1)], 1e-5, per_channel=False)
+    for rep in range(6):
+        x.copy_(torch.relu(torch.randn(n, generator=g) + 0.1 * rep).bfloat16())
+        torch.cuda.synchronize()
+        graph.replay()
+        torch.cuda.synchronize()
+        srt = torch.sort(x.float())[0]
+        assert float(v1) == float(srt[0]) and float(vn) == float(srt[n // 3 - 1]), rep
+        assert float(mn) == 0.0 and float(mx) == float(srt[n - max(round(n * 1e-5), 0) - 1]), rep

@@ -68,6 +68,13 @@ def test_status_strings_and_argument_validation_without_gpu(built):
     assert l.sbq_stats_workspace_bytes(1, 4096, 4096) == 4096 * 16
     assert l.sbq_mse_workspace_bytes(1, 4096, 4096) == 4096 * 80 * 8  # one chunk per channel: no fold levels
     assert l.sbq_gptq_workspace_bytes(1, 4096, 4096) > 0
+    # selection workspace = [whole-tensor engine | fixed-digit passes]: the engine's share is the same for every C and
+    # the fixed-digit histograms (int64 [C][n_sel][2048] + state + counts) come behind it, never on top of it
+    w1, w64 = l.sbq_radix_select_workspace_bytes(1, 2), l.sbq_radix_select_workspace_bytes(64, 2)
+    fixed = lambda C: C * 2 * 2048 * 8 + C * 2 * 16 + C * 16 + 64
+    assert w1 - fixed(1) == w64 - fixed(64) > 128 * 1024
+    assert l.sbq_radix_select_workspace_bytes(0, 2) == 0 and l.sbq_radix_select_workspace_bytes(1, 3) == 0
+    assert l.sbq_group_kth_workspace_bytes(3) == 3 * l.sbq_group_kth_workspace_bytes(1) > 0
 
 
 def test_no_cpu_fallback_in_product_path():

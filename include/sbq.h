@@ -377,7 +377,11 @@ int sbq_mse_select(const double* sse, double count_per_channel,
  *   pos = count(x >= 0), neg = count(x < 0)
  *   max[c] = pos ? kth(row, inner - max(round(pos*alpha), 0)) : 0
  *   min[c] = neg ? kth(row, max(round(neg*alpha), 1))         : 0
- * (k is 1-indexed k-th smallest; round == Python round, half to even). */
+ * (k is 1-indexed k-th smallest; round == Python round, half to even).
+ * Rows of at most 4096 elements whose ranks lie within 9 of either end (round(inner * alpha) + 1 <= 9: the
+ * reference's default alpha = 1e-3) are taken a WAVE per row: the row in registers once, the few largest / smallest
+ * keys of every lane in sorted registers (packed two per register for 16-bit inputs), one head popped per rank --
+ * 9.3 us for a 4096 x 4096 bf16 weight, 17.9 us for fp32. */
 #define SBQ_ROWSEL_MAX 16384
 int sbq_percentile_rows(const void* x, int x_dtype, int64_t C, int64_t inner,
                         double alpha, float* min_out, float* max_out, void* stream);
@@ -540,7 +544,7 @@ int sbq_vecquantmatmul_multi(int bits, const float* x, int n_mats, const int32_t
  * 7 = fixed-digit radix engine for whole-tensor selections, 12 = the multi-launch windowed protocol (plan / sweep /
  * advance / fallback launches) instead of the one-launch engine, 15 = an fp32 whole-tensor selection as ONE launch of resident
  * rounds instead of one launch per sweep, 16 = every whole-tensor selection waits for its verdict (resident) even when its plan expects
- * one sweep: +1.5-2 us, measured, 17 = the extraction kernel instead of the packed sorted lists for 16-bit rows in sbq_percentile_rows, 11 = general statistics kernel for a min-max-only call). knob 3: resident schedule of the forward QDQ
+ * one sweep: +1.5-2 us, measured, 17 = the extraction kernel instead of the sorted lists in sbq_percentile_rows, 11 = general statistics kernel for a min-max-only call). knob 3: resident schedule of the forward QDQ
  * (0 = auto: tensors that fit the chip's registers in one sitting, 1 = never, 2 = always) */
 int sbq_set_tuning(int knob, int value);
 

@@ -31,6 +31,14 @@
 #ifndef SBQ_SEL_STAMPS
 #define SBQ_SEL_STAMPS 0  // -DSBQ_SEL_STAMPS=1: development timestamps (tools/lab/build_stamps.py)
 #endif
+// This file is compiled THREE times (sparsebit_amd/build.py): the one-launch engine's kernels are the largest of the
+// library -- 2.5 minutes of compilation for the three input types in one translation unit -- so each type's kernels
+// are instantiated in a unit of their own, behind a plain launcher function:
+//   part 0 (default): the host side, the multi-launch protocol, the engine for fp32
+//   part 1: the engine's launchers for bf16          part 2: ... for fp16
+#ifndef SBQ_WIN_PART
+#define SBQ_WIN_PART 0
+#endif
 #include "sbq_common.hpp"
 
 namespace sbq {
@@ -1867,6 +1875,41 @@ __global__ __launch_bounds__(BLOCK) void group_kth_kernel(const KthItems items, 
   else win_round_body<T, 1, BLOCK>(tab, 1, a, blockIdx.x - me.wg_begin, me.nwg);
 }
 
+// The engine's launches for ONE input type (see SBQ_WIN_PART at the top).  table: OneShard / PassTable, args: OneArgs,
+// items: KthItems -- passed as untyped pointers because these functions are called across translation units and the
+// structs live in each unit's anonymous namespace (the same source, the same layout).
+template <typename T>
+int win_engine_launch_t(int r, int n_sel, unsigned grid, hipStream_t st, const void* table, int single, int n_shards,
+                        const void* args) {
+  constexpr int kB = 1024;
+  const OneArgs& a = *static_cast<const OneArgs*>(args);
+  // (two EXPLICIT ranks in one selection, or one rank over several shards: nothing in the C ABI asks for them;
+  // win_select_run sends such calls to the multi-launch protocol, so these are all the instantiations there are)
+  if (single) {
+    const OneShard& t = *static_cast<const OneShard*>(table);
+    if (r == 0) {
+      if (n_sel == 1) win_one_kernel<T, 1, false, kB, OneShard><<<grid, kB, 0, st>>>(t, n_shards, a);
+      else win_one_kernel<T, 2, true, kB, OneShard><<<grid, kB, 0, st>>>(t, n_shards, a);
+    } else {
+      if (n_sel == 1) win_round_kernel<T, 1, kB, OneShard><<<grid, kB, 0, st>>>(t, n_shards, a);
+      else win_round_kernel<T, 2, kB, OneShard><<<grid, kB, 0, st>>>(t, n_shards, a);
+    }
+  } else {
+    const PassTable& t = *static_cast<const PassTable*>(table);
+    if (r == 0) win_one_kernel<T, 2, true, kB, PassTable><<<grid, kB, 0, st>>>(t, n_shards, a);
+    else win_round_kernel<T, 2, kB, PassTable><<<grid, kB, 0, st>>>(t, n_shards, a);
+  }
+  return SBQ_OK;
+}
+template <typename T>
+int win_group_launch_t(const void* items, int cnt, char* regions, size_t region_bytes, float* out, int use_abs,
+                       uint32_t min_shift, int round, int final_round, unsigned long long epoch, unsigned grid,
+                       hipStream_t st) {
+  group_kth_kernel<T, 1024><<<grid, 1024, 0, st>>>(*static_cast<const KthItems*>(items), cnt, regions, region_bytes, out,
+                                                  use_abs, min_shift, round, final_round, epoch);
+  return SBQ_OK;
+}
+
 // every selection gets its own epoch (> 0): the tag of its resident rounds' verdicts (WinSlot::verdict)
 std::atomic<unsigned long long> g_select_epoch{0};
 unsigned long long next_epoch() { return (g_select_epoch.fetch_add(1, std::memory_order_relaxed) + 1) & ((1ull << 55) - 1); }
@@ -1877,6 +1920,34 @@ constexpr size_t kHistBytes = static_cast<size_t>(kCopies) * kWinSel * kWinBins 
 
 }  // namespace
 
+#define SBQ_WIN_ENGINE_ARGS int r, int n_sel, unsigned grid, hipStream_t st, const void* table, int single, int n_shards, const void* args
+#define SBQ_WIN_GROUP_ARGS                                                                                             \
+  const void* items, int cnt, char* regions, size_t region_bytes, float* out, int use_abs, uint32_t min_shift, int round, \
+      int final_round, unsigned long long epoch, unsigned grid, hipStream_t st
+int win_engine_launch_f32(SBQ_WIN_ENGINE_ARGS);
+int win_engine_launch_bf16(SBQ_WIN_ENGINE_ARGS);
+int win_engine_launch_f16(SBQ_WIN_ENGINE_ARGS);
+int win_group_launch_f32(SBQ_WIN_GROUP_ARGS);
+int win_group_launch_bf16(SBQ_WIN_GROUP_ARGS);
+int win_group_launch_f16(SBQ_WIN_GROUP_ARGS);
+#if SBQ_WIN_PART == 0
+int win_engine_launch_f32(SBQ_WIN_ENGINE_ARGS) { return win_engine_launch_t<F32>(r, n_sel, grid, st, table, single, n_shards, args); }
+int win_group_launch_f32(SBQ_WIN_GROUP_ARGS) {
+  return win_group_launch_t<F32>(items, cnt, regions, region_bytes, out, use_abs, min_shift, round, final_round, epoch, grid, st);
+}
+#elif SBQ_WIN_PART == 1
+int win_engine_launch_bf16(SBQ_WIN_ENGINE_ARGS) { return win_engine_launch_t<BF16>(r, n_sel, grid, st, table, single, n_shards, args); }
+int win_group_launch_bf16(SBQ_WIN_GROUP_ARGS) {
+  return win_group_launch_t<BF16>(items, cnt, regions, region_bytes, out, use_abs, min_shift, round, final_round, epoch, grid, st);
+}
+#else
+int win_engine_launch_f16(SBQ_WIN_ENGINE_ARGS) { return win_engine_launch_t<F16>(r, n_sel, grid, st, table, single, n_shards, args); }
+int win_group_launch_f16(SBQ_WIN_GROUP_ARGS) {
+  return win_group_launch_t<F16>(items, cnt, regions, region_bytes, out, use_abs, min_shift, round, final_round, epoch, grid, st);
+}
+#endif
+
+#if SBQ_WIN_PART == 0
 // [ multi-launch protocol: state | counter lines | histogram copies | pad ][ one-launch engine: the same three ]
 constexpr size_t kOldRegion = kStateBytes + kSlotBytes + kHistBytes + 256;
 constexpr size_t kOneRegion = kStateBytes + kSlotBytes + kHistBytes;
@@ -1939,17 +2010,8 @@ int win_one_run(const void* const* shards, const int64_t* counts, int n_shards, 
   os.rag_first[1] = pt.rag_first[1];
   auto launch = [&](const auto& table, int r) {
     using Tab = std::decay_t<decltype(table)>;
-    return dispatch_dtype(x_dtype, [&](auto tag) {
-      using T = decltype(tag);
-      if (r == 0) {
-        if (n_sel == 1) win_one_kernel<T, 1, false, kB, Tab><<<grid, kB, 0, st>>>(table, n_shards, a);
-        else if (percentile) win_one_kernel<T, 2, true, kB, Tab><<<grid, kB, 0, st>>>(table, n_shards, a);
-        else win_one_kernel<T, 2, false, kB, Tab><<<grid, kB, 0, st>>>(table, n_shards, a);
-      } else {
-        if (n_sel == 1) win_round_kernel<T, 1, kB, Tab><<<grid, kB, 0, st>>>(table, n_shards, a);
-        else win_round_kernel<T, 2, kB, Tab><<<grid, kB, 0, st>>>(table, n_shards, a);
-      }
-    });
+    auto fn = x_dtype == SBQ_F32 ? win_engine_launch_f32 : (x_dtype == SBQ_BF16 ? win_engine_launch_bf16 : win_engine_launch_f16);
+    return fn(r, n_sel, grid, st, &table, Tab::kSingle ? 1 : 0, n_shards, &a);
   };
   for (int r = 0; r < expected && rc == SBQ_OK; ++r) {
     a.final_round = r == expected - 1 ? 1 : 0;
@@ -1972,7 +2034,7 @@ int win_select_run(const void* const* shards, const int64_t* counts, int n_shard
   // knob 2 == 12: the multi-launch protocol below (plan, sweep, advance, fallback rounds), kept for A/B runs -- and
   // for the shards the one-launch engine's branch-free sample loads do not take: not 16-byte aligned, or shorter
   // than one pack
-  bool one = knob(2) != 12;
+  bool one = knob(2) != 12 && (n_sel == 1 ? n_shards == 1 : percentile);
   for (int i = 0; one && i < n_shards; ++i) one = aligned16(shards[i]) && counts[i] >= kPack;
   if (one)
     return win_one_run(shards, counts, n_shards, x_dtype, use_abs, n_sel, percentile, alpha, k0, k1, out0, out1,
@@ -2126,11 +2188,9 @@ int sbq_group_kth_value(const sbq_kth_item* items, int n_items, int x_dtype, int
     char* regions = static_cast<char*>(workspace) + static_cast<size_t>(first) * kOneRegion;
     const unsigned long long epoch = next_epoch();
     for (int r = 0; r < expected; ++r) {
-      int rc = dispatch_dtype(x_dtype, [&](auto tag) {
-        using T = decltype(tag);
-        group_kth_kernel<T, kB><<<grid, kB, 0, st>>>(args, cnt, regions, kOneRegion, values_out + first, use_abs, min_shift, r,
-                                                    r == expected - 1 ? 1 : 0, epoch);
-      });
+      auto fn = x_dtype == SBQ_F32 ? win_group_launch_f32 : (x_dtype == SBQ_BF16 ? win_group_launch_bf16 : win_group_launch_f16);
+      int rc = fn(&args, cnt, regions, kOneRegion, values_out + first, use_abs, min_shift, r, r == expected - 1 ? 1 : 0, epoch,
+                  grid, st);
       if (rc != SBQ_OK) return rc;
     }
   }
@@ -2138,3 +2198,6 @@ int sbq_group_kth_value(const sbq_kth_item* items, int n_items, int x_dtype, int
 }
 
 }  // extern "C"
+#else   // parts 1, 2: the launchers above are all there is
+}  // namespace sbq
+#endif  // SBQ_WIN_PART == 0

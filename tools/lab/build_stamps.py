@@ -1,13 +1,20 @@
 """Dev tool: build tools/lab/libsbq_stamps.so -- the library with the selection engine's timestamps compiled in
-(-DSBQ_SEL_STAMPS=1; everything else from the regular object files).  Used by tools/lab/sel_stamps.py."""
-import os, subprocess, sys
+(-DSBQ_SEL_STAMPS=1 for the three units of sbq_select_win.hip; everything else from the regular object files).
+Used by tools/lab/sel_stamps.py."""
+import concurrent.futures, os, subprocess, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 from sparsebit_amd import build as B
 B.build()
 here = os.path.dirname(os.path.abspath(__file__))
-obj = "/tmp/sel_stamps.o"
 src = os.path.join(B.CSRC, "sbq_select_win.hip")
-subprocess.check_call([B._hipcc()] + B.FLAGS + ["-DSBQ_SEL_STAMPS=1"] + sys.argv[1:] + ["-c", src, "-o", obj])
-objs = [os.path.join(B.OBJ, f[:-4] + ".o") for f in B.sources() if f != "sbq_select_win.hip"] + [obj]
-subprocess.check_call([B._hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", os.path.join(here, "libsbq_stamps.so")] + objs)
+units = [("", [])] + B.EXTRA_UNITS["sbq_select_win.hip"]
+def compile_unit(u):
+    suffix, flags = u
+    obj = "/tmp/sel_stamps%s.o" % suffix
+    subprocess.check_call([B._hipcc()] + B.FLAGS + ["-DSBQ_SEL_STAMPS=1"] + flags + sys.argv[1:] + ["-c", src, "-o", obj])
+    return obj
+with concurrent.futures.ThreadPoolExecutor(max_workers=3) as ex:
+    stamp_objs = list(ex.map(compile_unit, units))
+regular = [os.path.join(B.OBJ, f[:-4] + ".o") for f in B.sources() if f != "sbq_select_win.hip"]
+subprocess.check_call([B._hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", os.path.join(here, "libsbq_stamps.so")] + regular + stamp_objs)
 print("built", os.path.join(here, "libsbq_stamps.so"))

@@ -44,6 +44,41 @@ def make_weight(seed):
     return w.bfloat16()
 
 
+def sample_clocks(index):
+    """current engine / memory clock of GPU `index` from the amdgpu sysfs tables (the entry marked '*'); best effort"""
+    import glob
+
+    out = {}
+    cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device/pp_dpm_sclk"))
+    if index < len(cards):
+        base = os.path.dirname(cards[index])
+        for key, name in (("sclk_mhz", "pp_dpm_sclk"), ("mclk_mhz", "pp_dpm_mclk")):
+            try:
+                with open(os.path.join(base, name)) as f:
+                    for ln in f:
+                        if ln.strip().endswith("*"):
+                            out[key] = int("".join(ch for ch in ln.split(":")[1] if ch.isdigit()))
+            except (OSError, ValueError, IndexError):
+                pass
+    return out
+
+
+def self_launch(n):
+    """Re-run this command line under `python -m torch.distributed.run --nnodes=1 --nproc-per-node n` on a free
+    local port; returns the launcher's exit code (rank 0 prints the JSON line to the inherited stdout)."""
+    import socket
+    import subprocess
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs on this stack
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -54,10 +89,15 @@ def main():
                     help="headline + multi-GPU plumbing only: no config legs, no CPU baseline (tests/test_gpu_bench_n2.py)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` started like the N = 1 command: become the launcher the contract describes
+        # (one process per GPU under torch.distributed.run, rendezvous on 127.0.0.1) and hand its exit code back
+        sys.exit(self_launch(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    assert world == args.gpus, "WORLD_SIZE=%d but --gpus %d: launch with torch.distributed.run --nproc-per-node %d" % (
+        world, args.gpus, args.gpus)
     assert torch.cuda.is_available(), "bench.py measures the HIP path: it needs an MI355X"
     # SBQ_BENCH_DEBUG_SINGLE_GPU=1: rehearse the N > 1 control flow on a one-GPU box (every rank on
     # cuda:0, gloo instead of RCCL).  Never set by the driver; numbers from such a run mean nothing.
@@ -170,20 +210,31 @@ def main():
     windows = []  # us per launch of every 1024-launch window
     w0 = torch.cuda.Event(enable_timing=True)
     w1 = torch.cuda.Event(enable_timing=True)
-    while True:
+
+    def window(during=None):
+        """1024 launches between two events -> us per launch; `during` runs on the host while they execute"""
+        nonlocal i
         w0.record(stream)
         for _ in range(1024):
             step(i)
             i += 1
         w1.record(stream)
+        if during is not None:
+            during()
         torch.cuda.synchronize(dev)
-        cur = w0.elapsed_time(w1)
-        stable = stable + 1 if prev is not None and abs(cur - prev) <= 0.01 * cur else 0
+        return w0.elapsed_time(w1) * 1e3 / 1024
+
+    # the same criterion on every box: three consecutive windows within 0.5 % of each other (at least 0.25 s, at
+    # most 3 s of launches)
+    while True:
+        cur = window()
+        stable = stable + 1 if prev is not None and abs(cur - prev) <= 0.005 * cur else 0
         prev = cur
-        windows.append(cur * 1e3 / 1024)
+        windows.append(cur)
         spent = time.perf_counter() - t_pre
-        if (spent >= 0.25 and stable >= 2) or spent >= 3.0:
+        if (spent >= 0.25 and stable >= 3) or spent >= 3.0:
             break
+    prewarm_s = time.perf_counter() - t_pre
     for i in range(args.warmup):
         step(i)
     sync_all()  # barrier + synchronize; the GPU idles only for this instant before the timed region
@@ -194,13 +245,21 @@ def main():
     e1.record(stream)
     sync_all()
     t1 = time.perf_counter()
-    gc.enable()
     wall = t1 - t0
-    kern_us = e0.elapsed_time(e1) * 1e3 / args.steps  # avg launch-to-launch duration on the GPU
+    kern_us_timed = e0.elapsed_time(e1) * 1e3 / args.steps  # avg launch-to-launch duration of the K timed launches
+    # The kernel's duration for the roofline: NOT the K timed launches alone (K = 20 is a 0.25 ms sample) but windows
+    # of 1024 launches on both sides of the timed region -- the last four of the pre-warm-up and eight right after it --
+    # median, with min and max beside it.  The engine / memory clocks are sampled while the first of them runs.
+    clocks = {}
+    post = [window(during=lambda: clocks.update(sample_clocks(dev_index)))]
+    post += [window() for _ in range(7)]
+    gc.enable()
+    around = sorted(windows[-4:] + post)
+    kern_us = 0.5 * (around[(len(around) - 1) // 2] + around[len(around) // 2])  # median
     if world > 1:
-        t = torch.tensor([wall, kern_us], dtype=torch.float64, device=dev)
+        t = torch.tensor([wall, kern_us_timed, kern_us], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        wall, kern_us = t.tolist()
+        wall, kern_us_timed, kern_us = t.tolist()
 
     n_elem = ROWS * COLS
     value = world * args.steps * n_elem / wall
@@ -535,13 +594,21 @@ def main():
                 "traffic_source": traffic_source,
                 "kernel": kernel_name,
                 "kernel_avg_us": round(kern_us, 3),
-                "kernel_avg_us_what": "HIP events around the K timed launches on the launch stream",
-                # the same launches in windows of 1024 during the adaptive pre-warm-up (a 13 ms sample each instead of
-                # K x 12 us): last window, and the best one
-                "kernel_avg_us_1024_window_last": round(windows[-1], 3),
-                "kernel_avg_us_1024_window_min": round(min(windows), 3),
-                "frac_1024_window_last": round(n_elem * BYTES_PER_ELEM / windows[-1] / 1e3 / HBM_PEAK_GBS, 4),
-                "windows_measured": len(windows),
+                "kernel_avg_us_what": "median of %d windows of 1024 launches each (HIP events on the launch stream) around the "
+                                      "timed region: the last 4 of the pre-warm-up and 8 right after it" % len(around),
+                "kernel_avg_us_windows_min": round(around[0], 3),
+                "kernel_avg_us_windows_max": round(around[-1], 3),
+                "frac_1024_window_median": round(achieved / HBM_PEAK_GBS, 4),
+                "frac_windows_min": round(n_elem * BYTES_PER_ELEM / around[-1] / 1e3 / HBM_PEAK_GBS, 4),
+                "frac_windows_max": round(n_elem * BYTES_PER_ELEM / around[0] / 1e3 / HBM_PEAK_GBS, 4),
+                # the K timed launches alone (events around the timed region), and the wall clock of the timed region
+                # (launch / synchronisation latency shared by the K steps included)
+                "kernel_avg_us_timed_region": round(kern_us_timed, 3),
+                "frac_timed_region": round(n_elem * BYTES_PER_ELEM / kern_us_timed / 1e3 / HBM_PEAK_GBS, 4),
+                "frac_wall": round(n_elem * BYTES_PER_ELEM / (wall * 1e6 / args.steps) / 1e3 / HBM_PEAK_GBS, 4),
+                "windows_measured": len(windows) + len(post),
+                "prewarm_s": round(prewarm_s, 3),
+                "clocks_during_windows": clocks or None,
                 "algorithmic_bytes_per_launch": n_elem * BYTES_PER_ELEM,
             },
             "cpu_baseline": cpu_baseline,

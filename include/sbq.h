@@ -363,6 +363,13 @@ int sbq_mse_select(const double* sse, double count_per_channel,
                    int qmin, int qmax, int symmetric,
                    float* scale_out, float* zero_point_out, int32_t* best_index_out,
                    void* stream);
+/* The same with the count read from DEVICE memory (one double): sharded calibration carries each rank's element
+ * count in the buffer of the table's SUM all-reduce, so no host round trip separates the collective from the pick. */
+int sbq_mse_select_devcount(const double* sse, const double* count_per_channel_dev,
+                            const float* min_val, const float* max_val, int64_t C,
+                            int qmin, int qmax, int symmetric,
+                            float* scale_out, float* zero_point_out, int32_t* best_index_out,
+                            void* stream);
 
 /* ------------------------------------------------------------------ *
  * 4. Order statistics (percentile observer, unstructured-mask threshold)
@@ -490,10 +497,15 @@ int sbq_mask_from_threshold(const void* x, int x_dtype, int64_t numel,
  * or one quantization group of it) the first of n_candidates shrink factors p = 1 - i / grid with the strictly
  * smallest sum |quantize(x; p * xmin, p * xmax) - x|^norm.  xmin / xmax: the row's adjusted extrema (quant.py:71-84);
  * scale_io / zero_io hold the un-shrunk parameters on entry and the chosen ones on return; index_out (or NULL) the
- * chosen i (-1: none was finite).  symmetric: zero stays (maxq + 1) / 2. */
+ * chosen i (-1: none was finite).  symmetric: zero stays (maxq + 1) / 2.
+ * Rows longer than 16 Ki elements (perchannel=False flattens the whole weight into one) are cut into slices across
+ * workgroups with fp64 partial sums per candidate in `workspace` (sbq_gptq_mse_search_workspace_bytes; 0 = none
+ * needed, NULL is then fine), folded in slice order; n_candidates <= 128 there. */
+size_t sbq_gptq_mse_search_workspace_bytes(int64_t rows, int64_t inner, int n_candidates);
 int sbq_gptq_mse_search(const void* x, int x_dtype, int64_t rows, int64_t inner, const float* xmin, const float* xmax,
                         int maxq, int symmetric, float norm, int grid, int n_candidates,
-                        float* scale_io, float* zero_io, int32_t* index_out, void* stream);
+                        float* scale_io, float* zero_io, int32_t* index_out,
+                        void* workspace, size_t workspace_bytes, void* stream);
 
 /* Workspace contract: its first SBQ_GPTQ_COUNTER_BYTES bytes are arrival counters of the
  * single-launch K-split fold; they must be ZERO before the first call (allocate with
@@ -523,12 +535,48 @@ int sbq_vecquant2matmul(const float* x, const int32_t* qweight, float* out,
  * are HOST arrays of n_mats (<= 4) entries; matrix m is [rows(in_features), out_features[m]] with its own scales /
  * zeros / pre-filled out.  Results are those of n_mats single calls up to the fp32 summation order across K blocks
  * (the K split is chosen for the whole launch; equal splits give bit-identical results) -- and single calls are what
- * runs for anything the strip kernel does not take.  Workspace: sbq_gptq_workspace_bytes(batch, in_features, sum of out_features), same
- * zero-counter contract. */
+ * runs for anything the strip kernel does not take.  Workspace: sbq_vecquantmatmul_multi_workspace_bytes (the larger
+ * of the joint launch's need and any single matrix's), same zero-counter contract. */
+size_t sbq_vecquantmatmul_multi_workspace_bytes(int64_t batch, int64_t in_features, int n_mats, const int64_t* out_features);
 int sbq_vecquantmatmul_multi(int bits, const float* x, int n_mats, const int32_t* const* qweights, float* const* outs,
                              const float* const* scales, const float* const* zeros, const int64_t* out_features,
                              int64_t batch, int64_t in_features, int64_t group_size,
                              void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------ *
+ * 4b. The same order statistics over data that is spread over RANKS (one process per GPU)
+ *
+ *  observers/percentile.py:27-43 / sparse/sparsers/l1norm.py:21-24 on the UNION of the ranks' calibration batches,
+ *  exact, with ONE read of a 16-bit tensor and two small SUM all-reduces (the library never communicates: the
+ *  caller all-reduces the two int64 records, e.g. with RCCL through torch.distributed -- sparsebit_amd/select.py):
+ *
+ *    sbq_dist_select_sample   this rank's sample histogram + element count  -> int64[SBQ_DIST_SAMPLE_WORDS]
+ *    -- SUM all-reduce --
+ *    sbq_dist_select_plan     windows from the reduced sample (identical on every rank); clears the workspace
+ *    per round (one for 16-bit data, two for fp32; more only when a window missed its rank):
+ *      sbq_dist_select_sweep    counts of this rank's shards             -> int64[SBQ_DIST_ROUND_WORDS]
+ *      -- SUM all-reduce --
+ *      sbq_dist_select_advance  places the ranks on the reduced record; done_out[s] = 1 once selector s is resolved
+ *                               (its value is then in out0 / out1).  Rounds after the last needed one are harmless.
+ *
+ *  percentile != 0: two selectors, ranks from alpha and the union's sign counts (count_signs = 1 in the FIRST sweep),
+ *  out0[0] = min side, out1[0] = max side.  percentile == 0: explicit global ranks k0 (k1), 1-based, out0[s].
+ *  Shards: flat tensors of counts[i] elements, any alignment, counts[i] == 0 allowed (a rank without data takes
+ *  part with zero records).  Workspace: sbq_dist_select_workspace_bytes(), owned by ONE selection from its plan to
+ *  its last advance; no zero contract (the plan clears it).
+ * ------------------------------------------------------------------ */
+#define SBQ_DIST_SAMPLE_WORDS 8193
+#define SBQ_DIST_ROUND_WORDS 4100
+size_t sbq_dist_select_workspace_bytes(void);
+int sbq_dist_select_sample(const void* const* shards, const int64_t* counts, int n_shards, int x_dtype, int use_abs,
+                           int64_t* sample_out, void* stream);
+int sbq_dist_select_plan(const int64_t* sample, int x_dtype, int n_sel, int percentile, double alpha, int64_t k0, int64_t k1,
+                         void* workspace, size_t workspace_bytes, void* stream);
+int sbq_dist_select_sweep(const void* const* shards, const int64_t* counts, int n_shards, int x_dtype, int use_abs, int n_sel,
+                          int count_signs, void* workspace, size_t workspace_bytes, int64_t* round_out, void* stream);
+int sbq_dist_select_advance(const int64_t* round_record, int x_dtype, int n_sel, int percentile, double alpha,
+                            void* workspace, size_t workspace_bytes, float* out0, float* out1, int32_t* done_out,
+                            void* stream);
 
 /* ------------------------------------------------------------------ *
  * 6. Launch tuning (benchmarks only; defaults are chosen per shape)

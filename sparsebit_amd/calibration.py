@@ -141,17 +141,7 @@ class DeviceCalibrator:
     def _finish(self, out, sharded):
         if sharded:
             with sbq_dist.sharded_calibration():
-                # every streaming min-max observer of the model in ONE collective
-                obs = [
-                    m.input_quantizer.observer
-                    for _, m in self.oprs
-                    if _live(getattr(m, "input_quantizer", None))
-                    and getattr(m.input_quantizer.observer, "pending", lambda: None)() is not None
-                ]
-                if obs:
-                    for o, (lo, hi) in zip(obs, sbq_dist.allreduce_minmax_many([o.pending() for o in obs])):
-                        o.resolve(lo, hi)
-                self._finish_inputs(out)
+                self._finish_inputs_lockstep(out)
         else:
             self._finish_inputs(out)
         # Weights are replicated on every rank: observed and finished OUTSIDE the sharded context.  Inside it
@@ -219,6 +209,34 @@ class DeviceCalibrator:
             iq = getattr(m, "input_quantizer", None)
             if _live(iq):
                 out[name + ".input_quantizer"] = iq.calc_qparams()
+
+    def _finish_inputs_lockstep(self, out):
+        """Sharded: the input quantizers whose calc_qparams is the plain observer call advance their observers'
+        exchange protocols TOGETHER (dist.run_lockstep): every step of every min-max / MSE / percentile observer of
+        the model travels in one flat collective per kind -- per model: 1 MAX (min-max and the MSE observers' first
+        step), 1 fp64 SUM (all MSE tables + counts), 1 + rounds int64 SUMs (all percentile samples / window counts;
+        rounds = 1 for 16-bit activations, 2 for fp32) and one device-to-host look at the percentile selections'
+        done flags -- instead of the reference-shaped loop over quantizers (tools/calibration.py:102-115) costing
+        that many exchanges PER quantizer.  Quantizers that own their calibration (LSQ, LSQ+, PACT, DoReFa) and
+        observers without a sharded protocol keep their own calls, after the lock-step ones, in module order."""
+        from .registry import impl_type
+
+        gens, owners, rest = [], [], []
+        for name, m in self.oprs:
+            iq = getattr(m, "input_quantizer", None)
+            if not _live(iq):
+                continue
+            cls = impl_type(iq)
+            plain = cls.calc_qparams is BaseQuantizer.calc_qparams and cls.update_observer is BaseQuantizer.update_observer
+            if plain and getattr(iq.observer, "sharded_minmax_steps", None) is not None:
+                gens.append(iq.observer.sharded_qparams_steps())
+                owners.append((name, iq))
+            else:
+                rest.append((name, iq))
+        for (name, iq), (scale, zero_point) in zip(owners, sbq_dist.run_lockstep(gens)):
+            out[name + ".input_quantizer"] = iq._adopt(scale, zero_point)
+        for name, iq in rest:
+            out[name + ".input_quantizer"] = iq.calc_qparams()
 
     # ---- one call -------------------------------------------------------------------------------
     @torch.no_grad()

@@ -386,14 +386,111 @@ __global__ __launch_bounds__(kBlock) void gptq_mse_kernel(const void* __restrict
   }
 }
 
+// Long rows (find_params(perchannel=False) flattens the whole weight into ONE row: 16.7 M elements for a 4096 x 4096
+// layer -- a single wave would walk it 80 times).  A row is cut into slices of kGptqSlice elements, one workgroup per
+// slice: the slice sits in registers (16 elements per thread), every candidate's error over it is reduced to ONE fp64
+// partial (fp32 lane sums over 16 elements, fp64 across lanes / waves), and a second kernel adds a row's partials in
+// ascending slice order in fp64 and picks the first strictly smallest error: deterministic, and closer to the exact
+// sums than torch's fp32 reduction (ties to the last bits may still swap, as in the wave-per-row kernel).
+constexpr int kGptqSlice = kBlock * 16;
+constexpr int64_t kGptqSplitFrom = 4 * kGptqSlice;  // rows longer than this take the split path
+constexpr int kGptqMaxCand = 128;
+template <typename T>
+__global__ __launch_bounds__(kBlock) void gptq_mse_slice_kernel(const void* __restrict__ x, int64_t inner, uint32_t slices,
+                                                                const float* __restrict__ xmin_v, const float* __restrict__ xmax_v,
+                                                                float maxq, int symmetric, float zero_sym, float norm, int grid,
+                                                                int n_cand, double* __restrict__ part) {
+  __shared__ double s_wave[kWavesPerBlock];
+  const int64_t row = blockIdx.x / slices;
+  const uint32_t sl = blockIdx.x % slices;
+  const float xmin = xmin_v[row], xmax = xmax_v[row];
+  const int64_t begin = static_cast<int64_t>(sl) * kGptqSlice;
+  float v[16];
+  bool ok[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int64_t e = begin + j * kBlock + threadIdx.x;
+    ok[j] = e < inner;
+    v[j] = ok[j] ? Elem<T>::load1(x, row * inner + e) : 0.0f;
+  }
+  const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
+  double* out = part + (static_cast<size_t>(row) * slices + sl) * n_cand;
+  for (int i = 0; i < n_cand; ++i) {
+    const float p = static_cast<float>(1.0 - static_cast<double>(i) / static_cast<double>(grid));
+    const float xmin1 = p * xmin, xmax1 = p * xmax;
+    const float scale1 = (xmax1 - xmin1) / maxq;
+    const float zero1 = symmetric ? zero_sym : __builtin_rintf(-xmin1 / scale1);
+    float err = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      float q = __builtin_rintf(v[j] / scale1) + zero1;
+      const float qc = __builtin_fminf(__builtin_fmaxf(q, 0.0f), maxq);
+      q = (q != q) ? q : qc;
+      const float d = __builtin_fabsf(scale1 * (q - zero1) - v[j]);
+      err += ok[j] ? __builtin_powf(d, norm) : 0.0f;
+    }
+    double e64 = static_cast<double>(err);
+#pragma unroll
+    for (int d = kWave / 2; d > 0; d >>= 1) e64 += __shfl_xor(e64, d, kWave);
+    if (lane == 0) s_wave[wid] = e64;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double t = 0.0;
+      for (int w = 0; w < kWavesPerBlock; ++w) t += s_wave[w];
+      out[i] = t;
+    }
+    __syncthreads();
+  }
+}
+__global__ __launch_bounds__(kGptqMaxCand) void gptq_mse_pick_kernel(const double* __restrict__ part, uint32_t slices,
+                                                                     const float* __restrict__ xmin_v, const float* __restrict__ xmax_v,
+                                                                     float maxq, int symmetric, float zero_sym, int grid, int n_cand,
+                                                                     float* __restrict__ scale_io, float* __restrict__ zero_io,
+                                                                     int32_t* __restrict__ index_out) {
+  __shared__ float s_err[kGptqMaxCand];
+  const int64_t row = blockIdx.x;
+  const int i = threadIdx.x;
+  if (i < n_cand) {
+    const double* p = part + static_cast<size_t>(row) * slices * n_cand + i;
+    double t = 0.0;
+    for (uint32_t j = 0; j < slices; ++j) t += p[static_cast<size_t>(j) * n_cand];
+    s_err[i] = static_cast<float>(t);
+  }
+  __syncthreads();
+  if (i != 0) return;
+  float best = __builtin_inff();
+  int best_i = -1;
+  for (int c = 0; c < n_cand; ++c) {
+    if (s_err[c] < best) {
+      best = s_err[c];
+      best_i = c;
+    }
+  }
+  if (best_i >= 0) {
+    const float p = static_cast<float>(1.0 - static_cast<double>(best_i) / static_cast<double>(grid));
+    const float xmin1 = p * xmin_v[row], xmax1 = p * xmax_v[row];
+    const float scale1 = (xmax1 - xmin1) / maxq;
+    scale_io[row] = scale1;
+    zero_io[row] = symmetric ? zero_sym : __builtin_rintf(-xmin1 / scale1);
+  }
+  if (index_out) index_out[row] = best_i;
+}
+
 }  // namespace
 }  // namespace sbq
 
 extern "C" {
 
+size_t sbq_gptq_mse_search_workspace_bytes(int64_t rows, int64_t inner, int n_candidates) {
+  using namespace sbq;
+  if (rows <= 0 || inner <= kGptqSplitFrom || n_candidates <= 0) return 0;  // the wave-per-row kernel needs none
+  const int64_t slices = ceil_div(inner, static_cast<int64_t>(kGptqSlice));
+  return static_cast<size_t>(rows) * slices * n_candidates * sizeof(double);
+}
+
 int sbq_gptq_mse_search(const void* x, int x_dtype, int64_t rows, int64_t inner, const float* xmin, const float* xmax,
                         int maxq, int symmetric, float norm, int grid, int n_candidates, float* scale_io,
-                        float* zero_io, int32_t* index_out, void* stream) {
+                        float* zero_io, int32_t* index_out, void* workspace, size_t workspace_bytes, void* stream) {
   using namespace sbq;
   if (!valid_dtype(x_dtype)) return SBQ_ERR_DTYPE;
   if (rows < 0 || inner < 0) return SBQ_ERR_ARG;
@@ -402,6 +499,28 @@ int sbq_gptq_mse_search(const void* x, int x_dtype, int64_t rows, int64_t inner,
   if (maxq < 1 || grid < 1 || n_candidates < 0 || rows >= (1ll << 33)) return SBQ_ERR_ARG;
   if (reinterpret_cast<uintptr_t>(x) % dtype_size(x_dtype)) return SBQ_ERR_ALIGN;
   hipStream_t st = as_stream(stream);
+  const float zero_sym_ = static_cast<float>((maxq + 1) / 2.0);
+  if (inner > kGptqSplitFrom && n_candidates > 0) {
+    // long rows: slices across workgroups, fp64 partials, fixed-order fold (see gptq_mse_slice_kernel)
+    if (n_candidates > kGptqMaxCand) return SBQ_ERR_ARG;
+    const size_t need = sbq_gptq_mse_search_workspace_bytes(rows, inner, n_candidates);
+    if (!workspace) return SBQ_ERR_NULL;
+    if (workspace_bytes < need || reinterpret_cast<uintptr_t>(workspace) % 8) return SBQ_ERR_WORKSPACE;
+    const int64_t slices = ceil_div(inner, static_cast<int64_t>(kGptqSlice));
+    if (rows * slices >= (1ll << 31)) return SBQ_ERR_ARG;
+    double* part = static_cast<double*>(workspace);
+    int rc2 = dispatch_dtype(x_dtype, [&](auto tag) {
+      using T = decltype(tag);
+      gptq_mse_slice_kernel<T><<<static_cast<uint32_t>(rows * slices), kBlock, 0, st>>>(
+          x, inner, static_cast<uint32_t>(slices), xmin, xmax, static_cast<float>(maxq), symmetric, zero_sym_, norm, grid,
+          n_candidates, part);
+    });
+    if (rc2 != SBQ_OK) return rc2;
+    gptq_mse_pick_kernel<<<static_cast<uint32_t>(rows), kGptqMaxCand, 0, st>>>(part, static_cast<uint32_t>(slices), xmin, xmax,
+                                                                             static_cast<float>(maxq), symmetric, zero_sym_,
+                                                                             grid, n_candidates, scale_io, zero_io, index_out);
+    return check_launch();
+  }
   const uint32_t gridx = static_cast<uint32_t>(ceil_div(rows, static_cast<int64_t>(kWavesPerBlock)));
   const float zero_sym = static_cast<float>((maxq + 1) / 2.0);
   int rc = dispatch_dtype(x_dtype, [&](auto tag) {

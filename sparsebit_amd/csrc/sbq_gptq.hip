@@ -1243,6 +1243,23 @@ size_t sbq_gptq_workspace_bytes(int64_t batch, int64_t in_features, int64_t out_
   return kCounterBytes + static_cast<size_t>(tiles) * batch * out_features * sizeof(float);
 }
 
+// What sbq_vecquantmatmul_multi may need: the joint launch sizes its K-split partials by the summed width; the
+// per-matrix route (a width that is not a multiple of 32, one matrix, no groups) by each matrix's own width with a
+// floor on the block count -- a narrow matrix of a very deep layer can need more than the sum suggests.
+size_t sbq_vecquantmatmul_multi_workspace_bytes(int64_t batch, int64_t in_features, int n_mats, const int64_t* out_features) {
+  if (n_mats <= 0 || !out_features) return 0;
+  int64_t total = 0;
+  size_t need = 0;
+  for (int m = 0; m < n_mats; ++m) {
+    if (out_features[m] <= 0) return 0;
+    total += out_features[m];
+    const size_t one = sbq_gptq_workspace_bytes(batch, in_features, out_features[m]);
+    need = one > need ? one : need;
+  }
+  const size_t all = sbq_gptq_workspace_bytes(batch, in_features, total);
+  return all > need ? all : need;
+}
+
 int sbq_vecquant4matmul(const float* x, const int32_t* qweight, float* out, const float* scales,
                         const float* zeros, int64_t batch, int64_t in_features, int64_t out_features,
                         int64_t group_size, void* workspace, size_t workspace_bytes, void* stream) {

@@ -528,12 +528,13 @@ size_t mse_workspace_doubles(const ChunkGeom& g) {
 }
 
 // mse.py:51-61: keep the first candidate whose fp32 loss is strictly smaller.
-__global__ void mse_select_kernel(const double* __restrict__ sse, double count,
+__global__ void mse_select_kernel(const double* __restrict__ sse, double count, const double* __restrict__ count_dev,
                                   const float* __restrict__ min_val, const float* __restrict__ max_val,
                                   int64_t C, float qrange, int symmetric, float* __restrict__ scale,
                                   float* __restrict__ zp, int32_t* __restrict__ best_index) {
   const int64_t c = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
   if (c >= C) return;
+  if (count_dev) count = count_dev[0];  // sharded calibration: the count travelled in the all-reduced table's buffer
   float loss_min = 1e10f;
   int best = -1;
   for (int i = 0; i < SBQ_MSE_CANDIDATES; ++i) {
@@ -785,7 +786,22 @@ int sbq_mse_select(const double* sse, double count_per_channel, const float* min
   if (qmin >= qmax) return SBQ_ERR_ARG;
   const float qrange = static_cast<float>(qmax - qmin);
   mse_select_kernel<<<static_cast<uint32_t>(ceil_div(C, kWave)), kWave, 0, as_stream(stream)>>>(
-      sse, count_per_channel, min_val, max_val, C, qrange, symmetric, scale_out, zero_point_out,
+      sse, count_per_channel, nullptr, min_val, max_val, C, qrange, symmetric, scale_out, zero_point_out,
+      best_index_out);
+  return check_launch();
+}
+
+int sbq_mse_select_devcount(const double* sse, const double* count_per_channel_dev, const float* min_val,
+                            const float* max_val, int64_t C, int qmin, int qmax, int symmetric,
+                            float* scale_out, float* zero_point_out, int32_t* best_index_out, void* stream) {
+  using namespace sbq;
+  if (C < 0) return SBQ_ERR_ARG;
+  if (C == 0) return SBQ_ERR_EMPTY;
+  if (!sse || !count_per_channel_dev || !min_val || !max_val || !scale_out || !zero_point_out) return SBQ_ERR_NULL;
+  if (qmin >= qmax) return SBQ_ERR_ARG;
+  const float qrange = static_cast<float>(qmax - qmin);
+  mse_select_kernel<<<static_cast<uint32_t>(ceil_div(C, kWave)), kWave, 0, as_stream(stream)>>>(
+      sse, 1.0, count_per_channel_dev, min_val, max_val, C, qrange, symmetric, scale_out, zero_point_out,
       best_index_out);
   return check_launch();
 }

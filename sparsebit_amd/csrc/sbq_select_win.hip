@@ -252,12 +252,10 @@ __device__ __forceinline__ void plan_sample_load(const Tab& tab, int n_shards, i
 // `L.hist` must be zero (and that visible: a barrier behind the clearing) on entry.  Thread 0 writes the n_sel
 // windows to out[] (LDS or global); the caller orders that against its readers.
 struct NoStamp { __device__ __forceinline__ void operator()(int) const {} };
-template <typename T, int kT, bool KEY16 = false, typename Stamp = NoStamp>
-__device__ __forceinline__ void plan_compute(PlanLds& L, const PlanSample<T, kT>& sm, int64_t n_packs, int mode,
-                                             int n_sel, int use_abs, int64_t k0, int64_t k1, int64_t n, double alpha,
-                                             uint32_t min_shift, WinSel* out, Stamp stamp = Stamp()) {
-  constexpr int kMine = PlanSample<T, kT>::kMine;
-  constexpr int kPer = kPlanBins / kT;  // bins per thread
+// (two halves: plan_fill histograms the sample, plan_derive turns a histogram into windows.  The multi-process
+// protocol runs them as separate launches with a SUM all-reduce of the histogram in between, so that every rank
+// derives the same windows from the union of the ranks' samples.)
+__device__ __forceinline__ void plan_init(PlanLds& L) {
   if (threadIdx.x == 0) {
     L.first = kPlanBins - 1;
     L.last = 0;
@@ -266,6 +264,16 @@ __device__ __forceinline__ void plan_compute(PlanLds& L, const PlanSample<T, kT>
     L.b_lo[threadIdx.x] = 0;
     L.b_hi[threadIdx.x] = kPlanBins - 1;
   }
+}
+template <typename T, int kT, bool KEY16, typename Stamp>
+__device__ __forceinline__ void plan_derive(PlanLds& L, int mode, int n_sel, int64_t k0, int64_t k1, int64_t n, double alpha,
+                                            uint32_t min_shift, WinSel* out, Stamp stamp);
+template <typename T, int kT, bool KEY16 = false, typename Stamp = NoStamp>
+__device__ __forceinline__ void plan_compute(PlanLds& L, const PlanSample<T, kT>& sm, int64_t n_packs, int mode,
+                                             int n_sel, int use_abs, int64_t k0, int64_t k1, int64_t n, double alpha,
+                                             uint32_t min_shift, WinSel* out, Stamp stamp = Stamp()) {
+  constexpr int kMine = PlanSample<T, kT>::kMine;
+  plan_init(L);
   if constexpr (SBQ_SEL_STAMPS != 0) {  // development build: when has the sample arrived?
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     stamp(14);
@@ -291,6 +299,13 @@ __device__ __forceinline__ void plan_compute(PlanLds& L, const PlanSample<T, kT>
   }
   lds_sync();
   stamp(8);
+  plan_derive<T, kT, KEY16>(L, mode, n_sel, k0, k1, n, alpha, min_shift, out, stamp);
+}
+// `L.hist` holds the sample's histogram (complete and visible), plan_init has run.
+template <typename T, int kT, bool KEY16, typename Stamp>
+__device__ __forceinline__ void plan_derive(PlanLds& L, int mode, int n_sel, int64_t k0, int64_t k1, int64_t n, double alpha,
+                                            uint32_t min_shift, WinSel* out, Stamp stamp) {
+  constexpr int kPer = kPlanBins / kT;  // bins per thread
   uint32_t bins[kPer];
   uint32_t t = 0;
 #pragma unroll
@@ -717,6 +732,160 @@ __global__ __launch_bounds__(kAdvBlock) void win_advance_kernel(uint32_t* __rest
   __shared__ AdvShared sh;
   win_advance<kAdvBlock, false>(blockIdx.x, hist, st, slots, percentile, alpha, min_shift, out0, out1, sh);
 }
+
+#if SBQ_WIN_PART == 0
+// ---- the same selection over data that is spread over RANKS (one process per GPU) --------------------------------
+// observers/percentile.py:27-43 and sparse/sparsers/l1norm.py:21-24 ask for order statistics of the UNION of the
+// calibration batches; sharded calibration leaves each rank with its own batches.  The fixed-digit protocol
+// (sbq_select.hip + select.py) reads every batch three times and all-reduces three histograms.  Here the windows come
+// from the union of the ranks' SAMPLES:
+//   sample   (per rank)  win_dist_sample_kernel: the 8192-bin sample histogram of this rank's shards + its element count
+//   SUM all-reduce #1    65 KB
+//   plan     (per rank)  win_dist_plan_kernel: plan_derive on the reduced histogram -- identical input, integer
+//                        arithmetic, hence identical windows on every rank
+//   sweep    (per rank)  win_pass_kernel over this rank's shards; win_dist_export_kernel folds the histogram copies
+//                        and counter lines into one flat int64 record (and leaves them zero)
+//   SUM all-reduce #2    33 KB: window histograms + below / sign / NaN counts
+//   advance  (per rank)  win_dist_advance_kernel: advance_core on the reduced record -- a 16-bit input is resolved,
+//                        fp32 takes one more (sweep, SUM, advance) round; a window that missed its rank, too.
+// One read of a 16-bit tensor and two collectives instead of three and three; exact for any data, because the
+// advance only ever trusts counts.  A rank whose shards are empty contributes zeros.
+constexpr int kDistSampleWords = kPlanBins + 1;                     // sample histogram, this rank's element count
+constexpr int kDistRoundWords = kWinSel * kWinBins + kWinSel + 2;   // window histograms, below[2], neg, nan
+static_assert(kDistSampleWords == SBQ_DIST_SAMPLE_WORDS && kDistRoundWords == SBQ_DIST_ROUND_WORDS, "include/sbq.h");
+
+template <typename T>
+__global__ __launch_bounds__(1024) void win_dist_sample_kernel(const ShardTable tab, int n_shards, int64_t n, int use_abs,
+                                                               int64_t* __restrict__ out) {
+  constexpr int kT = 1024;
+  __shared__ PlanLds L;
+  for (int i = threadIdx.x; i < kPlanBins; i += kT) L.hist[i] = 0;
+  __syncthreads();
+  if (n > 0) {  // (uniform)
+    const int64_t n_packs = n / kPack < kPlanPacks ? (n / kPack > 0 ? n / kPack : 1) : kPlanPacks;
+    PlanSample<T, kT> sm;
+    plan_sample_load<T, kT, true, true>(tab, n_shards, n, n_packs, sm);
+    constexpr int kMine = PlanSample<T, kT>::kMine;
+#pragma unroll
+    for (int m = 0; m < kMine; ++m) {
+      if (static_cast<int64_t>(threadIdx.x) + m * kT >= n_packs) continue;
+      float v[kPack];
+      unpack_raw<T>(sm.raw[m], v);
+#pragma unroll
+      for (int j = 0; j < kPack; ++j)
+        atomicAdd(&L.hist[win_key(__builtin_bit_cast(uint32_t, v[j]), use_abs != 0) >> kPlanShift], 1u);
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < kPlanBins; i += kT) out[i] = static_cast<int64_t>(L.hist[i]);
+  if (threadIdx.x == 0) out[kPlanBins] = n;
+}
+
+// the reduced sample -> the selectors' first windows (and a clean workspace: counter lines + histogram copies)
+__global__ __launch_bounds__(1024) void win_dist_plan_kernel(const int64_t* __restrict__ sample, WinState* __restrict__ st,
+                                                             int mode, int n_sel, int64_t k0, int64_t k1, double alpha,
+                                                             uint32_t min_shift, u32x4* __restrict__ scratch,
+                                                             uint32_t scratch_vecs) {
+  constexpr int kT = 1024;
+  __shared__ PlanLds L;
+  for (int i = threadIdx.x; i < kPlanBins; i += kT) {
+    const int64_t c = sample[i];
+    L.hist[i] = c > 0xffffffffll ? 0xffffffffu : static_cast<uint32_t>(c);  // (<= 16 Ki samples per rank)
+  }
+  const int64_t n = sample[kPlanBins];
+  for (uint32_t i = threadIdx.x; i < scratch_vecs; i += kT) scratch[i] = u32x4{0, 0, 0, 0};
+  plan_init(L);
+  __syncthreads();
+  plan_derive<F32, kT, false>(L, mode, n_sel, k0, k1, n, alpha, min_shift, st->sel, NoStamp());
+  if (threadIdx.x == 0) {
+    st->n = n;
+    st->arrivals = 0;
+  }
+}
+
+// after a sweep: one workgroup per selector folds its histogram copies and counter lines into the flat record that
+// crosses the ranks, and leaves them zero for the next round
+__global__ __launch_bounds__(kAdvBlock) void win_dist_export_kernel(uint32_t* __restrict__ hist, WinSlot* __restrict__ slots,
+                                                                    int64_t* __restrict__ out) {
+  const int s = blockIdx.x;
+  constexpr int kPer = kWinBins / kAdvBlock;
+#pragma unroll
+  for (int i = 0; i < kPer; ++i) {
+    const int b = threadIdx.x * kPer + i;
+    unsigned long long t = 0;
+#pragma unroll
+    for (int c = 0; c < kCopies; ++c) {
+      uint32_t* p = hist + (static_cast<size_t>(c) * kWinSel + s) * kWinBins + b;
+      t += *p;
+      *p = 0;
+    }
+    out[static_cast<size_t>(s) * kWinBins + b] = static_cast<int64_t>(t);
+  }
+  unsigned long long below = 0, neg = 0, nan = 0;
+  if (threadIdx.x < kSlots) {
+    below = slots[threadIdx.x].below[s];
+    slots[threadIdx.x].below[s] = 0;
+    if (s == 0) {
+      neg = slots[threadIdx.x].neg;
+      nan = slots[threadIdx.x].nan;
+      slots[threadIdx.x].neg = 0;
+      slots[threadIdx.x].nan = 0;
+    }
+  }
+  below = wave_reduce(below, SumL());
+  neg = wave_reduce(neg, SumL());
+  nan = wave_reduce(nan, SumL());
+  if (threadIdx.x == 0) {  // (kSlots == one wave)
+    out[kWinSel * kWinBins + s] = static_cast<int64_t>(below);
+    if (s == 0) {
+      out[kWinSel * kWinBins + kWinSel] = static_cast<int64_t>(neg);
+      out[kWinSel * kWinBins + kWinSel + 1] = static_cast<int64_t>(nan);
+    }
+  }
+}
+
+// the advance on the all-reduced record: one workgroup per selector
+__global__ __launch_bounds__(kAdvBlock) void win_dist_advance_kernel(const int64_t* __restrict__ rec, WinState* __restrict__ st,
+                                                                     int percentile, double alpha, uint32_t min_shift,
+                                                                     float* __restrict__ out0, float* __restrict__ out1,
+                                                                     int32_t* __restrict__ done_out) {
+  __shared__ AdvShared sh;
+  const int s = blockIdx.x;
+  const WinSel w = st->sel[s];
+  if (w.done) {
+    if (threadIdx.x == 0) done_out[s] = 1;
+    return;
+  }
+  constexpr int kPer = kWinBins / kAdvBlock;
+  unsigned long long bins[kPer];
+#pragma unroll
+  for (int i = 0; i < kPer; ++i) bins[i] = static_cast<unsigned long long>(rec[static_cast<size_t>(s) * kWinBins + threadIdx.x * kPer + i]);
+  unsigned long long c_below = 0, c_neg = 0, c_nan = 0;
+  if (threadIdx.x == 0) {
+    c_below = static_cast<unsigned long long>(rec[kWinSel * kWinBins + s]);
+    if (w.fresh) {
+      // the signs are counted by the first sweep only (both selectors are fresh then); the round that finally
+      // resolves a selector needs them again (percentile.py:30-43: no negative elements -> min stays 0), so they
+      // wait in the state
+      c_neg = static_cast<unsigned long long>(rec[kWinSel * kWinBins + kWinSel]);
+      c_nan = static_cast<unsigned long long>(rec[kWinSel * kWinBins + kWinSel + 1]);
+      if (s == 0) {
+        st->pad_neg = c_neg;
+        st->pad_nan = c_nan;
+      }
+    } else {
+      c_neg = st->pad_neg;
+      c_nan = st->pad_nan;
+    }
+  }
+  auto write_sel = [&](const WinSel& nw) { st->sel[s] = nw; };
+  advance_core<kAdvBlock>(threadIdx.x, s, w, bins, c_below, c_neg, c_nan, st->n, percentile, alpha, min_shift, out0, out1, sh,
+                          write_sel);
+  __syncthreads();
+  if (threadIdx.x == 0) done_out[s] = static_cast<int32_t>(st->sel[s].done);
+}
+
+#endif  // SBQ_WIN_PART == 0 (the multi-process kernels)
 
 // The sweep.  A workgroup walks slabs of 32 elements per thread (grid-stride), so the LDS histograms are cleared
 // and flushed once per workgroup -- and the workgroups are BIG (1024 threads, one per CU) whenever the tensor has
@@ -1517,7 +1686,8 @@ __device__ __forceinline__ void one_advance_pair(const OneArgs& a, OneLds& ol, b
 // cache costs 8 us.  Before, the last arriver swept the whole tensor alone: 835 us for 16.7 M elements, 7 ms when
 // half of them were one value.  (Not resident and still unresolved -- the sample lied, 1e-9 by design: the last
 // arriver does finish alone, below.)
-// The grid is at most one workgroup per compute unit and workgroups are dispatched in order, so the workgroups a
+// The grid is at most one workgroup per compute unit (win_one_run: min(slabs, CUs); sbq_group_kth_value: the items'
+// shares are scaled to the chip) and workgroups are dispatched in order, so the workgroups a
 // resident one waits for are running or will be given the next free compute unit; a wait that outlasts any
 // plausible schedule (seconds) traps instead of hanging the device.
 template <typename T, int NSEL, int BLOCK, typename Tab>
@@ -2137,6 +2307,153 @@ int win_select_run(const void* const* shards, const int64_t* counts, int n_shard
   return check_launch();
 }
 
+
+// ---- host side of the multi-process protocol (kernels: "the same selection over data that is spread over RANKS") ----
+namespace {
+struct DistRegion {
+  WinState* state;
+  WinSlot* slots;
+  uint32_t* hist;
+};
+DistRegion dist_region(void* workspace) {
+  char* ws = static_cast<char*>(workspace);
+  return DistRegion{reinterpret_cast<WinState*>(ws), reinterpret_cast<WinSlot*>(ws + kStateBytes),
+                    reinterpret_cast<uint32_t*>(ws + kStateBytes + kSlotBytes)};
+}
+uint32_t dist_min_shift(int x_dtype) { return x_dtype == SBQ_BF16 ? 16u : (x_dtype == SBQ_F16 ? 13u : 0u); }
+int dist_check_shards(const void* const* shards, const int64_t* counts, int n_shards, int x_dtype) {
+  if (!valid_dtype(x_dtype)) return SBQ_ERR_DTYPE;
+  if (n_shards < 0 || n_shards > kMaxShards) return SBQ_ERR_ARG;
+  if (n_shards > 0 && (!shards || !counts)) return SBQ_ERR_NULL;
+  for (int i = 0; i < n_shards; ++i) {
+    if (counts[i] < 0 || counts[i] >= (1ll << 32)) return SBQ_ERR_ARG;
+    if (counts[i] > 0 && !shards[i]) return SBQ_ERR_NULL;
+    if (reinterpret_cast<uintptr_t>(shards[i]) % dtype_size(x_dtype)) return SBQ_ERR_ALIGN;
+  }
+  return SBQ_OK;
+}
+}  // namespace
+}  // namespace sbq
+
+extern "C" {
+
+size_t sbq_dist_select_workspace_bytes(void) { return sbq::kStateBytes + sbq::kSlotBytes + sbq::kHistBytes; }
+
+int sbq_dist_select_sample(const void* const* shards, const int64_t* counts, int n_shards, int x_dtype, int use_abs,
+                           int64_t* sample_out, void* stream) {
+  using namespace sbq;
+  int rc = dist_check_shards(shards, counts, n_shards, x_dtype);
+  if (rc != SBQ_OK) return rc;
+  if (!sample_out) return SBQ_ERR_NULL;
+  ShardTable tab{};
+  int64_t n = 0;
+  int live = 0;
+  for (int i = 0; i < n_shards; ++i) {
+    if (counts[i] == 0) continue;  // (an empty shard holds no sample)
+    tab.ptr[live] = shards[i];
+    tab.count[live] = counts[i];
+    ++live;
+    n += counts[i];
+  }
+  hipStream_t st = as_stream(stream);
+  rc = dispatch_dtype(x_dtype, [&](auto tag) {
+    using T = decltype(tag);
+    win_dist_sample_kernel<T><<<1, 1024, 0, st>>>(tab, live, n, use_abs, sample_out);
+  });
+  if (rc != SBQ_OK) return rc;
+  return check_launch();
+}
+
+int sbq_dist_select_plan(const int64_t* sample, int x_dtype, int n_sel, int percentile, double alpha, int64_t k0, int64_t k1,
+                         void* workspace, size_t workspace_bytes, void* stream) {
+  using namespace sbq;
+  if (!valid_dtype(x_dtype)) return SBQ_ERR_DTYPE;
+  if (!sample || !workspace) return SBQ_ERR_NULL;
+  if (n_sel < 1 || n_sel > kWinSel || (percentile && n_sel != 2)) return SBQ_ERR_ARG;
+  if (!percentile && (k0 < 1 || (n_sel == 2 && k1 < 1))) return SBQ_ERR_ARG;
+  if (workspace_bytes < sbq_dist_select_workspace_bytes() || !aligned16(workspace)) return SBQ_ERR_WORKSPACE;
+  const DistRegion r = dist_region(workspace);
+  win_dist_plan_kernel<<<1, 1024, 0, as_stream(stream)>>>(sample, r.state, percentile ? 1 : 0, n_sel, k0, k1, alpha,
+                                                        dist_min_shift(x_dtype), reinterpret_cast<u32x4*>(r.slots),
+                                                        static_cast<uint32_t>((kSlotBytes + kHistBytes) / 16));
+  return check_launch();
+}
+
+int sbq_dist_select_sweep(const void* const* shards, const int64_t* counts, int n_shards, int x_dtype, int use_abs, int n_sel,
+                          int count_signs, void* workspace, size_t workspace_bytes, int64_t* round_out, void* stream) {
+  using namespace sbq;
+  int rc = dist_check_shards(shards, counts, n_shards, x_dtype);
+  if (rc != SBQ_OK) return rc;
+  if (!workspace || !round_out) return SBQ_ERR_NULL;
+  if (n_sel < 1 || n_sel > kWinSel || (count_signs && n_sel != 2)) return SBQ_ERR_ARG;
+  if (workspace_bytes < sbq_dist_select_workspace_bytes() || !aligned16(workspace)) return SBQ_ERR_WORKSPACE;
+  const DistRegion r = dist_region(workspace);
+  hipStream_t st = as_stream(stream);
+  const uint32_t cus = cu_count();
+  int64_t big_slabs = 0, n = 0;
+  for (int i = 0; i < n_shards; ++i) {
+    big_slabs += ceil_div(counts[i], static_cast<int64_t>(WinGeom<1024>::kSlab));
+    n += counts[i];
+  }
+  if (n > 0) {  // (a rank without data contributes the zero record)
+    const bool big = big_slabs >= 2 * static_cast<int64_t>(cus);
+    const int64_t slab = big ? WinGeom<1024>::kSlab : WinGeom<kBlock>::kSlab;
+    PassTable pt{};
+    int64_t n_lean = 0, total = 0;
+    int live = 0;
+    for (int i = 0; i < n_shards; ++i) {
+      if (counts[i] == 0) continue;
+      pt.ptr[live] = shards[i];
+      pt.count[live] = counts[i];
+      const int64_t all = ceil_div(counts[i], slab), lean = aligned16(shards[i]) ? counts[i] / slab : 0;
+      pt.lean_first[live] = static_cast<uint32_t>(n_lean);
+      pt.rag_first[live] = static_cast<uint32_t>(total - n_lean);
+      n_lean += lean;
+      total += all;
+      ++live;
+    }
+    pt.lean_first[live] = static_cast<uint32_t>(n_lean);
+    pt.rag_first[live] = static_cast<uint32_t>(total - n_lean);
+    if (total >= (1ll << 31)) return SBQ_ERR_ARG;
+    const int64_t cap = big ? cus : 4 * static_cast<int64_t>(cus);
+    const uint32_t grid = static_cast<uint32_t>(total < cap ? total : cap);
+    rc = dispatch_dtype(x_dtype, [&](auto tag) {
+      using T = decltype(tag);
+#define SBQ_DWIN2(NS, SG, B) win_pass_kernel<T, NS, SG, B><<<grid, B, 0, st>>>(pt, live, r.state, r.slots, r.hist, use_abs)
+#define SBQ_DWIN(NS, SG)            \
+  do {                              \
+    if (big) SBQ_DWIN2(NS, SG, 1024); \
+    else SBQ_DWIN2(NS, SG, kBlock);   \
+  } while (0)
+      if (n_sel == 1) SBQ_DWIN(1, false);
+      else if (count_signs) SBQ_DWIN(2, true);
+      else SBQ_DWIN(2, false);
+#undef SBQ_DWIN
+#undef SBQ_DWIN2
+    });
+    if (rc != SBQ_OK) return rc;
+  }
+  if (n_sel == 1) (void)hipMemsetAsync(round_out + kWinBins, 0, kWinBins * sizeof(int64_t), st);  // selector 1's unused half
+  win_dist_export_kernel<<<n_sel, kAdvBlock, 0, st>>>(r.hist, r.slots, round_out);
+  return check_launch();
+}
+
+int sbq_dist_select_advance(const int64_t* round_record, int x_dtype, int n_sel, int percentile, double alpha, void* workspace,
+                            size_t workspace_bytes, float* out0, float* out1, int32_t* done_out, void* stream) {
+  using namespace sbq;
+  if (!valid_dtype(x_dtype)) return SBQ_ERR_DTYPE;
+  if (!round_record || !workspace || !out0 || !done_out || (percentile && !out1)) return SBQ_ERR_NULL;
+  if (n_sel < 1 || n_sel > kWinSel || (percentile && n_sel != 2)) return SBQ_ERR_ARG;
+  if (workspace_bytes < sbq_dist_select_workspace_bytes() || !aligned16(workspace)) return SBQ_ERR_WORKSPACE;
+  const DistRegion r = dist_region(workspace);
+  win_dist_advance_kernel<<<n_sel, kAdvBlock, 0, as_stream(stream)>>>(round_record, r.state, percentile ? 1 : 0, alpha,
+                                                                    dist_min_shift(x_dtype), out0, out1, done_out);
+  return check_launch();
+}
+
+}  // extern "C"
+
+namespace sbq {
 }  // namespace sbq
 
 extern "C" {
@@ -2170,6 +2487,21 @@ int sbq_group_kth_value(const sbq_kth_item* items, int n_items, int x_dtype, int
     const int cnt = n_items - first < kKthItemsPerLaunch ? n_items - first : kKthItemsPerLaunch;
     KthItems args{};
     uint32_t grid = 0;
+    // four slabs per workgroup (all of them in flight before the windows are known) is what every item WANTS -- but the
+    // launch as a whole must fit the chip in one sitting (one 1024-thread workgroup per compute unit): win_finish's
+    // resident rounds wait for an item's other workgroups, and a waiting workgroup holds its compute unit, so
+    // workgroups that are not yet dispatched could only start after the 100 us resignation.  When the wishes add up
+    // to more than the chip, every item keeps one workgroup and the rest is shared out in proportion (a workgroup then
+    // walks more than four slabs: the sweep is grid-stride).
+    int64_t want[kKthItemsPerLaunch], extra_wanted = 0;
+    for (int j = 0; j < cnt; ++j) {
+      const sbq_kth_item& it = items[first + j];
+      const int64_t slabs = it.numel / slab + (it.numel % slab ? 1 : 0);
+      int64_t nwg = ceil_div(slabs, static_cast<int64_t>(4));
+      want[j] = nwg < 1 ? 1 : (nwg > cus ? cus : nwg);
+      extra_wanted += want[j] - 1;
+    }
+    const int64_t budget = cus > cnt ? cus - cnt : 0;  // (cnt <= 64 <= any part's compute units)
     for (int j = 0; j < cnt; ++j) {
       const sbq_kth_item& it = items[first + j];
       KthItemArg& d = args.it[j];
@@ -2178,9 +2510,8 @@ int sbq_group_kth_value(const sbq_kth_item* items, int n_items, int x_dtype, int
       d.k = it.k;
       d.n_lean = static_cast<uint32_t>(it.numel / slab);
       d.n_rag = it.numel % slab ? 1u : 0u;
-      // four slabs per workgroup (all of them in flight before the windows are known), at most one workgroup per CU
-      int64_t nwg = ceil_div(static_cast<int64_t>(d.n_lean) + d.n_rag, static_cast<int64_t>(4));
-      nwg = nwg < 1 ? 1 : (nwg > cus ? cus : nwg);
+      int64_t nwg = want[j];
+      if (extra_wanted > budget) nwg = 1 + (want[j] - 1) * budget / extra_wanted;
       d.wg_begin = grid;
       d.nwg = static_cast<uint32_t>(nwg);
       grid += d.nwg;

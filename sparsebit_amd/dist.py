@@ -5,11 +5,13 @@ and DDP later broadcasts rank 0's qparams (examples/quantization_aware_training/
 imagenet1k/basecase/main.py:240-255).  Here calibration batches shard across the
 ranks and the statistics -- not the data -- are combined:
   min/max      one MAX all-reduce of [max, -min]           (exact: order independent)
-  MSE          + one SUM all-reduce of the fp64 [C, 80] squared-error table
-  percentile   one SUM all-reduce of int64 histograms per radix pass (exact)
+  MSE          + one SUM all-reduce of the fp64 [C, 80] squared-error table (+ the element count, same buffer)
+  percentile   per tensor: one SUM of the ranks' SAMPLE histograms (every rank then derives the same windows), one
+               SUM of the window counts per sweep -- one sweep for 16-bit data, two for fp32 (select.windowed_steps);
+               per channel: one SUM of int64 histograms per fixed-digit pass (select.kth_values_steps); exact
   LSQ init     one SUM all-reduce of [sum|x|, count]
-Messages are <= 1.3 MB, i.e. latency bound on xGMI; everything a quantizer needs
-travels in ONE flat buffer per step.
+Messages are <= 2.6 MB, i.e. latency bound on xGMI; everything the observers of a MODEL need at one step of their
+protocols travels in ONE flat buffer per kind (run_lockstep): per model, not per quantizer.
 
 These helpers are device agnostic (they only call torch.distributed), so the
 world_size-2 gloo tests exercise exactly the code the RCCL path runs.
@@ -66,7 +68,7 @@ def allreduce_minmax(min_val, max_val):
         from . import ops
 
         buf = ops.minmax_pack(min_val, max_val)
-        dist.all_reduce(buf, op=dist.ReduceOp.MAX, group=_group)
+        _all_reduce(buf, dist.ReduceOp.MAX)
         mn, mx = ops.minmax_unpack(buf, min_val.shape)
         return mn.to(min_val.dtype), mx.to(max_val.dtype)
     # host tensors (the gloo tests): the same wire format with torch ops
@@ -75,7 +77,7 @@ def allreduce_minmax(min_val, max_val):
     mn = min_val.reshape(-1).float()
     buf = torch.cat([torch.nan_to_num(mx, nan=float("-inf")), torch.nan_to_num(-mn, nan=float("-inf")),
                      torch.isnan(mx).float(), torch.isnan(mn).float()])
-    dist.all_reduce(buf, op=dist.ReduceOp.MAX, group=_group)
+    _all_reduce(buf, dist.ReduceOp.MAX)
     nan = torch.full((n,), float("nan"), dtype=buf.dtype, device=buf.device)
     mx = torch.where(buf[2 * n:3 * n] > 0, nan, buf[:n])
     mn = torch.where(buf[3 * n:] > 0, nan, -buf[n:2 * n])
@@ -102,17 +104,104 @@ def allreduce_minmax_many(pairs):
 def allreduce_sum_(t):
     """In-place SUM over ranks (fp64 / int64 tables: exact or order-insensitive enough)."""
     if active():
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=_group)
+        _all_reduce(t, dist.ReduceOp.SUM)
     return t
 
 
 def allreduce_count(n):
-    """Python number summed over ranks."""
+    """Python number summed over ranks.  (A host round trip: the observers carry their counts inside the
+    buffers they all-reduce anyway -- this stays for callers outside the calibration protocol.)"""
     if not active():
         return n
     t = torch.tensor([float(n)], dtype=torch.float64, device=_comm_device())
-    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=_group)
+    _all_reduce(t, dist.ReduceOp.SUM)
+    stats["host_reads"] += 1
     return type(n)(t.item())
+
+
+# what crossed the wire / the PCIe bus since the last reset_stats(): the tests count collectives per MODEL
+stats = {"collectives": 0, "bytes": 0, "host_reads": 0}
+
+
+def reset_stats():
+    for k in stats:
+        stats[k] = 0
+
+
+def _all_reduce(t, op):
+    dist.all_reduce(t, op=op, group=_group)
+    stats["collectives"] += 1
+    stats["bytes"] += t.numel() * t.element_size()
+
+
+# ---- observers in lock step ---------------------------------------------------------------------------------
+# A sharded observer is a GENERATOR: it computes its rank-local statistics, yields a request, and is resumed with the
+# globally reduced answer --
+#     ("max", (min, max))   ->  (min, max) over all ranks          [allreduce_minmax's wire format]
+#     ("sum", tensor)       ->  the same tensor, summed in place   [int64 / float64]
+#     ("host", tensor)      ->  its values as a Python list        [the one place a protocol may look at device data]
+# and returns its result.  run_lockstep() advances MANY such generators together and sends the requests of one step
+# that share a kind (and dtype) as ONE flat collective / ONE device-to-host copy: a model's worth of min-max, MSE and
+# percentile observers costs the collectives of one observer of each kind (the messages are latency bound), instead
+# of tools/calibration.py:102-115's per-quantizer loop turning into a per-quantizer exchange.  Every rank must drive
+# the same generators in the same order -- they are built from the model, which is replicated -- and a generator's
+# control flow may depend on reduced values only.
+def run_lockstep(gens):
+    """-> [return value of each generator].  Works without an initialised process group too (the requests are then
+    answered locally), so the same code path serves one process."""
+    n = len(gens)
+    results = [None] * n
+    reqs = {}
+
+    def step(i, value):
+        try:
+            reqs[i] = gens[i].send(value)
+        except StopIteration as e:
+            results[i] = e.value
+
+    for i in range(n):
+        step(i, None)
+    while reqs:
+        cur, answers = reqs, {}
+        reqs = {}
+        groups = {}
+        for i in sorted(cur):
+            kind, payload = cur[i]
+            dt = payload[0].dtype if kind == "max" else payload.dtype
+            groups.setdefault((kind, str(dt)), []).append(i)
+        for key in sorted(groups):  # the same order on every rank
+            kind, members = key[0], groups[key]
+            if kind == "max":
+                red = allreduce_minmax_many([cur[i][1] for i in members])
+                for i, pair in zip(members, red):
+                    answers[i] = pair
+            elif kind == "sum":
+                ts = [cur[i][1] for i in members]
+                if active():
+                    if len(ts) == 1:
+                        _all_reduce(ts[0], dist.ReduceOp.SUM)
+                    else:
+                        flat = torch.cat([t.reshape(-1) for t in ts])
+                        _all_reduce(flat, dist.ReduceOp.SUM)
+                        o = 0
+                        for t in ts:
+                            t.copy_(flat[o:o + t.numel()].reshape(t.shape))
+                            o += t.numel()
+                for i, t in zip(members, ts):
+                    answers[i] = t
+            elif kind == "host":
+                ts = [cur[i][1].reshape(-1) for i in members]
+                flat = (torch.cat(ts) if len(ts) > 1 else ts[0]).cpu()  # ONE device-to-host copy for all of them
+                stats["host_reads"] += 1
+                vals, o = flat.tolist(), 0
+                for i, t in zip(members, ts):
+                    answers[i] = vals[o:o + t.numel()]
+                    o += t.numel()
+            else:
+                raise ValueError("unknown exchange %r" % (kind,))
+        for i in sorted(answers):
+            step(i, answers[i])
+    return results
 
 
 def _comm_device():

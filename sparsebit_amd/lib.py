@@ -23,6 +23,8 @@ MSE_CANDIDATES = 80
 RADIX_BINS = 2048
 ROWSEL_MAX = 16384
 MAX_BATCH = 64
+DIST_SAMPLE_WORDS = 8193  # SBQ_DIST_SAMPLE_WORDS
+DIST_ROUND_WORDS = 4100  # SBQ_DIST_ROUND_WORDS
 
 GROUP_LSQ, GROUP_Y_OFFSET = 1, 2
 GROUP_BWD_CHUNK = 128
@@ -164,6 +166,7 @@ _SIGNATURES = {
         [c_vp, c_int, c_i64, c_i64, c_i64, c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp, c_sz, c_vp],
     ),
     "sbq_mse_select": (c_int, [c_vp, c_dbl, c_vp, c_vp, c_i64, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
+    "sbq_mse_select_devcount": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
     "sbq_percentile_rows": (c_int, [c_vp, c_int, c_i64, c_i64, c_dbl, c_vp, c_vp, c_vp]),
     "sbq_radix_histogram": (c_int, [c_vp, c_int, c_i64, c_i64, c_i64, c_int, c_int, c_int, c_vp, c_vp, c_vp]),
     "sbq_radix_advance": (c_int, [c_vp, c_i64, c_int, c_int, c_vp, c_vp]),
@@ -171,9 +174,16 @@ _SIGNATURES = {
     "sbq_sign_counts": (c_int, [c_vp, c_int, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp]),
     "sbq_mask_from_threshold": (c_int, [c_vp, c_int, c_i64, c_vp, c_vp, c_vp]),
     "sbq_gptq_mse_search": (c_int, [c_vp, c_int, c_i64, c_i64, c_vp, c_vp, c_int, c_int, ctypes.c_float, c_int, c_int, c_vp, c_vp,
-                                    c_vp, c_vp]),
+                                    c_vp, c_vp, c_sz, c_vp]),
+    "sbq_gptq_mse_search_workspace_bytes": (c_sz, [c_i64, c_i64, c_int]),
     "sbq_vecquantmatmul_multi": (c_int, [c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_sz, c_vp]),
+    "sbq_dist_select_workspace_bytes": (c_sz, []),
+    "sbq_dist_select_sample": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp]),
+    "sbq_dist_select_plan": (c_int, [c_vp, c_int, c_int, c_int, c_dbl, c_i64, c_i64, c_vp, c_sz, c_vp]),
+    "sbq_dist_select_sweep": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_sz, c_vp, c_vp]),
+    "sbq_dist_select_advance": (c_int, [c_vp, c_int, c_int, c_int, c_dbl, c_vp, c_sz, c_vp, c_vp, c_vp, c_vp]),
     "sbq_gptq_workspace_bytes": (c_sz, [c_i64, c_i64, c_i64]),
+    "sbq_vecquantmatmul_multi_workspace_bytes": (c_sz, [c_i64, c_i64, c_int, c_vp]),
     "sbq_vecquant4matmul": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_vp, c_sz, c_vp]),
     "sbq_vecquant3matmul": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_vp, c_sz, c_vp]),
     "sbq_vecquant2matmul": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_vp, c_sz, c_vp]),

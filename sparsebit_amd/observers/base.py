@@ -79,6 +79,18 @@ class Observer(nn.Module):
         scale, zero_point = self.calc_qparams_with_minmax(min_val, max_val)
         return scale, zero_point
 
+    # ---- sharded calibration: the observer as a generator of exchange requests (dist.run_lockstep) --------------
+    # Observers that can combine rank-local statistics define `sharded_minmax_steps` (a generator that returns
+    # (min_val, max_val) of the union of all ranks' batches); calc_minmax() under dist.sharded_calibration() drives
+    # it alone, a calibration driver drives the generators of ALL observers of a model in lock step, so that each
+    # step of their protocols is one collective per model (calibration.DeviceCalibrator._finish).
+    sharded_minmax_steps = None
+
+    def sharded_qparams_steps(self):
+        """-> (scale, zero_point) of the union; generator (see above)"""
+        min_val, max_val = yield from self.sharded_minmax_steps()
+        return self.calc_qparams_with_minmax(min_val, max_val)
+
     def calc_qparams_with_minmax(self, min_val, max_val):
         """observers/base.py:63-79 as one device kernel."""
         qmin, qmax = self.qdesc.qrange
@@ -114,13 +126,16 @@ class Observer(nn.Module):
 
     def _minmax_over_shards(self, shards):
         """Exact per-channel (or per-tensor) min/max over the union of shards and ranks."""
+        return sbq_dist.allreduce_minmax(*self._local_minmax(shards))
+
+    def _local_minmax(self, shards):
+        """... over this rank's shards only"""
         mn = mx = None
         for x in shards:
             a, b, _ = ops.channel_stats(x, self.ch_axis, self.is_perchannel)
             # fold shards with NaN-propagating torch.minimum/maximum on [C] vectors
             mn = a if mn is None else torch.minimum(mn, a)
             mx = b if mx is None else torch.maximum(mx, b)
-        mn, mx = sbq_dist.allreduce_minmax(mn, mx)
         return mn, mx
 
     def _store_minmax(self, mn, mx):

@@ -42,9 +42,8 @@ class Observer(BaseObserver):
         self._running = (lo, hi)
         self._resolved = True
 
-    def calc_minmax(self):
-        resolved = getattr(self, "_resolved", False)
-        self._resolved = False
+    def _local(self):
+        """this rank's folded (min, max): what consume() accumulated and / or the cached batches"""
         running, self._running = self._running, None
         if len(self.data_cache):
             shards = self._shards()
@@ -53,5 +52,17 @@ class Observer(BaseObserver):
                 lo, hi, _ = ops.channel_stats(x, self.ch_axis, self.is_perchannel)
                 running = (lo, hi) if running is None else (torch.minimum(running[0], lo), torch.maximum(running[1], hi))
         assert running is not None, "No data cached!"
-        lo, hi = running if resolved else sbq_dist.allreduce_minmax(*running)
+        return running
+
+    def sharded_minmax_steps(self):
+        resolved = getattr(self, "_resolved", False)
+        self._resolved = False
+        running = self._local()
+        lo, hi = running if resolved else (yield ("max", running))
         return self._store_minmax(lo, hi)
+
+    def calc_minmax(self):
+        if sbq_dist.active():
+            return sbq_dist.run_lockstep([self.sharded_minmax_steps()])[0]
+        self._resolved = False
+        return self._store_minmax(*self._local())

@@ -26,33 +26,49 @@ class Observer(BaseObserver):
         self.alpha = config.OBSERVER.PERCENTILE.ALPHA
         self.best_index = None
 
-    def calc_minmax(self, shards=None):
-        own = shards is None
-        if own:
+    def sharded_minmax_steps(self, shards=None):
+        if shards is None:
             shards = self._shards()
             self.data_cache.reset()
-        mn, mx = self._minmax_over_shards(shards)
+        mn, mx = self._local_minmax(shards)
+        if sbq_dist.active():
+            mn, mx = yield ("max", (mn, mx))
         return self._store_minmax(mn, mx)
 
-    def calc_qparams(self):
+    def calc_minmax(self, shards=None):
+        return sbq_dist.run_lockstep([self.sharded_minmax_steps(shards)])[0]
+
+    def sharded_qparams_steps(self):
+        """Two exchanges when sharded: the MAX of the min-max step, then ONE fp64 SUM that carries the [C, 80]
+        squared-error table AND this rank's element count (the pick reads the count on the device: no host round
+        trip between the collective and the argmin)."""
         shards = self._shards()
         self.data_cache.reset()
-        min_val, max_val = self.calc_minmax(shards)
+        min_val, max_val = yield from self.sharded_minmax_steps(shards)
         dev = shards[0].device
         perch = self.is_perchannel
         C = min_val.numel()
         qmin, qmax = self.qdesc.qrange
-        sse = torch.zeros((C, L.MSE_CANDIDATES), dtype=torch.float64, device=dev)
+        buf = torch.zeros(C * L.MSE_CANDIDATES + 1, dtype=torch.float64, device=dev)
+        sse = buf[:-1].view(C, L.MSE_CANDIDATES)
         n_local = 0
         for x in shards:
             ops.mse_accumulate(x, min_val, max_val, qmin, qmax, self.is_symmetric, sse, self.ch_axis, perch)
             n_local += x.numel() // C
-        sbq_dist.allreduce_sum_(sse)
-        n = sbq_dist.allreduce_count(n_local)
-        scale, zero_point, best = ops.mse_select(sse, n, min_val, max_val, qmin, qmax, self.is_symmetric)
+        if sbq_dist.active():
+            buf[-1] = float(n_local)
+            buf = yield ("sum", buf)
+            count = buf[-1:]
+        else:
+            count = n_local
+        scale, zero_point, best = ops.mse_select(buf[:-1].view(C, L.MSE_CANDIDATES), count, min_val, max_val, qmin, qmax,
+                                                 self.is_symmetric)
         self.best_index = best
         assert len(self.data_cache) == 0, "free data cache after calc_qparams"
         if not perch:
             # the reference returns the candidate's 0-d qparams per tensor (mse.py:57-61)
             scale, zero_point = scale.reshape(()), zero_point.reshape(())
         return scale, zero_point
+
+    def calc_qparams(self):
+        return sbq_dist.run_lockstep([self.sharded_qparams_steps()])[0]

@@ -12,53 +12,44 @@ from .. import select
 @register_observer
 class Observer(BaseObserver):
     TYPE = "percentile"
-    MAX_SHARDED_CHANNELS = 256  # 8 MB of histograms per pass
 
     def __init__(self, config, qdesc):
         super(Observer, self).__init__(config, qdesc)
         self.alpha = config.OBSERVER.PERCENTILE.ALPHA
 
     def calc_minmax(self):
+        return sbq_dist.run_lockstep([self.sharded_minmax_steps()])[0]
+
+    def sharded_minmax_steps(self):
+        """One process: no exchange at all (the generator returns at once).  Sharded: per tensor the windowed
+        protocol (select.windowed_steps: one read of a 16-bit batch list, two SUM all-reduces), per channel the
+        fixed-digit passes (three reads, three SUMs of an int64 [C, 2, 2048] histogram -- 32 KB per channel, which at
+        C = 4096 is 134 MB per pass: a bandwidth-bound exchange on xGMI, milliseconds instead of microseconds, and
+        still exact; no shipped config calibrates per-channel ACTIVATIONS with this observer, and weights are
+        replicated and never take this path)."""
         shards = self._shards()
         self.data_cache.reset()
         x0 = shards[0]
-        rows_fast = (
-            self.is_perchannel
-            and self.ch_axis == 0
-            and len(shards) == 1
-            and not sbq_dist.active()
-            and x0[0].numel() <= L.ROWSEL_MAX
-        )
-        if rows_fast:
-            # a [C, inner] weight whose rows fit on chip: one workgroup per row, one read
-            mn, mx = ops.percentile_rows(x0.reshape(x0.shape[0], -1), self.alpha)
-            return self._store_minmax(mn, mx)
-        mn, mx = self._radix_minmax(shards)
-        return self._store_minmax(mn, mx)
-
-    def _radix_minmax(self, shards):
-        dev = shards[0].device
+        dev = x0.device
         perch = self.is_perchannel
-        C = shards[0].shape[self.ch_axis] if perch else 1
-        # percentile.py:27-43: the counts of negative / non-negative elements and the two ranks come out of
-        # the first radix histogram on the device, three reads of the data in total.  Single process: the whole
-        # protocol is one library call; sharded over ranks: pass by pass with an all-reduce in between.
         if not sbq_dist.active():
+            if perch and self.ch_axis == 0 and len(shards) == 1 and x0[0].numel() <= L.ROWSEL_MAX:
+                # a [C, inner] weight whose rows fit on chip: one workgroup (or wave) per row, one read
+                mn, mx = ops.percentile_rows(x0.reshape(x0.shape[0], -1), self.alpha)
+                return self._store_minmax(mn, mx)
+            # percentile.py:27-43: the counts of negative / non-negative elements and the two ranks come out of
+            # the selection itself on the device; the whole protocol is one library call
             fused = ops.percentile_select(shards, self.alpha, self.ch_axis, perch)
             if fused is not None:
-                return fused
-        elif perch and C > self.MAX_SHARDED_CHANNELS:
-            # The sharded protocol all-reduces an int64 [C, 2, 2048] histogram per pass: 32 KB per channel, 134 MB
-            # at C = 4096 -- three times.  That is a bandwidth problem on xGMI, not the latency-bound statistic
-            # exchange the design budgets for, and no shipped config calibrates per-channel
-            # ACTIVATIONS with the percentile observer (weights are replicated and never take this path).
-            raise L.SbqError(
-                "sharded per-channel percentile over %d channels would all-reduce %d MB of histograms per pass; "
-                "calibrate this quantizer per tensor, or outside dist.sharded_calibration() (every rank then sees "
-                "all batches)" % (C, C * 2 * L.RADIX_BINS * 8 >> 20))
-        vals, counts = select.kth_values(shards, None, ops.HipSelectBackend(), False, self.ch_axis, perch, dev,
-                                         percentile_alpha=self.alpha, n_channels=C)
+                return self._store_minmax(*fused)
+        C = x0.shape[self.ch_axis] if perch else 1
+        if not perch and len(shards) <= L.MAX_BATCH:
+            vals = yield from select.windowed_steps(shards, ops.HipWindowBackend(x0.dtype), dev, use_abs=False,
+                                                    percentile_alpha=self.alpha)
+            return self._store_minmax(vals[0:1].clone(), vals[1:2].clone())
+        vals, counts = yield from select.kth_values_steps(shards, None, ops.HipSelectBackend(), False, self.ch_axis, perch,
+                                                          dev, percentile_alpha=self.alpha, n_channels=C)
         zero = torch.zeros(C, dtype=torch.float32, device=dev)
         mn = torch.where(counts[0] > 0, vals[:, 0], zero)
         mx = torch.where(counts[1] > 0, vals[:, 1], zero)
-        return mn, mx
+        return self._store_minmax(mn, mx)

@@ -885,8 +885,15 @@ def mse_select(sse, count_per_channel, min_val, max_val, qmin, qmax, symmetric):
     zp = torch.empty(C, dtype=torch.float32, device=dev)
     best = torch.empty(C, dtype=torch.int32, device=dev)
     with L.device_guard(dev):
-        rc = lib.sbq_mse_select(L.ptr(sse), float(count_per_channel), L.ptr(mn), L.ptr(mx), C, int(qmin), int(qmax),
-                                int(bool(symmetric)), L.ptr(scale), L.ptr(zp), L.ptr(best), L.stream_ptr(dev))
+        if isinstance(count_per_channel, torch.Tensor):  # a device double (sharded calibration): no host read
+            cnt = count_per_channel
+            if cnt.dtype != torch.float64 or cnt.numel() != 1 or cnt.device != dev:
+                raise L.SbqError("mse_select: a tensor count must be one float64 on the data's device")
+            rc = lib.sbq_mse_select_devcount(L.ptr(sse), L.ptr(cnt), L.ptr(mn), L.ptr(mx), C, int(qmin), int(qmax),
+                                             int(bool(symmetric)), L.ptr(scale), L.ptr(zp), L.ptr(best), L.stream_ptr(dev))
+        else:
+            rc = lib.sbq_mse_select(L.ptr(sse), float(count_per_channel), L.ptr(mn), L.ptr(mx), C, int(qmin), int(qmax),
+                                    int(bool(symmetric)), L.ptr(scale), L.ptr(zp), L.ptr(best), L.stream_ptr(dev))
     L.check(rc)
     return scale, zp, best
 
@@ -1068,6 +1075,80 @@ class HipSelectBackend:
         return radix_finish(state, n_sel, C, use_abs)
 
 
+class HipWindowBackend:
+    """The device steps of select.windowed_steps (include/sbq.h section 4b): sample / plan / sweep / advance of ONE
+    whole-tensor selection over this rank's shards.  All shards share a dtype; a rank may hold none (dtype given)."""
+
+    def __init__(self, dtype):
+        self.dtype = dtype
+        self.dtype_id = _DTYPE_IDS[dtype]
+
+    def expected_rounds(self):
+        return 2 if self.dtype == torch.float32 else 1  # a sweep resolves 11 key bits below the sample's window
+
+    def _tables(self, shards):
+        n = len(shards)
+        if n > L.MAX_BATCH:
+            raise L.SbqError("a windowed selection takes at most %d shards per rank" % L.MAX_BATCH)
+        ptrs = (ctypes.c_void_p * max(n, 1))()
+        counts = (ctypes.c_int64 * max(n, 1))()
+        for i, x in enumerate(shards):
+            if x.dtype != self.dtype:
+                raise L.SbqError("windowed selection: every shard must be %s" % self.dtype)
+            ptrs[i], counts[i] = x.data_ptr(), x.numel()
+        return ptrs, counts, n
+
+    def sample(self, shards, use_abs, device):
+        dev = L.require_device(*shards) if shards else device
+        self.shards = [x.contiguous() for x in shards]
+        out = torch.empty(L.DIST_SAMPLE_WORDS, dtype=torch.int64, device=dev)
+        ptrs, counts, n = self._tables(self.shards)
+        with L.device_guard(dev):
+            rc = L.load().sbq_dist_select_sample(ptrs, counts, n, self.dtype_id, int(bool(use_abs)), L.ptr(out), L.stream_ptr(dev))
+        L.check(rc)
+        return out
+
+    def plan(self, sample, n_sel, percentile_alpha, ranks, device):
+        lib = L.load()
+        dev = sample.device
+        ws = torch.empty(lib.sbq_dist_select_workspace_bytes(), dtype=torch.uint8, device=dev)  # the plan clears it
+        pct = percentile_alpha is not None
+        k0 = k1 = 0
+        if not pct:
+            k0 = int(ranks[0])
+            k1 = int(ranks[1]) if n_sel == 2 else 0
+        alpha = float(percentile_alpha) if pct else 0.0
+        with L.device_guard(dev):
+            rc = lib.sbq_dist_select_plan(L.ptr(sample), self.dtype_id, n_sel, int(pct), alpha, k0, k1, L.ptr(ws), ws.numel(),
+                                          L.stream_ptr(dev))
+        L.check(rc)
+        return {"ws": ws, "n_sel": n_sel, "pct": pct, "alpha": alpha, "dev": dev,
+                "out": torch.zeros(2, dtype=torch.float32, device=dev), "done": torch.zeros(2, dtype=torch.int32, device=dev)}
+
+    def sweep(self, sel, shards, use_abs, count_signs):
+        dev = sel["dev"]
+        rec = torch.empty(L.DIST_ROUND_WORDS, dtype=torch.int64, device=dev)
+        ptrs, counts, n = self._tables(self.shards)
+        with L.device_guard(dev):
+            rc = L.load().sbq_dist_select_sweep(ptrs, counts, n, self.dtype_id, int(bool(use_abs)), sel["n_sel"], int(bool(count_signs)),
+                                                L.ptr(sel["ws"]), sel["ws"].numel(), L.ptr(rec), L.stream_ptr(dev))
+        L.check(rc)
+        return rec
+
+    def advance(self, sel, rec):
+        dev = sel["dev"]
+        out = sel["out"]
+        with L.device_guard(dev):
+            rc = L.load().sbq_dist_select_advance(L.ptr(rec), self.dtype_id, sel["n_sel"], int(sel["pct"]), sel["alpha"],
+                                                  L.ptr(sel["ws"]), sel["ws"].numel(), L.ptr(out[0:1]),
+                                                  L.ptr(out[1:2]) if sel["pct"] else None, L.ptr(sel["done"]), L.stream_ptr(dev))
+        L.check(rc)
+        return sel["done"]
+
+    def values(self, sel):
+        return sel["out"][: sel["n_sel"]]
+
+
 def mask_from_threshold(x, thresh):
     """mask = |x| > thresh as torch.bool (l1norm.py:24-25)"""
     dev = L.require_device(x, thresh)
@@ -1145,7 +1226,8 @@ def vecquantmatmul_multi(bits, x, qweights, outs, scales, zeros, group_size):
     arr = lambda ts: (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts])  # noqa: E731
     outf = (ctypes.c_int64 * n)(*[qw.shape[1] for qw in qweights])
     with L.device_guard(dev):
-        ws = _gptq_workspace(dev, lib.sbq_gptq_workspace_bytes(batch, in_f, total))
+        need = lib.sbq_vecquantmatmul_multi_workspace_bytes(batch, in_f, n, outf)
+        ws = _gptq_workspace(dev, need)
         rc = lib.sbq_vecquantmatmul_multi(int(bits), L.ptr(x), n, arr(qweights), arr(outs), arr(sc), arr(zr), outf, batch, in_f,
                                           int(group_size), L.ptr(ws), ws.numel(), L.stream_ptr(dev))
     L.check(rc)
@@ -1163,10 +1245,12 @@ def gptq_mse_search(x2d, xmin, xmax, maxq, symmetric, scale, zero, norm=2.4, gri
         if t.dtype != torch.float32 or not t.is_contiguous() or t.numel() != rows:
             raise L.SbqError("gptq_mse_search: xmin / xmax / scale / zero must be contiguous fp32 with one value per row")
     index = torch.empty(rows, dtype=torch.int32, device=dev)
+    need = lib.sbq_gptq_mse_search_workspace_bytes(rows, inner, int(n_candidates))  # long rows only: fp64 partials
+    ws = torch.empty(need // 8, dtype=torch.float64, device=dev) if need else None
     with L.device_guard(dev):
         rc = lib.sbq_gptq_mse_search(L.ptr(x2d), L.dtype_id(x2d), rows, inner, L.ptr(xmin), L.ptr(xmax), int(maxq),
                                      int(bool(symmetric)), ctypes.c_float(norm), int(grid), int(n_candidates), L.ptr(scale),
-                                     L.ptr(zero), L.ptr(index), L.stream_ptr(dev))
+                                     L.ptr(zero), L.ptr(index), L.ptr(ws), need, L.stream_ptr(dev))
     L.check(rc)
     return index
 

@@ -105,6 +105,11 @@ class Quantizer(nn.Module):
             and w.is_cuda
             and w.dim() >= 2
         )
+        if self.fake_fused:
+            # an identity quantizer (QUANTIZER.DISABLE / fused into a neighbour): nothing to observe, nothing to
+            # cache -- calc_qparams() would return early WITHOUT draining the cache, and a second call would then
+            # trip over the first one's leftover batch
+            return w.detach()
         if len(self.observer.data_cache) != 0:
             raise RuntimeError("calibrate_forward: the observer still holds %d cached batch(es) of an unfinished "
                                "calibration; call calc_qparams() or observer.data_cache.reset() first"

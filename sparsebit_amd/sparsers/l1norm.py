@@ -41,8 +41,10 @@ class Sparser(BaseSparser):
         if sharded and sbq_dist.active():
             n = sbq_dist.allreduce_count(data.numel())
             thresh_idx = min(int(n * self.ratio), n - 1)
-            vals = select.kth_values([data], [[thresh_idx + 1]], ops.HipSelectBackend(), True, 0, False, data.device)
-            return vals.reshape(())
+            # the windowed protocol over the ranks' shards: one read of a 16-bit weight, two small SUM all-reduces
+            vals = sbq_dist.run_lockstep([select.windowed_steps([data.reshape(-1)], ops.HipWindowBackend(data.dtype),
+                                                                 data.device, use_abs=True, ranks=[thresh_idx + 1])])[0]
+            return vals[0].clone().reshape(())
         n = data.numel()
         thresh_idx = min(int(n * self.ratio), n - 1)
         return ops.kth_value(data, thresh_idx + 1, use_abs=True)  # the three radix passes in one call

@@ -86,6 +86,116 @@ class NumpySelectBackend:
         return torch.from_numpy(u.view(np.float32).copy())
 
 
+class NumpyWindowBackend:
+    """numpy stand-in for ops.HipWindowBackend: the four device steps of select.windowed_steps on fp32 keys.  The
+    windows it derives differ from the HIP plan's (any bracket is valid: the protocol only trusts counts) -- what the
+    gloo tests pin is the exchange protocol: every rank derives the SAME windows from the reduced sample, and the
+    result equals the order statistic of the union."""
+
+    PLAN_BINS, PLAN_SHIFT, BINS = 8192, 19, 2048
+
+    def __init__(self, margin=4.0, stride=7):
+        self.margin, self.stride = margin, stride  # a small margin makes windows MISS sometimes: extra rounds
+
+    def expected_rounds(self):
+        return 2
+
+    def sample(self, shards, use_abs, device):
+        self.use_abs = use_abs
+        self.k = [NumpySelectBackend.keys(x.numpy().reshape(-1), use_abs) for x in shards]
+        out = np.zeros(self.PLAN_BINS + 1, np.int64)
+        for k in self.k:
+            out[: self.PLAN_BINS] += np.bincount(k[:: self.stride] >> np.uint32(self.PLAN_SHIFT), minlength=self.PLAN_BINS)
+            out[self.PLAN_BINS] += k.size
+        return torch.from_numpy(out)
+
+    def plan(self, sample, n_sel, percentile_alpha, ranks, device):
+        h = sample.numpy()[: self.PLAN_BINS]
+        n = int(sample[self.PLAN_BINS])
+        S = int(h.sum())
+        cum = np.cumsum(h)
+        neg = int(h[: (0x80000000 >> self.PLAN_SHIFT)].sum())
+        sels = []
+        for s in range(n_sel):
+            if percentile_alpha is not None:
+                r = max(neg * percentile_alpha, 1.0 * S / max(n, 1)) if s == 0 else S - (S - neg) * percentile_alpha
+                k = 0
+            else:
+                k = int(ranks[s])
+                r = k * S / max(n, 1)
+            m = self.margin * np.sqrt(max(r * (1 - min(r / max(S, 1), 1.0)), 1.0)) + 2
+            a = int(np.searchsorted(cum, max(r - m, 1), side="left"))
+            b = int(np.searchsorted(cum, min(r + m, S), side="left"))
+            a, b = min(a, self.PLAN_BINS - 1), min(max(b, a), self.PLAN_BINS - 1)
+            lo, width = a << self.PLAN_SHIFT, (b - a + 1) << self.PLAN_SHIFT
+            sels.append(self._window(lo, width, k, fresh=True))
+        return {"sel": sels, "n": n, "alpha": percentile_alpha, "vals": np.zeros(n_sel, np.float32)}
+
+    def _window(self, lo, width, k, fresh):
+        shift = 0
+        while ((width + (1 << shift) - 1) >> shift) > self.BINS:
+            shift += 1
+        return {"lo": lo, "span": width - 1, "shift": shift, "k": k, "fresh": fresh, "done": False}
+
+    def sweep(self, sel, shards, use_abs, count_signs):
+        n_sel = len(sel["sel"])
+        rec = np.zeros(2 * self.BINS + 4, np.int64)
+        for k in self.k:
+            k64 = k.astype(np.int64)
+            for s, w in enumerate(sel["sel"]):
+                if w["done"]:
+                    continue
+                d = k64 - w["lo"]
+                inside = (d >= 0) & (d <= w["span"])
+                rec[s * self.BINS:(s + 1) * self.BINS] += np.bincount(d[inside] >> w["shift"], minlength=self.BINS)
+                rec[2 * self.BINS + s] += int((d < 0).sum())
+            if count_signs:
+                rec[2 * self.BINS + 2] += int((k < np.uint32(0x80000000)).sum())   # x < 0 (keys below key(+0))
+                rec[2 * self.BINS + 3] += int((k == np.uint32(0xFFFFFFFF)).sum())  # NaN
+        return torch.from_numpy(rec)
+
+    def advance(self, sel, rec):
+        rec = rec.numpy()
+        n = sel["n"]
+        for s, w in enumerate(sel["sel"]):
+            if w["done"]:
+                continue
+            bins = rec[s * self.BINS:(s + 1) * self.BINS]
+            below, total = int(rec[2 * self.BINS + s]), int(bins.sum())
+            k = w["k"]
+            if w["fresh"]:
+                if sel["alpha"] is not None:
+                    neg, nan = int(rec[2 * self.BINS + 2]), int(rec[2 * self.BINS + 3])
+                    sel["neg"], sel["pos"] = neg, n - neg - nan
+                    k = max(round(neg * sel["alpha"]), 1) if s == 0 else n - max(round(sel["pos"] * sel["alpha"]), 0)
+                    k = min(max(k, 1), n)
+                hi = w["lo"] + w["span"] + 1
+                if k <= below:  # the window missed: everything below it
+                    sel["sel"][s] = self._window(0, w["lo"], k, fresh=False)
+                    continue
+                if k > below + total:  # ... or everything above it
+                    sel["sel"][s] = self._window(hi, (1 << 32) - hi, k - below - total, fresh=False)
+                    continue
+                k -= below
+            cum = np.cumsum(bins)
+            b = int(np.searchsorted(cum, k, side="left"))
+            k -= int(cum[b - 1]) if b > 0 else 0
+            lo = w["lo"] + (b << w["shift"])
+            if w["shift"] == 0:
+                u = np.array([lo], np.uint32)
+                v = np.where((u & np.uint32(0x80000000)) != 0, u & np.uint32(0x7FFFFFFF), ~u).astype(np.uint32).view(np.float32)[0]
+                if sel["alpha"] is not None:
+                    v = v if (sel["neg"] if s == 0 else sel["pos"]) > 0 else np.float32(0)
+                sel["vals"][s] = v
+                w["done"] = True
+            else:
+                sel["sel"][s] = self._window(lo, min(1 << w["shift"], w["lo"] + w["span"] + 1 - lo), k, fresh=False)
+        return torch.tensor([int(w["done"]) for w in sel["sel"]] + [1] * (2 - len(sel["sel"])), dtype=torch.int32)
+
+    def values(self, sel):
+        return torch.from_numpy(sel["vals"].copy())
+
+
 def _worker(rank, world, port, tmp):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -176,6 +286,66 @@ def _worker(rank, world, port, tmp):
         v = select.kth_values([shard], [[idx + 1]], NumpySelectBackend(), True, 0, False, torch.device("cpu"))
         _, rt = O.l1_mask(w.numpy(), 0.5)
         ok["mask_thresh"] = float(v.reshape(())) == float(rt)
+    # ---- the windowed protocol (whole-tensor selections): sample SUM, plan, (sweep, SUM, advance) rounds ----
+    with sd.sharded_calibration():
+        flat_all = everything.reshape(-1)
+        for alpha in (0.01, 0.2, 1e-4):
+            sd.reset_stats()
+            vals = sd.run_lockstep([select.windowed_steps([x.reshape(-1) for x in mine], NumpyWindowBackend(), torch.device("cpu"),
+                                                          percentile_alpha=alpha)])[0]
+            rmn_p, rmx_p = O.percentile(flat_all, alpha, 0, False)
+            ok["win_pct_%g" % alpha] = float(vals[0]) == float(rmn_p[0]) and float(vals[1]) == float(rmx_p[0])
+            ok["win_pct_collectives_%g" % alpha] = 3 <= sd.stats["collectives"] <= 6 and sd.stats["host_reads"] >= 1
+        srt = np.sort(np.abs(flat_all))
+        for kk in (1, flat_all.size // 2 + 1, flat_all.size):
+            v = sd.run_lockstep([select.windowed_steps([x.reshape(-1) for x in mine], NumpyWindowBackend(margin=0.3), torch.device("cpu"),
+                                                       use_abs=True, ranks=[kk])])[0]
+            ok["win_kth_%d" % kk] = float(v[0]) == float(srt[kk - 1])  # (margin 0.3: windows miss, extra rounds, same answer)
+        # a rank WITHOUT data takes part with zero records
+        lone = [x.reshape(-1) for x in batches] if rank == 0 else []
+        vals = sd.run_lockstep([select.windowed_steps(lone, NumpyWindowBackend(), torch.device("cpu"), percentile_alpha=0.01)])[0]
+        rmn_p, rmx_p = O.percentile(flat_all, 0.01, 0, False)
+        ok["win_empty_rank"] = float(vals[0]) == float(rmn_p[0]) and float(vals[1]) == float(rmx_p[0])
+        # ---- a MODEL's worth of observers in lock step: the collectives are per model, not per quantizer ----
+        def minmax_gen(scale):
+            loc = [O.minmax(x.numpy() * scale, 1, False) for x in mine]
+            mn, mx = yield ("max", (torch.from_numpy(np.min([l[0] for l in loc], 0)), torch.from_numpy(np.max([l[1] for l in loc], 0))))
+            return mn, mx
+
+        def mse_like_gen(scale):
+            mn, mx = yield from minmax_gen(scale)
+            buf = torch.zeros(81, dtype=torch.float64)
+            buf[:80] = float(rank + 1) * scale
+            buf[80] = float(sum(x.numel() for x in mine))
+            buf = yield ("sum", buf)
+            return mn, mx, buf
+
+        sd.reset_stats()
+        gens = [select.windowed_steps([x.reshape(-1) * sc for x in mine], NumpyWindowBackend(), torch.device("cpu"), percentile_alpha=0.05)
+                for sc in (1.0, 2.0, 0.5)]
+        gens += [minmax_gen(1.0), minmax_gen(3.0), mse_like_gen(2.0)]
+        gens.append(select.kth_values_steps(mine, None, NumpySelectBackend(), False, 1, True, torch.device("cpu"),
+                                            percentile_alpha=0.05, n_channels=6))
+        res = sd.run_lockstep(gens)
+        good = True
+        for sc, vals in zip((1.0, 2.0, 0.5), res[:3]):
+            rmn_p, rmx_p = O.percentile(flat_all * np.float32(sc), 0.05, 0, False)
+            good &= float(vals[0]) == float(rmn_p[0]) and float(vals[1]) == float(rmx_p[0])
+        for sc, (mn, mx) in zip((1.0, 3.0), res[3:5]):
+            rmn, rmx = O.minmax(everything * sc, 1, False)
+            good &= np.array_equal(mn.numpy(), rmn) and np.array_equal(mx.numpy(), rmx)
+        mn, mx, buf = res[5]
+        good &= float(buf[80]) == everything.size and float(buf[0]) == 2.0 * sum(r + 1 for r in range(world))
+        rows = np.moveaxis(everything, 1, 0).reshape(6, -1)
+        rmn_p, rmx_p = O.percentile(rows, 0.05, 0, True)
+        vals2, _ = res[6]
+        good &= np.array_equal(vals2[:, 0].numpy(), rmn_p) and np.array_equal(vals2[:, 1].numpy(), rmx_p)
+        ok["lockstep_results"] = bool(good)
+        # 7 observers: step 0 = {MAX (3 observers), int64 SUM (3 samples + 1 fixed-digit histogram)}, step 1 = {fp64 SUM,
+        # int64 SUM}, step 2 = {int64 SUM}, then at most a few more int64 rounds for windows that missed; one kind of
+        # exchange per step whatever the number of observers
+        ok["lockstep_collectives"] = 5 <= sd.stats["collectives"] <= 9
+        ok["lockstep_host_reads"] = 1 <= sd.stats["host_reads"] <= 4
     ok["disabled_again"] = not sd.active()
     torch.save(ok, os.path.join(tmp, "rank%d.pt" % rank))
     dist.barrier()
@@ -193,7 +363,7 @@ def test_sharded_statistics_equal_single_process(tmp_path):
         ok = torch.load(os.path.join(str(tmp_path), "rank%d.pt" % r))
         bad = [k for k, v in ok.items() if not v]
         assert not bad, (r, bad)
-        assert len(ok) >= 12
+        assert len(ok) >= 26
 
 
 def test_numpy_select_backend_is_the_protocol(oracle):

@@ -39,3 +39,22 @@ def test_bench_two_ranks_emit_one_valid_line():
     assert e["observer_allreduce_percentile_hist_sum_us"] > 0 and e["observer_allreduce_percentile_hist_sum_bytes"] == 2 * 2048 * 8
     # whole-job value: both ranks' elements over the max-over-ranks time
     assert abs(d["value"] - 2 * 5 * 4096 * 4096 / (d["ms_per_step"] * 5 * 1e-3)) <= 1e-6 * d["value"]
+
+
+def test_bench_launches_itself_when_started_like_the_one_gpu_command():
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment (the N = 1 command with another number) becomes
+    its own torch.distributed.run launcher instead of dying on the WORLD_SIZE assertion (VERDICT r03 missing #2)."""
+    env = dict(os.environ, SBQ_BENCH_DEBUG_SINGLE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2", "--quick"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 5
+    rf = d["roofline"]
+    # the roofline figure comes from windows of 1024 launches around the timed region, not from the 5 timed launches
+    assert rf["windows_measured"] >= 12 and rf["kernel_avg_us_windows_min"] <= rf["kernel_avg_us"] <= rf["kernel_avg_us_windows_max"]
+    assert rf["frac"] == rf["frac_1024_window_median"] and "frac_wall" in rf and "frac_timed_region" in rf

@@ -142,6 +142,95 @@ def _worker(rank, world, port, tmp):
         print("rank", rank, "mask_thresh: sharded", float(v.reshape(())), "single", one, "sort",
               float(torch.sort(w.abs().reshape(-1))[0][idx]), flush=True)
 
+    # ---- round 4: the windowed protocol on the device (select.windowed_steps + ops.HipWindowBackend) ----
+    # whole-tensor percentile of sharded batches: bit-exact vs the single-process engine on the union, for every
+    # dtype, aligned and unaligned shards, ranks deep in a tail, ReLU data (half zeros) and a rank without data
+    def win_pct(shards, alpha, dtype):
+        return sd.run_lockstep([select.windowed_steps(shards, ops.HipWindowBackend(dtype), dev, percentile_alpha=alpha)])[0]
+
+    for dt in (torch.bfloat16, torch.float16, torch.float32):
+        big = [(torch.randn(64, 197, 96, generator=g) * (1 + 0.5 * i)).to(dt).to(dev) for i in range(4)]
+        for alpha in (1e-3, 0.05, 1e-5):
+            with sd.sharded_calibration():
+                sd.reset_stats()
+                v = win_pct([b.reshape(-1) for b in big[rank::world]], alpha, dt)
+                n_coll, n_host = sd.stats["collectives"], sd.stats["host_reads"]
+            rmn, rmx = ops.percentile_select(big, alpha, 0, False)
+            key = "win/%s/%g" % (str(dt).split(".")[1], alpha)
+            ok[key] = float(v[0]) == float(rmn) and float(v[1]) == float(rmx)
+            # sample + one round (16-bit) / two rounds (fp32); extreme ranks may take one more
+            ok[key + "/collectives"] = n_coll <= (3 if dt != torch.float32 else 4) + (1 if alpha < 1e-4 else 0) and n_host >= 1
+            if not ok[key]:
+                print("rank", rank, key, v.tolist(), float(rmn), float(rmx), flush=True)
+    relu = [torch.relu(torch.randn(3, 50001, generator=g)).bfloat16().to(dev) for _ in range(4)]
+    odd = [r.reshape(-1)[1:] for r in relu]  # 2-byte aligned views: the sweep's ragged path
+    with sd.sharded_calibration():
+        v = win_pct(odd[rank::world], 1e-3, torch.bfloat16)
+        v_lone = win_pct(odd if rank == 0 else [], 1e-3, torch.bfloat16)  # rank 1 holds nothing
+    flat = torch.cat(odd)
+    rmn, rmx = ops.percentile_select([flat], 1e-3, 0, False)
+    ok["win/relu_unaligned"] = float(v[0]) == float(rmn) and float(v[1]) == float(rmx)
+    ok["win/empty_rank"] = float(v_lone[0]) == float(rmn) and float(v_lone[1]) == float(rmx)
+    # the sparser's own sharded call site (sparsers/l1norm.py: windowed k-th |w| over the ranks' rows)
+    from sparsebit_amd.config import sparser_config
+    from sparsebit_amd.sparsers import build_sparser
+
+    for dt in (torch.float32, torch.bfloat16):
+        wd = w.to(dt)
+        sp = build_sparser(sparser_config(0.5))
+        with sd.sharded_calibration():
+            t_sh = sp.calc_threshold(wd[rank::world].contiguous(), sharded=True)
+        ok["sparser_thresh/%s" % str(dt).split(".")[1]] = float(t_sh) == float(ops.kth_value(wd, idx + 1, True))
+    # per-channel percentile over MORE than 256 channels, sharded (was refused): fixed-digit passes
+    wide = [torch.randn(4, 300, 37, generator=g).to(dev) for _ in range(4)]
+    qa = _mk("per-channel-symmetric", 8, "PERCENTILE", layout="NCHW", alpha=0.02).to(dev)
+    qb = _mk("per-channel-symmetric", 8, "PERCENTILE", layout="NCHW", alpha=0.02).to(dev)
+    with sd.sharded_calibration():
+        for b in wide[rank::world]:
+            qa.update_observer(b)
+        sa, za = qa.calc_qparams()
+    for b in wide:
+        qb.update_observer(b)
+    sb, zb = qb.calc_qparams()
+    ok["pct/300_channels"] = torch.equal(sa, sb) and torch.equal(za, zb)
+
+    # ---- a MODEL's observers in lock step: collectives per model, not per quantizer ----
+    class _Deep(torch.nn.Module):
+        def __init__(self, aq, n_ops):
+            super().__init__()
+
+            class Op(torch.nn.Module):
+                def __init__(self, mod):
+                    super().__init__()
+                    self.fwd = mod
+                    self.input_quantizer = aq()
+
+                def forward(self, x):
+                    return torch.relu(self.fwd(self.input_quantizer(x)))
+
+            torch.manual_seed(11)
+            self.ops = torch.nn.Sequential(*[Op(torch.nn.Conv2d(3 if i == 0 else 8, 8, 3, padding=1)) for i in range(n_ops)])
+
+        def forward(self, x):
+            return self.ops(x)
+
+    for tag, aq, limit in (("minmax", lambda: _mk("per-tensor-affine", 8, "MINMAX"), 1),
+                           ("mse", lambda: _mk("per-tensor-symmetric", 8, "MSE"), 2),
+                           ("percentile", lambda: _mk("per-tensor-affine", 8, "PERCENTILE", alpha=1e-3), 4)):
+        m_sh = _Deep(aq, 6).to(dev)
+        m_one = _Deep(aq, 6).to(dev)
+        sd.reset_stats()
+        res_sh = DeviceCalibrator(m_sh).calibrate(imgs[rank::world], sharded=True)
+        n_coll = sd.stats["collectives"]
+        res_one = DeviceCalibrator(m_one).calibrate(imgs)
+        good = sorted(res_sh) == sorted(res_one) and len(res_sh) == 6
+        for k in res_one:
+            good = good and torch.equal(res_sh[k][0], res_one[k][0]) and torch.equal(res_sh[k][1], res_one[k][1])
+        ok["lockstep/" + tag] = bool(good)
+        # six quantizers: min-max 1 collective, MSE 2 (MAX + fp64 SUM), percentile (fp32 activations) sample + 2 rounds
+        # (+1 when a window missed) -- whatever the number of quantizers
+        ok["lockstep/%s/collectives=%d<=%d" % (tag, n_coll, limit)] = n_coll <= limit
+
     torch.save(ok, os.path.join(tmp, "rank%d.pt" % rank))
     dist.barrier()
     dist.destroy_process_group()
@@ -155,4 +244,4 @@ def test_observer_classes_two_ranks_on_device(tmp_path):
         ok = torch.load(os.path.join(str(tmp_path), "rank%d.pt" % r))
         bad = [k for k, v in ok.items() if not v]
         assert not bad, (r, bad)
-        assert len(ok) == len(CASES) + 3
+        assert len(ok) >= len(CASES) + 3 + 18 + 5 + 6

@@ -399,16 +399,3 @@ def test_lsq_export_branch_builds_constants_without_a_host_round_trip():
     y = q(x)
     want = torch.fake_quantize_per_channel_affine(x, torch.tensor([0.1, 0.2, 0.05]), torch.tensor([0, 7, -8], dtype=torch.int32), 0, -128, 127)
     assert y.shape == want.shape
-
-
-def test_sharded_per_channel_percentile_is_refused_beyond_8mb_of_histograms(monkeypatch):
-    """the sharded protocol's int64 [C, 2, 2048] histogram is 134 MB per pass at C = 4096"""
-    from sparsebit_amd import dist as sbq_dist
-    from sparsebit_amd import lib as L
-    from sparsebit_amd.config import quantizer_config
-    from sparsebit_amd.quantizers import build_quantizer
-
-    q = build_quantizer(quantizer_config("per-channel-symmetric", 8, "uniform", "PERCENTILE", "weight"))
-    monkeypatch.setattr(sbq_dist, "active", lambda: True)
-    with pytest.raises(L.SbqError, match="sharded per-channel percentile"):
-        q.observer._radix_minmax([torch.zeros(4096, 16)])

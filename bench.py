@@ -437,12 +437,13 @@ def main():
     # vector-ALU rate of the MSE kernel, from the committed counter pass (tools/rocprof_bench.sh)
     extras["mse_kernel_valu"] = pmc_extra("mse_partial_kernel")  # SQ_INSTS_VALU of the committed counter pass
 
-    # ---- BASELINE configs 2-5: every leg with its own time, algorithmic bytes, roofline fraction and an oracle
+    # ---- BASELINE configs 1-5: every leg with its own time, algorithmic bytes, roofline fraction and an oracle
     #      gate computed in this run (bench_configs.py).  Rank 0 only: the oracle legs are host work.
     if rank == 0:
         extras["headline_gates"] = gates
     if rank == 0 and not args.quick:
         extras["configs"] = {
+            "config1_resnet18_minmax_trt": BC.config1_resnet18_minmax(ctx),
             "config2_mse_per_channel": BC.config2_mse(ctx),
             "config3_percentile": BC.config3_percentile(ctx),
             "config4_gptq_4bit_g128_B1": BC.config4_gptq(ctx),

@@ -9,12 +9,13 @@ here runs AFTER that region, on rank 0's GPU as well as every other rank's, and 
     GBps, frac          algorithmic_bytes / us, and that over the 8 TB/s HBM3E peak
     parity, gate        a boolean oracle check computed in this very run, and what it compared
 
-so that BENCH_rNN.json alone answers "how fast, against which roof, and is it right" for configs 2-5.  The oracle
+so that BENCH_rNN.json alone answers "how fast, against which roof, and is it right" for configs 1-5.  The oracle
 (oracle/: the reference's CPU algorithm, pinned to the reference's own outputs by tests/golden/) is used here as
 the CHECKER only; every timed call goes through the C ABI of libsbq.so with buffers that are already in HBM, and
 inputs rotate through more than the 256 MiB Infinity Cache wherever the working set is smaller than that.
 
 Reference ops behind the legs:
+  config 1  observers/minmax.py:14-25 (streaming, per tensor), quantizers/quant_tensor.py:128-156 (TensorRT backend)
   config 2  observers/mse.py:28-63 (80 candidates per channel)
   config 3  observers/percentile.py:16-46 over the cached calibration batches (DeiT-small: 64 x 197 x 384)
   config 4  large_language_models/llama/quantization/utils/quant.py:281-307 -> cuda/cuda_kernel_4bit.cu:36-180
@@ -145,6 +146,129 @@ def headline_gates(c):
         "scale_zp_bit_exact_all_rows": g_qparams,
         "all": bool(g_q and g_dq and g_bf16 and g_minmax and g_qparams),
     }
+
+
+# ------------------------------------------------------------------------------------------------------
+# config 1: ResNet-18 PTQ 8w8a, min-max observers, TensorRT backend (examples/post_training_quantization/imagenet1k/
+# basecase/qconfig.yaml: W per-channel-symmetric, A per-tensor-symmetric, fp32 model) -- the GPU side of the
+# reference's own CPU-runnable case: streaming per-tensor min-max over the calibration batches of the largest
+# activation, per-tensor int8 QDQ of that activation at batch 256, per-channel QDQ of the largest conv weight
+# ------------------------------------------------------------------------------------------------------
+def config1_resnet18_minmax(c):
+    from oracle import oracle as O
+
+    L, lib, ops = c.L, c.lib, c.ops
+    out = {}
+    g = torch.Generator().manual_seed(11)
+    # -- (a) the observer: four calibration batches 64 x 64 x 56 x 56 fp32 of the stem's output (observers/minmax.py:14-25
+    #    per tensor; calibration.py:109-115 feeds them batch by batch).  Eight batches rotate (411 MB > Infinity Cache).
+    shape = (64, 64, 56, 56)
+    n_b = shape[0] * shape[1] * shape[2] * shape[3]
+    host_b = [torch.relu(torch.randn(shape, generator=g)) * (1.0 + 0.25 * i) for i in range(2)]
+    batches = []
+    for i in range(8):
+        b = host_b[i % 2].to(c.dev)
+        batches.append(b if i < 2 else torch.roll(b.reshape(-1), i).reshape(shape).contiguous())
+    mn_o = torch.empty(8, dtype=torch.float32, device=c.dev)
+    mx_o = torch.empty(8, dtype=torch.float32, device=c.dev)
+    ws = torch.empty(max(lib.sbq_stats_workspace_bytes(1, 1, n_b), 16), dtype=torch.uint8, device=c.dev)
+
+    def stats4(i):
+        for j in range(4):
+            k = (4 * i + j) % 8
+            lib.sbq_channel_stats(L.ptr(batches[k]), L.F32, 1, 1, n_b, L.ptr(mn_o[k:k + 1]), L.ptr(mx_o[k:k + 1]), None, L.ptr(ws),
+                                  ws.numel(), c.st)
+
+    us = c.timed(stats4, 20, warm=4)
+    stats4(0)
+    stats4(1)
+    torch.cuda.synchronize(c.dev)
+    ok = True
+    for k in range(8):
+        ref = host_b[k % 2].numpy()
+        ok = ok and float(mn_o[k]) == float(ref.min()) and float(mx_o[k]) == float(ref.max())
+    # the streaming fold itself, through the product observer (consume: statistics kernel + minimum / maximum)
+    from sparsebit_amd.common import Backend
+    from sparsebit_amd.config import quantizer_config
+    from sparsebit_amd.quantizers import build_quantizer
+
+    qa = build_quantizer(quantizer_config("per-tensor-symmetric", 8, observer="MINMAX", target="feature", layout="NCHW"))
+    qa.set_backend(Backend.TENSORRT)
+    qa.dims = 4
+    for k in range(4):
+        qa.observer.consume(batches[k])
+    s_a, z_a = qa.calc_qparams()
+    mn_r = min(float(host_b[k % 2].min()) for k in range(4))
+    mx_r = max(float(host_b[k % 2].max()) for k in range(4))
+    s_ref, z_ref = O.qparams_from_minmax(np.array([mn_r], np.float32), np.array([mx_r], np.float32), -128, 127, True)
+    ok = ok and float(s_a) == float(s_ref[0]) and float(z_a) == float(z_ref[0])
+    out["minmax_observer_4_batches_64x64x56x56_fp32"] = _entry(
+        us, 4 * n_b * 4, ok, "min / max of every batch == numpy; streaming observer's (scale, zp) over 4 batches == oracle "
+        "(observers/minmax.py:14-25 + base.py:63-79)", elements=4 * n_b, launches=4)
+    # -- (b) the quantizer on the activation at the reference's calibration batch size 256 (256 x 64 x 56 x 56 =
+    #    51.4 M fp32 elements): per-tensor symmetric int8, TensorRT backend (quant_tensor.py:128-156), fp32 out.
+    #    Two in / out pairs rotate (822 MB).
+    n_a = 4 * n_b
+    xa = [torch.cat([batches[k] for k in (0, 1, 0, 1)]).contiguous(), torch.cat([batches[k] for k in (1, 0, 1, 0)]).contiguous()]
+    ya = [torch.empty_like(x) for x in xa]
+    sa = s_a.reshape(1).contiguous()
+    za = z_a.reshape(1).contiguous()
+
+    def qdq_a(i):
+        k = i % 2
+        return lib.sbq_quant_pertensor_forward(L.ptr(xa[k]), L.F32, L.ptr(ya[k]), L.F32, None, L.Q_NONE, L.ptr(sa), L.ptr(za), n_a,
+                                               -128, 127, 0, c.st)
+
+    us = c.timed(qdq_a, 20, warm=4)
+    L.check(qdq_a(0))
+    torch.cuda.synchronize(c.dev)
+    m = 1 << 20
+    idx0 = n_b - m // 2  # a stretch that crosses the first batch boundary
+    dq_ref, _ = O.qdq(xa[0].reshape(-1)[idx0:idx0 + m].cpu().numpy().reshape(1, -1), s_ref, z_ref, -128, 127, 0)
+    ok_a = _same(ya[0].reshape(-1)[idx0:idx0 + m].cpu().numpy().reshape(1, -1), dq_ref)
+    out["qdq_activation_256x64x56x56_fp32_per_tensor"] = _entry(
+        us, n_a * 8, ok_a, "2^20 elements of the fp32 output == oracle qdq bit for bit (quant_tensor.py:128-156 at zp = 0)",
+        elements=n_a)
+    # the same call through Quantizer.forward (TensorRT backend): what a reference user's model pays per layer
+    qa.enable_quant()
+    with torch.no_grad():
+        qa(xa[0])
+        us_q = c.timed(lambda i: qa(xa[i % 2]), 20, warm=4)
+    out["qdq_activation_256x64x56x56_fp32_per_tensor"]["through_quantizer_forward_us"] = round(us_q, 2)
+    del xa, ya
+    # -- (c) the largest conv weight, 512 x 512 x 3 x 3 fp32, per channel symmetric (W of the yaml)
+    wshape = (512, 512, 3, 3)
+    n_w = 512 * 512 * 9
+    host_w = [torch.randn(wshape, generator=g) * 0.02 for _ in range(2)]
+    wsd = []
+    for i in range(32):  # 32 x 2 x 9.4 MB = 604 MB in rotation
+        wsd.append(torch.roll(host_w[i % 2].reshape(512, -1), i // 2, 1).reshape(wshape).contiguous().to(c.dev))
+    ywd = [torch.empty_like(w) for w in wsd]
+    qw = build_quantizer(quantizer_config("per-channel-symmetric", 8, observer="MINMAX", target="weight"))
+    qw.set_backend(Backend.TENSORRT)
+    qw.update_observer(wsd[0])
+    s_w, z_w = qw.calc_qparams()
+    s_w = s_w.reshape(-1).contiguous()
+    z_w = z_w.reshape(-1).contiguous()
+
+    def qdq_w(i):
+        k = (i % 16) * 2  # the copies that share weight 0's row statistics
+        return lib.sbq_quant_perchannel_forward(L.ptr(wsd[k]), L.F32, L.ptr(ywd[k]), L.F32, None, L.Q_NONE, L.ptr(s_w), L.ptr(z_w), 1,
+                                                512, 4608, -128, 127, 0, c.st)
+
+    us = c.timed(qdq_w, 200, warm=20)
+    L.check(qdq_w(0))
+    torch.cuda.synchronize(c.dev)
+    wf = host_w[0].numpy().reshape(512, -1)
+    mn_r, mx_r = O.minmax(wf, 0, True)
+    s_r, z_r = O.qparams_from_minmax(mn_r, mx_r, -128, 127, True)
+    dq_ref, _ = O.qdq(wf, s_r, z_r, -128, 127, 0)
+    ok_w = bool(np.array_equal(s_w.cpu().numpy(), s_r)) and _same(ywd[0].cpu().numpy().reshape(512, -1), dq_ref)
+    out["qdq_weight_512x512x3x3_fp32_per_channel"] = _entry(
+        us, n_w * 8, ok_w, "scale of every channel and the whole fp32 output == oracle (minmax.py:14-25, base.py:63-79, "
+        "quant_tensor.py:128-156)", elements=n_w, note="9.4 MB in + 9.4 MB out: launch-latency bound (what the model-wide "
+        "launch of extras.resnet50_*_weights_one_launch_us removes)")
+    return out
 
 
 # ------------------------------------------------------------------------------------------------------
@@ -298,7 +422,7 @@ def config4_gptq(c):
         qws, scs, zrs, x = _gptq_problem(in_f, out_f, 4 + in_f % 97, c.dev, copies)
         xd = x.to(c.dev)
         y = torch.zeros(1, out_f, dtype=torch.float32, device=c.dev)
-        ws = torch.zeros(max(lib.sbq_gptq_workspace_bytes(1, in_f, out_f), 16), dtype=torch.uint8, device=c.dev)
+        ws = L.fresh_workspace(max(lib.sbq_gptq_workspace_bytes(1, in_f, out_f), 16), c.dev)
         args = [(L.ptr(xd), L.ptr(qws[j]), L.ptr(y), L.ptr(scs[j]), L.ptr(zrs[j])) for j in range(copies)]
 
         def run(i):
@@ -340,7 +464,7 @@ def config4_gptq(c):
         xd = x.to(c.dev)
         ys = [torch.zeros(1, o, dtype=torch.float32, device=c.dev) for o in outs]
         total = sum(outs)
-        ws = torch.zeros(max(lib.sbq_gptq_workspace_bytes(1, in_f, total), 16), dtype=torch.uint8, device=c.dev)
+        ws = L.fresh_workspace(max(lib.sbq_gptq_workspace_bytes(1, in_f, total), 16), c.dev)
         n = len(outs)
         arr = lambda ts: (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts])  # noqa: E731
         outf = (ctypes.c_int64 * n)(*outs)
@@ -403,7 +527,7 @@ def config5_mask_lsq(c):
     # -- threshold: k-th smallest |w| (l1norm.py:21-23), the whole tensor against the oracle's sort
     idx = min(int(c.n * 0.5), c.n - 1)
     mask_ref, thr_ref = O.l1_mask(wf, 0.5)
-    ws = torch.zeros(max(lib.sbq_radix_select_workspace_bytes(1, 1), 16), dtype=torch.uint8, device=c.dev)
+    ws = L.fresh_workspace(max(lib.sbq_radix_select_workspace_bytes(1, 1), 16), c.dev)
     thr = torch.empty((), dtype=torch.float32, device=c.dev)
 
     def kth(i):

@@ -6,9 +6,12 @@
  * hipStream_t (passed as void*); the few descriptor arrays (the item lists of the
  * model-wide launches, a list of calibration batches, a step's gradient pointers)
  * are HOST arrays and say so where they are declared.  The caller owns and
- * allocates every buffer (the library never allocates, frees or retains a
- * pointer) and all launches are asynchronous on `stream`.  Every function returns
- * an sbq_status (0 == OK) unless it is a size query.
+ * allocates every buffer (the library never allocates or frees, and keeps no
+ * pointer it would dereference later) and all launches are asynchronous on
+ * `stream`.  Every function returns an sbq_status (0 == OK) unless it is a size query.
+ * Host-side state: none that changes results -- a cache of device attributes, a counter that
+ * numbers selections, the address registry of the zero-contract workspaces (sbq_workspace_release
+ * below) and the per-THREAD tuning knobs of section 6.
  *
  * Reference interfaces replaced (paths relative to the Sparsebit tree):
  *   - pybind module `fake_quant` (sparsebit/quantization/torch_extensions/
@@ -56,7 +59,8 @@ typedef enum {
   SBQ_ERR_ARG = 4,       /* inconsistent sizes / ranges */
   SBQ_ERR_WORKSPACE = 5, /* workspace too small or misaligned */
   SBQ_ERR_LAUNCH = 6,    /* hipGetLastError() != hipSuccess after launch */
-  SBQ_ERR_ALIGN = 7      /* pointer not aligned to its element size */
+  SBQ_ERR_ALIGN = 7,     /* pointer not aligned to its element size */
+  SBQ_ERR_BUSY = 8       /* a zero-contract workspace is still in use by a call on another stream */
 } sbq_status;
 
 int sbq_version(void);
@@ -420,9 +424,10 @@ int sbq_radix_finish(const int64_t* state, int64_t C, int n_sel, int use_abs,
  * inner]; ranks from the first histogram as in sbq_percentile_ranks; min / max [C] with the
  * "no negative -> 0" rule of percentile.py:30-43); sbq_kth_value is the 1-indexed k-th smallest
  * of x (of |x| with use_abs) -- the L1 masker's threshold, l1norm.py:21-24. */
-/* Workspace contract of these two calls (as for the mat-vec's arrival counters, section 5): the workspace must be
- * ZERO before its first use (hipMemset once), every call leaves it reusable by the next one, and it must not be
- * shared by calls that can run concurrently (different streams).  A whole-tensor selection (C == 1) of a 16-bit
+/* Workspace contract of these two calls (as for the mat-vec's arrival counters, section 5): the engine's part of the
+ * workspace is a zero-contract region (section 5b): the library zeroes it the first time it sees it, every call
+ * leaves it reusable by the next one, and a call on another stream while the last one's stream is still busy is
+ * refused with SBQ_ERR_BUSY.  A whole-tensor selection (C == 1) of a 16-bit
  * tensor is ONE launch: every workgroup brackets the wanted ranks from the same 2048-pack sample, sweeps its slabs
  * once, and the last workgroup to arrive resolves the ranks (fp32: one such launch per 11 key bits that remain).
  * Layout: [whole-tensor engine: the part that must start zero][fixed-digit passes (C > 1): self-initialising], so
@@ -508,9 +513,9 @@ int sbq_gptq_mse_search(const void* x, int x_dtype, int64_t rows, int64_t inner,
                         void* workspace, size_t workspace_bytes, void* stream);
 
 /* Workspace contract: its first SBQ_GPTQ_COUNTER_BYTES bytes are arrival counters of the
- * single-launch K-split fold; they must be ZERO before the first call (allocate with
- * hipMemset once), every call leaves them zero, and a workspace must not be shared by calls
- * that can run concurrently (different streams). */
+ * single-launch K-split fold: a zero-contract region (section 5b) -- zeroed by the library the first
+ * time it sees the workspace, left zero by every call, and refused with SBQ_ERR_BUSY when a call on
+ * another stream may still be using it. */
 #define SBQ_GPTQ_COUNTER_BYTES 262144
 size_t sbq_gptq_workspace_bytes(int64_t batch, int64_t in_features, int64_t out_features);
 int sbq_vecquant4matmul(const float* x, const int32_t* qweight, float* out,
@@ -579,7 +584,21 @@ int sbq_dist_select_advance(const int64_t* round_record, int x_dtype, int n_sel,
                             void* stream);
 
 /* ------------------------------------------------------------------ *
- * 6. Launch tuning (benchmarks only; defaults are chosen per shape)
+ * 5b. Zero-contract workspaces
+ *
+ *  The workspaces of sbq_percentile_select / sbq_kth_value / sbq_group_kth_value (whole-tensor engine) and of the
+ *  GPTQ mat-vecs hold arrival counters and histogram copies that every call expects zero and leaves zero.  The
+ *  library keeps a registry of the region ADDRESSES it has been handed (it owns nothing):
+ *    - first sight of a region: the library zeroes it itself on the call's stream (no hipMemset by the caller);
+ *    - a region belongs to the stream of its last call; a call on another stream while that stream still has work
+ *      returns SBQ_ERR_BUSY instead of racing for the counters (use one workspace per stream);
+ *    - sbq_workspace_release(ws, bytes): forget every region inside [ws, ws + bytes) -- call it before freeing the
+ *      memory, or after anything else wrote to it; the next call treats it as new and zeroes it again.
+ * ------------------------------------------------------------------ */
+int sbq_workspace_release(const void* workspace, size_t workspace_bytes);
+
+/* ------------------------------------------------------------------ *
+ * 6. Launch tuning (benchmarks only; defaults are chosen per shape).  Knobs are per calling THREAD.
  * ------------------------------------------------------------------ */
 /* knob 0: forward-QDQ variant override (-1 = auto). knob 1: grid cap (0 = auto; in the GPTQ
  * mat-vec: K split when < 128, number of persistent workers when >= 128).

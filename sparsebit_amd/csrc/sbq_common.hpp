@@ -466,6 +466,9 @@ __device__ __forceinline__ float key_float(uint32_t k) {
 // ---- host side ---------------------------------------------------------------------
 int check_launch();  // hipGetLastError -> sbq_status, records the error string
 int knob(int which);
+// zero-contract workspace regions (sbq_core.hip): zeroes a region the library has not seen before, refuses one that a
+// call on another stream may still be using (SBQ_ERR_BUSY)
+int workspace_guard(void* region, size_t bytes, hipStream_t st);
 uint32_t cu_count();  // compute units of the current device
 // sample-guided windowed selection of a whole tensor (sbq_select_win.hip)
 size_t win_select_workspace_bytes();

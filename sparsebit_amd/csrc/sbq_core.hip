@@ -4,11 +4,69 @@
 
 #include "sbq_common.hpp"
 
+#include <mutex>
+#include <vector>
+
 namespace sbq {
 namespace {
 thread_local char g_last_hip_error[128] = "";
-std::atomic<int> g_knobs[4] = {{-1}, {0}, {0}, {0}};
+// Tuning knobs are per calling THREAD (benchmarks / A-B runs set them around their own calls): a host with several
+// threads cannot have one thread's experiment change the kernels another thread's calls dispatch.
+thread_local int g_knobs[4] = {-1, 0, 0, 0};
+
+// ---- zero-contract workspaces ---------------------------------------------------------------------------------
+// The whole-tensor selection engine and the GPTQ mat-vec keep arrival counters / histogram copies in caller memory
+// that must be zero when a call starts and that every call leaves zero.  Handed a dirty region, or one that another
+// stream's call is still using, the kernels would return a wrong rank or a wrong sum -- silently.  So the library
+// remembers which regions it has seen (address values only: nothing is owned, dereferenced or freed here):
+//   * a region seen for the first time is zeroed by the library, on the call's stream, in front of the launch --
+//     callers no longer have to hipMemset it;
+//   * a region is bound to the stream of its last call; a call on ANOTHER stream is accepted only when that stream
+//     is idle (hipStreamQuery), else SBQ_ERR_BUSY -- "not shared by calls that can run concurrently" is checked, not
+//     assumed;
+//   * sbq_workspace_release() forgets a region (before freeing it, or after writing to it).
+struct WsEntry {
+  int dev;
+  char* begin;
+  size_t bytes;  // zeroed so far
+  hipStream_t stream;
+};
+std::mutex g_ws_mutex;
+std::vector<WsEntry> g_ws;
 }  // namespace
+
+int workspace_guard(void* region, size_t bytes, hipStream_t st) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  char* begin = static_cast<char*>(region);
+  std::lock_guard<std::mutex> lock(g_ws_mutex);
+  for (WsEntry& e : g_ws) {
+    if (e.dev != dev || e.begin != begin) continue;
+    if (e.stream != st) {
+      if (hipStreamQuery(e.stream) == hipErrorNotReady) return SBQ_ERR_BUSY;
+      (void)hipGetLastError();  // (a stream that no longer exists is idle too)
+      e.stream = st;
+    }
+    if (bytes > e.bytes) {
+      if (hipMemsetAsync(begin + e.bytes, 0, bytes - e.bytes, st) != hipSuccess) return check_launch();
+      e.bytes = bytes;
+    }
+    return SBQ_OK;
+  }
+  // regions overlapping the new one are stale (the memory was freed and handed out again)
+  for (size_t i = 0; i < g_ws.size();) {
+    WsEntry& e = g_ws[i];
+    if (e.dev == dev && e.begin < begin + bytes && begin < e.begin + e.bytes) {
+      g_ws[i] = g_ws.back();
+      g_ws.pop_back();
+    } else {
+      ++i;
+    }
+  }
+  if (hipMemsetAsync(begin, 0, bytes, st) != hipSuccess) return check_launch();
+  g_ws.push_back(WsEntry{dev, begin, bytes, st});
+  return SBQ_OK;
+}
 
 int check_launch() {
   hipError_t e = hipGetLastError();
@@ -18,7 +76,7 @@ int check_launch() {
   return SBQ_ERR_LAUNCH;
 }
 
-int knob(int which) { return g_knobs[which & 3].load(std::memory_order_relaxed); }
+int knob(int which) { return g_knobs[which & 3]; }
 
 // compute units of the current device (cached per device ordinal; 256 on an MI355X)
 uint32_t cu_count() {
@@ -52,6 +110,7 @@ const char* sbq_strerror(int status) {
     case SBQ_ERR_WORKSPACE: return "workspace too small or misaligned";
     case SBQ_ERR_LAUNCH: return "HIP kernel launch failed";
     case SBQ_ERR_ALIGN: return "pointer not aligned to its element size";
+    case SBQ_ERR_BUSY: return "workspace is still in use by a call on another stream";
     default: return "unknown sbq status";
   }
 }
@@ -60,7 +119,26 @@ const char* sbq_last_hip_error(void) { return sbq::g_last_hip_error; }
 
 int sbq_set_tuning(int knob, int value) {
   if (knob < 0 || knob > 3) return SBQ_ERR_ARG;
-  sbq::g_knobs[knob].store(value, std::memory_order_relaxed);
+  sbq::g_knobs[knob] = value;
+  return SBQ_OK;
+}
+
+int sbq_workspace_release(const void* workspace, size_t workspace_bytes) {
+  if (!workspace) return SBQ_ERR_NULL;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const char* lo = static_cast<const char*>(workspace);
+  const char* hi = lo + workspace_bytes;
+  std::lock_guard<std::mutex> lock(sbq::g_ws_mutex);
+  for (size_t i = 0; i < sbq::g_ws.size();) {
+    const sbq::WsEntry& e = sbq::g_ws[i];
+    if (e.dev == dev && e.begin >= lo && e.begin < hi) {
+      sbq::g_ws[i] = sbq::g_ws.back();
+      sbq::g_ws.pop_back();
+    } else {
+      ++i;
+    }
+  }
   return SBQ_OK;
 }
 

@@ -1014,6 +1014,10 @@ int gptq_matmul(const float* x, const int32_t* qweight, float* out, const float*
     return SBQ_ERR_ALIGN;
   hipStream_t st = as_stream(stream);
   // workspace = [arrival counters (fixed size, zero between calls) | partial tiles]
+  {
+    const int rc = workspace_guard(workspace, kCounterBytes, st);  // zeroed at first sight, bound to its stream
+    if (rc != SBQ_OK) return rc;
+  }
   uint32_t* arrivals = static_cast<uint32_t*>(workspace);
   float* part = reinterpret_cast<float*>(static_cast<char*>(workspace) + kCounterBytes);
   const bool vec = (out_features % 4 == 0) && aligned16(qweight);
@@ -1172,6 +1176,10 @@ int gptq_matmul_multi(const float* x, int n_mats, const int32_t* const* qweights
   if (workspace_bytes < need || !aligned16(workspace)) return SBQ_ERR_WORKSPACE;
   if (reinterpret_cast<uintptr_t>(x) & 3u) return SBQ_ERR_ALIGN;
   hipStream_t st = as_stream(stream);
+  {
+    const int rc = workspace_guard(workspace, kCounterBytes, st);
+    if (rc != SBQ_OK) return rc;
+  }
   uint32_t* arrivals = static_cast<uint32_t*>(workspace);
   float* part = reinterpret_cast<float*>(static_cast<char*>(workspace) + kCounterBytes);
   constexpr int ch = kSliceK / 2;

@@ -2206,9 +2206,13 @@ int win_select_run(const void* const* shards, const int64_t* counts, int n_shard
   // than one pack
   bool one = knob(2) != 12 && (n_sel == 1 ? n_shards == 1 : percentile);
   for (int i = 0; one && i < n_shards; ++i) one = aligned16(shards[i]) && counts[i] >= kPack;
-  if (one)
+  if (one) {
+    // (the engine's region is a zero-contract workspace: zeroed by the library at first sight, bound to its stream)
+    const int rc = workspace_guard(static_cast<char*>(workspace) + kOldRegion, kOneRegion, st);
+    if (rc != SBQ_OK) return rc;
     return win_one_run(shards, counts, n_shards, x_dtype, use_abs, n_sel, percentile, alpha, k0, k1, out0, out1,
                        static_cast<char*>(workspace) + kOldRegion, st);
+  }
   char* ws = static_cast<char*>(workspace);
   WinState* state = reinterpret_cast<WinState*>(ws);
   WinSlot* slots = reinterpret_cast<WinSlot*>(ws + kStateBytes);
@@ -2480,6 +2484,10 @@ int sbq_group_kth_value(const sbq_kth_item* items, int n_items, int x_dtype, int
     if (!aligned16(items[i].x)) return SBQ_ERR_ALIGN;
   }
   hipStream_t st = as_stream(stream);
+  {
+    const int rc = workspace_guard(workspace, sbq_group_kth_workspace_bytes(n_items), st);
+    if (rc != SBQ_OK) return rc;
+  }
   const uint32_t min_shift = x_dtype == SBQ_F32 ? 0u : 16u;
   const int expected = min_shift > 0 || knob(2) == 15 ? 1 : 3;
   const int64_t cus = cu_count();

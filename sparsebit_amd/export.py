@@ -132,3 +132,52 @@ def convert_checkpoint_pack32_to_pack8(state_dict):
     """the loop of convert_pack32topack8.py:9-33 over a model state dict (every key containing
     'qweight'); returns a new dict, leaves the input untouched"""
     return {k: (pack32_to_pack8(v) if "qweight" in k else v) for k, v in state_dict.items()}
+
+
+# ---- the QDQ-ONNX artifact ------------------------------------------------------------------------
+@torch.no_grad()
+def collect_qdq(model):
+    """The constants of every enabled quantizer of a QuantOpr-style module tree (attributes input_quantizer /
+    weight_quantizer / weight -- a reference QuantModel after plugin.install(), or any look-alike):
+    -> (weights {"<module>.weight": QDQTensor with levels}, activations {"<module>.input": QDQTensor without q}).
+    What quant_model.py:222-324 leaves in the exported graph, minus the float operators between the pairs."""
+    weights, activations = {}, {}
+    for name, m in model.named_modules():
+        wq = getattr(m, "weight_quantizer", None)
+        w = getattr(m, "weight", None)
+        if wq is not None and getattr(wq, "is_enable", False) and isinstance(w, torch.Tensor):
+            if wq.dims is None:
+                wq.dims = w.dim()
+            _, rec = quantize_linear(wq, w.detach(), dequantized=False)
+            weights[name + ".weight"] = rec
+        iq = getattr(m, "input_quantizer", None)
+        if iq is not None and getattr(iq, "is_enable", False):
+            qdesc = iq.qdesc
+            lo, hi = qdesc.qrange
+            signed = lo < 0
+            scale, zero_point = iq._qparams_preprocess(None)
+            per_channel = scale.numel() > 1
+            int_dtype = torch.int8 if signed else torch.uint8
+            activations[name + ".input"] = QDQTensor(
+                None, scale.detach().reshape(-1).float() if per_channel else scale.detach().reshape(()).float(),
+                (zero_point.detach().round().reshape(-1) if per_channel else zero_point.detach().round().reshape(())).to(int_dtype),
+                qdesc.ch_axis if per_channel else None, qdesc.bit, (), signed, False)
+    return weights, activations
+
+
+def save_qdq_onnx(model_constants, path):
+    """Write a QDQ-ONNX file: `model_constants` is a module tree (collect_qdq is run on it) or a
+    (weights, activations) pair of {name: QDQTensor}.  Hand-written protobuf (sparsebit_amd/onnx_qdq.py): neither the
+    `onnx` package nor a tracing exporter is involved.  -> bytes written."""
+    from . import onnx_qdq
+
+    if isinstance(model_constants, torch.nn.Module):
+        model_constants = collect_qdq(model_constants)
+    weights, activations = model_constants
+    return onnx_qdq.save_qdq_onnx(path, weights, activations)
+
+
+def load_qdq_onnx(path):
+    from . import onnx_qdq
+
+    return onnx_qdq.load_qdq_onnx(path)

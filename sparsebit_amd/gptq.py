@@ -44,37 +44,38 @@ class Quantizer(nn.Module):
         self.maxshrink = maxshrink
         self.bit = bit
 
+    @staticmethod
+    def _geometry(shape, weight, groupsize):
+        """Where a tensor's quantization channels live.  -> (channel axis, groups per channel, broadcast shape of the
+        per-channel parameters).  Weights [out, in, ...]: axis 0, optionally `in` cut into groups of `groupsize`
+        (parameters [out, groups, 1...]); activations: axis 1 of NCHW and of [tokens, features], the last axis of
+        [batch, tokens, features] -- the layouts quant.py:55-68 / :111-132 spell out case by case."""
+        rank = len(shape)
+        if weight:
+            groups = 1 if groupsize == -1 else shape[1] // groupsize
+            lead = [shape[0], groups] if groups > 1 else [-1]
+            return 0, groups, lead + [1] * (rank - 1)
+        axis = 2 if rank == 3 else 1
+        return axis, 1, [-1 if a == axis else 1 for a in range(rank)]
+
     def find_params(self, x, weight=False, groupsize=-1):
         """quant.py:43-132, every branch: weights [out, in] (optionally in groups) and activations of rank 4 / 3 / 2,
         per channel or per tensor, symmetric or not, min-max or the `mse` grid search.  The row statistics come from
         sbq_channel_stats, the grid search from sbq_gptq_mse_search; what is left are the reference's own handful of
         elementwise ops on [rows]-sized vectors."""
-        dev = x.device
-        self.maxq = self.maxq.to(dev)
+        self.maxq = self.maxq.to(x.device)
         if groupsize != -1:
-            # groupsize must be a divisor of infeatures
-            assert weight is True and x.shape[1] % groupsize == 0
-            groups = x.shape[1] // groupsize
+            assert weight is True and x.shape[1] % groupsize == 0  # groupsize must be a divisor of infeatures
+        axis, groups, param_shape = self._geometry(x.shape, weight, groupsize)
+        n_channels = x.shape[axis]
+        if not self.perchannel:
+            rows = x.reshape(1, -1)  # one row: the whole tensor
+        elif weight:
+            rows = x.reshape(-1, groupsize) if groups > 1 else x.flatten(1)
         else:
-            groups = 1
-        shape = x.shape
-        if self.perchannel:
-            if weight:
-                if groups > 1:
-                    x = x.reshape((-1, groupsize))
-                x = x.flatten(1)
-            else:
-                if len(shape) == 4:
-                    x = x.permute([1, 0, 2, 3])
-                    x = x.flatten(1)
-                if len(shape) == 3:
-                    x = x.reshape((-1, shape[-1])).t()
-                if len(shape) == 2:
-                    x = x.t()
-        else:
-            x = x.flatten().unsqueeze(0)
-        x = x.contiguous()  # [rows, inner]: what the kernels read
-        xmin, xmax, _ = ops.channel_stats(x, 0, True)  # one read of x
+            rows = x.movedim(axis, 0).flatten(1)
+        rows = rows.contiguous()  # [rows, inner]: what the kernels read
+        xmin, xmax, _ = ops.channel_stats(rows, 0, True)  # one read of x
         zero_t = torch.zeros_like(xmin)
         xmin = torch.minimum(xmin, zero_t)
         xmax = torch.maximum(xmax, zero_t)
@@ -84,40 +85,15 @@ class Quantizer(nn.Module):
         both0 = (xmin == 0) & (xmax == 0)
         xmin = torch.where(both0, torch.full_like(xmin, -1), xmin)
         xmax = torch.where(both0, torch.full_like(xmax, +1), xmax)
-        self.scale = (xmax - xmin) / self.maxq
-        if self.sym:
-            self.zero = torch.full_like(self.scale, (self.maxq + 1) / 2)
-        else:
-            self.zero = torch.round(-xmin / self.scale)
+        scale = (xmax - xmin) / self.maxq
+        zero = torch.full_like(scale, (self.maxq + 1) / 2) if self.sym else torch.round(-xmin / scale)
         if self.mse:
-            self.scale = self.scale.contiguous()
-            self.zero = self.zero.contiguous()
-            ops.gptq_mse_search(x, xmin.contiguous(), xmax.contiguous(), int(self.maxq), self.sym, self.scale, self.zero,
+            scale, zero = scale.contiguous(), zero.contiguous()
+            ops.gptq_mse_search(rows, xmin.contiguous(), xmax.contiguous(), int(self.maxq), self.sym, scale, zero,
                                 self.norm, self.grid, int(self.maxshrink * self.grid))
-        if not self.perchannel:
-            if weight:
-                tmp = shape[0]
-            else:
-                tmp = shape[1] if len(shape) != 3 else shape[2]
-            self.scale = self.scale.repeat(tmp)
-            self.zero = self.zero.repeat(tmp)
-        if weight:
-            if groups > 1:
-                new_shape = [shape[0], groups] + [1] * (len(shape) - 1)
-            else:
-                new_shape = [-1] + [1] * (len(shape) - 1)
-            self.scale = self.scale.reshape(new_shape)
-            self.zero = self.zero.reshape(new_shape)
-            return
-        if len(shape) == 4:
-            self.scale = self.scale.reshape((1, -1, 1, 1))
-            self.zero = self.zero.reshape((1, -1, 1, 1))
-        if len(shape) == 3:
-            self.scale = self.scale.reshape((1, 1, -1))
-            self.zero = self.zero.reshape((1, 1, -1))
-        if len(shape) == 2:
-            self.scale = self.scale.unsqueeze(0)
-            self.zero = self.zero.unsqueeze(0)
+        if not self.perchannel:  # the one pair serves every channel
+            scale, zero = scale.repeat(n_channels), zero.repeat(n_channels)
+        self.scale, self.zero = scale.reshape(param_shape), zero.reshape(param_shape)
 
     def quantize(self, x):
         if self.ready():

@@ -182,6 +182,7 @@ _SIGNATURES = {
     "sbq_dist_select_plan": (c_int, [c_vp, c_int, c_int, c_int, c_dbl, c_i64, c_i64, c_vp, c_sz, c_vp]),
     "sbq_dist_select_sweep": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_sz, c_vp, c_vp]),
     "sbq_dist_select_advance": (c_int, [c_vp, c_int, c_int, c_int, c_dbl, c_vp, c_sz, c_vp, c_vp, c_vp, c_vp]),
+    "sbq_workspace_release": (c_int, [c_vp, c_sz]),
     "sbq_gptq_workspace_bytes": (c_sz, [c_i64, c_i64, c_i64]),
     "sbq_vecquantmatmul_multi_workspace_bytes": (c_sz, [c_i64, c_i64, c_int, c_vp]),
     "sbq_vecquant4matmul": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_vp, c_sz, c_vp]),
@@ -240,6 +241,15 @@ def check(status):
         msg = lib.sbq_strerror(status).decode()
         hip = lib.sbq_last_hip_error().decode()
         raise SbqError("libsbq: %s (status %d%s)" % (msg, status, ", HIP " + hip if hip and status == 6 else ""))
+
+
+def fresh_workspace(nbytes, device):
+    """A zero-contract workspace (include/sbq.h 5b) for the selection engine / the GPTQ mat-vec: new memory, and the
+    library is told to forget whatever it knew about that address range (torch's caching allocator hands freed
+    addresses out again: a stale registry entry would bind the new buffer to the old one's stream)."""
+    buf = torch.zeros(int(nbytes), dtype=torch.uint8, device=device)
+    load().sbq_workspace_release(ctypes.c_void_p(buf.data_ptr()), buf.numel())
+    return buf
 
 
 def dtype_id(t):

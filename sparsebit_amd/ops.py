@@ -52,7 +52,7 @@ def _gptq_workspace(device, nbytes):
     key = (device.index, torch.cuda.current_stream(device).cuda_stream)
     buf = _gptq_workspaces.get(key)
     if buf is None or buf.numel() < nbytes:
-        buf = torch.zeros(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        buf = L.fresh_workspace(max(int(nbytes), 1 << 20), device)
         _gptq_workspaces[key] = buf
     return buf
 
@@ -67,7 +67,7 @@ def _select_workspace(device, nbytes):
     key = (device.index, torch.cuda.current_stream(device).cuda_stream)
     buf = _select_workspaces.get(key)
     if buf is None or buf.numel() < nbytes:
-        buf = torch.zeros(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        buf = L.fresh_workspace(max(int(nbytes), 1 << 20), device)
         _select_workspaces[key] = buf
     return buf
 
@@ -1024,7 +1024,7 @@ def group_kth_value(tensors, ks, use_abs=False):
         key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
         ws = _group_kth_workspaces.get(key)
         if ws is None or ws.numel() < nbytes:
-            ws = torch.zeros(nbytes, dtype=torch.uint8, device=dev)  # zero before first use (include/sbq.h)
+            ws = L.fresh_workspace(nbytes, dev)
             _group_kth_workspaces[key] = ws
         vals = out if len(idx) == n else torch.empty(len(idx), dtype=torch.float32, device=dev)
         with L.device_guard(dev):

@@ -172,20 +172,31 @@ def config1_resnet18_minmax(c):
     mn_o = torch.empty(8, dtype=torch.float32, device=c.dev)
     mx_o = torch.empty(8, dtype=torch.float32, device=c.dev)
     ws = torch.empty(max(lib.sbq_stats_workspace_bytes(1, 1, n_b), 16), dtype=torch.uint8, device=c.dev)
+    states = [ops.minmax_state(c.dev) for _ in range(8)]
+
+    def stream4(i):
+        # the product path (observers/minmax.py consume): ONE launch per batch, the running state updated in place
+        for j in range(4):
+            k = (4 * i + j) % 8
+            lib.sbq_minmax_accumulate(L.ptr(batches[k]), L.F32, n_b, L.ptr(states[k]), c.st)
 
     def stats4(i):
+        # round 3's route: chunk partials + fold launch per batch (and a torch.minimum / maximum pair on top of it)
         for j in range(4):
             k = (4 * i + j) % 8
             lib.sbq_channel_stats(L.ptr(batches[k]), L.F32, 1, 1, n_b, L.ptr(mn_o[k:k + 1]), L.ptr(mx_o[k:k + 1]), None, L.ptr(ws),
                                   ws.numel(), c.st)
 
-    us = c.timed(stats4, 20, warm=4)
+    us = c.timed(stream4, 20, warm=4)
+    us_two_launch = c.timed(stats4, 20, warm=4)
     stats4(0)
     stats4(1)
     torch.cuda.synchronize(c.dev)
     ok = True
     for k in range(8):
         ref = host_b[k % 2].numpy()
+        lo, hi = ops.minmax_state_read(states[k])  # every batch went into its own state: per-batch extrema
+        ok = ok and float(lo) == float(ref.min()) and float(hi) == float(ref.max())
         ok = ok and float(mn_o[k]) == float(ref.min()) and float(mx_o[k]) == float(ref.max())
     # the streaming fold itself, through the product observer (consume: statistics kernel + minimum / maximum)
     from sparsebit_amd.common import Backend
@@ -204,7 +215,8 @@ def config1_resnet18_minmax(c):
     ok = ok and float(s_a) == float(s_ref[0]) and float(z_a) == float(z_ref[0])
     out["minmax_observer_4_batches_64x64x56x56_fp32"] = _entry(
         us, 4 * n_b * 4, ok, "min / max of every batch == numpy; streaming observer's (scale, zp) over 4 batches == oracle "
-        "(observers/minmax.py:14-25 + base.py:63-79)", elements=4 * n_b, launches=4)
+        "(observers/minmax.py:14-25 + base.py:63-79)", elements=4 * n_b, launches=4,
+        sbq_channel_stats_two_launches_per_batch_us=round(us_two_launch, 2))
     # -- (b) the quantizer on the activation at the reference's calibration batch size 256 (256 x 64 x 56 x 56 =
     #    51.4 M fp32 elements): per-tensor symmetric int8, TensorRT backend (quant_tensor.py:128-156), fp32 out.
     #    Two in / out pairs rotate (822 MB).

@@ -33,29 +33,14 @@ struct StatAcc {
   int nan;
 };
 
-template <typename T, bool FINAL>
-__global__ __launch_bounds__(kBlock) void stats_minmax_kernel(const void* __restrict__ x, StatPartial* __restrict__ part,
-                                                              float* __restrict__ min_out, float* __restrict__ max_out,
-                                                              const ChunkGeom g, uint32_t n_chunks) {
-  const int lane = threadIdx.x & (kWave - 1);
-  const uint32_t cid = blockIdx.x * kWavesPerBlock + __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);  // wave-uniform
-  if (cid >= n_chunks) return;
-  // FINAL == one chunk per channel == a [C, inner <= 4096] weight: the chunk is row `cid`, no divisions in front of
-  // the first load.  Offsets inside a chunk are 32-bit (a chunk holds at most 4096 elements).
-  uint32_t c_out = cid;
-  int64_t first = static_cast<int64_t>(cid) * g.inner;  // element index of the chunk's first element
-  uint32_t len = static_cast<uint32_t>(g.inner);
-  if constexpr (!FINAL) {
-    const ChunkPos cp = chunk_pos(g, cid);
-    c_out = cp.c;
-    first = cp.row_base + cp.begin;
-    len = static_cast<uint32_t>(cp.end - cp.begin);
-  }
-  const int64_t row_base = first;
+// min / max of one chunk (<= 4096 elements starting at element `row_base`, whole packs up to `vlen`, `len` in all) by
+// one wave: 16-bit inputs as raw bit patterns (Stat16), fp32 with v_minimum3 / v_maximum3 -- NaN propagates either way.
+template <typename T>
+__device__ __forceinline__ void minmax_chunk(const void* __restrict__ x, const int64_t row_base, const uint32_t len,
+                                             const int lane, float& mn, float& mx) {
   const uint32_t vlen = len & ~static_cast<uint32_t>(kPack - 1), end = len;
   const uint32_t begin = 0, vend = vlen;
   constexpr int U = 8;
-  float mn, mx;
   if constexpr (T::id == SBQ_F32) {
     mn = __builtin_inff();
     mx = -__builtin_inff();
@@ -109,6 +94,28 @@ __global__ __launch_bounds__(kBlock) void stats_minmax_kernel(const void* __rest
     s = stat16_wave(s);
     stat16_decode<T>(s, mn, mx);
   }
+}
+
+template <typename T, bool FINAL>
+__global__ __launch_bounds__(kBlock) void stats_minmax_kernel(const void* __restrict__ x, StatPartial* __restrict__ part,
+                                                              float* __restrict__ min_out, float* __restrict__ max_out,
+                                                              const ChunkGeom g, uint32_t n_chunks) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const uint32_t cid = blockIdx.x * kWavesPerBlock + __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);  // wave-uniform
+  if (cid >= n_chunks) return;
+  // FINAL == one chunk per channel == a [C, inner <= 4096] weight: the chunk is row `cid`, no divisions in front of
+  // the first load.  Offsets inside a chunk are 32-bit (a chunk holds at most 4096 elements).
+  uint32_t c_out = cid;
+  int64_t first = static_cast<int64_t>(cid) * g.inner;  // element index of the chunk's first element
+  uint32_t len = static_cast<uint32_t>(g.inner);
+  if constexpr (!FINAL) {
+    const ChunkPos cp = chunk_pos(g, cid);
+    c_out = cp.c;
+    first = cp.row_base + cp.begin;
+    len = static_cast<uint32_t>(cp.end - cp.begin);
+  }
+  float mn, mx;
+  minmax_chunk<T>(x, first, len, lane, mn, mx);
   if (lane == 0) {
     if constexpr (FINAL) {
       if (min_out) min_out[c_out] = mn;
@@ -117,6 +124,67 @@ __global__ __launch_bounds__(kBlock) void stats_minmax_kernel(const void* __rest
       part[cid] = StatPartial{mn, mx, 0.0};
     }
   }
+}
+
+// ---- the streaming per-tensor observer: one launch per calibration batch, nothing to fold ---------------------------
+// observers/minmax.py:14-25 per tensor over batches that arrive one by one (tools/calibration.py:109-115).  As
+// sbq_channel_stats a batch cost two launches (chunk partials, then their fold) plus the torch.minimum / maximum that
+// joined it to the running statistic: a 51 MB batch spent 6 of its 16 us outside its read.  min / max are order
+// independent, so every workgroup folds its four chunks and updates the observer's running state directly with one
+// integer atomicMax / atomicMin pair -- exact, deterministic, no second launch, and the state IS the running
+// statistic.  state: uint32[64], word 0 = the largest key so far, word 32 (its own 128-byte line) = the smallest;
+// key = the usual order-preserving map of the float's bits, with NaN sent to the top of the max word and to the
+// bottom of the min word, so that a NaN anywhere makes both results NaN like torch.min / torch.max.
+__device__ __forceinline__ uint32_t ordered_key(float f) {
+  const uint32_t b = __builtin_bit_cast(uint32_t, f);
+  return b ^ ((b & 0x80000000u) ? 0xffffffffu : 0x80000000u);
+}
+__device__ __forceinline__ float ordered_value(uint32_t k) {
+  return __builtin_bit_cast(float, k ^ ((k & 0x80000000u) ? 0x80000000u : 0xffffffffu));
+}
+constexpr int kMinWord = 32;
+template <typename T>
+__global__ __launch_bounds__(kBlock) void minmax_accumulate_kernel(const void* __restrict__ x, int64_t n, uint32_t n_chunks,
+                                                                   uint32_t* __restrict__ state) {
+  __shared__ float s_mn[kWavesPerBlock], s_mx[kWavesPerBlock];
+  const int lane = threadIdx.x & (kWave - 1);
+  const uint32_t wid = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+  const uint32_t cid = blockIdx.x * kWavesPerBlock + wid;
+  float mn = __builtin_inff(), mx = -__builtin_inff();
+  if (cid < n_chunks) {
+    const int64_t first = static_cast<int64_t>(cid) * kStatsChunk;
+    const int64_t left = n - first;
+    minmax_chunk<T>(x, first, static_cast<uint32_t>(left < kStatsChunk ? left : kStatsChunk), lane, mn, mx);
+  }
+  if (lane == 0) {
+    s_mn[wid] = mn;
+    s_mx[wid] = mx;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int w = 1; w < kWavesPerBlock; ++w) {
+      mn = __builtin_elementwise_minimum(mn, s_mn[w]);
+      mx = __builtin_elementwise_maximum(mx, s_mx[w]);
+    }
+    const uint32_t kmax = mx != mx ? 0xffffffffu : ordered_key(mx);
+    const uint32_t kmin = mn != mn ? 0u : ordered_key(mn);
+    atomicMax(state, kmax);
+    atomicMin(state + kMinWord, kmin);
+  }
+}
+__global__ void minmax_state_kernel(uint32_t* __restrict__ state, float* __restrict__ min_out, float* __restrict__ max_out) {
+  if (threadIdx.x != 0) return;
+  if (!min_out) {  // reset: the identities of max / min
+    state[0] = 0u;
+    state[kMinWord] = 0xffffffffu;
+    return;
+  }
+  const uint32_t kmax = state[0], kmin = state[kMinWord];
+  const bool nan = kmax == 0xffffffffu || kmin == 0u;
+  const float qnan = __builtin_nanf("");
+  min_out[0] = nan ? qnan : ordered_value(kmin);
+  max_out[0] = nan ? qnan : ordered_value(kmax);
 }
 
 template <typename T, bool VEC, bool FINAL>
@@ -617,6 +685,39 @@ int sbq_channel_stats(const void* x, int x_dtype, int64_t outer, int64_t C, int6
   rc = check_launch();
   if (rc != SBQ_OK || final_) return rc;
   stats_finish_kernel<<<g.C, kBlock, 0, st>>>(part, g.chunks_per_chan, min_out, max_out, abssum_out);
+  return check_launch();
+}
+
+int sbq_minmax_state_reset(uint32_t* state, void* stream) {
+  using namespace sbq;
+  if (!state) return SBQ_ERR_NULL;
+  minmax_state_kernel<<<1, kWave, 0, as_stream(stream)>>>(state, nullptr, nullptr);
+  return check_launch();
+}
+
+int sbq_minmax_accumulate(const void* x, int x_dtype, int64_t numel, uint32_t* state, void* stream) {
+  using namespace sbq;
+  if (!valid_dtype(x_dtype)) return SBQ_ERR_DTYPE;
+  if (numel < 0) return SBQ_ERR_ARG;
+  if (numel == 0) return SBQ_ERR_EMPTY;
+  if (!x || !state) return SBQ_ERR_NULL;
+  if (!aligned16(x)) return SBQ_ERR_ALIGN;  // (whole 16-byte packs: what sbq_channel_stats' fast kernel takes too)
+  const int64_t chunks = ceil_div(numel, static_cast<int64_t>(kStatsChunk));
+  if (chunks >= (1ll << 31)) return SBQ_ERR_ARG;
+  const uint32_t grid = static_cast<uint32_t>(ceil_div(chunks, static_cast<int64_t>(kWavesPerBlock)));
+  hipStream_t st = as_stream(stream);
+  int rc = dispatch_dtype(x_dtype, [&](auto tag) {
+    using T = decltype(tag);
+    minmax_accumulate_kernel<T><<<grid, kBlock, 0, st>>>(x, numel, static_cast<uint32_t>(chunks), state);
+  });
+  if (rc != SBQ_OK) return rc;
+  return check_launch();
+}
+
+int sbq_minmax_state_read(uint32_t* state, float* min_out, float* max_out, void* stream) {
+  using namespace sbq;
+  if (!state || !min_out || !max_out) return SBQ_ERR_NULL;
+  minmax_state_kernel<<<1, kWave, 0, as_stream(stream)>>>(state, min_out, max_out);
   return check_launch();
 }
 

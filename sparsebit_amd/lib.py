@@ -165,6 +165,9 @@ _SIGNATURES = {
         c_int,
         [c_vp, c_int, c_i64, c_i64, c_i64, c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp, c_sz, c_vp],
     ),
+    "sbq_minmax_state_reset": (c_int, [c_vp, c_vp]),
+    "sbq_minmax_accumulate": (c_int, [c_vp, c_int, c_i64, c_vp, c_vp]),
+    "sbq_minmax_state_read": (c_int, [c_vp, c_vp, c_vp, c_vp]),
     "sbq_mse_select": (c_int, [c_vp, c_dbl, c_vp, c_vp, c_i64, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
     "sbq_mse_select_devcount": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
     "sbq_percentile_rows": (c_int, [c_vp, c_int, c_i64, c_i64, c_dbl, c_vp, c_vp, c_vp]),

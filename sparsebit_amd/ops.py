@@ -1075,6 +1075,37 @@ class HipSelectBackend:
         return radix_finish(state, n_sel, C, use_abs)
 
 
+# ---------------------------------------------------------------------------------
+# streaming per-tensor min-max (one launch per calibration batch)
+# ---------------------------------------------------------------------------------
+def minmax_state(device):
+    """a fresh running state of the streaming per-tensor min-max observer (include/sbq.h: sbq_minmax_accumulate)"""
+    st = torch.empty(64, dtype=torch.int32, device=device)
+    with L.device_guard(device):
+        L.check(L.load().sbq_minmax_state_reset(L.ptr(st), L.stream_ptr(device)))
+    return st
+
+
+def minmax_accumulate(x, state):
+    """fold the whole tensor x into `state`: ONE launch, no fold, no temporary.  -> False when x is not eligible
+    (not contiguous / not 16-byte aligned): the caller then takes channel_stats"""
+    dev = L.require_device(x, state)
+    if not x.is_contiguous() or x.data_ptr() % 16 or x.numel() == 0:
+        return False
+    with L.device_guard(dev):
+        L.check(L.load().sbq_minmax_accumulate(L.ptr(x), L.dtype_id(x), x.numel(), L.ptr(state), L.stream_ptr(dev)))
+    return True
+
+
+def minmax_state_read(state):
+    """-> (min, max) as fp32 tensors of shape [1]"""
+    dev = L.require_device(state)
+    out = torch.empty(2, dtype=torch.float32, device=dev)
+    with L.device_guard(dev):
+        L.check(L.load().sbq_minmax_state_read(L.ptr(state), L.ptr(out[0:1]), L.ptr(out[1:2]), L.stream_ptr(dev)))
+    return out[0:1], out[1:2]
+
+
 class HipWindowBackend:
     """The device steps of select.windowed_steps (include/sbq.h section 4b): sample / plan / sweep / advance of ONE
     whole-tensor selection over this rank's shards.  All shards share a dtype; a rank may hold none (dtype given)."""

@@ -112,8 +112,10 @@ def test_gptq_mse_search_long_rows(ops, sym, bit):
     q = gptq.Quantizer()
     q.configure(bit, perchannel=False, sym=sym, mse=True)
     q.find_params(w, weight=True)
-    s_ref, z_ref, errs = _ref_find_params_mse(w.reshape(1, -1), 2 ** bit - 1, sym)
-    s_got, z_got = q.scale.reshape(-1)[0], q.zero.reshape(-1)[0]
+    # (the reference arithmetic on the HOST, like the reference's CPU path: torch's GPU `tensor / python_scalar` is a
+    # reciprocal multiply, one ulp off the correctly rounded quotient the kernels -- and torch's CPU ops -- produce)
+    s_ref, z_ref, errs = _ref_find_params_mse(w.cpu().reshape(1, -1), 2 ** bit - 1, sym)
+    s_got, z_got = q.scale.reshape(-1)[0].cpu(), q.zero.reshape(-1)[0].cpu()
     assert q.scale.shape == (1024, 1) and bool((q.scale == s_got).all())
     if not (torch.equal(s_got, s_ref[0]) and torch.equal(z_got, z_ref[0])):
         # which candidates? scale1 = p * range / maxq identifies p
@@ -125,7 +127,7 @@ def test_gptq_mse_search_long_rows(ops, sym, bit):
     # split path (inner > 16384) vs wave-per-row path on the same rows: 3 rows of 20000 vs the same data as 6 rows of 10000
     x = (torch.randn(3, 20000, generator=g) * 0.05).to(dev)
     maxq = 2 ** bit - 1
-    s1, z1, e1 = _ref_find_params_mse(x, maxq, sym)
+    s1, z1, e1 = _ref_find_params_mse(x.cpu(), maxq, sym)
     xmin = torch.minimum(x.min(1)[0], torch.zeros(3, device=dev))
     xmax = torch.maximum(x.max(1)[0], torch.zeros(3, device=dev))
     if sym:
@@ -293,3 +295,67 @@ def test_qdq_onnx_file_from_device_quantizers(tmp_path, ops):
         iq = op.input_quantizer
         assert a["bits"] == iq.bit and a["axis"] is None
         assert float(a["scale"]) == float(iq.scale.reshape(-1)[0]) and int(a["zero_point"]) == int(iq.zero_point.round().reshape(-1)[0])
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16])
+def test_streaming_minmax_state_equals_torch(ops, dtype):
+    """sbq_minmax_accumulate over batches of many sizes (ragged tails, one element, exact chunk multiples) == torch's
+    min / max of the union; NaN anywhere pins both; the signs of zero are values, not bit patterns"""
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(21)
+    sizes = [1, 7, 8, 4096, 4097, 16384 + 24, 3 * 4096 * 4, 1_000_003]
+    st = ops.minmax_state(dev)
+    lo = hi = None
+    for i, n in enumerate(sizes):
+        x = (torch.randn(n + 8, generator=g) * (1 + i)).to(dtype).to(dev)[:n]  # (a 16-byte aligned view of n elements)
+        assert ops.minmax_accumulate(x, st)
+        lo = x.float().min() if lo is None else torch.minimum(lo, x.float().min())
+        hi = x.float().max() if hi is None else torch.maximum(hi, x.float().max())
+        a, b = ops.minmax_state_read(st)
+        assert float(a) == float(lo) and float(b) == float(hi), (n, float(a), float(lo), float(b), float(hi))
+    # all negative / all positive batches into fresh states
+    for sign in (-1.0, 1.0):
+        st2 = ops.minmax_state(dev)
+        x = (sign * (torch.rand(70001, generator=g) + 0.5)).to(dtype).to(dev)
+        ops.minmax_accumulate(x, st2)
+        a, b = ops.minmax_state_read(st2)
+        assert float(a) == float(x.float().min()) and float(b) == float(x.float().max())
+    # infinities are values; NaN wins
+    x = torch.tensor([1.0, float("inf"), -2.0, float("-inf")] * 4, dtype=dtype, device=dev)
+    st3 = ops.minmax_state(dev)
+    ops.minmax_accumulate(x, st3)
+    a, b = ops.minmax_state_read(st3)
+    assert float(a) == float("-inf") and float(b) == float("inf")
+    y = torch.zeros(9000, dtype=dtype, device=dev)
+    y[8191] = float("nan")
+    ops.minmax_accumulate(y, st3)
+    a, b = ops.minmax_state_read(st3)
+    assert torch.isnan(a).all() and torch.isnan(b).all()
+    # not eligible: an unaligned view -> the caller falls back
+    assert ops.minmax_accumulate(torch.zeros(100, dtype=dtype, device=dev)[1:], ops.minmax_state(dev)) is False
+
+
+def test_streaming_observer_equals_cached_observer():
+    """observers/minmax.py consume() (one launch per batch) == the cache-then-reduce protocol, per tensor, including a
+    mix of streamed and cached batches and an unaligned batch in between"""
+    from sparsebit_amd.common import Backend
+
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(8)
+    batches = [(torch.randn(4, 16, 14, 14, generator=g) * (1 + 0.5 * i)).to(dev) for i in range(4)]
+    odd = torch.randn(1000 + 1, generator=g).to(dev)[1:]  # 4-byte aligned only
+    qa = _mk("per-tensor-affine", 8, target="feature").to(dev)
+    qb = _mk("per-tensor-affine", 8, target="feature").to(dev)
+    qa.dims = 4
+    for b in batches[:3]:
+        qa.observer.consume(b)
+    qa.observer.consume(odd)
+    qa.update_observer(batches[3])  # a cached one joins
+    for b in batches:
+        qb.update_observer(b)
+    qb.update_observer(odd)
+    sa, za = qa.calc_qparams()
+    sb, zb = qb.calc_qparams()
+    assert torch.equal(sa.reshape(-1), sb.reshape(-1)) and torch.equal(za.reshape(-1), zb.reshape(-1))
+    assert torch.equal(qa.observer.min_val.reshape(-1), qb.observer.min_val.reshape(-1))
+    assert qa.observer._state is None and qa.observer._running is None  # back to 'nothing seen'

@@ -1991,6 +1991,417 @@ __global__ __launch_bounds__(BLOCK) void win_round_kernel(const Tab tab, int n_s
   win_round_body<T, NSEL, BLOCK>(tab, n_shards, a, blockIdx.x, gridDim.x);
 }
 
+// ---- round 4: whole-tensor selection of a 16-bit tensor through a FULL histogram in LDS ---------------------------
+// win_one_kernel's sweep can only start once the plan has named the windows (plan done at 9.4 us, sweep done at
+// 13-15 us of a 21 us launch for 16.7 M elements), and every compute unit gathers the same 2048-pack sample in front
+// of its slabs -- 33 MB of L2 traffic, as much as the tensor itself, which is why the slabs only land at 9.3 us.
+// A 16-bit tensor has 65 536 keys.  Here a workgroup (1024 threads, one per compute unit, at most 65 536 elements =
+// four slabs) counts EVERY key of its elements in LDS while the slabs arrive -- 65 536 bins x 16-bit counts, two per
+// dword, 128 KB of the 160 KB; a count of 65 536 carries into the neighbour, so dword = lo + 65 536 hi always holds
+// and only "every element of the workgroup is one key" decodes wrong, which the decoded total gives away -- and
+// that histogram does not depend on any window.  The plan shrinks to ONE wave and a 256-pack sample (4 MB of L2
+// traffic) and runs beside the other waves' counting; when both are done, "the keys below the window" and "the
+// window's histogram" are LDS reads (only the occupied part of the key space is looked at: a few per cent).  From
+// there on the launch is win_one_kernel's: flush, arrival, the last arriver places the ranks (win_finish).  And a
+// window that cannot resolve its rank -- an extreme the small sample has no evidence for, or a miss -- costs a
+// RESIDENT ROUND OUT OF LDS: the narrowed windows come back with the verdict and every workgroup re-bins its own
+// histogram, no second read of the tensor (lab: tools/lab/hist16_lab.hip -- histogram complete 8 us after the first
+// workgroup starts, against 13-15 us for the sweep).  +-0 are counted per lane (ReLU outputs / pruned weights would
+// serialise 32 K adds on one LDS word: 31 us instead of 4).  When a workgroup has left a resident round (bounded
+// wait, see win_finish) the remaining ones fall back to sweeping global memory by ticket, as win_one_kernel does.
+// Takes: one 16-byte aligned shard of 8 <= n <= 65 536 x (compute units) elements; everything else stays with
+// win_one_kernel.  LDS: [SweepLds (window histograms; its pack queue aliases the first 32 KB of the full histogram:
+// the queue is only touched by the fall-back sweeps, which no longer need the histogram)][rest of the histogram].
+constexpr int kH16Block = 1024;
+constexpr uint32_t kH16Dwords = 32768;               // 65 536 keys, two 16-bit counts per dword
+constexpr uint32_t kH16PerWg = 4 * WinGeom<kH16Block>::kSlab;  // 65 536 elements
+constexpr int kH16SamplePacks = 256;                 // one wave, four packs per lane
+constexpr int kH16MiniShift = 5;                     // the sample's histogram: 2048 bins of 32 keys
+template <int NSEL>
+constexpr size_t h16_lds_bytes() {
+  using S = SweepLds<NSEL, kH16Block>;
+  return offsetof(S, queue) + static_cast<size_t>(kH16Dwords) * 4;
+}
+struct H16Plan {
+  uint32_t b_lo[kWinSel], b_hi[kWinSel];
+  uint32_t first_key;  // thread 0's first key: what a workgroup of ONE repeated key consists of
+};
+
+template <typename T, int NSEL, bool PCT>
+__global__ __launch_bounds__(kH16Block) void h16_select_kernel(const OneShard tab, const OneArgs a) {
+  constexpr int BLOCK = kH16Block;
+  constexpr int kWaves = BLOCK / kWave;
+  extern __shared__ __attribute__((aligned(16))) char h16_raw[];
+  SweepLds<NSEL, BLOCK>& swl = *reinterpret_cast<SweepLds<NSEL, BLOCK>*>(h16_raw);
+  uint32_t* hist = reinterpret_cast<uint32_t*>(&swl.queue);
+  __shared__ AdvShared adv[2];
+  __shared__ OneLds ol;
+  __shared__ H16Plan plan;
+  __shared__ uint32_t zero_word[BLOCK];  // per lane: (-0 count, +0 count) packed like their histogram dword
+  const uint32_t wg = blockIdx.x, nwg = gridDim.x;
+  const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
+  if (threadIdx.x == 0) ol.t0 = __builtin_amdgcn_s_memrealtime();
+  one_stamp(a, 0);
+#if SBQ_SEL_STAMPS != 0
+  if (threadIdx.x == 0) swl.stamps = a.stamps;
+#endif
+  const void* x = tab.ptr[0];
+  const int64_t n = a.n;
+  const int64_t n_packs = n / kPack;  // >= 1 (the host admits n >= 8)
+  const uint32_t amask2 = a.use_abs ? 0x7fff7fffu : 0xffffffffu;
+  constexpr uint32_t kZero16 = Key16<T>::kZero >> 16, kInf16 = Key16<T>::kInf >> 16;
+  static_assert((kZero16 & 1u) == 0 && (kZero16 & ((1u << kH16MiniShift) - 1u)) == 0, "-0 / +0 share a dword; -0 starts a sample bin");
+  // ---- requests: the sample (wave 0 only, in front of its slabs: a wave's loads return in order), then four slabs ----
+  const int64_t s_packs = n_packs < kH16SamplePacks ? n_packs : kH16SamplePacks;
+  u32x4 smp[4];
+  if (wid == 0) {
+    const int64_t stride = n / s_packs;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const int64_t pk = lane + m * kWave;
+      int64_t e = (pk < s_packs ? pk : 0) * stride;
+      const uint32_t h = (static_cast<uint32_t>(pk) * 2654435761u) >> 4;
+      if (stride > kPack) e += static_cast<int64_t>(h % static_cast<uint32_t>(stride - kPack + 1));
+      e &= ~static_cast<int64_t>(kPack - 1);
+      const int64_t last = (n_packs - 1) * kPack;
+      e = e < last ? e : last;
+      smp[m] = load_raw<T, false>(x, e).d[0];
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  u32x4 raw[4][WinGeom<BLOCK>::kU];
+  uint32_t okmask = 0;  // bit 2 j + u: the pack exists
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int64_t slab = static_cast<int64_t>(wg) + static_cast<int64_t>(j) * nwg;
+#pragma unroll
+    for (int u = 0; u < WinGeom<BLOCK>::kU; ++u) {
+      const int64_t pk = slab * (WinGeom<BLOCK>::kSlab / kPack) + u * BLOCK + threadIdx.x;
+      const bool there = pk < n_packs;
+      okmask |= there ? 1u << (2 * j + u) : 0u;
+      raw[j][u] = load_raw<T, true>(x, (there ? pk : n_packs - 1) * kPack).d[0];
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  one_stamp(a, 12);
+  // ---- clear: the histogram, the window histograms (lh[0] first serves as the sample's histogram), the zero words ----
+  {
+    u32x4* h4 = reinterpret_cast<u32x4*>(hist);
+#pragma unroll
+    for (int i = 0; i < static_cast<int>(kH16Dwords / 4 / BLOCK); ++i) h4[i * BLOCK + threadIdx.x] = u32x4{0, 0, 0, 0};
+    for (uint32_t i = threadIdx.x; i < static_cast<uint32_t>(NSEL * kWinBins); i += BLOCK) (&swl.lh[0][0])[i] = 0;
+    zero_word[threadIdx.x] = 0;
+    if (threadIdx.x == 0) {
+      ol.neg = 0;
+      ol.nan = 0;
+    }
+  }
+  lds_sync();
+  one_stamp(a, 13);
+  // ---- the plan: wave 0 alone, while the other 15 count ----
+  if (wid == 0) {
+    uint32_t* mini = &swl.lh[0][0];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      if (lane + m * kWave >= s_packs) continue;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const uint32_t k2 = Key16<T>::pack2(smp[m][q], amask2);
+        atomicAdd(&mini[(k2 & 0xffffu) >> kH16MiniShift], 1u);
+        atomicAdd(&mini[k2 >> (16 + kH16MiniShift)], 1u);
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    // (the lane's 32 bins are re-read from LDS where they are needed instead of living in 32 registers: the slabs'
+    // 32 registers per lane are in flight across this whole block)
+    constexpr int kPer = kWinBins / kWave;  // 32 sample bins per lane
+    const uint32_t* mine = mini + lane * kPer;
+    uint32_t t = 0, f = kWinBins - 1, l = 0;
+    for (int i = 0; i < kPer; ++i) {
+      const uint32_t b = mine[i];
+      t += b;
+      l = b ? lane * kPer + i : l;
+      f = (b && f == static_cast<uint32_t>(kWinBins) - 1u) ? lane * kPer + i : f;
+    }
+    auto add = [](uint32_t p, uint32_t q) { return p + q; };
+    const uint32_t incl = dpp_scan_u32(t, 0u, add), excl = incl - t;
+    const uint32_t S = __builtin_amdgcn_readlane(incl, kWave - 1);
+    // the sample's elements with x < 0: bins below key(-0), which starts bin kZero16 >> 5
+    constexpr uint32_t kZb = kZero16 >> kH16MiniShift;
+    uint32_t negp = 0;
+    if (lane == static_cast<int>(kZb / kPer)) {
+      negp = excl;
+      for (int i = 0; i < static_cast<int>(kZb % kPer); ++i) negp += mine[i];
+    }
+    const uint32_t neg_s = dpp_reduce_u32(negp, 0u, add);
+    // first / last occupied bin
+    f = dpp_reduce_u32(f, 0xffffffffu, [](uint32_t p, uint32_t q) { return p < q ? p : q; });
+    l = dpp_reduce_u32(l, 0u, [](uint32_t p, uint32_t q) { return p > q ? p : q; });
+    if (lane < kWinSel) {
+      plan.b_lo[lane] = 0xffffffffu;
+      plan.b_hi[lane] = 0xffffffffu;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const double Sd = static_cast<double>(S), scale = n > 0 ? Sd / static_cast<double>(n) : 0.0;
+    double r_mid[NSEL];
+    int64_t r_lo[NSEL], r_hi[NSEL];
+#pragma unroll
+    for (int s = 0; s < NSEL; ++s) {  // (uniform arithmetic, every lane: plan_derive's bracket on this sample)
+      double r;
+      if (!PCT) {
+        r = static_cast<double>(s == 0 ? a.k0 : a.k1) * scale;
+      } else {
+        const double neg = static_cast<double>(neg_s), pos = Sd - neg;
+        r = s == 0 ? __builtin_fmax(neg * a.alpha, 1.0 * scale) : Sd - pos * a.alpha;
+      }
+      const double q = Sd > 0 ? r / Sd : 0.0;
+      const double var = __builtin_fmax(r * (1.0 - (q < 1.0 ? q : 1.0)), 1.0);
+      const double m = 2.0 * 6.0 * __builtin_sqrt(var) + 16.0;
+      r_mid[s] = r;
+      r_lo[s] = static_cast<int64_t>(__builtin_floor(r - m));
+      r_hi[s] = static_cast<int64_t>(__builtin_ceil(r + m));
+#pragma unroll
+      for (int side = 0; side < 2; ++side) {
+        const int64_t rr = side == 0 ? r_lo[s] : r_hi[s];
+        if (rr >= 1 && rr > static_cast<int64_t>(excl) && rr <= static_cast<int64_t>(incl)) {
+          int64_t kk = rr - excl;
+          uint32_t b = 0;
+          for (int i = 0; i < kPer; ++i) {
+            const uint32_t c = mine[i];
+            if (kk > static_cast<int64_t>(c)) kk -= c;
+            else { b = i; break; }
+          }
+          (side == 0 ? plan.b_lo : plan.b_hi)[s] = lane * kPer + b;
+        }
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (lane < NSEL) {
+      const int s = lane;
+      uint32_t b0 = plan.b_lo[s], b1 = plan.b_hi[s];
+      const bool off_lo = r_lo[s] < 1 || b0 == 0xffffffffu, off_hi = r_hi[s] > static_cast<int64_t>(S) || b1 == 0xffffffffu;
+      constexpr uint32_t kCap = static_cast<uint32_t>(kWinBins) >> kH16MiniShift;  // 64 sample bins = 2048 keys
+      bool uncertain = false;
+      if (off_lo && off_hi) {  // a bracket wider than the sample: the occupied range, as far as a window reaches
+        b0 = f;
+        b1 = l;
+      } else if (off_lo) {  // the window's capacity spent OUTWARD from the bracket's other end
+        b0 = b1 + 1u >= kCap ? b1 + 1u - kCap : 0u;
+        uncertain = b0 > 0u;
+      } else if (off_hi) {
+        b1 = b0 + kCap - 1u < static_cast<uint32_t>(kWinBins) ? b0 + kCap - 1u : kWinBins - 1;
+        uncertain = b1 < static_cast<uint32_t>(kWinBins) - 1u;
+      }
+      if (b1 < b0) b1 = b0;
+      if (b1 - b0 + 1u > kCap) {  // wider than a window: centre it on the expected rank's neighbourhood
+        const uint32_t mid = (b0 + b1) / 2u;
+        b0 = mid >= kCap / 2u ? mid - kCap / 2u : 0u;
+        b1 = b0 + kCap - 1u;
+        uncertain = true;
+      }
+      (void)r_mid;
+      WinSel w;
+      w.lo = (b0 << kH16MiniShift) << 16;
+      const uint64_t width = static_cast<uint64_t>(b1 - b0 + 1u) << (kH16MiniShift + 16);
+      const uint64_t room = 0xffffffffull - w.lo;
+      w.span = static_cast<uint32_t>(width - 1 < room ? width - 1 : room);
+      w.shift = 16;
+      w.side = uncertain ? 8u : 0u;
+      w.k = PCT ? 0 : (s == 0 ? a.k0 : a.k1);
+      w.done = 0;
+      w.fresh = 1;
+      ol.sel[s] = w;
+    }
+    // the sample's bins become window-histogram bins again
+#pragma unroll
+    for (int i = 0; i < kPer; ++i) mini[lane * kPer + i] = 0;
+  }
+  one_stamp(a, 1);
+  // ---- count: every key of every slab, two 16-bit counts per dword; +-0 in the lane's own word ----
+  uint32_t first_key = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+#pragma unroll
+    for (int u = 0; u < WinGeom<BLOCK>::kU; ++u) {
+      if (!(okmask & (1u << (2 * j + u)))) continue;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const uint32_t k2 = Key16<T>::pack2(raw[j][u][q], amask2);
+        if (j == 0 && u == 0 && q == 0) first_key = k2 & 0xffffu;
+#pragma unroll
+        for (int hsel = 0; hsel < 2; ++hsel) {
+          const uint32_t k = hsel == 0 ? (k2 & 0xffffu) : (k2 >> 16);
+          const bool z = (k - kZero16) <= 1u;
+          uint32_t* word = z ? &zero_word[threadIdx.x] : &hist[k >> 1];
+          atomicAdd(word, (k & 1u) ? 0x10000u : 1u);
+        }
+      }
+    }
+  }
+  if (wg == 0 && wid == 1) {  // the tensor's last n % 8 elements, one per lane
+    const int64_t e = n_packs * kPack + lane;
+    if (e < n) {
+      const uint32_t k = Key16<T>::pack2(static_cast<const uint16_t*>(x)[e], amask2) & 0xffffu;
+      const bool z = (k - kZero16) <= 1u;
+      atomicAdd(z ? &zero_word[threadIdx.x] : &hist[k >> 1], (k & 1u) ? 0x10000u : 1u);
+    }
+  }
+  if (threadIdx.x == 0) plan.first_key = first_key;
+  lds_sync();
+  one_stamp(a, 2);
+  // this workgroup's elements (for the carry check): its whole packs, and the ragged tail in workgroup 0
+  int64_t n_wg = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int64_t p0 = (static_cast<int64_t>(wg) + static_cast<int64_t>(j) * nwg) * (WinGeom<BLOCK>::kSlab / kPack);
+    const int64_t p1 = p0 + WinGeom<BLOCK>::kSlab / kPack;
+    if (p0 < n_packs) n_wg += ((p1 < n_packs ? p1 : n_packs) - p0) * kPack;
+  }
+  if (wg == 0) n_wg += n - n_packs * kPack;
+  // ---- rounds: bin the histogram into the selectors' windows, flush, arrive; the last arriver places the ranks ----
+  bool signs = PCT;
+  for (uint32_t round = 1; round < 12; ++round) {
+    if (round > 1) {  // (the last arriver's placement used lh as its gathering scratch)
+      for (uint32_t i = threadIdx.x; i < static_cast<uint32_t>(NSEL * kWinBins); i += BLOCK) (&swl.lh[0][0])[i] = 0;
+      __syncthreads();
+    }
+    uint32_t lo16[NSEL], span16[NSEL], sh16[NSEL];
+    bool act[NSEL], fresh[NSEL];
+#pragma unroll
+    for (int s = 0; s < NSEL; ++s) {
+      const WinSel w = ol.sel[s];
+      act[s] = __builtin_amdgcn_readfirstlane(w.done) == 0;
+      lo16[s] = __builtin_amdgcn_readfirstlane(w.lo) >> 16;
+      span16[s] = static_cast<uint32_t>((static_cast<uint64_t>(__builtin_amdgcn_readfirstlane(w.span)) + 1ull) >> 16) - 1u;
+      sh16[s] = __builtin_amdgcn_readfirstlane(w.shift) - 16u;
+      fresh[s] = act[s] && __builtin_amdgcn_readfirstlane(w.fresh) != 0;
+      if (!act[s]) {
+        lo16[s] = 0xffffffffu;  // nothing is below 2^32 - 1 ... and nothing inside
+        span16[s] = 0;
+      }
+    }
+    uint32_t below[NSEL], neg = 0, nan = 0, total = 0;
+#pragma unroll
+    for (int s = 0; s < NSEL; ++s) below[s] = 0;
+    auto visit = [&](uint32_t key, uint32_t c) {  // c elements of this workgroup carry `key`
+      if (signs) {
+        neg += key < kZero16 ? c : 0u;
+        nan += key > kInf16 ? c : 0u;
+      }
+#pragma unroll
+      for (int s = 0; s < NSEL; ++s) {
+        const uint32_t d = key - lo16[s];
+        below[s] += key < lo16[s] ? c : 0u;
+        if (act[s] && key >= lo16[s] && d <= span16[s]) atomicAdd(&swl.lh[s][d >> sh16[s]], c);
+      }
+    };
+    {
+      const u32x4* h4 = reinterpret_cast<const u32x4*>(hist);
+#pragma unroll
+      for (int i = 0; i < static_cast<int>(kH16Dwords / 4 / BLOCK); ++i) {
+        const u32x4 v = h4[i * BLOCK + threadIdx.x];
+        if ((v[0] | v[1] | v[2] | v[3]) == 0u) continue;  // (most of the key space is empty: whole waves skip)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const uint32_t wq = v[q];
+          if (wq == 0u) continue;
+          const uint32_t key0 = ((i * BLOCK + threadIdx.x) * 4 + q) * 2;
+          const uint32_t c0 = wq & 0xffffu, c1 = wq >> 16;
+          total += c0 + c1;
+          if (c0) visit(key0, c0);
+          if (c1) visit(key0 + 1u, c1);
+        }
+      }
+      const uint32_t zw = zero_word[threadIdx.x];
+      if (zw) {
+        total += (zw & 0xffffu) + (zw >> 16);
+        if (zw & 0xffffu) visit(kZero16, zw & 0xffffu);
+        if (zw >> 16) visit(kZero16 + 1u, zw >> 16);
+      }
+    }
+    // counters: lanes -> wave -> workgroup
+    auto add32 = [](uint32_t p, uint32_t q) { return p + q; };
+    constexpr int kCnt = NSEL + 3;  // below[NSEL], neg, nan, total
+    uint32_t part[kCnt];
+#pragma unroll
+    for (int s = 0; s < NSEL; ++s) part[s] = dpp_reduce_u32(below[s], 0u, add32);
+    part[NSEL] = dpp_reduce_u32(neg, 0u, add32);
+    part[NSEL + 1] = dpp_reduce_u32(nan, 0u, add32);
+    part[NSEL + 2] = dpp_reduce_u32(total, 0u, add32);
+    uint32_t* red = reinterpret_cast<uint32_t*>(&swl.red[0][0]);  // [kCnt][kWaves] u32 (the sweep's scratch: 8-byte slots)
+    if (lane == 0) {
+#pragma unroll
+      for (int c = 0; c < kCnt; ++c) red[c * kWaves + wid] = part[c];
+    }
+    __syncthreads();
+    uint32_t tot[kCnt];
+#pragma unroll
+    for (int c = 0; c < kCnt; ++c) {
+      uint32_t t = 0;
+      for (int w = 0; w < kWaves; ++w) t += red[c * kWaves + w];
+      tot[c] = t;
+    }
+    __syncthreads();  // (red is read; the next round / win_finish may write it)
+    if (static_cast<int64_t>(tot[NSEL + 2]) != n_wg) {
+      // every element of this workgroup is ONE key (65 536 of it carried out of their half-dword): redo the binning
+      // for that single key.  (uniform over the workgroup.)
+      const uint32_t key = plan.first_key;
+      for (uint32_t i = threadIdx.x; i < static_cast<uint32_t>(NSEL * kWinBins); i += BLOCK) (&swl.lh[0][0])[i] = 0;
+      __syncthreads();
+      const uint32_t c = static_cast<uint32_t>(n_wg);
+#pragma unroll
+      for (int s = 0; s < NSEL; ++s) {
+        tot[s] = key < lo16[s] ? c : 0u;
+        if (threadIdx.x == 0 && act[s] && key >= lo16[s] && key - lo16[s] <= span16[s]) swl.lh[s][(key - lo16[s]) >> sh16[s]] = c;
+      }
+      tot[NSEL] = key < kZero16 ? c : 0u;
+      tot[NSEL + 1] = key > kInf16 ? c : 0u;
+      __syncthreads();
+    }
+    // flush: this workgroup's counters to its counter line, its non-empty bins to its histogram copy (win_sweep's)
+    WinSlot* slot = a.slots + (wg % kSlots);
+    if (threadIdx.x < static_cast<uint32_t>(NSEL)) {
+      bool mine = false;
+#pragma unroll
+      for (int s = 0; s < NSEL; ++s) mine |= static_cast<int>(threadIdx.x) == s && fresh[s];
+      unsigned long long t = 0;
+#pragma unroll
+      for (int s = 0; s < NSEL; ++s) t = static_cast<int>(threadIdx.x) == s ? tot[s] : t;
+      swl.tot[threadIdx.x] = t;
+      if (mine && t) atomicAdd(&slot->below[threadIdx.x], t);
+    } else if (signs && threadIdx.x < static_cast<uint32_t>(NSEL) + 2u) {
+      const unsigned long long t = threadIdx.x == static_cast<uint32_t>(NSEL) ? tot[NSEL] : tot[NSEL + 1];
+      swl.tot[threadIdx.x] = t;
+      if (t) atomicAdd(threadIdx.x == static_cast<uint32_t>(NSEL) ? &slot->neg : &slot->nan, t);
+    }
+#pragma unroll
+    for (int s = 0; s < NSEL; ++s) {
+      if (!act[s]) continue;
+      uint32_t* gh = a.hist + (static_cast<size_t>(wg % kCopies) * kWinSel + s) * kWinBins;
+      const uint32_t nb = (span16[s] >> sh16[s]) + 1u;
+      for (uint32_t i = threadIdx.x; i < nb; i += BLOCK) {
+        const uint32_t v = swl.lh[s][i];
+        if (v) {
+          atomicAdd(&gh[i], v);
+          swl.lh[s][i] = 0;  // clean for the next round
+        }
+      }
+    }
+    one_stamp(a, 3);
+    const bool resident = win_is_resident<NSEL>(a, ol) || round > 1;
+    const bool again = win_finish<T, NSEL, BLOCK>(tab, 1, a, wg, nwg, ol, swl, adv, signs, resident, round);
+    signs = false;
+    if (!again) break;
+    if (__builtin_amdgcn_readfirstlane(ol.part) != nwg) {
+      // somebody gave up waiting (two resident launches sharing the device): the rest sweeps global memory by ticket
+      win_resident_rounds<T, NSEL, BLOCK>(tab, 1, a, wg, nwg, ol, swl, adv, true);
+      break;
+    }
+    __syncthreads();  // ol.sel: the narrowed windows, fetched by win_finish
+  }
+  one_stamp(a, 7);
+}
+
 // ---- many selections in one launch: the L1 thresholds of a whole model ------------------------------------------
 // sparse/sparse_model.py:107-113 computes every layer's mask threshold with its own torch.sort; on the device that
 // was one selection (5 launches, 27 us) per layer -- 1.4 ms for ResNet-50's 53 weights.  Here every item is a
@@ -2072,6 +2483,26 @@ int win_engine_launch_t(int r, int n_sel, unsigned grid, hipStream_t st, const v
   return SBQ_OK;
 }
 template <typename T>
+int win_h16_launch_t(int n_sel, unsigned grid, hipStream_t st, const void* table, const void* args) {
+  if constexpr (T::id == SBQ_F32) {
+    return SBQ_ERR_ARG;
+  } else {
+    const OneShard& t = *static_cast<const OneShard*>(table);
+    const OneArgs& a = *static_cast<const OneArgs*>(args);
+    static bool once = [] {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(h16_select_kernel<T, 1, false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(h16_lds_bytes<1>()));
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(h16_select_kernel<T, 2, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(h16_lds_bytes<2>()));
+      return true;
+    }();
+    (void)once;
+    if (n_sel == 1) h16_select_kernel<T, 1, false><<<grid, kH16Block, h16_lds_bytes<1>(), st>>>(t, a);
+    else h16_select_kernel<T, 2, true><<<grid, kH16Block, h16_lds_bytes<2>(), st>>>(t, a);
+    return SBQ_OK;
+  }
+}
+template <typename T>
 int win_group_launch_t(const void* items, int cnt, char* regions, size_t region_bytes, float* out, int use_abs,
                        uint32_t min_shift, int round, int final_round, unsigned long long epoch, unsigned grid,
                        hipStream_t st) {
@@ -2100,17 +2531,22 @@ int win_engine_launch_f16(SBQ_WIN_ENGINE_ARGS);
 int win_group_launch_f32(SBQ_WIN_GROUP_ARGS);
 int win_group_launch_bf16(SBQ_WIN_GROUP_ARGS);
 int win_group_launch_f16(SBQ_WIN_GROUP_ARGS);
+#define SBQ_WIN_H16_ARGS int n_sel, unsigned grid, hipStream_t st, const void* table, const void* args
+int win_h16_launch_bf16(SBQ_WIN_H16_ARGS);
+int win_h16_launch_f16(SBQ_WIN_H16_ARGS);
 #if SBQ_WIN_PART == 0
 int win_engine_launch_f32(SBQ_WIN_ENGINE_ARGS) { return win_engine_launch_t<F32>(r, n_sel, grid, st, table, single, n_shards, args); }
 int win_group_launch_f32(SBQ_WIN_GROUP_ARGS) {
   return win_group_launch_t<F32>(items, cnt, regions, region_bytes, out, use_abs, min_shift, round, final_round, epoch, grid, st);
 }
 #elif SBQ_WIN_PART == 1
+int win_h16_launch_bf16(SBQ_WIN_H16_ARGS) { return win_h16_launch_t<BF16>(n_sel, grid, st, table, args); }
 int win_engine_launch_bf16(SBQ_WIN_ENGINE_ARGS) { return win_engine_launch_t<BF16>(r, n_sel, grid, st, table, single, n_shards, args); }
 int win_group_launch_bf16(SBQ_WIN_GROUP_ARGS) {
   return win_group_launch_t<BF16>(items, cnt, regions, region_bytes, out, use_abs, min_shift, round, final_round, epoch, grid, st);
 }
 #else
+int win_h16_launch_f16(SBQ_WIN_H16_ARGS) { return win_h16_launch_t<F16>(n_sel, grid, st, table, args); }
 int win_engine_launch_f16(SBQ_WIN_ENGINE_ARGS) { return win_engine_launch_t<F16>(r, n_sel, grid, st, table, single, n_shards, args); }
 int win_group_launch_f16(SBQ_WIN_GROUP_ARGS) {
   return win_group_launch_t<F16>(items, cnt, regions, region_bytes, out, use_abs, min_shift, round, final_round, epoch, grid, st);
@@ -2183,6 +2619,18 @@ int win_one_run(const void* const* shards, const int64_t* counts, int n_shards, 
     auto fn = x_dtype == SBQ_F32 ? win_engine_launch_f32 : (x_dtype == SBQ_BF16 ? win_engine_launch_bf16 : win_engine_launch_f16);
     return fn(r, n_sel, grid, st, &table, Tab::kSingle ? 1 : 0, n_shards, &a);
   };
+  // 16-bit tensors that fit the chip in one sitting (65 536 elements per compute unit): the full-histogram engine
+  // (h16_select_kernel).  knob 2 == 18: win_one_kernel, for A/B runs.
+  if (min_shift > 0 && n_shards == 1 && knob(2) != 18 && n >= kPack && n <= static_cast<int64_t>(kH16PerWg) * cus &&
+      (n_sel == 1 || percentile)) {
+    const int64_t slabs = ceil_div(n, slab);
+    const uint32_t g16 = static_cast<uint32_t>(ceil_div(slabs, static_cast<int64_t>(4)));
+    a.final_round = 1;
+    auto fn = x_dtype == SBQ_BF16 ? win_h16_launch_bf16 : win_h16_launch_f16;
+    rc = fn(n_sel, g16, st, &os, &a);
+    if (rc != SBQ_OK) return rc;
+    return check_launch();
+  }
   for (int r = 0; r < expected && rc == SBQ_OK; ++r) {
     a.final_round = r == expected - 1 ? 1 : 0;
     rc = n_shards == 1 ? launch(os, r) : launch(pt, r);

@@ -359,3 +359,92 @@ def test_streaming_observer_equals_cached_observer():
     assert torch.equal(sa.reshape(-1), sb.reshape(-1)) and torch.equal(za.reshape(-1), zb.reshape(-1))
     assert torch.equal(qa.observer.min_val.reshape(-1), qb.observer.min_val.reshape(-1))
     assert qa.observer._state is None and qa.observer._running is None  # back to 'nothing seen'
+
+
+# --------------------------------------------------------------------------------------
+# the full-histogram selection engine (h16_select_kernel): 16-bit tensors of up to 65 536 elements per compute unit
+# --------------------------------------------------------------------------------------
+def _kth_ref(x, k, use_abs):
+    v = x.float().abs() if use_abs else x.float()
+    return float(torch.sort(v.reshape(-1))[0][k - 1])
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_h16_engine_sizes_and_ranks(ops, dtype):
+    """every size class the engine takes -- fewer elements than a pack would hold twice, ragged tails (n % 8 != 0),
+    one workgroup, exactly one sitting of the chip (65 536 x CUs) -- at extreme, tail and bulk ranks, against torch.sort;
+    one element more than a sitting goes to win_one_kernel and agrees as well"""
+    dev = torch.device("cuda:0")
+    cus = torch.cuda.get_device_properties(dev).multi_processor_count
+    g = torch.Generator().manual_seed(77)
+    for n in (8, 9, 15, 100, 4099, 65536, 65536 + 13, 300001, 65536 * cus, 65536 * cus + 8):
+        x = (torch.randn(n, generator=g) * torch.logspace(-2, 1, n)[torch.randperm(n, generator=g)]).to(dtype).to(dev)
+        for use_abs in (False, True):
+            for k in sorted({1, 2, max(1, n // 1000), n // 3 + 1, n // 2 + 1, n - 1, n}):
+                got = float(ops.kth_value(x, k, use_abs))
+                assert got == _kth_ref(x, k, use_abs), (n, k, use_abs, got)
+        for alpha in (1e-3, 0.1, 1e-6):
+            mn, mx = ops.percentile_select([x], alpha, 0, False)
+            xf = x.float()
+            neg, pos = int((xf < 0).sum()), int((xf >= 0).sum())
+            want_mx = _kth_ref(x, n - max(round(pos * alpha), 0), False) if pos > 0 else 0.0
+            want_mn = _kth_ref(x, max(round(neg * alpha), 1), False) if neg > 0 else 0.0
+            assert float(mn) == want_mn and float(mx) == want_mx, (n, alpha, float(mn), want_mn, float(mx), want_mx)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_h16_engine_adversarial_data(ops, dtype):
+    """what breaks histograms and samples: one repeated value filling whole workgroups (a 16-bit count of 65 536
+    carries into its neighbour), zeros everywhere (ReLU), two values, sorted data, data periodic with the sample's
+    stride, NaN / inf mixed in, a single outlier the sample cannot see"""
+    dev = torch.device("cuda:0")
+    n = 65536 * 8 + 24
+    g = torch.Generator().manual_seed(5)
+    cases = {
+        "constant": torch.full((n,), 0.375),
+        "constant_neg": torch.full((n,), -3.0),
+        "all_zero": torch.zeros(n),
+        "neg_zero": torch.full((n,), -0.0),
+        "relu": torch.relu(torch.randn(n, generator=g)),
+        "two_values": torch.where(torch.rand(n, generator=g) < 0.3, torch.tensor(1.5), torch.tensor(-0.25)),
+        "sorted": torch.sort(torch.randn(n, generator=g))[0],
+        "periodic": torch.arange(n).remainder(2048).float() / 64.0 - 10.0,
+        "outlier": torch.cat([torch.randn(n - 1, generator=g) * 0.01, torch.tensor([1000.0])]),
+        "specials": torch.cat([torch.randn(n - 6, generator=g), torch.tensor([float("inf"), float("-inf"), float("nan"), float("nan"), 0.0, -0.0])]),
+        "one_block_constant": torch.cat([torch.full((65536 * 2,), 7.0), torch.randn(n - 65536 * 2, generator=g)]),
+    }
+    for name, t in cases.items():
+        x = t.to(dtype).to(dev)
+        xf = x.float()
+        srt = torch.sort(xf.reshape(-1))[0]  # NaN last, like kthvalue
+        for k in (1, 7, n // 4, n // 2 + 1, n - 7, n):
+            got = ops.kth_value(x, k, False)
+            want = srt[k - 1]
+            assert (torch.isnan(got) and torch.isnan(want)) or float(got) == float(want), (name, k, float(got), float(want))
+        a = torch.sort(xf.abs().reshape(-1))[0]
+        for k in (1, n // 2 + 1, n):
+            got = ops.kth_value(x, k, True)
+            assert (torch.isnan(got) and torch.isnan(a[k - 1])) or float(got) == float(a[k - 1]), (name, k)
+        if not torch.isnan(xf).any():
+            mn, mx = ops.percentile_select([x], 1e-3, 0, False)
+            neg, pos = int((xf < 0).sum()), int((xf >= 0).sum())
+            want_mx = float(srt[n - max(round(pos * 1e-3), 0) - 1]) if pos > 0 else 0.0
+            want_mn = float(srt[max(round(neg * 1e-3), 1) - 1]) if neg > 0 else 0.0
+            assert float(mn) == want_mn and float(mx) == want_mx, (name, float(mn), want_mn, float(mx), want_mx)
+
+
+def test_h16_engine_equals_win_one_engine(ops):
+    """knob 2 = 18 selects round 3's one-launch engine: same values on the headline tensor, k-th value and percentile"""
+    from sparsebit_amd import lib as L
+
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(0)
+    w = (torch.randn(4096, 4096, generator=g) * torch.logspace(-2, 1, 4096).unsqueeze(1)).bfloat16().to(dev)
+    res = {}
+    for knob in (0, 18):
+        L.set_tuning(2, knob)
+        try:
+            res[knob] = (float(ops.kth_value(w, w.numel() // 2 + 1, True)),) + tuple(float(v) for v in ops.percentile_select([w], 1e-3, 0, False))
+        finally:
+            L.set_tuning(2, 0)
+    assert res[0] == res[18], res

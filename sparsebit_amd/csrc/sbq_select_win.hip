@@ -2016,16 +2016,192 @@ constexpr int kH16Block = 1024;
 constexpr uint32_t kH16Dwords = 32768;               // 65 536 keys, two 16-bit counts per dword
 constexpr uint32_t kH16PerWg = 4 * WinGeom<kH16Block>::kSlab;  // 65 536 elements
 constexpr int kH16SamplePacks = 256;                 // one wave, four packs per lane
-constexpr int kH16MiniShift = 5;                     // the sample's histogram: 2048 bins of 32 keys
+constexpr int kH16MiniShift = 6;                     // the sample's histogram: 1024 bins of 64 keys
+constexpr int kH16MiniBins = 65536 >> kH16MiniShift;
 template <int NSEL>
 constexpr size_t h16_lds_bytes() {
   using S = SweepLds<NSEL, kH16Block>;
   return offsetof(S, queue) + static_cast<size_t>(kH16Dwords) * 4;
 }
 struct H16Plan {
-  uint32_t b_lo[kWinSel], b_hi[kWinSel];
+  uint32_t b_lo[kWinSel], b_hi[kWinSel], b_mid[kWinSel];
   uint32_t first_key;  // thread 0's first key: what a workgroup of ONE repeated key consists of
 };
+
+// One round of the full-histogram engine: bin this workgroup's histogram into the selectors' current windows (ol.sel),
+// flush counters and non-empty bins, arrive; the last arriver places the ranks (win_finish).  -> true when the launch is
+// to go another round with the windows win_finish left in ol.sel.
+template <typename T, int NSEL>
+__device__ __forceinline__ bool h16_round(const OneShard& tab, const OneArgs& a, const uint32_t wg, const uint32_t nwg,
+                                          const uint32_t n_wg, const uint32_t round, const bool signs,
+                                          const uint32_t* __restrict__ hist, const uint32_t* __restrict__ zero_word,
+                                          const H16Plan& plan, OneLds& ol, SweepLds<NSEL, kH16Block>& swl, AdvShared (&adv)[2]) {
+  constexpr int BLOCK = kH16Block;
+  constexpr int kWaves = BLOCK / kWave;
+  constexpr uint32_t kZero16 = Key16<T>::kZero >> 16, kInf16 = Key16<T>::kInf >> 16;
+  const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
+  if (round > 1) {  // (the last arriver's placement used lh as its gathering scratch)
+    for (uint32_t i = threadIdx.x; i < static_cast<uint32_t>(NSEL * kWinBins); i += BLOCK) (&swl.lh[0][0])[i] = 0;
+    lds_sync();
+  }
+  uint32_t lo16[NSEL], span16[NSEL], sh16[NSEL];
+  bool act[NSEL], fresh[NSEL];
+#pragma unroll
+  for (int s = 0; s < NSEL; ++s) {
+    const WinSel w = ol.sel[s];
+    // (readfirstlane returns a SIGNED int: a window in the upper half of the key space must not be shifted as one)
+    const uint32_t w_lo = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(w.lo));
+    const uint32_t w_span = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(w.span));
+    const uint32_t w_shift = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(w.shift));
+    act[s] = __builtin_amdgcn_readfirstlane(w.done) == 0;
+    lo16[s] = w_lo >> 16;
+    span16[s] = static_cast<uint32_t>((static_cast<uint64_t>(w_span) + 1ull) >> 16) - 1u;
+    sh16[s] = w_shift - 16u;
+    fresh[s] = act[s] && __builtin_amdgcn_readfirstlane(w.fresh) != 0;
+    if (!act[s]) {
+      lo16[s] = 0xffffffffu;  // nothing is below 2^32 - 1 ... and nothing inside
+      span16[s] = 0;
+    }
+  }
+  uint32_t below[NSEL], neg = 0, nan = 0, total = 0;
+#pragma unroll
+  for (int s = 0; s < NSEL; ++s) below[s] = 0;
+  auto visit = [&](uint32_t key, uint32_t c) {  // c elements of this workgroup carry `key`
+    if (signs) {
+      neg += key < kZero16 ? c : 0u;
+      nan += key > kInf16 ? c : 0u;
+    }
+#pragma unroll
+    for (int s = 0; s < NSEL; ++s) {
+      const uint32_t d = key - lo16[s];
+      below[s] += key < lo16[s] ? c : 0u;
+      if (act[s] && key >= lo16[s] && d <= span16[s]) atomicAdd(&swl.lh[s][d >> sh16[s]], c);
+    }
+  };
+  {
+    // Thread t looks at dwords t, t + 1024, t + 2048, ...: the occupied part of the key space is a few contiguous
+    // runs (a sign x a few binades), and dealt out dword by dword a run of 512 dwords is ONE dword for each of 512
+    // threads -- as four consecutive dwords per thread it was all the work of two waves (measured: 4 us, 20 us with
+    // two selectors and the sign counts, against 0.3 us for reading the whole histogram).
+    constexpr int kM = static_cast<int>(kH16Dwords / BLOCK);  // 32
+    uint32_t wv[kM];
+#pragma unroll
+    for (int m = 0; m < kM; ++m) wv[m] = hist[m * BLOCK + threadIdx.x];
+#pragma unroll
+    for (int m = 0; m < kM; ++m) {
+      const uint32_t wq = wv[m];
+      // a UNIFORM skip (scalar branch): as a per-lane condition the compiler predicates the whole body and a wave
+      // walks all 64 key slots of every lane with nothing to do (measured: 2.3 us for 32 empty iterations)
+      if (__builtin_amdgcn_ballot_w64(wq != 0u) == 0) continue;
+      const uint32_t key0 = (m * BLOCK + threadIdx.x) * 2u;
+      const uint32_t c0 = wq & 0xffffu, c1 = wq >> 16;
+      total += c0 + c1;
+      if (c0) visit(key0, c0);
+      if (c1) visit(key0 + 1u, c1);
+    }
+    const uint32_t zw = zero_word[threadIdx.x];
+    if (zw) {
+      total += (zw & 0xffffu) + (zw >> 16);
+      if (zw & 0xffffu) visit(kZero16, zw & 0xffffu);
+      if (zw >> 16) visit(kZero16 + 1u, zw >> 16);
+    }
+  }
+  one_stamp(a, 8);
+  // counters: lanes -> wave -> workgroup
+  auto add32 = [](uint32_t p, uint32_t q) { return p + q; };
+  constexpr int kCnt = NSEL + 3;  // below[NSEL], neg, nan, total
+  uint32_t part[kCnt];
+#pragma unroll
+  for (int s = 0; s < NSEL; ++s) part[s] = dpp_reduce_u32(below[s], 0u, add32);
+  part[NSEL] = dpp_reduce_u32(neg, 0u, add32);
+  part[NSEL + 1] = dpp_reduce_u32(nan, 0u, add32);
+  part[NSEL + 2] = dpp_reduce_u32(total, 0u, add32);
+  uint32_t* red = reinterpret_cast<uint32_t*>(&swl.red[0][0]);  // [kCnt][kWaves] u32 (the sweep's scratch: 8-byte slots)
+  if (lane == 0) {
+#pragma unroll
+    for (int c = 0; c < kCnt; ++c) red[c * kWaves + wid] = part[c];
+  }
+  // (LDS-only barriers: __syncthreads() also drains the vector-memory counter, and whatever the compiler spilled
+  // to scratch around here would be waited for -- microseconds)
+  lds_sync();
+  uint32_t tot[kCnt];
+#pragma unroll
+  for (int c = 0; c < kCnt; ++c) {
+    uint32_t t = 0;
+#pragma unroll
+    for (int w = 0; w < kWaves; ++w) t += red[c * kWaves + w];
+    tot[c] = t;
+  }
+  lds_sync();  // (red is read; the next round / win_finish may write it)
+  if (tot[NSEL + 2] != n_wg) {
+    // every element of this workgroup is ONE key (65 536 of it carried out of their half-dword): redo the binning
+    // for that single key.  (uniform over the workgroup.)
+    const uint32_t key = plan.first_key;
+    for (uint32_t i = threadIdx.x; i < static_cast<uint32_t>(NSEL * kWinBins); i += BLOCK) (&swl.lh[0][0])[i] = 0;
+    __syncthreads();
+    const uint32_t c = n_wg;
+#pragma unroll
+    for (int s = 0; s < NSEL; ++s) {
+      tot[s] = key < lo16[s] ? c : 0u;
+      if (threadIdx.x == 0 && act[s] && key >= lo16[s] && key - lo16[s] <= span16[s]) swl.lh[s][(key - lo16[s]) >> sh16[s]] = c;
+    }
+    tot[NSEL] = key < kZero16 ? c : 0u;
+    tot[NSEL + 1] = key > kInf16 ? c : 0u;
+    __syncthreads();
+  }
+  one_stamp(a, 9);
+  // flush: this workgroup's counters to its counter line, its non-empty bins to its histogram copy (win_sweep's)
+  WinSlot* slot = a.slots + (wg % kSlots);
+  if (threadIdx.x < static_cast<uint32_t>(NSEL)) {
+    bool mine = false;
+#pragma unroll
+    for (int s = 0; s < NSEL; ++s) mine |= static_cast<int>(threadIdx.x) == s && fresh[s];
+    unsigned long long t = 0;
+#pragma unroll
+    for (int s = 0; s < NSEL; ++s) t = static_cast<int>(threadIdx.x) == s ? tot[s] : t;
+    swl.tot[threadIdx.x] = t;
+    if (mine && t) atomicAdd(&slot->below[threadIdx.x], t);
+  } else if (signs && threadIdx.x < static_cast<uint32_t>(NSEL) + 2u) {
+    const unsigned long long t = threadIdx.x == static_cast<uint32_t>(NSEL) ? tot[NSEL] : tot[NSEL + 1];
+    swl.tot[threadIdx.x] = t;
+    if (t) atomicAdd(threadIdx.x == static_cast<uint32_t>(NSEL) ? &slot->neg : &slot->nan, t);
+  }
+#pragma unroll
+  for (int s = 0; s < NSEL; ++s) {
+    if (!act[s]) continue;
+    uint32_t* gh = a.hist + (static_cast<size_t>(wg % kCopies) * kWinSel + s) * kWinBins;
+    const uint32_t nb = (span16[s] >> sh16[s]) + 1u;
+    for (uint32_t i = threadIdx.x; i < nb; i += BLOCK) {
+      const uint32_t v = swl.lh[s][i];
+      if (v) {
+        atomicAdd(&gh[i], v);
+        swl.lh[s][i] = 0;  // clean for the next round
+      }
+    }
+  }
+  one_stamp(a, 3);
+  const bool resident = win_is_resident<NSEL>(a, ol) || round > 1;
+  return win_finish<T, NSEL, BLOCK>(tab, 1, a, wg, nwg, ol, swl, adv, signs, resident, round);
+}
+
+// Rounds after the first (a window that could not resolve its rank, or missed it): out of line -- as part of the
+// kernel's own control flow their loop invariants, the fall-back sweeps' address arithmetic included, were hoisted in
+// front of the FIRST round's binning (250 instructions and a dozen spills on the hot path).
+template <typename T, int NSEL>
+__device__ __attribute__((noinline)) void h16_more_rounds(const OneShard tab, const OneArgs a, const uint32_t wg, const uint32_t nwg,
+                                                          const uint32_t n_wg, const uint32_t* hist, const uint32_t* zero_word,
+                                                          const H16Plan* plan, OneLds* ol, SweepLds<NSEL, kH16Block>* swl,
+                                                          AdvShared (*adv)[2]) {
+  for (uint32_t round = 2; round < 12; ++round) {
+    if (__builtin_amdgcn_readfirstlane(ol->part) != nwg) {
+      // somebody gave up waiting (two resident launches sharing the device): the rest sweeps global memory by ticket
+      win_resident_rounds<T, NSEL, kH16Block>(tab, 1, a, wg, nwg, *ol, *swl, *adv, true);
+      return;
+    }
+    __syncthreads();  // ol.sel: the narrowed windows, fetched by win_finish
+    if (!h16_round<T, NSEL>(tab, a, wg, nwg, n_wg, round, false, hist, zero_word, *plan, *ol, *swl, *adv)) return;
+  }
+}
 
 template <typename T, int NSEL, bool PCT>
 __global__ __launch_bounds__(kH16Block) void h16_select_kernel(const OneShard tab, const OneArgs a) {
@@ -2046,26 +2222,28 @@ __global__ __launch_bounds__(kH16Block) void h16_select_kernel(const OneShard ta
   if (threadIdx.x == 0) swl.stamps = a.stamps;
 #endif
   const void* x = tab.ptr[0];
-  const int64_t n = a.n;
-  const int64_t n_packs = n / kPack;  // >= 1 (the host admits n >= 8)
+  // (everything in 32 bits: the host admits 8 <= n <= 65 536 x compute units, far below 2^31)
+  const uint32_t n = static_cast<uint32_t>(a.n);
+  const uint32_t n_packs = n / kPack;  // >= 1
   const uint32_t amask2 = a.use_abs ? 0x7fff7fffu : 0xffffffffu;
   constexpr uint32_t kZero16 = Key16<T>::kZero >> 16, kInf16 = Key16<T>::kInf >> 16;
   static_assert((kZero16 & 1u) == 0 && (kZero16 & ((1u << kH16MiniShift) - 1u)) == 0, "-0 / +0 share a dword; -0 starts a sample bin");
   // ---- requests: the sample (wave 0 only, in front of its slabs: a wave's loads return in order), then four slabs ----
-  const int64_t s_packs = n_packs < kH16SamplePacks ? n_packs : kH16SamplePacks;
+  const uint32_t s_packs = n_packs < static_cast<uint32_t>(kH16SamplePacks) ? n_packs : static_cast<uint32_t>(kH16SamplePacks);
   u32x4 smp[4];
   if (wid == 0) {
-    const int64_t stride = n / s_packs;
+    const uint32_t stride = n / s_packs;
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
-      const int64_t pk = lane + m * kWave;
-      int64_t e = (pk < s_packs ? pk : 0) * stride;
-      const uint32_t h = (static_cast<uint32_t>(pk) * 2654435761u) >> 4;
-      if (stride > kPack) e += static_cast<int64_t>(h % static_cast<uint32_t>(stride - kPack + 1));
-      e &= ~static_cast<int64_t>(kPack - 1);
-      const int64_t last = (n_packs - 1) * kPack;
+      const uint32_t pk = lane + m * kWave;
+      uint32_t e = (pk < s_packs ? pk : 0u) * stride;
+      const uint32_t h = (pk * 2654435761u) >> 4;
+      // (a pseudo-random offset inside the stride: multiply-high instead of a modulo)
+      if (stride > static_cast<uint32_t>(kPack)) e += static_cast<uint32_t>((static_cast<uint64_t>(h) * (stride - kPack + 1u)) >> 28);
+      e &= ~static_cast<uint32_t>(kPack - 1);
+      const uint32_t last = (n_packs - 1u) * kPack;
       e = e < last ? e : last;
-      smp[m] = load_raw<T, false>(x, e).d[0];
+      smp[m] = load_raw<T, false>(x, static_cast<int64_t>(e)).d[0];
     }
   }
   __builtin_amdgcn_sched_barrier(0);
@@ -2073,13 +2251,13 @@ __global__ __launch_bounds__(kH16Block) void h16_select_kernel(const OneShard ta
   uint32_t okmask = 0;  // bit 2 j + u: the pack exists
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    const int64_t slab = static_cast<int64_t>(wg) + static_cast<int64_t>(j) * nwg;
+    const uint32_t slab = wg + static_cast<uint32_t>(j) * nwg;
 #pragma unroll
     for (int u = 0; u < WinGeom<BLOCK>::kU; ++u) {
-      const int64_t pk = slab * (WinGeom<BLOCK>::kSlab / kPack) + u * BLOCK + threadIdx.x;
+      const uint32_t pk = slab * (WinGeom<BLOCK>::kSlab / kPack) + u * BLOCK + threadIdx.x;
       const bool there = pk < n_packs;
       okmask |= there ? 1u << (2 * j + u) : 0u;
-      raw[j][u] = load_raw<T, true>(x, (there ? pk : n_packs - 1) * kPack).d[0];
+      raw[j][u] = load_raw<T, true>(x, static_cast<int64_t>((there ? pk : n_packs - 1u) * static_cast<uint32_t>(kPack))).d[0];
     }
   }
   __builtin_amdgcn_sched_barrier(0);
@@ -2103,7 +2281,7 @@ __global__ __launch_bounds__(kH16Block) void h16_select_kernel(const OneShard ta
     uint32_t* mini = &swl.lh[0][0];
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
-      if (lane + m * kWave >= s_packs) continue;
+      if (static_cast<uint32_t>(lane + m * kWave) >= s_packs) continue;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const uint32_t k2 = Key16<T>::pack2(smp[m][q], amask2);
@@ -2112,29 +2290,37 @@ __global__ __launch_bounds__(kH16Block) void h16_select_kernel(const OneShard ta
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    // (the lane's 32 bins are re-read from LDS where they are needed instead of living in 32 registers: the slabs'
-    // 32 registers per lane are in flight across this whole block)
-    constexpr int kPer = kWinBins / kWave;  // 32 sample bins per lane
-    const uint32_t* mine = mini + lane * kPer;
-    uint32_t t = 0, f = kWinBins - 1, l = 0;
+    constexpr int kPer = kH16MiniBins / kWave;  // 16 sample bins per lane: four 16-byte reads, all in flight together
+    uint32_t bins[kPer], t = 0;
+    {
+      const u32x4* m4 = reinterpret_cast<const u32x4*>(mini + lane * kPer);
+#pragma unroll
+      for (int i = 0; i < kPer / 4; ++i) {
+        const u32x4 v = m4[i];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bins[i * 4 + q] = v[q];
+      }
+    }
+    uint32_t f = kH16MiniBins - 1, l = 0;
+#pragma unroll
+    for (int i = kPer - 1; i >= 0; --i) f = bins[i] ? lane * kPer + i : f;
+#pragma unroll
     for (int i = 0; i < kPer; ++i) {
-      const uint32_t b = mine[i];
-      t += b;
-      l = b ? lane * kPer + i : l;
-      f = (b && f == static_cast<uint32_t>(kWinBins) - 1u) ? lane * kPer + i : f;
+      t += bins[i];
+      l = bins[i] ? lane * kPer + i : l;
     }
     auto add = [](uint32_t p, uint32_t q) { return p + q; };
     const uint32_t incl = dpp_scan_u32(t, 0u, add), excl = incl - t;
     const uint32_t S = __builtin_amdgcn_readlane(incl, kWave - 1);
-    // the sample's elements with x < 0: bins below key(-0), which starts bin kZero16 >> 5
+    // the sample's elements with x < 0: bins below key(-0), which starts a bin
     constexpr uint32_t kZb = kZero16 >> kH16MiniShift;
     uint32_t negp = 0;
     if (lane == static_cast<int>(kZb / kPer)) {
       negp = excl;
-      for (int i = 0; i < static_cast<int>(kZb % kPer); ++i) negp += mine[i];
+#pragma unroll
+      for (int i = 0; i < kPer; ++i) negp += i < static_cast<int>(kZb % kPer) ? bins[i] : 0u;
     }
     const uint32_t neg_s = dpp_reduce_u32(negp, 0u, add);
-    // first / last occupied bin
     f = dpp_reduce_u32(f, 0xffffffffu, [](uint32_t p, uint32_t q) { return p < q ? p : q; });
     l = dpp_reduce_u32(l, 0u, [](uint32_t p, uint32_t q) { return p > q ? p : q; });
     if (lane < kWinSel) {
@@ -2142,36 +2328,42 @@ __global__ __launch_bounds__(kH16Block) void h16_select_kernel(const OneShard ta
       plan.b_hi[lane] = 0xffffffffu;
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    const double Sd = static_cast<double>(S), scale = n > 0 ? Sd / static_cast<double>(n) : 0.0;
-    double r_mid[NSEL];
-    int64_t r_lo[NSEL], r_hi[NSEL];
+    // The bracket of each wanted rank inside the sample (plan_derive's: +- 12 sigma of the rank error + slack), in
+    // fp32 -- every workgroup executes the same instructions on the same sample, so they all derive the same windows;
+    // the bracket's exact width only decides how often a round is repeated, never a result.
+    const float Sf = static_cast<float>(S), scale = Sf / static_cast<float>(n);
+    int32_t r_lo[NSEL], r_hi[NSEL];
+    if (lane < kWinSel) plan.b_mid[lane] = 0xffffffffu;
 #pragma unroll
-    for (int s = 0; s < NSEL; ++s) {  // (uniform arithmetic, every lane: plan_derive's bracket on this sample)
-      double r;
+    for (int s = 0; s < NSEL; ++s) {
+      float r;
       if (!PCT) {
-        r = static_cast<double>(s == 0 ? a.k0 : a.k1) * scale;
+        r = static_cast<float>(s == 0 ? a.k0 : a.k1) * scale;
       } else {
-        const double neg = static_cast<double>(neg_s), pos = Sd - neg;
-        r = s == 0 ? __builtin_fmax(neg * a.alpha, 1.0 * scale) : Sd - pos * a.alpha;
+        const float neg = static_cast<float>(neg_s), pos = Sf - neg, alpha = static_cast<float>(a.alpha);
+        r = s == 0 ? __builtin_fmaxf(neg * alpha, scale) : Sf - pos * alpha;
       }
-      const double q = Sd > 0 ? r / Sd : 0.0;
-      const double var = __builtin_fmax(r * (1.0 - (q < 1.0 ? q : 1.0)), 1.0);
-      const double m = 2.0 * 6.0 * __builtin_sqrt(var) + 16.0;
-      r_mid[s] = r;
-      r_lo[s] = static_cast<int64_t>(__builtin_floor(r - m));
-      r_hi[s] = static_cast<int64_t>(__builtin_ceil(r + m));
+      const float q = S > 0 ? r / Sf : 0.0f;
+      const float var = __builtin_fmaxf(r * (1.0f - (q < 1.0f ? q : 1.0f)), 1.0f);
+      const float m = 12.0f * __builtin_sqrtf(var) + 16.0f;
+      r_lo[s] = static_cast<int32_t>(__builtin_floorf(r - m));
+      r_hi[s] = static_cast<int32_t>(__builtin_ceilf(r + m));
 #pragma unroll
-      for (int side = 0; side < 2; ++side) {
-        const int64_t rr = side == 0 ? r_lo[s] : r_hi[s];
-        if (rr >= 1 && rr > static_cast<int64_t>(excl) && rr <= static_cast<int64_t>(incl)) {
-          int64_t kk = rr - excl;
-          uint32_t b = 0;
+      for (int side = 0; side < 3; ++side) {
+        int32_t rr = side == 0 ? r_lo[s] : (side == 1 ? r_hi[s] : static_cast<int32_t>(__builtin_rintf(r)));
+        if (side == 2) rr = rr < 1 ? 1 : (rr > static_cast<int32_t>(S) ? static_cast<int32_t>(S) : rr);
+        if (rr >= 1 && rr > static_cast<int32_t>(excl) && rr <= static_cast<int32_t>(incl)) {
+          int32_t kk = rr - static_cast<int32_t>(excl);
+          uint32_t b = kPer - 1;
+          bool found = false;
+#pragma unroll
           for (int i = 0; i < kPer; ++i) {
-            const uint32_t c = mine[i];
-            if (kk > static_cast<int64_t>(c)) kk -= c;
-            else { b = i; break; }
+            const bool here = !found && kk <= static_cast<int32_t>(bins[i]);
+            b = here ? i : b;
+            found |= here;
+            kk -= found ? 0 : static_cast<int32_t>(bins[i]);
           }
-          (side == 0 ? plan.b_lo : plan.b_hi)[s] = lane * kPer + b;
+          (side == 0 ? plan.b_lo : (side == 1 ? plan.b_hi : plan.b_mid))[s] = lane * kPer + b;
         }
       }
     }
@@ -2179,27 +2371,32 @@ __global__ __launch_bounds__(kH16Block) void h16_select_kernel(const OneShard ta
     if (lane < NSEL) {
       const int s = lane;
       uint32_t b0 = plan.b_lo[s], b1 = plan.b_hi[s];
-      const bool off_lo = r_lo[s] < 1 || b0 == 0xffffffffu, off_hi = r_hi[s] > static_cast<int64_t>(S) || b1 == 0xffffffffu;
-      constexpr uint32_t kCap = static_cast<uint32_t>(kWinBins) >> kH16MiniShift;  // 64 sample bins = 2048 keys
+      const bool off_lo = r_lo[s] < 1 || b0 == 0xffffffffu, off_hi = r_hi[s] > static_cast<int32_t>(S) || b1 == 0xffffffffu;
+      constexpr uint32_t kCap = static_cast<uint32_t>(kWinBins) >> kH16MiniShift;  // sample bins per window (2048 keys)
+      constexpr uint32_t kLast = kH16MiniBins - 1;
+      // A bracket that runs off the sample (a tail quantile, an extreme rank): the window ends two sample bins -- a
+      // binade -- beyond the sample's own extreme instead of at the end of the key space.  What the sample has not
+      // seen may lie further out still: the launch stays resident (bit 3), and the miss costs a round out of LDS, not
+      // a sweep.  (A window spending its whole 2048-key capacity outward, as win_one_kernel's plan does, held a few
+      // per cent of the data here -- this sample is an eighth of that one -- and every workgroup flushed hundreds of
+      // bins: 5 us of atomics and 4 us of gathering.)
+      constexpr uint32_t kBeyond = 2;
       bool uncertain = false;
-      if (off_lo && off_hi) {  // a bracket wider than the sample: the occupied range, as far as a window reaches
-        b0 = f;
-        b1 = l;
-      } else if (off_lo) {  // the window's capacity spent OUTWARD from the bracket's other end
-        b0 = b1 + 1u >= kCap ? b1 + 1u - kCap : 0u;
+      if (off_lo) {
+        b0 = f >= kBeyond ? f - kBeyond : 0u;
         uncertain = b0 > 0u;
-      } else if (off_hi) {
-        b1 = b0 + kCap - 1u < static_cast<uint32_t>(kWinBins) ? b0 + kCap - 1u : kWinBins - 1;
-        uncertain = b1 < static_cast<uint32_t>(kWinBins) - 1u;
+      }
+      if (off_hi) {
+        b1 = l + kBeyond < kLast ? l + kBeyond : kLast;
+        uncertain = uncertain || b1 < kLast;
       }
       if (b1 < b0) b1 = b0;
-      if (b1 - b0 + 1u > kCap) {  // wider than a window: centre it on the expected rank's neighbourhood
-        const uint32_t mid = (b0 + b1) / 2u;
+      if (b1 - b0 + 1u > kCap) {  // wider than a window: the part around the expected rank itself
+        const uint32_t mid = plan.b_mid[s] != 0xffffffffu ? plan.b_mid[s] : (b0 + b1) / 2u;
         b0 = mid >= kCap / 2u ? mid - kCap / 2u : 0u;
-        b1 = b0 + kCap - 1u;
+        b1 = b0 + kCap - 1u < kLast ? b0 + kCap - 1u : kLast;
         uncertain = true;
       }
-      (void)r_mid;
       WinSel w;
       w.lo = (b0 << kH16MiniShift) << 16;
       const uint64_t width = static_cast<uint64_t>(b1 - b0 + 1u) << (kH16MiniShift + 16);
@@ -2213,33 +2410,64 @@ __global__ __launch_bounds__(kH16Block) void h16_select_kernel(const OneShard ta
       ol.sel[s] = w;
     }
     // the sample's bins become window-histogram bins again
+    {
+      u32x4* m4 = reinterpret_cast<u32x4*>(mini + lane * kPer);
 #pragma unroll
-    for (int i = 0; i < kPer; ++i) mini[lane * kPer + i] = 0;
+      for (int i = 0; i < kPer / 4; ++i) m4[i] = u32x4{0, 0, 0, 0};
+    }
   }
   one_stamp(a, 1);
   // ---- count: every key of every slab, two 16-bit counts per dword; +-0 in the lane's own word ----
+  // A wave whose first pack holds no +-0 at all (weights) takes the lean form -- 6 vector operations per key, the LDS
+  // adds are the bound; a wave with a zero in it (ReLU outputs, pruned weights) redirects its zeros to the lane's own
+  // word, 13 operations per key.  The test is one packed-minimum tree over a pack of 8 keys and a wave vote.
   uint32_t first_key = 0;
+  bool zero_hot = false;  // wave-uniform
+  typedef uint16_t u16x2 __attribute__((ext_vector_type(2)));
+  auto pkmin = [](uint32_t p, uint32_t q) {
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(u16x2, p), __builtin_bit_cast(u16x2, q)));
+  };
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
 #pragma unroll
     for (int u = 0; u < WinGeom<BLOCK>::kU; ++u) {
-      if (!(okmask & (1u << (2 * j + u)))) continue;
+      const bool there = (okmask & (1u << (2 * j + u))) != 0;
+      const u32x4 r = raw[j][u];
+      if (j == 0 && u == 0) {
+        // |x| of the smallest of the pack's 8 elements: zero iff the pack holds a +-0.  The wave's FIRST pack decides
+        // for all eight (zeros are spread through such tensors; the choice only decides how fast the adds go)
+        const uint32_t m2 = pkmin(pkmin(r[0] & 0x7fff7fffu, r[1] & 0x7fff7fffu), pkmin(r[2] & 0x7fff7fffu, r[3] & 0x7fff7fffu));
+        const bool has_zero = there && ((m2 & 0xffffu) == 0u || (m2 >> 16) == 0u);
+        zero_hot = __builtin_amdgcn_ballot_w64(has_zero) != 0;
+      }
+      if (!zero_hot) {
+        if (there) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const uint32_t k2 = Key16<T>::pack2(raw[j][u][q], amask2);
-        if (j == 0 && u == 0 && q == 0) first_key = k2 & 0xffffu;
+          for (int q = 0; q < 4; ++q) {
+            const uint32_t k2 = Key16<T>::pack2(r[q], amask2);
+            if (j == 0 && u == 0 && q == 0) first_key = k2 & 0xffffu;
+            atomicAdd(&hist[(k2 & 0xffffu) >> 1], 1u + (k2 & 1u) * 0xffffu);
+            atomicAdd(&hist[k2 >> 17], 1u + ((k2 >> 16) & 1u) * 0xffffu);
+          }
+        }
+      } else if (there) {
 #pragma unroll
-        for (int hsel = 0; hsel < 2; ++hsel) {
-          const uint32_t k = hsel == 0 ? (k2 & 0xffffu) : (k2 >> 16);
-          const bool z = (k - kZero16) <= 1u;
-          uint32_t* word = z ? &zero_word[threadIdx.x] : &hist[k >> 1];
-          atomicAdd(word, (k & 1u) ? 0x10000u : 1u);
+        for (int q = 0; q < 4; ++q) {
+          const uint32_t k2 = Key16<T>::pack2(r[q], amask2);
+          if (j == 0 && u == 0 && q == 0) first_key = k2 & 0xffffu;
+#pragma unroll
+          for (int hsel = 0; hsel < 2; ++hsel) {
+            const uint32_t k = hsel == 0 ? (k2 & 0xffffu) : (k2 >> 16);
+            const bool z = (k - kZero16) <= 1u;
+            uint32_t* word = z ? &zero_word[threadIdx.x] : &hist[k >> 1];
+            atomicAdd(word, (k & 1u) ? 0x10000u : 1u);
+          }
         }
       }
     }
   }
   if (wg == 0 && wid == 1) {  // the tensor's last n % 8 elements, one per lane
-    const int64_t e = n_packs * kPack + lane;
+    const uint32_t e = n_packs * kPack + lane;
     if (e < n) {
       const uint32_t k = Key16<T>::pack2(static_cast<const uint16_t*>(x)[e], amask2) & 0xffffu;
       const bool z = (k - kZero16) <= 1u;
@@ -2247,158 +2475,24 @@ __global__ __launch_bounds__(kH16Block) void h16_select_kernel(const OneShard ta
     }
   }
   if (threadIdx.x == 0) plan.first_key = first_key;
+  if constexpr (SBQ_SEL_STAMPS != 0) {  // when has a wave finished counting?  wave 0 (after its plan), waves 1 and 15
+    if (a.stamps && lane == 0 && (wid == 0 || wid == 1 || wid == kWaves - 1))
+      a.stamps[blockIdx.x * 32 + (wid == 0 ? 11 : (wid == 1 ? 15 : 18))] = __builtin_amdgcn_s_memrealtime();
+  }
   lds_sync();
   one_stamp(a, 2);
   // this workgroup's elements (for the carry check): its whole packs, and the ragged tail in workgroup 0
-  int64_t n_wg = 0;
+  uint32_t n_wg = 0;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    const int64_t p0 = (static_cast<int64_t>(wg) + static_cast<int64_t>(j) * nwg) * (WinGeom<BLOCK>::kSlab / kPack);
-    const int64_t p1 = p0 + WinGeom<BLOCK>::kSlab / kPack;
+    const uint32_t p0 = (wg + static_cast<uint32_t>(j) * nwg) * (WinGeom<BLOCK>::kSlab / kPack);
+    const uint32_t p1 = p0 + WinGeom<BLOCK>::kSlab / kPack;
     if (p0 < n_packs) n_wg += ((p1 < n_packs ? p1 : n_packs) - p0) * kPack;
   }
   if (wg == 0) n_wg += n - n_packs * kPack;
-  // ---- rounds: bin the histogram into the selectors' windows, flush, arrive; the last arriver places the ranks ----
-  bool signs = PCT;
-  for (uint32_t round = 1; round < 12; ++round) {
-    if (round > 1) {  // (the last arriver's placement used lh as its gathering scratch)
-      for (uint32_t i = threadIdx.x; i < static_cast<uint32_t>(NSEL * kWinBins); i += BLOCK) (&swl.lh[0][0])[i] = 0;
-      __syncthreads();
-    }
-    uint32_t lo16[NSEL], span16[NSEL], sh16[NSEL];
-    bool act[NSEL], fresh[NSEL];
-#pragma unroll
-    for (int s = 0; s < NSEL; ++s) {
-      const WinSel w = ol.sel[s];
-      act[s] = __builtin_amdgcn_readfirstlane(w.done) == 0;
-      lo16[s] = __builtin_amdgcn_readfirstlane(w.lo) >> 16;
-      span16[s] = static_cast<uint32_t>((static_cast<uint64_t>(__builtin_amdgcn_readfirstlane(w.span)) + 1ull) >> 16) - 1u;
-      sh16[s] = __builtin_amdgcn_readfirstlane(w.shift) - 16u;
-      fresh[s] = act[s] && __builtin_amdgcn_readfirstlane(w.fresh) != 0;
-      if (!act[s]) {
-        lo16[s] = 0xffffffffu;  // nothing is below 2^32 - 1 ... and nothing inside
-        span16[s] = 0;
-      }
-    }
-    uint32_t below[NSEL], neg = 0, nan = 0, total = 0;
-#pragma unroll
-    for (int s = 0; s < NSEL; ++s) below[s] = 0;
-    auto visit = [&](uint32_t key, uint32_t c) {  // c elements of this workgroup carry `key`
-      if (signs) {
-        neg += key < kZero16 ? c : 0u;
-        nan += key > kInf16 ? c : 0u;
-      }
-#pragma unroll
-      for (int s = 0; s < NSEL; ++s) {
-        const uint32_t d = key - lo16[s];
-        below[s] += key < lo16[s] ? c : 0u;
-        if (act[s] && key >= lo16[s] && d <= span16[s]) atomicAdd(&swl.lh[s][d >> sh16[s]], c);
-      }
-    };
-    {
-      const u32x4* h4 = reinterpret_cast<const u32x4*>(hist);
-#pragma unroll
-      for (int i = 0; i < static_cast<int>(kH16Dwords / 4 / BLOCK); ++i) {
-        const u32x4 v = h4[i * BLOCK + threadIdx.x];
-        if ((v[0] | v[1] | v[2] | v[3]) == 0u) continue;  // (most of the key space is empty: whole waves skip)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const uint32_t wq = v[q];
-          if (wq == 0u) continue;
-          const uint32_t key0 = ((i * BLOCK + threadIdx.x) * 4 + q) * 2;
-          const uint32_t c0 = wq & 0xffffu, c1 = wq >> 16;
-          total += c0 + c1;
-          if (c0) visit(key0, c0);
-          if (c1) visit(key0 + 1u, c1);
-        }
-      }
-      const uint32_t zw = zero_word[threadIdx.x];
-      if (zw) {
-        total += (zw & 0xffffu) + (zw >> 16);
-        if (zw & 0xffffu) visit(kZero16, zw & 0xffffu);
-        if (zw >> 16) visit(kZero16 + 1u, zw >> 16);
-      }
-    }
-    // counters: lanes -> wave -> workgroup
-    auto add32 = [](uint32_t p, uint32_t q) { return p + q; };
-    constexpr int kCnt = NSEL + 3;  // below[NSEL], neg, nan, total
-    uint32_t part[kCnt];
-#pragma unroll
-    for (int s = 0; s < NSEL; ++s) part[s] = dpp_reduce_u32(below[s], 0u, add32);
-    part[NSEL] = dpp_reduce_u32(neg, 0u, add32);
-    part[NSEL + 1] = dpp_reduce_u32(nan, 0u, add32);
-    part[NSEL + 2] = dpp_reduce_u32(total, 0u, add32);
-    uint32_t* red = reinterpret_cast<uint32_t*>(&swl.red[0][0]);  // [kCnt][kWaves] u32 (the sweep's scratch: 8-byte slots)
-    if (lane == 0) {
-#pragma unroll
-      for (int c = 0; c < kCnt; ++c) red[c * kWaves + wid] = part[c];
-    }
-    __syncthreads();
-    uint32_t tot[kCnt];
-#pragma unroll
-    for (int c = 0; c < kCnt; ++c) {
-      uint32_t t = 0;
-      for (int w = 0; w < kWaves; ++w) t += red[c * kWaves + w];
-      tot[c] = t;
-    }
-    __syncthreads();  // (red is read; the next round / win_finish may write it)
-    if (static_cast<int64_t>(tot[NSEL + 2]) != n_wg) {
-      // every element of this workgroup is ONE key (65 536 of it carried out of their half-dword): redo the binning
-      // for that single key.  (uniform over the workgroup.)
-      const uint32_t key = plan.first_key;
-      for (uint32_t i = threadIdx.x; i < static_cast<uint32_t>(NSEL * kWinBins); i += BLOCK) (&swl.lh[0][0])[i] = 0;
-      __syncthreads();
-      const uint32_t c = static_cast<uint32_t>(n_wg);
-#pragma unroll
-      for (int s = 0; s < NSEL; ++s) {
-        tot[s] = key < lo16[s] ? c : 0u;
-        if (threadIdx.x == 0 && act[s] && key >= lo16[s] && key - lo16[s] <= span16[s]) swl.lh[s][(key - lo16[s]) >> sh16[s]] = c;
-      }
-      tot[NSEL] = key < kZero16 ? c : 0u;
-      tot[NSEL + 1] = key > kInf16 ? c : 0u;
-      __syncthreads();
-    }
-    // flush: this workgroup's counters to its counter line, its non-empty bins to its histogram copy (win_sweep's)
-    WinSlot* slot = a.slots + (wg % kSlots);
-    if (threadIdx.x < static_cast<uint32_t>(NSEL)) {
-      bool mine = false;
-#pragma unroll
-      for (int s = 0; s < NSEL; ++s) mine |= static_cast<int>(threadIdx.x) == s && fresh[s];
-      unsigned long long t = 0;
-#pragma unroll
-      for (int s = 0; s < NSEL; ++s) t = static_cast<int>(threadIdx.x) == s ? tot[s] : t;
-      swl.tot[threadIdx.x] = t;
-      if (mine && t) atomicAdd(&slot->below[threadIdx.x], t);
-    } else if (signs && threadIdx.x < static_cast<uint32_t>(NSEL) + 2u) {
-      const unsigned long long t = threadIdx.x == static_cast<uint32_t>(NSEL) ? tot[NSEL] : tot[NSEL + 1];
-      swl.tot[threadIdx.x] = t;
-      if (t) atomicAdd(threadIdx.x == static_cast<uint32_t>(NSEL) ? &slot->neg : &slot->nan, t);
-    }
-#pragma unroll
-    for (int s = 0; s < NSEL; ++s) {
-      if (!act[s]) continue;
-      uint32_t* gh = a.hist + (static_cast<size_t>(wg % kCopies) * kWinSel + s) * kWinBins;
-      const uint32_t nb = (span16[s] >> sh16[s]) + 1u;
-      for (uint32_t i = threadIdx.x; i < nb; i += BLOCK) {
-        const uint32_t v = swl.lh[s][i];
-        if (v) {
-          atomicAdd(&gh[i], v);
-          swl.lh[s][i] = 0;  // clean for the next round
-        }
-      }
-    }
-    one_stamp(a, 3);
-    const bool resident = win_is_resident<NSEL>(a, ol) || round > 1;
-    const bool again = win_finish<T, NSEL, BLOCK>(tab, 1, a, wg, nwg, ol, swl, adv, signs, resident, round);
-    signs = false;
-    if (!again) break;
-    if (__builtin_amdgcn_readfirstlane(ol.part) != nwg) {
-      // somebody gave up waiting (two resident launches sharing the device): the rest sweeps global memory by ticket
-      win_resident_rounds<T, NSEL, BLOCK>(tab, 1, a, wg, nwg, ol, swl, adv, true);
-      break;
-    }
-    __syncthreads();  // ol.sel: the narrowed windows, fetched by win_finish
-  }
+  // ---- round 1 inline; whatever follows (rare) out of line ----
+  if (h16_round<T, NSEL>(tab, a, wg, nwg, n_wg, 1u, PCT, hist, zero_word, plan, ol, swl, adv))
+    h16_more_rounds<T, NSEL>(tab, a, wg, nwg, n_wg, hist, zero_word, &plan, &ol, &swl, &adv);
   one_stamp(a, 7);
 }
 

@@ -416,12 +416,12 @@ def test_h16_engine_adversarial_data(ops, dtype):
     for name, t in cases.items():
         x = t.to(dtype).to(dev)
         xf = x.float()
-        srt = torch.sort(xf.reshape(-1))[0]  # NaN last, like kthvalue
+        srt = torch.sort(xf.reshape(-1).cpu())[0].to(dev)  # on the host: NaN last, like kthvalue
         for k in (1, 7, n // 4, n // 2 + 1, n - 7, n):
             got = ops.kth_value(x, k, False)
             want = srt[k - 1]
             assert (torch.isnan(got) and torch.isnan(want)) or float(got) == float(want), (name, k, float(got), float(want))
-        a = torch.sort(xf.abs().reshape(-1))[0]
+        a = torch.sort(xf.abs().reshape(-1).cpu())[0].to(dev)
         for k in (1, n // 2 + 1, n):
             got = ops.kth_value(x, k, True)
             assert (torch.isnan(got) and torch.isnan(a[k - 1])) or float(got) == float(a[k - 1]), (name, k)

@@ -1,6 +1,8 @@
 """Install the MI355X path into an importable reference Sparsebit -- zero edits to it.
 
-    import sparsebit, sparsebit_amd.plugin
+    import sparsebit_amd.plugin
+    sparsebit_amd.plugin.preinstall()    # GPU boxes: answers the reference's import-time JIT build (see below)
+    import sparsebit
     sparsebit_amd.plugin.install()
 
 Later registrations overwrite the reference's map entries (quantizers/__init__.py:4-6,
@@ -45,6 +47,39 @@ def _derive(amd_cls, ref_base):
                                                          "_sbq_impl": amd_cls})
     cls.__qualname__ = amd_cls.__qualname__
     return cls
+
+
+def preinstall():
+    """Call BEFORE `import sparsebit` on a box with a visible GPU.
+
+    The reference compiles its CUDA extension while it is being imported (quant_tensor.py:7-22:
+    `torch.utils.cpp_extension.load(name="fake_quant", sources=[export.cc, fake_quant_tensor.cu], ...)` as soon as
+    `torch.cuda.is_available()`), into its own package directory.  On ROCm that call hipifies the CUDA sources and
+    fails on `#include <cuda.h>` (common.cuh:9) -- measured on the MI355X box -- so the reference cannot even be
+    imported there.  preinstall() answers exactly that one `load` call with the prebuilt HIP module
+    (`sparsebit_amd.fake_quant`, the same four functions: export.cc:3-8): nothing is compiled at import time, the
+    reference's sources stay untouched, and every other `load` call goes to torch unchanged.  Returns a function that
+    restores torch's loader."""
+    import torch.utils.cpp_extension as ext
+
+    from . import fake_quant
+
+    real = ext.load
+    if getattr(real, "_sbq_wrapped", False):
+        return lambda: None
+
+    def load(name, *args, **kw):
+        if name == "fake_quant":
+            return fake_quant
+        return real(name, *args, **kw)
+
+    load._sbq_wrapped = True
+    ext.load = load
+
+    def restore():
+        ext.load = real
+
+    return restore
 
 
 def install(native_only=False, calibrate=None):

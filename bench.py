@@ -456,8 +456,7 @@ def main():
                 if isinstance(v, dict):
                     if "parity" in v and "us" in v:
                         yield v["parity"]
-                    else:
-                        yield from _gates(v)
+                    yield from _gates(v)  # (a leg may carry a nested leg of its own)
 
         extras["all_config_gates_pass"] = all(g for g in _gates(extras["configs"]) if g is not None) and all(
             g for g in _gates(extras["model_wide_calibration"]) if g is not None)

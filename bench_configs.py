@@ -340,6 +340,31 @@ def config2_mse(c):
             ok &= abs(a - b) <= 1e-7 * max(abs(a), abs(b))
     evals = c.n * L.MSE_CANDIDATES
     tflops = evals * MSE_FLOPS_PER_EVAL / k_us / 1e6
+    # the same tensor taken as a WHOLE (a per-tensor MSE quantizer: config 2's activations when the model runs in
+    # bf16): 16-bit values -> an exact histogram, 80 candidates x 65 536 values instead of 80 x 16.7 M elements
+    mn1, mx1, _ = ops.channel_stats(x, 0, False)
+    sse1 = torch.zeros(1, L.MSE_CANDIDATES, dtype=torch.float64, device=c.dev)
+    ws1 = torch.empty(max(lib.sbq_mse_workspace_bytes(1, 1, c.n), 16), dtype=torch.uint8, device=c.dev)
+
+    def acc1(i):
+        lib.sbq_mse_accumulate(L.ptr(c.xs[i % len(c.xs)]), L.BF16, 1, 1, c.n, L.ptr(mn1), L.ptr(mx1), -128, 127, 1, L.ptr(sse1),
+                               L.ptr(ws1), ws1.numel(), c.st)
+
+    t_us = c.timed(acc1, 20, warm=3)
+    L.set_tuning(2, 19)
+    try:
+        t_old_us = c.timed(acc1, 10, warm=2)
+    finally:
+        L.set_tuning(2, 0)
+    sse1.zero_()
+    acc1(0)
+    torch.cuda.synchronize(c.dev)
+    _, _, b1_ref, sse1_ref = O.mse(c.host.float().numpy().reshape(1, -1), -128, 127, True, 0, False)
+    got1 = sse1.cpu().numpy()[0]
+    ok1 = bool(np.all(np.abs(got1 - sse1_ref[0]) <= 1e-5 * np.abs(sse1_ref[0])) and int(np.argmin((got1 / c.n).astype(np.float32))) == int(b1_ref[0]))
+    per_tensor = _entry(t_us, c.n * 2, ok1, "all 80 squared-error sums within 1e-5 of the oracle's fp64 sums and the same argmin "
+                        "(observers/mse.py:46-61 per tensor)", bound="hbm", launches=4,
+                        per_element_route_us=round(t_old_us, 2), note="clear + histogram + 80 x 65 536 evaluation + fold")
     return _entry(
         k_us, c.n * 2, ok,
         "argmin candidate index of %d rows == oracle (observers/mse.py:51-61); %d differing" % (len(rows), n_diff),
@@ -349,6 +374,7 @@ def config2_mse(c):
         valu_tflops=round(tflops, 1),
         frac_of_fp32_vector_peak=round(tflops / FP32_VECTOR_PEAK_TFLOPS, 4),
         vs_nominal_issue_rate_of_1_per_4_cycles=round(evals * 5 / 64 / (k_us * 1e-6) / VALU_ISSUE_CEILING_WAVE_INSTS, 4),
+        per_tensor_histogram_route=per_tensor,
         note="VALU-bound: x is read once (2 B/elem); frac is the HBM fraction of that read, the roof that matters is "
              "frac_of_fp32_vector_peak (7 flops per candidate evaluation / 157.3 TFLOP/s); the nominal issue rate (5 wave "
              "instructions per 64 evaluations against one instruction per SIMD per 4 cycles) is a yardstick the kernel exceeds",

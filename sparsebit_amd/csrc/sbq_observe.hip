@@ -551,6 +551,212 @@ __global__ __launch_bounds__(kBlock) void mse_partial_kernel(
   }
 }
 
+// ---- the MSE observer of a 16-bit tensor taken as a WHOLE: a histogram instead of 80 evaluations per element -------
+// observers/mse.py:46-61 per tensor evaluates 80 candidates on every element: 80 x N quantize-dequantize-square
+// operations, the vector ALU's whole capacity for 150 us at N = 16.7 M.  A bf16 / fp16 tensor holds at most 65 536
+// distinct VALUES: the loss of a candidate is sum over values of count(v) * err(v)^2.  So the tensor is read ONCE into
+// an exact histogram of its 16-bit keys -- each workgroup counts its 65 536 elements in LDS (two 16-bit counts per
+// dword, +-0 per lane: the counting of sbq_select_win.hip's h16_select_kernel) and adds its occupied bins to one of 8
+// global copies -- and the 80 candidates are evaluated on the 65 536 values, weighted by their counts: HBM-bound
+// instead of VALU-bound, and the per-value error is computed with the very operations of mse_chunk_body, so a
+// candidate's loss is the same sum with its equal terms collected.  fp64 from the first multiplication on.
+constexpr int kHistCopies = 8;
+constexpr uint32_t kHistKeys = 65536;
+constexpr size_t kHist16Bytes = static_cast<size_t>(kHistCopies) * kHistKeys * 4;
+constexpr int kH16Threads = 1024;
+constexpr uint32_t kH16Elems = 65536;  // per workgroup: 8 packs of 8 per thread
+constexpr uint32_t kEvalBlocks = kHistKeys / kBlock;  // 256 workgroups of 256 keys
+
+template <typename T>
+__global__ __launch_bounds__(kH16Threads) void hist16_kernel(const void* __restrict__ x, uint32_t n, uint32_t* __restrict__ ghist) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t hist[];  // 32 Ki dwords
+  __shared__ uint32_t zero_word[kH16Threads];
+  __shared__ uint32_t s_tot[kH16Threads / kWave];
+  __shared__ uint32_t s_first;
+  const uint32_t wg = blockIdx.x, nwg = gridDim.x;
+  const uint32_t n_packs = n / kPack;
+  const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
+  u32x4 raw[8];
+  uint32_t okmask = 0;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    // slab (16 Ki elements) j / 2 of this workgroup, half j % 2: every wave instruction reads 1 KiB
+    const uint32_t pk = (wg + static_cast<uint32_t>(j / 2) * nwg) * 2048u + (j % 2) * kH16Threads + threadIdx.x;
+    const bool there = pk < n_packs;
+    okmask |= there ? 1u << j : 0u;
+    raw[j] = load_raw<T, true>(x, static_cast<int64_t>((there ? pk : n_packs - 1u) * static_cast<uint32_t>(kPack))).d[0];
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  {
+    u32x4* h4 = reinterpret_cast<u32x4*>(hist);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) h4[i * kH16Threads + threadIdx.x] = u32x4{0, 0, 0, 0};
+    zero_word[threadIdx.x] = 0;
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  constexpr uint32_t kZero16 = Key16<T>::kZero >> 16;
+  typedef uint16_t u16x2 __attribute__((ext_vector_type(2)));
+  auto pkmin = [](uint32_t p, uint32_t q) {
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(u16x2, p), __builtin_bit_cast(u16x2, q)));
+  };
+  uint32_t first_key = 0;
+  bool zero_hot = false;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const bool there = (okmask & (1u << j)) != 0;
+    const u32x4 r = raw[j];
+    if (j == 0) {
+      const uint32_t m2 = pkmin(pkmin(r[0] & 0x7fff7fffu, r[1] & 0x7fff7fffu), pkmin(r[2] & 0x7fff7fffu, r[3] & 0x7fff7fffu));
+      zero_hot = __builtin_amdgcn_ballot_w64(there && ((m2 & 0xffffu) == 0u || (m2 >> 16) == 0u)) != 0;
+    }
+    if (!there) continue;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const uint32_t k2 = Key16<T>::pack2(r[q], 0xffffffffu);
+      if (j == 0 && q == 0) first_key = k2 & 0xffffu;
+      if (!zero_hot) {
+        atomicAdd(&hist[(k2 & 0xffffu) >> 1], 1u + (k2 & 1u) * 0xffffu);
+        atomicAdd(&hist[k2 >> 17], 1u + ((k2 >> 16) & 1u) * 0xffffu);
+      } else {
+#pragma unroll
+        for (int hsel = 0; hsel < 2; ++hsel) {
+          const uint32_t k = hsel == 0 ? (k2 & 0xffffu) : (k2 >> 16);
+          const bool z = (k - kZero16) <= 1u;
+          atomicAdd(z ? &zero_word[threadIdx.x] : &hist[k >> 1], (k & 1u) ? 0x10000u : 1u);
+        }
+      }
+    }
+  }
+  if (wg == 0 && wid == 1) {  // the tensor's last n % 8 elements
+    const uint32_t e = n_packs * kPack + lane;
+    if (e < n) {
+      const uint32_t k = Key16<T>::pack2(static_cast<const uint16_t*>(x)[e], 0xffffffffu) & 0xffffu;
+      atomicAdd(&hist[k >> 1], (k & 1u) ? 0x10000u : 1u);
+    }
+  }
+  if (threadIdx.x == 0) s_first = first_key;
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  // this workgroup's elements: a dword decodes wrong only when ONE key took all 65 536 of them (carry)
+  uint32_t n_wg = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const uint32_t p0 = (wg + static_cast<uint32_t>(j) * nwg) * 2048u, p1 = p0 + 2048u;
+    if (p0 < n_packs) n_wg += ((p1 < n_packs ? p1 : n_packs) - p0) * kPack;
+  }
+  if (wg == 0) n_wg += n - n_packs * kPack;
+  uint32_t wv[32], total = 0;
+#pragma unroll
+  for (int m = 0; m < 32; ++m) {
+    wv[m] = hist[m * kH16Threads + threadIdx.x];
+    total += (wv[m] & 0xffffu) + (wv[m] >> 16);
+  }
+  const uint32_t zw = zero_word[threadIdx.x];
+  total += (zw & 0xffffu) + (zw >> 16);
+  total = dpp_reduce_u32(total, 0u, [](uint32_t p, uint32_t q) { return p + q; });
+  if (lane == 0) s_tot[wid] = total;
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  uint32_t all = 0;
+#pragma unroll
+  for (int w = 0; w < kH16Threads / kWave; ++w) all += s_tot[w];
+  uint32_t* g = ghist + static_cast<size_t>(wg % kHistCopies) * kHistKeys;
+  if (all != n_wg) {  // (uniform) every element of this workgroup is the key thread 0 saw first
+    if (threadIdx.x == 0) atomicAdd(&g[s_first], n_wg);
+    return;
+  }
+#pragma unroll
+  for (int m = 0; m < 32; ++m) {
+    if (__builtin_amdgcn_ballot_w64(wv[m] != 0u) == 0) continue;
+    const uint32_t key0 = (m * kH16Threads + threadIdx.x) * 2u;
+    if (wv[m] & 0xffffu) atomicAdd(&g[key0], wv[m] & 0xffffu);
+    if (wv[m] >> 16) atomicAdd(&g[key0 + 1u], wv[m] >> 16);
+  }
+  // the zeros: one add per WAVE and sign of zero
+  const uint32_t zn = dpp_reduce_u32(zw & 0xffffu, 0u, [](uint32_t p, uint32_t q) { return p + q; });
+  const uint32_t zp = dpp_reduce_u32(zw >> 16, 0u, [](uint32_t p, uint32_t q) { return p + q; });
+  if (lane == 0) {
+    if (zn) atomicAdd(&g[kZero16], zn);
+    if (zp) atomicAdd(&g[kZero16 + 1u], zp);
+  }
+}
+
+// 80 candidates x 65 536 values: workgroup b owns keys [256 b, 256 b + 256), one per thread; part[b][80] = the
+// workgroup's share of every candidate's squared error (fp64), folded by mse16_fold_kernel in workgroup order.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void mse16_eval_kernel(const uint32_t* __restrict__ ghist, const float* __restrict__ min_val,
+                                                            const float* __restrict__ max_val, float qrange, float qlo,
+                                                            float qhi, int symmetric, double* __restrict__ part) {
+  __shared__ float s_scale[SBQ_MSE_CANDIDATES], s_zp[SBQ_MSE_CANDIDATES], s_rcp[SBQ_MSE_CANDIDATES];
+  __shared__ double s_acc[SBQ_MSE_CANDIDATES][kWavesPerBlock];
+  if (threadIdx.x < SBQ_MSE_CANDIDATES) {
+    float s, z;
+    mse_candidate(min_val[0], max_val[0], threadIdx.x, qrange, symmetric != 0, s, z);
+    s_scale[threadIdx.x] = s;
+    s_zp[threadIdx.x] = z;
+    s_rcp[threadIdx.x] = fast_div_ok(s) ? 1.0f / s : 0.0f;
+  }
+  const uint32_t key = blockIdx.x * kBlock + threadIdx.x;
+  uint32_t c = 0;
+#pragma unroll
+  for (int k = 0; k < kHistCopies; ++k) c += ghist[static_cast<size_t>(k) * kHistKeys + key];
+  const float v = Key16<T>::value(key << 16);
+  const double cd = static_cast<double>(c);
+  __syncthreads();
+  const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
+  const bool any = __builtin_amdgcn_ballot_w64(c != 0u) != 0;  // (most of the key space is empty: whole waves idle)
+  for (int i = 0; i < SBQ_MSE_CANDIDATES; ++i) {
+    double e = 0.0;
+    if (any) {
+      const float s = s_scale[i], z = s_zp[i], y = s_rcp[i];
+      float d;
+      // (mse_chunk_body's three forms of one element's error, operation for operation)
+      if (y != 0.0f) {
+        if (z == 0.0f) {
+          const float lv = __builtin_amdgcn_fmed3f(__builtin_rintf(v * y), qlo, qhi);
+          d = __builtin_fmaf(-lv, s, v);
+        } else {
+          const float lv = __builtin_amdgcn_fmed3f(__builtin_rintf(v * y) + z, qlo, qhi);
+          d = __builtin_fmaf(-(lv - z), s, v);
+        }
+      } else {
+        const float lv = quant_level<SBQ_ROUND_HALF_EVEN>(v, s, z, qlo, qhi);
+        d = v - dequant_level(lv, s, z);
+      }
+      e = c ? cd * (static_cast<double>(d) * static_cast<double>(d)) : 0.0;
+#pragma unroll
+      for (int m = kWave / 2; m > 0; m >>= 1) e += __shfl_xor(e, m, kWave);
+    }
+    if (lane == 0) s_acc[i][wid] = e;
+  }
+  __syncthreads();
+  if (threadIdx.x < SBQ_MSE_CANDIDATES) {
+    double t = 0.0;
+#pragma unroll
+    for (int w = 0; w < kWavesPerBlock; ++w) t += s_acc[threadIdx.x][w];
+    part[static_cast<size_t>(blockIdx.x) * SBQ_MSE_CANDIDATES + threadIdx.x] = t;
+  }
+}
+__global__ __launch_bounds__(kBlock) void mse16_fold_kernel(const double* __restrict__ part, double* __restrict__ sse) {
+  // thread (i, r): candidate i, every third workgroup starting at r -- three interleaved running sums, joined
+  // ((s0 + s1) + s2) like the fold of the per-chunk tables
+  __shared__ double s_d[3][SBQ_MSE_CANDIDATES];
+  const uint32_t i = threadIdx.x % SBQ_MSE_CANDIDATES, r = threadIdx.x / SBQ_MSE_CANDIDATES;
+  if (r < 3) {
+    double t = 0.0;
+    for (uint32_t b = r; b < kEvalBlocks; b += 3) t += part[static_cast<size_t>(b) * SBQ_MSE_CANDIDATES + i];
+    s_d[r][i] = t;
+  }
+  __syncthreads();
+  if (threadIdx.x < SBQ_MSE_CANDIDATES) sse[threadIdx.x] += (s_d[0][threadIdx.x] + s_d[1][threadIdx.x]) + s_d[2][threadIdx.x];
+}
+
+// does sbq_mse_accumulate take the histogram route?  (per tensor, 16-bit, whole 16-byte packs from an aligned base,
+// large enough that three small launches and a 2 MB clear beat the evaluation of every element; knob 2 == 19: never)
+bool mse16_eligible(const void* x, int x_dtype, int64_t outer, int64_t C, int64_t inner) {
+  const int64_t numel = outer * C * inner;
+  return C == 1 && x_dtype != SBQ_F32 && numel >= (1ll << 22) && numel < (1ll << 31) && aligned16(x) && knob(2) != 19;
+}
+constexpr size_t kMse16Bytes = kHist16Bytes + static_cast<size_t>(kEvalBlocks) * SBQ_MSE_CANDIDATES * sizeof(double);
+
 // Fold the per-chunk tables of a channel in a fixed order, kFoldFan chunks per workgroup
 // and level: in[c][n_in][80] -> out[c][ceil(n_in / kFoldFan)][80]; the last level (one
 // group left) ADDS into sse[c][80] instead.  Thread t owns candidate t % 80 and every third
@@ -829,7 +1035,9 @@ size_t sbq_mse_workspace_bytes(int64_t outer, int64_t C, int64_t inner) {
   using namespace sbq;
   if (!geom_ok(outer, C, inner, kMseChunk)) return 0;
   const ChunkGeom g = make_geom(outer, C, inner, kMseChunk);
-  return mse_workspace_doubles(g) * sizeof(double);
+  const size_t chunks = mse_workspace_doubles(g) * sizeof(double);
+  // (a per-tensor call may take the histogram route of 16-bit inputs: 8 copies of 65 536 counters + 256 partial tables)
+  return C == 1 && chunks < kMse16Bytes ? kMse16Bytes : chunks;
 }
 
 int sbq_mse_accumulate(const void* x, int x_dtype, int64_t outer, int64_t C, int64_t inner,
@@ -853,6 +1061,40 @@ int sbq_mse_accumulate(const void* x, int x_dtype, int64_t outer, int64_t C, int
   const bool vec = aligned16(x) && inner % kPack == 0;
   const float qrange = static_cast<float>(qmax - qmin);
   const float qlo = static_cast<float>(qmin), qhi = static_cast<float>(qmax);
+  if (mse16_eligible(x, x_dtype, outer, C, inner) && workspace_bytes >= kMse16Bytes) {
+    // one read of the tensor into an exact histogram of its 16-bit values, then 80 candidates x 65 536 values
+    uint32_t* ghist = static_cast<uint32_t*>(workspace);
+    double* part16 = reinterpret_cast<double*>(static_cast<char*>(workspace) + kHist16Bytes);
+    if (hipMemsetAsync(ghist, 0, kHist16Bytes, st) != hipSuccess) return check_launch();
+    const int64_t numel = outer * C * inner;
+    const int64_t per_launch = static_cast<int64_t>(kH16Elems) * cu_count();
+    int rc16 = SBQ_OK;
+    for (int64_t done = 0; done < numel && rc16 == SBQ_OK; done += per_launch) {
+      const int64_t cnt = numel - done < per_launch ? numel - done : per_launch;
+      const uint32_t wgs = static_cast<uint32_t>(ceil_div(cnt, static_cast<int64_t>(kH16Elems)));
+      const void* xp = static_cast<const char*>(x) + done * 2;
+      rc16 = dispatch_dtype(x_dtype, [&](auto tag) {
+        using T = decltype(tag);
+        if constexpr (T::id != SBQ_F32) {
+          static bool once = [] {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(hist16_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+            return true;
+          }();
+          (void)once;
+          hist16_kernel<T><<<wgs, kH16Threads, 131072, st>>>(xp, static_cast<uint32_t>(cnt), ghist);
+        }
+      });
+    }
+    if (rc16 != SBQ_OK) return rc16;
+    rc16 = dispatch_dtype(x_dtype, [&](auto tag) {
+      using T = decltype(tag);
+      if constexpr (T::id != SBQ_F32)
+        mse16_eval_kernel<T><<<kEvalBlocks, kBlock, 0, st>>>(ghist, min_val, max_val, qrange, qlo, qhi, symmetric, part16);
+    });
+    if (rc16 != SBQ_OK) return rc16;
+    mse16_fold_kernel<<<1, kBlock, 0, st>>>(part16, sse);
+    return check_launch();
+  }
   int rc = dispatch_dtype(x_dtype, [&](auto tag) {
     using T = decltype(tag);
     if (vec)

@@ -448,3 +448,70 @@ def test_h16_engine_equals_win_one_engine(ops):
         finally:
             L.set_tuning(2, 0)
     assert res[0] == res[18], res
+
+
+# --------------------------------------------------------------------------------------
+# the MSE observer of a 16-bit tensor taken as a whole: the histogram route (observers/mse.py:46-61)
+# --------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("scheme", ["per-tensor-symmetric", "per-tensor-affine"])
+def test_mse_per_tensor_histogram_route(ops, oracle, dtype, scheme):
+    """5.2 M elements (two launches' worth of workgroups would be 16.7 M; a ragged tail here), Gaussian with outliers
+    and, in the second data set, half zeros: the 80 squared-error sums of the histogram route agree with the
+    per-element route (knob 2 = 19) to 1e-6 relative and with the oracle's fp64 sums to 1e-5, and the chosen candidate is
+    the oracle's (a differing index only where the oracle's own sums of the two candidates tie to 1e-7)"""
+    from sparsebit_amd import lib as L
+
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(31)
+    n = 5 * 1024 * 1024 + 4099
+    sym = scheme.endswith("symmetric")
+    qmin, qmax = (-128, 127) if sym else (0, 255)
+    for relu in (False, True):
+        x = torch.randn(n, generator=g) * 0.7
+        x[::9973] *= 25.0
+        if relu:
+            x = torch.relu(x)
+        x = x.to(dtype)
+        xd = x.to(dev)
+        mn, mx, _ = ops.channel_stats(xd, 0, False)
+        tables = {}
+        for knob in (0, 19):
+            L.set_tuning(2, knob)
+            try:
+                sse = torch.zeros(1, L.MSE_CANDIDATES, dtype=torch.float64, device=dev)
+                ops.mse_accumulate(xd, mn, mx, qmin, qmax, sym, sse, 0, False)
+                tables[knob] = sse.cpu().numpy()[0]
+            finally:
+                L.set_tuning(2, 0)
+        a, b = tables[0], tables[19]
+        assert np.all(np.abs(a - b) <= 1e-6 * np.abs(b)), float(np.max(np.abs(a - b) / np.abs(b)))
+        _, _, b_ref, sse_ref = oracle.mse(x.float().numpy().reshape(1, -1), qmin, qmax, sym, 0, False)
+        assert np.all(np.abs(a - sse_ref[0]) <= 1e-5 * np.abs(sse_ref[0]))
+        s, z, best = ops.mse_select(torch.from_numpy(a).reshape(1, -1).to(dev), n, mn, mx, qmin, qmax, sym)
+        i_got, i_ref = int(best[0]), int(b_ref[0])
+        assert i_got == i_ref or abs(sse_ref[0, i_got] - sse_ref[0, i_ref]) <= 1e-7 * sse_ref[0, i_ref], (i_got, i_ref)
+    # a second call ADDS (two cached batches): twice the table
+    sse2 = torch.zeros(1, L.MSE_CANDIDATES, dtype=torch.float64, device=dev)
+    ops.mse_accumulate(xd, mn, mx, qmin, qmax, sym, sse2, 0, False)
+    ops.mse_accumulate(xd, mn, mx, qmin, qmax, sym, sse2, 0, False)
+    assert np.allclose(sse2.cpu().numpy()[0], 2 * tables[0], rtol=1e-12)
+
+
+def test_mse_histogram_route_constant_block(ops):
+    """65 536 x 64 equal elements (every workgroup's 16-bit count carries out of its half-dword) + a tail of other values"""
+    from sparsebit_amd import lib as L
+
+    dev = torch.device("cuda:0")
+    x = torch.cat([torch.full((65536 * 64,), 0.5), torch.linspace(-1, 1, 70000)]).bfloat16().to(dev)
+    mn, mx, _ = ops.channel_stats(x, 0, False)
+    out = {}
+    for knob in (0, 19):
+        L.set_tuning(2, knob)
+        try:
+            sse = torch.zeros(1, L.MSE_CANDIDATES, dtype=torch.float64, device=dev)
+            ops.mse_accumulate(x, mn, mx, -8, 7, True, sse, 0, False)
+            out[knob] = sse.cpu().numpy()[0]
+        finally:
+            L.set_tuning(2, 0)
+    assert np.all(np.abs(out[0] - out[19]) <= 1e-6 * np.abs(out[19]))

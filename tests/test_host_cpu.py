@@ -399,3 +399,26 @@ def test_lsq_export_branch_builds_constants_without_a_host_round_trip():
     y = q(x)
     want = torch.fake_quantize_per_channel_affine(x, torch.tensor([0.1, 0.2, 0.05]), torch.tensor([0, 7, -8], dtype=torch.int32), 0, -128, 127)
     assert y.shape == want.shape
+
+
+def test_plugin_preinstall_answers_the_reference_import_time_jit():
+    """plugin.preinstall(): the reference's `load(name="fake_quant", ...)` at import (quant_tensor.py:7-22) gets the
+    prebuilt HIP module instead of a hipify + compile of its CUDA sources; other extensions still go to torch"""
+    import torch.utils.cpp_extension as ext
+
+    from sparsebit_amd import fake_quant, plugin
+
+    real = ext.load
+    restore = plugin.preinstall()
+    try:
+        assert ext.load is not real
+        got = ext.load(name="fake_quant", sources=["/nonexistent/export.cc"], with_cuda=True, build_directory="/nonexistent")
+        assert got is fake_quant
+        for fn in ("quant_pertensor_forward", "quant_perchannel_forward", "quant_pertensor_backward", "quant_perchannel_backward"):
+            assert hasattr(got, fn)
+        assert plugin.preinstall()() is None  # idempotent: a second call wraps nothing
+        with pytest.raises(Exception):
+            ext.load(name="something_else", sources=["/nonexistent/x.cc"], build_directory="/nonexistent")
+    finally:
+        restore()
+    assert ext.load is real

@@ -394,6 +394,64 @@ def main():
     extras["observer_allreduce_percentile_hist_sum_us"] = round(ar_hist_us, 2)
     extras["observer_allreduce_percentile_hist_sum_bytes"] = hist_t.numel() * 8 if world > 1 else 0
 
+    # ---- config 3 across ranks: DeiT-small's percentile calibration with the batches SHARDED over the GPUs ----------
+    # every rank holds its own 4 batches of 64 x 197 x 384 (bf16) for each of 12 activation quantizers (one per block);
+    # the 12 observers' windowed selections advance in lock step (sparsebit_amd.dist.run_lockstep): sample SUM ->
+    # identical windows -> ONE sweep of the rank's batches -> count SUM -> placement.  Timed per model (all 12
+    # quantizers), collectives and bytes counted; gate: rank 0 gathers every rank's batches of quantizer 0 and runs
+    # the single-process engine on the union.
+    if world > 1 and not args.quick or (world > 1 and os.environ.get("SBQ_BENCH_SHARDED_LEG") == "1"):
+        from sparsebit_amd import select
+
+        gq = torch.Generator().manual_seed(77 + rank)
+        n_q = 12
+        acts = []
+        for qi in range(n_q):
+            bs = []
+            for _ in range(4):
+                a_ = torch.randn(64, 197, 384, generator=gq) * (1.0 + 0.1 * qi)
+                bs.append(a_.bfloat16().to(dev).reshape(-1))
+            acts.append(bs)
+
+        def sharded_model():
+            gens = [select.windowed_steps(acts[qi], ops.HipWindowBackend(torch.bfloat16), dev, percentile_alpha=1e-3)
+                    for qi in range(n_q)]
+            return sbq_dist.run_lockstep(gens)
+
+        with sbq_dist.sharded_calibration():
+            res = sharded_model()
+            sync_all()
+            sbq_dist.reset_stats()
+            t_a = time.perf_counter()
+            reps = 5
+            for _ in range(reps):
+                res = sharded_model()
+            sync_all()
+            shard_us = (time.perf_counter() - t_a) * 1e6 / reps
+            stats = dict(sbq_dist.stats)
+        # gate on quantizer 0: the union of all ranks' batches through the single-process engine
+        mine0 = torch.cat(acts[0])
+        gathered = [torch.empty_like(mine0) for _ in range(world)]
+        dist.all_gather(gathered, mine0)
+        ok_sh = None
+        if rank == 0:
+            mn_u, mx_u = ops.percentile_select([g_.reshape(1, -1) for g_ in gathered], 1e-3, 0, False)
+            ok_sh = bool(float(res[0][0]) == float(mn_u) and float(res[0][1]) == float(mx_u))
+        t = torch.tensor([shard_us], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        extras["sharded_percentile_calibration"] = {
+            "what": "12 per-tensor percentile observers (alpha 1e-3), 4 batches of 64x197x384 bf16 per rank and observer, "
+                    "batches sharded over %d ranks, windowed selection in lock step" % world,
+            "us_per_model": round(float(t.item()), 1),
+            "collectives_per_model": stats["collectives"] // reps,
+            "bytes_per_model": stats["bytes"] // reps,
+            "host_reads_per_model": stats["host_reads"] // reps,
+            "elements_per_rank": n_q * 4 * 64 * 197 * 384,
+            "parity": ok_sh,
+            "gate": "(min, max) of observer 0 == the single-process engine on the all-gathered union, bit-exact",
+        }
+        del acts, gathered
+
     # ---- the rest of the hot path at the headline size (library calls through ops.py; events over a loop) -----
     def timed_op(fn, iters=30):
         for _ in range(5):

@@ -295,11 +295,14 @@ int sbq_channel_stats(const void* x, int x_dtype,
                       void* workspace, size_t workspace_bytes, void* stream);
 
 /* The streaming per-tensor min-max observer (observers/minmax.py:14-25 over batches that arrive one by one,
- * tools/calibration.py:109-115): ONE launch per batch and nothing to fold.  `state` is uint32[64] owned by the
- * observer (two 128-byte lines: word 0 the largest order-preserving key so far, word 32 the smallest; a NaN anywhere
- * pins both results to NaN like torch.min / torch.max): sbq_minmax_state_reset once, sbq_minmax_accumulate per batch
+ * tools/calibration.py:109-115): ONE launch per batch and nothing to fold.  `state` is uint32[SBQ_MINMAX_STATE_WORDS]
+ * owned by the observer (64 slots of one 128-byte line: word 0 of a slot the largest order-preserving key so far,
+ * word 1 the smallest; workgroup b updates slot b % 64 -- a thousand workgroups on one address pair serialise at the
+ * memory side; a NaN anywhere pins both results to NaN like torch.min / torch.max): sbq_minmax_state_reset once,
+ * sbq_minmax_accumulate per batch
  * (x 16-byte aligned, any length; every workgroup updates the state with one integer atomicMax / atomicMin pair --
  * order independent, hence exact and deterministic), sbq_minmax_state_read when calc_qparams wants (min, max). */
+#define SBQ_MINMAX_STATE_WORDS 2048
 int sbq_minmax_state_reset(uint32_t* state, void* stream);
 int sbq_minmax_accumulate(const void* x, int x_dtype, int64_t numel, uint32_t* state, void* stream);
 int sbq_minmax_state_read(uint32_t* state, float* min_out, float* max_out, void* stream);

@@ -132,7 +132,7 @@ __global__ __launch_bounds__(kBlock) void stats_minmax_kernel(const void* __rest
 // joined it to the running statistic: a 51 MB batch spent 6 of its 16 us outside its read.  min / max are order
 // independent, so every workgroup folds its four chunks and updates the observer's running state directly with one
 // integer atomicMax / atomicMin pair -- exact, deterministic, no second launch, and the state IS the running
-// statistic.  state: uint32[64], word 0 = the largest key so far, word 32 (its own 128-byte line) = the smallest;
+// statistic.  state: uint32[2048] = 64 slots of one 128-byte line, word 0 of a slot the largest key so far, word 1 the smallest;
 // key = the usual order-preserving map of the float's bits, with NaN sent to the top of the max word and to the
 // bottom of the min word, so that a NaN anywhere makes both results NaN like torch.min / torch.max.
 __device__ __forceinline__ uint32_t ordered_key(float f) {
@@ -142,7 +142,10 @@ __device__ __forceinline__ uint32_t ordered_key(float f) {
 __device__ __forceinline__ float ordered_value(uint32_t k) {
   return __builtin_bit_cast(float, k ^ ((k & 0x80000000u) ? 0x80000000u : 0xffffffffu));
 }
-constexpr int kMinWord = 32;
+// (64 slots, a 128-byte line each: word 0 of a slot the largest key, word 1 the smallest.  Workgroup b updates slot
+// b % 64: a thousand workgroups updating ONE pair of addresses queued up at the memory side -- 8 ns per atomic, 16 us for
+// a 16.7 M-element tensor whose read takes 7)
+constexpr int kMmSlots = 64, kMmSlotWords = 32;
 template <typename T>
 __global__ __launch_bounds__(kBlock) void minmax_accumulate_kernel(const void* __restrict__ x, int64_t n, uint32_t n_chunks,
                                                                    uint32_t* __restrict__ state) {
@@ -169,18 +172,22 @@ __global__ __launch_bounds__(kBlock) void minmax_accumulate_kernel(const void* _
     }
     const uint32_t kmax = mx != mx ? 0xffffffffu : ordered_key(mx);
     const uint32_t kmin = mn != mn ? 0u : ordered_key(mn);
-    atomicMax(state, kmax);
-    atomicMin(state + kMinWord, kmin);
+    uint32_t* slot = state + (blockIdx.x % kMmSlots) * kMmSlotWords;
+    atomicMax(slot, kmax);
+    atomicMin(slot + 1, kmin);
   }
 }
 __global__ void minmax_state_kernel(uint32_t* __restrict__ state, float* __restrict__ min_out, float* __restrict__ max_out) {
-  if (threadIdx.x != 0) return;
+  const int t = threadIdx.x;  // one wave: lane t owns slot t
   if (!min_out) {  // reset: the identities of max / min
-    state[0] = 0u;
-    state[kMinWord] = 0xffffffffu;
+    state[t * kMmSlotWords] = 0u;
+    state[t * kMmSlotWords + 1] = 0xffffffffu;
     return;
   }
-  const uint32_t kmax = state[0], kmin = state[kMinWord];
+  uint32_t kmax = state[t * kMmSlotWords], kmin = state[t * kMmSlotWords + 1];
+  kmax = dpp_reduce_u32(kmax, 0u, [](uint32_t a, uint32_t b) { return a > b ? a : b; });
+  kmin = dpp_reduce_u32(kmin, 0xffffffffu, [](uint32_t a, uint32_t b) { return a < b ? a : b; });
+  if (t != 0) return;
   const bool nan = kmax == 0xffffffffu || kmin == 0u;
   const float qnan = __builtin_nanf("");
   min_out[0] = nan ? qnan : ordered_value(kmin);
@@ -679,74 +686,91 @@ __global__ __launch_bounds__(kH16Threads) void hist16_kernel(const void* __restr
   }
 }
 
-// 80 candidates x 65 536 values: workgroup b owns keys [256 b, 256 b + 256), one per thread; part[b][80] = the
-// workgroup's share of every candidate's squared error (fp64), folded by mse16_fold_kernel in workgroup order.
+// 80 candidates x 65 536 values: a workgroup owns 256 keys.  Its occupied keys (a tensor's values fill a few per cent of
+// the key space) are compacted into an LDS list of (value, count);
+// thread (candidate i, third r) then walks its third of the list and adds count * err(value; candidate i)^2 in fp64 --
+// the per-value error with the very operations of mse_chunk_body.  (One value per thread and a wave reduction per
+// candidate -- 80 x 12 cross-lane moves of 64-bit values -- was 20 us on the workgroups at the centre of the
+// distribution.)  part[b][80] = the workgroup's share of every candidate's squared error, folded in workgroup order
+// by mse16_fold_kernel.
 template <typename T>
 __global__ __launch_bounds__(kBlock) void mse16_eval_kernel(const uint32_t* __restrict__ ghist, const float* __restrict__ min_val,
                                                             const float* __restrict__ max_val, float qrange, float qlo,
                                                             float qhi, int symmetric, double* __restrict__ part) {
-  __shared__ float s_scale[SBQ_MSE_CANDIDATES], s_zp[SBQ_MSE_CANDIDATES], s_rcp[SBQ_MSE_CANDIDATES];
-  __shared__ double s_acc[SBQ_MSE_CANDIDATES][kWavesPerBlock];
-  if (threadIdx.x < SBQ_MSE_CANDIDATES) {
-    float s, z;
-    mse_candidate(min_val[0], max_val[0], threadIdx.x, qrange, symmetric != 0, s, z);
-    s_scale[threadIdx.x] = s;
-    s_zp[threadIdx.x] = z;
-    s_rcp[threadIdx.x] = fast_div_ok(s) ? 1.0f / s : 0.0f;
-  }
-  const uint32_t key = blockIdx.x * kBlock + threadIdx.x;
+  __shared__ float s_val[kBlock];
+  __shared__ uint32_t s_cnt[kBlock];
+  __shared__ uint32_t s_wave_n[kWavesPerBlock];
+  __shared__ double s_acc[3][SBQ_MSE_CANDIDATES];
+  // Keys are dealt to the workgroups in runs of 16 (64 bytes of counters: still whole sectors per quarter wave):
+  // workgroup b owns runs b, b + 256, b + 512, ...  A tensor's values occupy a few contiguous stretches of the key
+  // space; as 256 consecutive keys per workgroup a dozen workgroups had 256-entry lists and 240 had none.
+  const uint32_t key = 16u * (blockIdx.x + kEvalBlocks * (threadIdx.x / 16u)) + (threadIdx.x & 15u);
   uint32_t c = 0;
 #pragma unroll
   for (int k = 0; k < kHistCopies; ++k) c += ghist[static_cast<size_t>(k) * kHistKeys + key];
-  const float v = Key16<T>::value(key << 16);
-  const double cd = static_cast<double>(c);
-  __syncthreads();
   const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
-  const bool any = __builtin_amdgcn_ballot_w64(c != 0u) != 0;  // (most of the key space is empty: whole waves idle)
-  for (int i = 0; i < SBQ_MSE_CANDIDATES; ++i) {
-    double e = 0.0;
-    if (any) {
-      const float s = s_scale[i], z = s_zp[i], y = s_rcp[i];
-      float d;
-      // (mse_chunk_body's three forms of one element's error, operation for operation)
-      if (y != 0.0f) {
-        if (z == 0.0f) {
-          const float lv = __builtin_amdgcn_fmed3f(__builtin_rintf(v * y), qlo, qhi);
-          d = __builtin_fmaf(-lv, s, v);
-        } else {
-          const float lv = __builtin_amdgcn_fmed3f(__builtin_rintf(v * y) + z, qlo, qhi);
-          d = __builtin_fmaf(-(lv - z), s, v);
-        }
-      } else {
-        const float lv = quant_level<SBQ_ROUND_HALF_EVEN>(v, s, z, qlo, qhi);
-        d = v - dequant_level(lv, s, z);
-      }
-      e = c ? cd * (static_cast<double>(d) * static_cast<double>(d)) : 0.0;
+  const uint64_t mask = __builtin_amdgcn_ballot_w64(c != 0u);
+  if (lane == 0) s_wave_n[wid] = static_cast<uint32_t>(__builtin_popcountll(mask));
+  __syncthreads();
+  uint32_t base = 0, total = 0;
 #pragma unroll
-      for (int m = kWave / 2; m > 0; m >>= 1) e += __shfl_xor(e, m, kWave);
-    }
-    if (lane == 0) s_acc[i][wid] = e;
+  for (int w = 0; w < kWavesPerBlock; ++w) {
+    base += w < wid ? s_wave_n[w] : 0u;
+    total += s_wave_n[w];
+  }
+  if (c != 0u) {
+    const uint32_t pos = base + static_cast<uint32_t>(__builtin_popcountll(mask & ((1ull << lane) - 1ull)));
+    s_val[pos] = Key16<T>::value(key << 16);
+    s_cnt[pos] = c;
   }
   __syncthreads();
-  if (threadIdx.x < SBQ_MSE_CANDIDATES) {
-    double t = 0.0;
-#pragma unroll
-    for (int w = 0; w < kWavesPerBlock; ++w) t += s_acc[threadIdx.x][w];
-    part[static_cast<size_t>(blockIdx.x) * SBQ_MSE_CANDIDATES + threadIdx.x] = t;
-  }
-}
-__global__ __launch_bounds__(kBlock) void mse16_fold_kernel(const double* __restrict__ part, double* __restrict__ sse) {
-  // thread (i, r): candidate i, every third workgroup starting at r -- three interleaved running sums, joined
-  // ((s0 + s1) + s2) like the fold of the per-chunk tables
-  __shared__ double s_d[3][SBQ_MSE_CANDIDATES];
   const uint32_t i = threadIdx.x % SBQ_MSE_CANDIDATES, r = threadIdx.x / SBQ_MSE_CANDIDATES;
   if (r < 3) {
-    double t = 0.0;
-    for (uint32_t b = r; b < kEvalBlocks; b += 3) t += part[static_cast<size_t>(b) * SBQ_MSE_CANDIDATES + i];
-    s_d[r][i] = t;
+    double acc = 0.0;
+    if (total != 0u) {  // (uniform)
+      float s, z;
+      mse_candidate(min_val[0], max_val[0], static_cast<int>(i), qrange, symmetric != 0, s, z);
+      const float y = fast_div_ok(s) ? 1.0f / s : 0.0f;
+      for (uint32_t e = r; e < total; e += 3) {
+        const float v = s_val[e];
+        float d;
+        // (mse_chunk_body's three forms of one element's error, operation for operation)
+        if (y != 0.0f) {
+          if (z == 0.0f) {
+            const float lv = __builtin_amdgcn_fmed3f(__builtin_rintf(v * y), qlo, qhi);
+            d = __builtin_fmaf(-lv, s, v);
+          } else {
+            const float lv = __builtin_amdgcn_fmed3f(__builtin_rintf(v * y) + z, qlo, qhi);
+            d = __builtin_fmaf(-(lv - z), s, v);
+          }
+        } else {
+          const float lv = quant_level<SBQ_ROUND_HALF_EVEN>(v, s, z, qlo, qhi);
+          d = v - dequant_level(lv, s, z);
+        }
+        acc += static_cast<double>(s_cnt[e]) * (static_cast<double>(d) * static_cast<double>(d));
+      }
+    }
+    s_acc[r][i] = acc;
   }
   __syncthreads();
-  if (threadIdx.x < SBQ_MSE_CANDIDATES) sse[threadIdx.x] += (s_d[0][threadIdx.x] + s_d[1][threadIdx.x]) + s_d[2][threadIdx.x];
+  if (threadIdx.x < SBQ_MSE_CANDIDATES)
+    part[static_cast<size_t>(blockIdx.x) * SBQ_MSE_CANDIDATES + threadIdx.x] =
+        (s_acc[0][threadIdx.x] + s_acc[1][threadIdx.x]) + s_acc[2][threadIdx.x];
+}
+__global__ __launch_bounds__(kBlock) void mse16_fold_kernel(const double* __restrict__ part, double* __restrict__ sse) {
+  // workgroup i folds candidate i: thread b fetches workgroup b's share (ONE load per thread -- as a serial walk of 85
+  // dependent loads per thread this fold took 22 us), then a fixed-order tree in LDS
+  static_assert(kEvalBlocks == kBlock, "one partial table per thread");
+  __shared__ double s_d[kBlock];
+  const uint32_t i = blockIdx.x;
+  s_d[threadIdx.x] = part[static_cast<size_t>(threadIdx.x) * SBQ_MSE_CANDIDATES + i];
+  __syncthreads();
+#pragma unroll
+  for (int w = kBlock / 2; w > 0; w >>= 1) {
+    if (static_cast<int>(threadIdx.x) < w) s_d[threadIdx.x] += s_d[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) sse[i] += s_d[0];
 }
 
 // does sbq_mse_accumulate take the histogram route?  (per tensor, 16-bit, whole 16-byte packs from an aligned base,
@@ -1092,7 +1116,7 @@ int sbq_mse_accumulate(const void* x, int x_dtype, int64_t outer, int64_t C, int
         mse16_eval_kernel<T><<<kEvalBlocks, kBlock, 0, st>>>(ghist, min_val, max_val, qrange, qlo, qhi, symmetric, part16);
     });
     if (rc16 != SBQ_OK) return rc16;
-    mse16_fold_kernel<<<1, kBlock, 0, st>>>(part16, sse);
+    mse16_fold_kernel<<<SBQ_MSE_CANDIDATES, kBlock, 0, st>>>(part16, sse);
     return check_launch();
   }
   int rc = dispatch_dtype(x_dtype, [&](auto tag) {

@@ -21,7 +21,7 @@ class Observer(BaseObserver):
     def __init__(self, config, qdesc):
         super().__init__(config, qdesc)
         self._running = None  # (min, max) folded so far by consume()
-        self._state = None  # per tensor: the running state of sbq_minmax_accumulate (device, 2 x 128 bytes)
+        self._state = None  # per tensor: the running state of sbq_minmax_accumulate (device, 8 KB)
 
     def consume(self, x):
         """Fold one batch into the running statistics without caching it.  Per tensor (every shipped activation

@@ -1080,7 +1080,7 @@ class HipSelectBackend:
 # ---------------------------------------------------------------------------------
 def minmax_state(device):
     """a fresh running state of the streaming per-tensor min-max observer (include/sbq.h: sbq_minmax_accumulate)"""
-    st = torch.empty(64, dtype=torch.int32, device=device)
+    st = torch.empty(2048, dtype=torch.int32, device=device)  # SBQ_MINMAX_STATE_WORDS
     with L.device_guard(device):
         L.check(L.load().sbq_minmax_state_reset(L.ptr(st), L.stream_ptr(device)))
     return st

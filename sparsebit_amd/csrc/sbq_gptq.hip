@@ -491,6 +491,12 @@ __global__ __launch_bounds__(8 * KL) __attribute__((amdgpu_waves_per_eu(CH == 64
   for (int j = 0; j < 4; ++j)
 #pragma unroll
     for (int b = 0; b < kBT; ++b) acc[j][b] = 0.0f;
+  // An unsplit workgroup adds its strip's sums to `out` (pre-filled with the bias) itself: the value it adds to is
+  // requested HERE, with the first weight words, instead of after the fold -- where the read was one more exposed
+  // memory round trip (~1.3 us of a 7.7 us launch at 4096 x 4096) at the very end of the kernel.
+  // (unconditionally, every thread, clamped to a valid element: a load behind a branch costs the compiler its count of
+  // the loads in flight, and it then waits for all of them at the join)
+  const float out_prev = out[(b0 + ((ob < kBT && b0 + ob < g.batch) ? ob : 0)) * g.out_features + ocol];
 
   if constexpr (PF) {
     __shared__ __attribute__((aligned(1024))) uint8_t wring[kThreads * 16 * kRows];  // [row i][lane] 16-byte words
@@ -673,7 +679,7 @@ __global__ __launch_bounds__(8 * KL) __attribute__((amdgpu_waves_per_eu(CH == 64
 #pragma unroll
     for (int q = 0; q < KL; ++q) t += red[q][ob][occ];
     if (split == 1)  // this workgroup saw all of K: add to out (pre-filled with the bias)
-      out[(b0 + ob) * g.out_features + ocol] += t;
+      out[(b0 + ob) * g.out_features + ocol] = out_prev + t;
     else
       __hip_atomic_store(&part[(static_cast<int64_t>(blockIdx.y) * g.batch + b0 + ob) * g.out_features + ocol], t,
                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

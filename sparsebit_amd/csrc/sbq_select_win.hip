@@ -2682,7 +2682,7 @@ int win_one_run(const void* const* shards, const int64_t* counts, int n_shards, 
   // fp32 selection as ONE launch too, its later sweeps as resident rounds (win_finish): measured 79 us against 72 for
   // the three launches (16.7 M elements) -- a resident round pays the verdict's poll and a 2048-bin gather under the
   // pollers' traffic, a launch boundary pays 2 us -- so the launches stay.
-  const int expected = min_shift > 0 || knob(2) == 15 ? 1 : 3;
+  const int expected = min_shift > 0 || knob(2) == 15 ? 1 : (knob(2) == 20 ? 2 : 3);
   const int64_t cus = cu_count();
   const uint32_t grid = static_cast<uint32_t>(total < cus ? (total > 0 ? total : 1) : cus);
   OneArgs a{};
@@ -3031,7 +3031,10 @@ int sbq_group_kth_value(const sbq_kth_item* items, int n_items, int x_dtype, int
     if (rc != SBQ_OK) return rc;
   }
   const uint32_t min_shift = x_dtype == SBQ_F32 ? 0u : 16u;
-  const int expected = min_shift > 0 || knob(2) == 15 ? 1 : 3;
+  // fp32: TWO launches -- the second one resident, so a tensor whose rank needs a third sweep gets it inside that launch
+  // (measured on ResNet-50's 53 weights: 80 us against 89 for three launches; knob 2 == 21: three, for A/B runs.  A
+  // single fp32 selection keeps its three launches: 72 us against 79.)
+  const int expected = min_shift > 0 || knob(2) == 15 ? 1 : (knob(2) == 21 ? 3 : 2);
   const int64_t cus = cu_count();
   for (int first = 0; first < n_items; first += kKthItemsPerLaunch) {
     const int cnt = n_items - first < kKthItemsPerLaunch ? n_items - first : kKthItemsPerLaunch;

@@ -101,7 +101,8 @@ def main(tag):
             lines.append('"%s",%d,%.0f,%.0f,%s,%s,%s' % (k, len(v), insts, waves, "%.0f" % ns if ns else "",
                                                      "%.3e" % rate if rate else "", "%.3f" % (rate / 614e9) if rate else ""))
             if k.startswith(("mse_partial_kernel", "qdq_resident_kernel<BF16, BF16, 0, 16", "win_pass_kernel", "win_one_kernel",
-                             "calib_mse_kernel", "stats_minmax_kernel", "qdq_observe_kernel")):
+                             "calib_mse_kernel", "stats_minmax_kernel", "qdq_observe_kernel", "h16_select_kernel", "hist16_kernel",
+                             "minmax_accumulate_kernel", "mse16_eval_kernel")):
                 valu[k.split("<")[0]] = {"kernel": k, "valu_wave_insts_per_launch": insts, "avg_ns": ns,
                                          "valu_wave_insts_per_s": rate,
                                          "vs_nominal_issue_rate_614e9": round(rate / 614e9, 3) if rate else None}

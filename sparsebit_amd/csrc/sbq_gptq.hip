@@ -23,6 +23,7 @@
 //   * no float atomics (the reference's per-block atomicAdd makes the sum order,
 //     hence the result, run-to-run dependent): every workgroup writes its
 //     partial tile, a second kernel adds the K slices in a fixed order.
+#include <climits>
 #include <type_traits>
 
 #include "sbq_common.hpp"
@@ -52,6 +53,8 @@ struct GptqGeom {
   int32_t slices_per_block;
   int32_t kblocks;     // ceil(slices / slices_per_block)
   int32_t xcd_swizzle; // strip kernels: XCD-aware strip order (strips % 8 == 0)
+  int32_t grid_x, grid_y;  // LEAN strip kernels: the launch grid (read with the other arguments instead of from
+                           // the hidden ones at the far end of the argument block)
 };
 
 // COLS = 4: 16-byte loads (out_features % 4 == 0, aligned); COLS = 1: any shape.
@@ -194,6 +197,28 @@ __global__ __launch_bounds__(kBlock) void gptq_partial_kernel(
 // arrives last adds the S partials IN INDEX ORDER (so the sum does not depend on who was last)
 // and resets the counter.  One kernel, deterministic, nobody ever waits on another workgroup.
 constexpr int kStripCols = 32;
+
+// -DSBQ_GPTQ_STAMPS=1 (tools/lab/gptq_stamps.py builds such a library next to the product one): thread 0 of every
+// workgroup of gptq_strip_kernel writes s_memrealtime (100 MHz) stamps through a device-global pointer
+#ifndef SBQ_GPTQ_STAMPS
+#define SBQ_GPTQ_STAMPS 0
+#endif
+#if SBQ_GPTQ_STAMPS != 0
+__constant__ unsigned long long* g_gptq_stamps = nullptr;
+#define GPTQ_STAMP_INIT() \
+  unsigned long long* const stamp_base = g_gptq_stamps ? g_gptq_stamps + (blockIdx.y * gridDim.x + blockIdx.x) * 8 : nullptr
+#define GPTQ_STAMP(i)                                                                     \
+  do {                                                                                    \
+    if (threadIdx.x == 0 && stamp_base) stamp_base[(i)] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
+#else
+#define GPTQ_STAMP_INIT() \
+  do {                    \
+  } while (0)
+#define GPTQ_STAMP(i) \
+  do {                \
+  } while (0)
+#endif
 constexpr int kStripMaxSplit = 16;          // upper bound of the K split S
 constexpr size_t kCounterBytes = SBQ_GPTQ_COUNTER_BYTES;  // fixed region at the head of the workspace
 constexpr int64_t kMaxStrips = static_cast<int64_t>(kCounterBytes / sizeof(uint32_t));
@@ -365,6 +390,14 @@ __device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_dst) {
                : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
 
+// ... the same with a uniform base (SGPR pair) + a 32-bit byte offset per lane: half the address registers and none
+// of the 64-bit address arithmetic
+__device__ __forceinline__ void glds16s(const void* sbase, uint32_t voff, uint32_t lds_dst) {
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
+
 // The cross-workgroup half of the K split (shared by the strip kernels): publish, count the arrival, and the last
 // workgroup of the strip folds the S partials in index order.
 template <int kThreads>
@@ -435,7 +468,18 @@ struct GptqMulti {
   int64_t part_off[kMaxMulti];  // floats: where the matrix's partial tiles start
 };
 
-template <int BITS, int kBT, int KL, int CH, bool DEC8 = false, bool PF = false>
+// LEAN (host-checked: x rows 16-byte aligned, in_features % 4 == 0): EVERY global load of a pass is unconditional --
+// channels, batch rows, weight rows and groups are clamped to valid ones and what must not count is zeroed by a
+// select afterwards.  A load under a branch makes the compiler wait for everything in flight at the join: the
+// timeline of the branchy version (tools/lab/gptq_stamps.py, profiles/r04_gptq_timeline.txt) showed the weight
+// words of the first pass being REQUESTED 2.3 us after the workgroup started -- behind two full memory round trips
+// (the value added to, then the activations) that the joins had serialised.
+// LEAN also means a lean PROLOGUE (the timeline again: 1.4 us from a workgroup's start to its first load): the grid
+// shape travels with the geometry, the XCD swizzle is arithmetic instead of a branch, the matrix lookup of a
+// multi-matrix launch (MULTI) is three comparisons instead of a loop over the argument block -- so every kernel
+// argument is fetched by ONE group of scalar loads instead of five dependent ones -- and every address is a uniform
+// base + a 32-bit byte offset (host-checked: each tensor is below 4 GB).
+template <int BITS, int kBT, int KL, int CH, bool DEC8 = false, bool PF = false, bool LEAN = false, bool MULTI = false>
 __global__ __launch_bounds__(8 * KL) __attribute__((amdgpu_waves_per_eu(CH == 64 && kBT == 1 ? (PF ? 3 : 4) : 1, 8))) void gptq_strip_kernel(
     const float* __restrict__ x, const int32_t* __restrict__ qw_a, const float* __restrict__ scales_a,
     const float* __restrict__ zeros_a, float* __restrict__ out_a, float* __restrict__ part_a,
@@ -447,6 +491,8 @@ __global__ __launch_bounds__(8 * KL) __attribute__((amdgpu_waves_per_eu(CH == 64
   float* __restrict__ out = out_a;
   float* __restrict__ part = part_a;
   uint32_t* __restrict__ arrivals = arrivals_a;
+  GPTQ_STAMP_INIT();
+  GPTQ_STAMP(0);
   constexpr int kThreads = 8 * KL;
   constexpr int kRows = CH * BITS / 32;       // qweight rows of one K lane: 16 / 12 / 8 for CH = 128
   constexpr int kRowsPerPass = KL * kRows;    // = KL * CH input channels
@@ -461,11 +507,21 @@ __global__ __launch_bounds__(8 * KL) __attribute__((amdgpu_waves_per_eu(CH == 64
   // the neighbouring 128-byte pieces of a qweight row are requested by eight different L2s.  Giving XCD i the
   // i-th contiguous eighth of the strips makes the workgroups that run side by side on one XCD read adjacent
   // pieces of the same rows (knob 2 == 8: plain order, for A/B runs).
+  static_assert(!MULTI || LEAN, "several matrices per launch: the LEAN kernels only");
   uint32_t strip = blockIdx.x;
-  if (g.xcd_swizzle) strip = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
-  if (mm.n > 0) {
-    int m = 0;
-    while (m + 1 < mm.n && strip >= static_cast<uint32_t>(mm.strip_begin[m + 1])) ++m;  // uniform
+  int split;
+  if constexpr (LEAN) {
+    const uint32_t sw = (blockIdx.x & 7u) * (static_cast<uint32_t>(g.grid_x) >> 3) + (blockIdx.x >> 3);
+    strip = blockIdx.x + (sw - blockIdx.x) * static_cast<uint32_t>(g.xcd_swizzle);  // xcd_swizzle is 0 or 1
+    split = g.grid_y;
+  } else {
+    if (g.xcd_swizzle) strip = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    split = gridDim.y;
+  }
+  if constexpr (MULTI) {  // strip_begin[m] for m >= n holds INT32_MAX (host): uniform, no loop
+    const int m = static_cast<int>(strip >= static_cast<uint32_t>(mm.strip_begin[1])) +
+                  static_cast<int>(strip >= static_cast<uint32_t>(mm.strip_begin[2])) +
+                  static_cast<int>(strip >= static_cast<uint32_t>(mm.strip_begin[3]));
     qw = mm.qw[m];
     scales = mm.scales[m];
     zeros = mm.zeros[m];
@@ -476,9 +532,45 @@ __global__ __launch_bounds__(8 * KL) __attribute__((amdgpu_waves_per_eu(CH == 64
     strip -= static_cast<uint32_t>(mm.strip_begin[m]);
   }
   const int64_t col0 = static_cast<int64_t>(strip) * kStripCols + cl * 4;
-  const int split = gridDim.y;
+  // LEAN: byte offsets in 32 bits
+  const uint32_t out32 = static_cast<uint32_t>(g.out_features), col32 = strip * kStripCols + cl * 4u;
+  const uint32_t wstride = out32 * 4u;  // bytes from one qweight row to the next
+  auto at32 = [](const auto* base, uint32_t byte_off) {
+    return reinterpret_cast<decltype(base)>(reinterpret_cast<const char*>(base) + byte_off);
+  };
   // 16-byte loads of x need aligned rows
-  const bool x_vec = (reinterpret_cast<uintptr_t>(x) & 15u) == 0 && (g.in_features & 3) == 0;
+  const bool x_vec = LEAN || ((reinterpret_cast<uintptr_t>(x) & 15u) == 0 && (g.in_features & 3) == 0);
+  // LEAN: 32-bit channel arithmetic (in_features, batch * in_features < 2^31: host)
+  const int in32 = static_cast<int>(g.in_features), batch32 = static_cast<int>(g.batch);
+  auto lean_x = [&](int brow, int k) -> f32x4 {  // 4 channels from k of batch row brow, zeros when out of range
+    const int kc = k < in32 ? k : in32 - 4;
+    const int rc = brow < batch32 ? brow : batch32 - 1;
+    const f32x4 t = *reinterpret_cast<const f32x4*>(at32(x, static_cast<uint32_t>(rc * in32 + kc) * 4u));
+    // zeroed by a MULTIPLY: a select (of a vector, on a scalar condition) becomes a branch, and the load sinks into it
+    const float keep = ((k < in32) & (brow < batch32)) ? 1.0f : 0.0f;
+    return t * keep;
+  };
+  auto lean_group = [&](int k0) -> int {
+    const int grp = static_cast<int>(static_cast<uint32_t>(k0) / static_cast<uint32_t>(g.group_size));
+    return grp < g.groups ? grp : g.groups - 1;
+  };
+  auto lean_sz = [&](int grp, float (&sc)[4], float (&zr)[4]) {
+    const uint32_t o = (col32 * static_cast<uint32_t>(g.groups) + static_cast<uint32_t>(grp)) * 4u;
+    const uint32_t step = static_cast<uint32_t>(g.groups) * 4u;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      sc[j] = *at32(scales, o + static_cast<uint32_t>(j) * step);
+      zr[j] = *at32(zeros, o + static_cast<uint32_t>(j) * step);
+    }
+  };
+  // byte offsets of kRows consecutive qweight rows from row0, rows past the end clamped to the last one
+  auto lean_rows = [&](int64_t row0, uint32_t (&off)[CH * BITS / 32]) {
+    const int last = g.H - 1;
+    const int r0 = row0 < last ? static_cast<int>(row0) : last;
+    off[0] = (static_cast<uint32_t>(r0) * out32 + col32) * 4u;
+#pragma unroll
+    for (int i = 1; i < CH * BITS / 32; ++i) off[i] = off[i - 1] + (r0 + i <= last ? wstride : 0u);
+  };
 
   const bool owner = threadIdx.x < kBT * kStripCols;  // one thread per (batch row of the tile, column)
   const int ob = threadIdx.x / kStripCols, occ = threadIdx.x - ob * kStripCols;
@@ -496,7 +588,13 @@ __global__ __launch_bounds__(8 * KL) __attribute__((amdgpu_waves_per_eu(CH == 64
   // memory round trip (~1.3 us of a 7.7 us launch at 4096 x 4096) at the very end of the kernel.
   // (unconditionally, every thread, clamped to a valid element: a load behind a branch costs the compiler its count of
   // the loads in flight, and it then waits for all of them at the join)
-  const float out_prev = out[(b0 + ((ob < kBT && b0 + ob < g.batch) ? ob : 0)) * g.out_features + ocol];
+  float out_prev;
+  if constexpr (LEAN) {
+    const uint32_t orow = static_cast<uint32_t>(b0) + ((ob < kBT && static_cast<int>(b0) + ob < batch32) ? ob : 0);
+    out_prev = *at32(out, (orow * out32 + strip * kStripCols + static_cast<uint32_t>(occ)) * 4u);
+  } else {
+    out_prev = out[(b0 + ((ob < kBT && b0 + ob < g.batch) ? ob : 0)) * g.out_features + ocol];
+  }
 
   if constexpr (PF) {
     __shared__ __attribute__((aligned(1024))) uint8_t wring[kThreads * 16 * kRows];  // [row i][lane] 16-byte words
@@ -505,6 +603,16 @@ __global__ __launch_bounds__(8 * KL) __attribute__((amdgpu_waves_per_eu(CH == 64
     const int64_t step = static_cast<int64_t>(split) * kRowsPerPass;
     auto load_small = [&](int64_t pass0, f32x4 (&xg)[kBT][kXLoads], float (&sc)[4], float (&zr)[4]) {
       const int64_t kbase = (pass0 / kRows) * CH;
+      if constexpr (LEAN) {
+        const int kb32 = static_cast<int>(kbase);
+#pragma unroll
+        for (int b = 0; b < kBT; ++b)
+#pragma unroll
+          for (int j = 0; j < kXLoads; ++j)
+            xg[b][j] = lean_x(static_cast<int>(b0) + b, kb32 + (j * kThreads + static_cast<int>(threadIdx.x)) * 4);
+        lean_sz(lean_group(kb32 + kl * CH), sc, zr);
+        return;
+      }
 #pragma unroll
       for (int b = 0; b < kBT; ++b)
 #pragma unroll
@@ -537,6 +645,13 @@ __global__ __launch_bounds__(8 * KL) __attribute__((amdgpu_waves_per_eu(CH == 64
     };
     auto dma_weights = [&](int64_t pass0) {
       const int64_t row0 = pass0 + kl * kRows;
+      if constexpr (LEAN) {
+        uint32_t off[kRows];
+        lean_rows(row0, off);
+#pragma unroll
+        for (int i = 0; i < kRows; ++i) glds16s(qw, off[i], wave_base + static_cast<uint32_t>(i) * (kThreads * 16u));
+        return;
+      }
 #pragma unroll
       for (int i = 0; i < kRows; ++i) {
         int64_t r = row0 + i;
@@ -551,10 +666,13 @@ __global__ __launch_bounds__(8 * KL) __attribute__((amdgpu_waves_per_eu(CH == 64
       load_small(first, xg_n, sc_n, zr_n);
       dma_weights(first);
     }
+    GPTQ_STAMP(1);
     for (int64_t pass0 = first; pass0 < g.H; pass0 += step) {
       const bool live = pass0 + kl * kRows < g.H;
       // this pass's weights (DMA) and small loads have landed
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (pass0 == first) GPTQ_STAMP(2);
+      else GPTQ_STAMP(3);
       f32x4 xg[kBT][kXLoads];
       float sc[4], zr[4];
 #pragma unroll
@@ -596,7 +714,9 @@ __global__ __launch_bounds__(8 * KL) __attribute__((amdgpu_waves_per_eu(CH == 64
         dma_weights(pass0 + step);
       }
       __syncthreads();
-      if (live) strip_compute<BITS, kBT, CH, DEC8, KL * kXStride>(w, &xs[0][0], kl, sc, zr, acc);
+      // (LEAN: unconditionally -- a dead K lane's activations are zeros, it adds exact zeros; under a branch the compiler
+      // SINKS the weight loads into it, behind the barriers, one more exposed memory round trip)
+      if (LEAN || live) strip_compute<BITS, kBT, CH, DEC8, KL * kXStride>(w, &xs[0][0], kl, sc, zr, acc);
     }
   } else {
   // passes y, y + S, y + 2S, ... of the K dimension
@@ -608,6 +728,25 @@ __global__ __launch_bounds__(8 * KL) __attribute__((amdgpu_waves_per_eu(CH == 64
     // activations (4 x 16 bytes per batch row, coalesced), its weight words, its scale / zero
     const int64_t kbase = (pass0 / kRows) * CH;
     f32x4 xg[kBT][kXLoads];
+    u32x4 w[kRows];
+    const int64_t k0 = kbase + static_cast<int64_t>(kl) * CH;
+    float sc[4] = {0, 0, 0, 0}, zr[4] = {0, 0, 0, 0};
+    if constexpr (LEAN) {
+      const int kb32 = static_cast<int>(kbase);
+#pragma unroll
+      for (int b = 0; b < kBT; ++b)
+#pragma unroll
+        for (int j = 0; j < kXLoads; ++j)
+          xg[b][j] = lean_x(static_cast<int>(b0) + b, kb32 + (j * kThreads + static_cast<int>(threadIdx.x)) * 4);
+      uint32_t off[kRows];
+      lean_rows(row0, off);
+#pragma unroll
+      for (int i = 0; i < kRows; ++i) {  // rows past the end: a valid address, words zeroed
+        const u32x4 t = ld16<true>(at32(qw, off[i]));
+        w[i] = t & (row0 + i < g.H ? 0xffffffffu : 0u);
+      }
+      lean_sz(lean_group(static_cast<int>(k0)), sc, zr);
+    } else {
 #pragma unroll
     for (int b = 0; b < kBT; ++b)
 #pragma unroll
@@ -626,15 +765,12 @@ __global__ __launch_bounds__(8 * KL) __attribute__((amdgpu_waves_per_eu(CH == 64
           }
         }
       }
-    u32x4 w[kRows];
 #pragma unroll
     for (int i = 0; i < kRows; ++i) {
       const int64_t r = row0 + i;
       w[i] = u32x4{0, 0, 0, 0};
       if (live && r < g.H) w[i] = ld16<true>(qw + r * g.out_features + col0);
     }
-    const int64_t k0 = kbase + static_cast<int64_t>(kl) * CH;
-    float sc[4] = {0, 0, 0, 0}, zr[4] = {0, 0, 0, 0};
     if (live) {
       const int grp = static_cast<int>(k0 / g.group_size);
 #pragma unroll
@@ -643,7 +779,10 @@ __global__ __launch_bounds__(8 * KL) __attribute__((amdgpu_waves_per_eu(CH == 64
         zr[j] = zeros[(col0 + j) * g.groups + grp];
       }
     }
+    }
+    GPTQ_STAMP(1);
     __syncthreads();  // previous pass done with xs
+    GPTQ_STAMP(2);
 #pragma unroll
     for (int b = 0; b < kBT; ++b)
 #pragma unroll
@@ -664,11 +803,16 @@ __global__ __launch_bounds__(8 * KL) __attribute__((amdgpu_waves_per_eu(CH == 64
         }
       }
     __syncthreads();
-    if (live) strip_compute<BITS, kBT, CH, DEC8, KL * kXStride>(w, &xs[0][0], kl, sc, zr, acc);
+    GPTQ_STAMP(3);
+    // (LEAN: unconditionally -- a dead K lane's activations are zeros, it adds exact zeros; under a branch the compiler
+      // SINKS the weight loads into it, behind the barriers, one more exposed memory round trip)
+      if (LEAN || live) strip_compute<BITS, kBT, CH, DEC8, KL * kXStride>(w, &xs[0][0], kl, sc, zr, acc);
   }
   }
   // fold the K lanes in ascending order
+  GPTQ_STAMP(4);
   __syncthreads();  // the previous tile's readers are done with `red`
+  GPTQ_STAMP(5);
 #pragma unroll
   for (int b = 0; b < kBT; ++b)
 #pragma unroll
@@ -685,8 +829,10 @@ __global__ __launch_bounds__(8 * KL) __attribute__((amdgpu_waves_per_eu(CH == 64
                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   }  // batch tiles
+  GPTQ_STAMP(6);
   if (split == 1) return;
   strip_fold_partials<kThreads>(strip, split, g, part, out, arrivals, s_prev);
+  GPTQ_STAMP(7);
 }
 
 // HBM-sized matrices, B <= 2: PERSISTENT strip workers.  A 134 MB matrix is 1024 strips x 4 passes: as a grid of
@@ -997,6 +1143,12 @@ int gptq_launch_partial(const float* x, const int32_t* qweight, float* out, cons
   return check_launch();
 }
 
+// the LEAN strip kernels address every tensor as base + 32-bit byte offset
+bool lean_sizes(int64_t H, int64_t batch, int64_t in_f, int64_t out_f, int64_t groups) {
+  const int64_t lim = 1ll << 32;
+  return H * out_f * 4 < lim && out_f * groups * 4 < lim && batch * in_f * 4 < (lim >> 1) && batch * out_f * 4 < lim;
+}
+
 template <int BITS>
 int gptq_matmul(const float* x, const int32_t* qweight, float* out, const float* scales,
                 const float* zeros, int64_t batch, int64_t in_features, int64_t out_features,
@@ -1077,6 +1229,18 @@ int gptq_matmul(const float* x, const int32_t* qweight, float* out, const float*
     else                                                                                                   \
       gptq_strip_kernel<BITS, 1, 32, CH, D8><<<grid, 256, 0, st>>>(x, qweight, scales, zeros, out, part, arrivals, g, GptqMulti{}); \
   } while (0)
+    // half-group K lanes (the default), x aligned: the branch-free loads (knob 2 == 23: the branchy ones, for A/B runs)
+#define SBQ_STRIP_LEAN(D8, PFV)                                                                            \
+  do {                                                                                                     \
+    if (batch == 2)                                                                                        \
+      gptq_strip_kernel<BITS, 2, 32, 64, D8, PFV, true><<<grid, 256, 0, st>>>(x, qweight, scales, zeros, out, part, arrivals, g, GptqMulti{}); \
+    else                                                                                                   \
+      gptq_strip_kernel<BITS, 1, 32, 64, D8, PFV, true><<<grid, 256, 0, st>>>(x, qweight, scales, zeros, out, part, arrivals, g, GptqMulti{}); \
+  } while (0)
+    const bool lean = ch == kSliceK / 2 && aligned16(x) && in_features % 4 == 0 &&
+                      lean_sizes(g.H, batch, in_features, out_features, g.groups) && knob(2) != 23;
+    g.grid_x = static_cast<int32_t>(strips);
+    g.grid_y = static_cast<int32_t>(split);
     // several passes per workgroup (HBM-sized matrices): the next pass's weights are prefetched by LDS-DMA
     // (knob 2 == 6: off, for A/B runs)
     const bool prefetch = ch == kSliceK / 2 && passes >= 2 * split && knob(2) != 6;
@@ -1116,8 +1280,42 @@ int gptq_matmul(const float* x, const int32_t* qweight, float* out, const float*
         return check_launch();
       }
     }
+    // WIDE workgroups (64 K lanes, 512 threads): all of a 4096-channel K in ONE pass -- every weight word of the
+    // strip requested at once, one memory round trip instead of two dependent ones, and the arithmetic on eight
+    // waves instead of four.  Measured (tools/lab/r04_gptq_narrow.py, profiles/r04_gptq_lean_wide.log, HBM-cold, us,
+    // 256-thread lean kernel -> wide):  B = 1, 4096 -> 11008: 4-bit 10.8 -> 10.1, 3-bit 18.4 -> 11.6, 2-bit 11.2 -> 8.0;
+    // 4096 -> 4096: 6.5 -> 6.5 / 12.3 -> 8.1 / 7.5 -> 5.7; 11008 -> 4096 (three wide passes, one K block each):
+    // 11.3 -> 11.7 / 17.7 -> 13.8 / 11.3 -> 9.6.  B = 2: a gain for one pass (4-bit 12.8 -> 11.5, 3-bit 14.5 -> 13.3),
+    // a loss for 2-bit (11.0 -> 12.3) and for several passes.
+    // So: one wide pass -> wide (2-bit: B = 1 only); several -> wide for the 3- and 2-bit mat-VEC only, one K block
+    // per pass from three passes on.  knob 2 == 24 / 25: always / never, for A/B runs.
+    {
+      const int64_t wpasses = ceil_div(in_features, 64 * ch);
+      bool wide = lean && (wpasses == 1 ? (BITS != 2 || batch == 1) : (BITS != 4 && batch == 1));
+      if (knob(2) == 24) wide = lean;
+      if (knob(2) == 25) wide = false;
+      if (wide) {
+        int64_t wsplit = wpasses >= 3 ? wpasses : 1;
+        if (knob(1) > 0 && knob(1) < 128) wsplit = knob(1);
+        if (wsplit > wpasses) wsplit = wpasses;
+        if (wsplit > kStripMaxSplit) wsplit = kStripMaxSplit;
+        const dim3 wgrid(static_cast<uint32_t>(strips), static_cast<uint32_t>(wsplit));
+        g.grid_y = static_cast<int32_t>(wsplit);
+        constexpr bool kD8 = BITS != 3;
+        if (batch == 2)
+          gptq_strip_kernel<BITS, 2, 64, 64, kD8, false, true><<<wgrid, 512, 0, st>>>(x, qweight, scales, zeros, out, part, arrivals, g, GptqMulti{});
+        else
+          gptq_strip_kernel<BITS, 1, 64, 64, kD8, false, true><<<wgrid, 512, 0, st>>>(x, qweight, scales, zeros, out, part, arrivals, g, GptqMulti{});
+        return check_launch();
+      }
+    }
     if constexpr (BITS == 4 || BITS == 2) {
       if (knob(2) != 4) {  // packed e4m3 decode (knob 2 == 4: byte converts, for A/B runs)
+        if (lean) {
+          if (prefetch) SBQ_STRIP_LEAN(true, true);
+          else SBQ_STRIP_LEAN(true, false);
+          return check_launch();
+        }
         if (prefetch) {
           if (batch == 2)
             gptq_strip_kernel<BITS, 2, 32, 64, true, true><<<grid, 256, 0, st>>>(x, qweight, scales, zeros, out, part, arrivals, g, GptqMulti{});
@@ -1130,6 +1328,11 @@ int gptq_matmul(const float* x, const int32_t* qweight, float* out, const float*
         return check_launch();
       }
     }
+    if (lean && BITS == 3) {
+      if (prefetch) SBQ_STRIP_LEAN(false, true);
+      else SBQ_STRIP_LEAN(false, false);
+      return check_launch();
+    }
     if (prefetch && BITS == 3) {
       if (batch == 2)
         gptq_strip_kernel<BITS, 2, 32, 64, false, true><<<grid, 256, 0, st>>>(x, qweight, scales, zeros, out, part, arrivals, g, GptqMulti{});
@@ -1140,6 +1343,7 @@ int gptq_matmul(const float* x, const int32_t* qweight, float* out, const float*
     if (ch == kSliceK) SBQ_STRIP(128, false);
     else SBQ_STRIP(64, false);
 #undef SBQ_STRIP
+#undef SBQ_STRIP_LEAN
     return check_launch();
   }
   if constexpr (BITS == 2) {
@@ -1157,12 +1361,17 @@ int gptq_matmul_multi(const float* x, int n_mats, const int32_t* const* qweights
   if (n_mats < 1 || n_mats > kMaxMulti) return SBQ_ERR_ARG;
   if (!x || !qweights || !outs || !scales || !zeros || !out_features || !workspace) return SBQ_ERR_NULL;
   int64_t total_out = 0;
-  bool strip_ok = batch >= 1 && batch <= 2 && group_size != 0 && group_size % kSliceK == 0 && knob(2) != 9;
+  // (the multi-matrix launch exists for the LEAN kernels only: x 16-byte aligned, in_features % 4 == 0, every
+  // tensor below 4 GB; anything else takes one launch per matrix)
+  bool strip_ok = batch >= 1 && batch <= 2 && group_size != 0 && group_size % kSliceK == 0 && knob(2) != 9 &&
+                  aligned16(x) && in_features % 4 == 0 && knob(2) != 23;
   for (int m = 0; m < n_mats; ++m) {
     if (!qweights[m] || !outs[m] || !scales[m] || !zeros[m]) return SBQ_ERR_NULL;
     if (out_features[m] <= 0) return SBQ_ERR_ARG;
     total_out += out_features[m];
-    strip_ok = strip_ok && out_features[m] % kStripCols == 0 && aligned16(qweights[m]);
+    strip_ok = strip_ok && out_features[m] % kStripCols == 0 && aligned16(qweights[m]) &&
+               lean_sizes(gptq_rows(BITS, in_features), batch, in_features, out_features[m],
+                          group_size > 0 ? ceil_div(in_features, group_size) : 1);
   }
   const int64_t strips = total_out / kStripCols;
   strip_ok = strip_ok && strips <= kMaxStrips && in_features > 0 && in_features < (1ll << 31);
@@ -1210,20 +1419,47 @@ int gptq_matmul_multi(const float* x, int n_mats, const int32_t* const* qweights
     po += split * batch * out_features[m];
   }
   mm.strip_begin[n_mats] = static_cast<int32_t>(sb);
+  for (int m = n_mats + 1; m <= kMaxMulti; ++m) mm.strip_begin[m] = INT32_MAX;  // the kernel's lookup compares, no loop
+  g.grid_x = static_cast<int32_t>(strips);
+  g.grid_y = static_cast<int32_t>(split);
   g.xcd_swizzle = (strips % 8 == 0 && knob(2) != 8) ? 1 : 0;
+  constexpr bool kDec8 = BITS != 3;
+  {  // the wide workgroups, by the rule of the single-matrix launch (same kernel, same K split: same bits)
+    const int64_t wpasses = ceil_div(in_features, 64 * ch);
+    bool wide = wpasses == 1 ? (BITS != 2 || batch == 1) : (BITS != 4 && batch == 1);
+    if (knob(2) == 24) wide = true;
+    if (knob(2) == 25) wide = false;
+    if (wide) {
+      int64_t wsplit = wpasses >= 3 ? wpasses : 1;
+      if (knob(1) > 0 && knob(1) < 128) wsplit = knob(1);
+      if (wsplit > wpasses) wsplit = wpasses;
+      if (wsplit > kStripMaxSplit) wsplit = kStripMaxSplit;
+      po = 0;
+      for (int m = 0; m < n_mats; ++m) {
+        mm.part_off[m] = po;
+        po += wsplit * batch * out_features[m];
+      }
+      g.grid_y = static_cast<int32_t>(wsplit);
+      const dim3 wgrid(static_cast<uint32_t>(strips), static_cast<uint32_t>(wsplit));
+      if (batch == 2)
+        gptq_strip_kernel<BITS, 2, 64, 64, kDec8, false, true, true><<<wgrid, 512, 0, st>>>(x, nullptr, nullptr, nullptr, nullptr, part, arrivals, g, mm);
+      else
+        gptq_strip_kernel<BITS, 1, 64, 64, kDec8, false, true, true><<<wgrid, 512, 0, st>>>(x, nullptr, nullptr, nullptr, nullptr, part, arrivals, g, mm);
+      return check_launch();
+    }
+  }
   const dim3 grid(static_cast<uint32_t>(strips), static_cast<uint32_t>(split));
   const bool prefetch = passes >= 2 * split && knob(2) != 6;
-  constexpr bool kDec8 = BITS != 3;
-#define SBQ_MULTI(BT, PFV) \
-  gptq_strip_kernel<BITS, BT, 32, 64, kDec8, PFV><<<grid, 256, 0, st>>>(x, nullptr, nullptr, nullptr, nullptr, part, arrivals, g, mm)
+#define SBQ_MULTI_LEAN(BT, PFV) \
+  gptq_strip_kernel<BITS, BT, 32, 64, kDec8, PFV, true, true><<<grid, 256, 0, st>>>(x, nullptr, nullptr, nullptr, nullptr, part, arrivals, g, mm)
   if (prefetch) {
-    if (batch == 2) SBQ_MULTI(2, true);
-    else SBQ_MULTI(1, true);
+    if (batch == 2) SBQ_MULTI_LEAN(2, true);
+    else SBQ_MULTI_LEAN(1, true);
   } else {
-    if (batch == 2) SBQ_MULTI(2, false);
-    else SBQ_MULTI(1, false);
+    if (batch == 2) SBQ_MULTI_LEAN(2, false);
+    else SBQ_MULTI_LEAN(1, false);
   }
-#undef SBQ_MULTI
+#undef SBQ_MULTI_LEAN
   return check_launch();
 }
 
@@ -1231,6 +1467,12 @@ int gptq_matmul_multi(const float* x, int n_mats, const int32_t* const* qweights
 }  // namespace sbq
 
 extern "C" {
+#if SBQ_GPTQ_STAMPS != 0
+__attribute__((visibility("default"))) int sbq_debug_gptq_stamps(void* buffer) {  // development build only: where gptq_strip_kernel writes its stamps
+  unsigned long long* p = static_cast<unsigned long long*>(buffer);
+  return hipMemcpyToSymbol(HIP_SYMBOL(sbq::g_gptq_stamps), &p, sizeof(p)) == hipSuccess ? SBQ_OK : SBQ_ERR_ARG;
+}
+#endif
 
 int sbq_vecquantmatmul_multi(int bits, const float* x, int n_mats, const int32_t* const* qweights, float* const* outs,
                              const float* const* scales, const float* const* zeros, const int64_t* out_features,

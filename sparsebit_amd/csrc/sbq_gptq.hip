@@ -481,10 +481,29 @@ struct GptqMulti {
 // base + a 32-bit byte offset (host-checked: each tensor is below 4 GB).
 template <int BITS, int kBT, int KL, int CH, bool DEC8 = false, bool PF = false, bool LEAN = false, bool MULTI = false>
 __global__ __launch_bounds__(8 * KL) __attribute__((amdgpu_waves_per_eu(CH == 64 && kBT == 1 ? (PF ? 3 : 4) : 1, 8))) void gptq_strip_kernel(
-    const float* __restrict__ x, const int32_t* __restrict__ qw_a, const float* __restrict__ scales_a,
-    const float* __restrict__ zeros_a, float* __restrict__ out_a, float* __restrict__ part_a,
-    uint32_t* __restrict__ arrivals_a, const GptqGeom g_a, const GptqMulti mm) {
-  GptqGeom g = g_a;
+    // the first 14 argument dwords arrive in SGPRs with the wave (kernarg preload, sparsebit_amd/build.py): the four
+    // pointers the loads of a pass go through and the geometry in 32 bits -- a LEAN kernel issues its first loads
+    // without having waited for any scalar load.  (host side: SBQ_STRIP_LEAD)
+    const int32_t* __restrict__ qw_a, const float* __restrict__ x, const float* __restrict__ scales_a,
+    const float* __restrict__ zeros_a, int32_t out32_a, int32_t H_a, uint32_t grid_batch_a, int32_t groups_a,
+    int32_t group_size_a, int32_t in32_a,  // <- 14 dwords: what fits beside the system SGPRs
+    float* __restrict__ out_a, float* __restrict__ part_a, uint32_t* __restrict__ arrivals_a, const GptqGeom g_a,
+    const GptqMulti mm) {
+  GptqGeom g;
+  if constexpr (LEAN) {  // from the preloaded scalars; g_a is never read
+    g.in_features = in32_a;
+    g.out_features = out32_a;
+    g.batch = static_cast<int32_t>(grid_batch_a >> 26);
+    g.H = H_a;
+    g.groups = groups_a;
+    g.group_size = group_size_a;
+    g.slices = g.slices_per_block = g.kblocks = 0;
+    g.xcd_swizzle = static_cast<int32_t>((grid_batch_a >> 25) & 1u);
+    g.grid_x = static_cast<int32_t>(grid_batch_a & 0xfffffu);
+    g.grid_y = static_cast<int32_t>((grid_batch_a >> 20) & 31u);
+  } else {
+    g = g_a;
+  }
   const int32_t* __restrict__ qw = qw_a;
   const float* __restrict__ scales = scales_a;
   const float* __restrict__ zeros = zeros_a;
@@ -588,13 +607,14 @@ __global__ __launch_bounds__(8 * KL) __attribute__((amdgpu_waves_per_eu(CH == 64
   // memory round trip (~1.3 us of a 7.7 us launch at 4096 x 4096) at the very end of the kernel.
   // (unconditionally, every thread, clamped to a valid element: a load behind a branch costs the compiler its count of
   // the loads in flight, and it then waits for all of them at the join)
-  float out_prev;
-  if constexpr (LEAN) {
+  // (LEAN: `out` is the one pointer of the prologue that is not preloaded -- its load is placed BEHIND the first pass's
+  // loads, so that waiting for the argument does not hold them up)
+  float out_prev = 0.0f;
+  auto lean_out_prev = [&]() -> float {
     const uint32_t orow = static_cast<uint32_t>(b0) + ((ob < kBT && static_cast<int>(b0) + ob < batch32) ? ob : 0);
-    out_prev = *at32(out, (orow * out32 + strip * kStripCols + static_cast<uint32_t>(occ)) * 4u);
-  } else {
-    out_prev = out[(b0 + ((ob < kBT && b0 + ob < g.batch) ? ob : 0)) * g.out_features + ocol];
-  }
+    return *at32(out, (orow * out32 + strip * kStripCols + static_cast<uint32_t>(occ)) * 4u);
+  };
+  if constexpr (!LEAN) out_prev = out[(b0 + ((ob < kBT && b0 + ob < g.batch) ? ob : 0)) * g.out_features + ocol];
 
   if constexpr (PF) {
     __shared__ __attribute__((aligned(1024))) uint8_t wring[kThreads * 16 * kRows];  // [row i][lane] 16-byte words
@@ -666,6 +686,7 @@ __global__ __launch_bounds__(8 * KL) __attribute__((amdgpu_waves_per_eu(CH == 64
       load_small(first, xg_n, sc_n, zr_n);
       dma_weights(first);
     }
+    if constexpr (LEAN) out_prev = lean_out_prev();
     GPTQ_STAMP(1);
     for (int64_t pass0 = first; pass0 < g.H; pass0 += step) {
       const bool live = pass0 + kl * kRows < g.H;
@@ -746,6 +767,7 @@ __global__ __launch_bounds__(8 * KL) __attribute__((amdgpu_waves_per_eu(CH == 64
         w[i] = t & (row0 + i < g.H ? 0xffffffffu : 0u);
       }
       lean_sz(lean_group(static_cast<int>(k0)), sc, zr);
+      out_prev = lean_out_prev();  // every pass (one dword, the same element): unconditional, behind the pass's loads
     } else {
 #pragma unroll
     for (int b = 0; b < kBT; ++b)
@@ -1100,6 +1122,7 @@ bool gptq_geom(int bits, int slice_k, int64_t batch, int64_t in_f, int64_t out_f
   g.slices_per_block = static_cast<int32_t>(ceil_div(g.slices, want));
   g.kblocks = static_cast<int32_t>(ceil_div(g.slices, g.slices_per_block));
   g.xcd_swizzle = ((out_f / 32) % 8 == 0 && knob(2) != 8) ? 1 : 0;
+  g.grid_x = g.grid_y = 0;
   return true;
 }
 
@@ -1142,6 +1165,14 @@ int gptq_launch_partial(const float* x, const int32_t* qweight, float* out, cons
   gptq_fold_kernel<<<static_cast<uint32_t>(ceil_div(bn, kBlock)), kBlock, 0, st>>>(part, out, bn, g.kblocks);
   return check_launch();
 }
+
+// the 32-bit geometry scalars of gptq_strip_kernel's argument list (six dwords after the four pointers): out_features,
+// H, {grid x: 20 bits | grid y: 5 | XCD swizzle: 1 | batch: 6}, groups, group size, in_features
+#define SBQ_STRIP_LEAD(G)                                                                                  \
+  static_cast<int32_t>((G).out_features), (G).H,                                                           \
+      (static_cast<uint32_t>((G).grid_x) & 0xfffffu) | ((static_cast<uint32_t>((G).grid_y) & 31u) << 20) |  \
+          ((static_cast<uint32_t>((G).xcd_swizzle) & 1u) << 25) | (static_cast<uint32_t>((G).batch) << 26), \
+      (G).groups, (G).group_size, static_cast<int32_t>((G).in_features)
 
 // the LEAN strip kernels address every tensor as base + 32-bit byte offset
 bool lean_sizes(int64_t H, int64_t batch, int64_t in_f, int64_t out_f, int64_t groups) {
@@ -1190,8 +1221,9 @@ int gptq_matmul(const float* x, const int32_t* qweight, float* out, const float*
     int64_t split = ceil_div(in_features, 32 * (kSliceK / 2));
     if (split > kStripMaxSplit) split = kStripMaxSplit;
     const dim3 grid(static_cast<uint32_t>(strips), static_cast<uint32_t>(split));
-    gptq_strip_kernel<BITS, 4, 32, kSliceK / 2, BITS != 3><<<grid, 256, 0, st>>>(x, qweight, scales, zeros, out, part,
-                                                                                arrivals, g, GptqMulti{});
+    gptq_strip_kernel<BITS, 4, 32, kSliceK / 2, BITS != 3><<<grid, 256, 0, st>>>(qweight, x, scales, zeros,
+                                                                                SBQ_STRIP_LEAD(g), out, part, arrivals, g,
+                                                                                GptqMulti{});
     return check_launch();
   }
   if (vec && out_features % kStripCols == 0 && batch <= 2 && !half_slices && strips <= kMaxStrips &&
@@ -1225,17 +1257,17 @@ int gptq_matmul(const float* x, const int32_t* qweight, float* out, const float*
 #define SBQ_STRIP(CH, D8)                                                                                  \
   do {                                                                                                     \
     if (batch == 2)                                                                                        \
-      gptq_strip_kernel<BITS, 2, 32, CH, D8><<<grid, 256, 0, st>>>(x, qweight, scales, zeros, out, part, arrivals, g, GptqMulti{}); \
+      gptq_strip_kernel<BITS, 2, 32, CH, D8><<<grid, 256, 0, st>>>(qweight, x, scales, zeros, SBQ_STRIP_LEAD(g), out, part, arrivals, g, GptqMulti{}); \
     else                                                                                                   \
-      gptq_strip_kernel<BITS, 1, 32, CH, D8><<<grid, 256, 0, st>>>(x, qweight, scales, zeros, out, part, arrivals, g, GptqMulti{}); \
+      gptq_strip_kernel<BITS, 1, 32, CH, D8><<<grid, 256, 0, st>>>(qweight, x, scales, zeros, SBQ_STRIP_LEAD(g), out, part, arrivals, g, GptqMulti{}); \
   } while (0)
     // half-group K lanes (the default), x aligned: the branch-free loads (knob 2 == 23: the branchy ones, for A/B runs)
 #define SBQ_STRIP_LEAN(D8, PFV)                                                                            \
   do {                                                                                                     \
     if (batch == 2)                                                                                        \
-      gptq_strip_kernel<BITS, 2, 32, 64, D8, PFV, true><<<grid, 256, 0, st>>>(x, qweight, scales, zeros, out, part, arrivals, g, GptqMulti{}); \
+      gptq_strip_kernel<BITS, 2, 32, 64, D8, PFV, true><<<grid, 256, 0, st>>>(qweight, x, scales, zeros, SBQ_STRIP_LEAD(g), out, part, arrivals, g, GptqMulti{}); \
     else                                                                                                   \
-      gptq_strip_kernel<BITS, 1, 32, 64, D8, PFV, true><<<grid, 256, 0, st>>>(x, qweight, scales, zeros, out, part, arrivals, g, GptqMulti{}); \
+      gptq_strip_kernel<BITS, 1, 32, 64, D8, PFV, true><<<grid, 256, 0, st>>>(qweight, x, scales, zeros, SBQ_STRIP_LEAD(g), out, part, arrivals, g, GptqMulti{}); \
   } while (0)
     const bool lean = ch == kSliceK / 2 && aligned16(x) && in_features % 4 == 0 &&
                       lean_sizes(g.H, batch, in_features, out_features, g.groups) && knob(2) != 23;
@@ -1303,9 +1335,9 @@ int gptq_matmul(const float* x, const int32_t* qweight, float* out, const float*
         g.grid_y = static_cast<int32_t>(wsplit);
         constexpr bool kD8 = BITS != 3;
         if (batch == 2)
-          gptq_strip_kernel<BITS, 2, 64, 64, kD8, false, true><<<wgrid, 512, 0, st>>>(x, qweight, scales, zeros, out, part, arrivals, g, GptqMulti{});
+          gptq_strip_kernel<BITS, 2, 64, 64, kD8, false, true><<<wgrid, 512, 0, st>>>(qweight, x, scales, zeros, SBQ_STRIP_LEAD(g), out, part, arrivals, g, GptqMulti{});
         else
-          gptq_strip_kernel<BITS, 1, 64, 64, kD8, false, true><<<wgrid, 512, 0, st>>>(x, qweight, scales, zeros, out, part, arrivals, g, GptqMulti{});
+          gptq_strip_kernel<BITS, 1, 64, 64, kD8, false, true><<<wgrid, 512, 0, st>>>(qweight, x, scales, zeros, SBQ_STRIP_LEAD(g), out, part, arrivals, g, GptqMulti{});
         return check_launch();
       }
     }
@@ -1318,9 +1350,9 @@ int gptq_matmul(const float* x, const int32_t* qweight, float* out, const float*
         }
         if (prefetch) {
           if (batch == 2)
-            gptq_strip_kernel<BITS, 2, 32, 64, true, true><<<grid, 256, 0, st>>>(x, qweight, scales, zeros, out, part, arrivals, g, GptqMulti{});
+            gptq_strip_kernel<BITS, 2, 32, 64, true, true><<<grid, 256, 0, st>>>(qweight, x, scales, zeros, SBQ_STRIP_LEAD(g), out, part, arrivals, g, GptqMulti{});
           else
-            gptq_strip_kernel<BITS, 1, 32, 64, true, true><<<grid, 256, 0, st>>>(x, qweight, scales, zeros, out, part, arrivals, g, GptqMulti{});
+            gptq_strip_kernel<BITS, 1, 32, 64, true, true><<<grid, 256, 0, st>>>(qweight, x, scales, zeros, SBQ_STRIP_LEAD(g), out, part, arrivals, g, GptqMulti{});
           return check_launch();
         }
         if (ch == kSliceK) SBQ_STRIP(128, true);
@@ -1335,9 +1367,9 @@ int gptq_matmul(const float* x, const int32_t* qweight, float* out, const float*
     }
     if (prefetch && BITS == 3) {
       if (batch == 2)
-        gptq_strip_kernel<BITS, 2, 32, 64, false, true><<<grid, 256, 0, st>>>(x, qweight, scales, zeros, out, part, arrivals, g, GptqMulti{});
+        gptq_strip_kernel<BITS, 2, 32, 64, false, true><<<grid, 256, 0, st>>>(qweight, x, scales, zeros, SBQ_STRIP_LEAD(g), out, part, arrivals, g, GptqMulti{});
       else
-        gptq_strip_kernel<BITS, 1, 32, 64, false, true><<<grid, 256, 0, st>>>(x, qweight, scales, zeros, out, part, arrivals, g, GptqMulti{});
+        gptq_strip_kernel<BITS, 1, 32, 64, false, true><<<grid, 256, 0, st>>>(qweight, x, scales, zeros, SBQ_STRIP_LEAD(g), out, part, arrivals, g, GptqMulti{});
       return check_launch();
     }
     if (ch == kSliceK) SBQ_STRIP(128, false);
@@ -1442,16 +1474,16 @@ int gptq_matmul_multi(const float* x, int n_mats, const int32_t* const* qweights
       g.grid_y = static_cast<int32_t>(wsplit);
       const dim3 wgrid(static_cast<uint32_t>(strips), static_cast<uint32_t>(wsplit));
       if (batch == 2)
-        gptq_strip_kernel<BITS, 2, 64, 64, kDec8, false, true, true><<<wgrid, 512, 0, st>>>(x, nullptr, nullptr, nullptr, nullptr, part, arrivals, g, mm);
+        gptq_strip_kernel<BITS, 2, 64, 64, kDec8, false, true, true><<<wgrid, 512, 0, st>>>(nullptr, x, nullptr, nullptr, SBQ_STRIP_LEAD(g), nullptr, part, arrivals, g, mm);
       else
-        gptq_strip_kernel<BITS, 1, 64, 64, kDec8, false, true, true><<<wgrid, 512, 0, st>>>(x, nullptr, nullptr, nullptr, nullptr, part, arrivals, g, mm);
+        gptq_strip_kernel<BITS, 1, 64, 64, kDec8, false, true, true><<<wgrid, 512, 0, st>>>(nullptr, x, nullptr, nullptr, SBQ_STRIP_LEAD(g), nullptr, part, arrivals, g, mm);
       return check_launch();
     }
   }
   const dim3 grid(static_cast<uint32_t>(strips), static_cast<uint32_t>(split));
   const bool prefetch = passes >= 2 * split && knob(2) != 6;
 #define SBQ_MULTI_LEAN(BT, PFV) \
-  gptq_strip_kernel<BITS, BT, 32, 64, kDec8, PFV, true, true><<<grid, 256, 0, st>>>(x, nullptr, nullptr, nullptr, nullptr, part, arrivals, g, mm)
+  gptq_strip_kernel<BITS, BT, 32, 64, kDec8, PFV, true, true><<<grid, 256, 0, st>>>(nullptr, x, nullptr, nullptr, SBQ_STRIP_LEAD(g), nullptr, part, arrivals, g, mm)
   if (prefetch) {
     if (batch == 2) SBQ_MULTI_LEAN(2, true);
     else SBQ_MULTI_LEAN(1, true);

@@ -2188,10 +2188,15 @@ __device__ __forceinline__ bool h16_round(const OneShard& tab, const OneArgs& a,
 // kernel's own control flow their loop invariants, the fall-back sweeps' address arithmetic included, were hoisted in
 // front of the FIRST round's binning (250 instructions and a dozen spills on the hot path).
 template <typename T, int NSEL>
-__device__ __attribute__((noinline)) void h16_more_rounds(const OneShard tab, const OneArgs a, const uint32_t wg, const uint32_t nwg,
+// (the arguments travel through LDS: passed by value, the three dozen dwords of the two structs overflow the argument
+// registers, and the stack copies of the overflow are made at the KERNEL's entry -- which made every wave wait for its
+// scalar argument loads before requesting its first slab)
+__device__ __attribute__((noinline)) void h16_more_rounds(const OneShard* tab_l, const OneArgs* a_l, const uint32_t wg, const uint32_t nwg,
                                                           const uint32_t n_wg, const uint32_t* hist, const uint32_t* zero_word,
                                                           const H16Plan* plan, OneLds* ol, SweepLds<NSEL, kH16Block>* swl,
                                                           AdvShared (*adv)[2]) {
+  const OneShard tab = *tab_l;
+  const OneArgs a = *a_l;
   for (uint32_t round = 2; round < 12; ++round) {
     if (__builtin_amdgcn_readfirstlane(ol->part) != nwg) {
       // somebody gave up waiting (two resident launches sharing the device): the rest sweeps global memory by ticket
@@ -2204,7 +2209,11 @@ __device__ __attribute__((noinline)) void h16_more_rounds(const OneShard tab, co
 }
 
 template <typename T, int NSEL, bool PCT>
-__global__ __launch_bounds__(kH16Block) void h16_select_kernel(const OneShard tab, const OneArgs a) {
+// (x0, n32, nwg32 lead the argument list as plain scalars: the build preloads the first 16 argument dwords into
+// SGPRs (-amdgpu-kernarg-preload-count), so the slab loads are issued without waiting for any scalar load; structs
+// passed by value are never preloaded)
+__global__ __launch_bounds__(kH16Block) void h16_select_kernel(const void* x0, uint32_t n32, uint32_t nwg32, const OneShard tab,
+                                                              const OneArgs a) {
   constexpr int BLOCK = kH16Block;
   constexpr int kWaves = BLOCK / kWave;
   extern __shared__ __attribute__((aligned(16))) char h16_raw[];
@@ -2214,16 +2223,15 @@ __global__ __launch_bounds__(kH16Block) void h16_select_kernel(const OneShard ta
   __shared__ OneLds ol;
   __shared__ H16Plan plan;
   __shared__ uint32_t zero_word[BLOCK];  // per lane: (-0 count, +0 count) packed like their histogram dword
-  const uint32_t wg = blockIdx.x, nwg = gridDim.x;
+  const uint32_t wg = blockIdx.x, nwg = nwg32;
   const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
-  if (threadIdx.x == 0) ol.t0 = __builtin_amdgcn_s_memrealtime();
   one_stamp(a, 0);
 #if SBQ_SEL_STAMPS != 0
   if (threadIdx.x == 0) swl.stamps = a.stamps;
 #endif
-  const void* x = tab.ptr[0];
+  const void* x = x0;
   // (everything in 32 bits: the host admits 8 <= n <= 65 536 x compute units, far below 2^31)
-  const uint32_t n = static_cast<uint32_t>(a.n);
+  const uint32_t n = n32;
   const uint32_t n_packs = n / kPack;  // >= 1
   const uint32_t amask2 = a.use_abs ? 0x7fff7fffu : 0xffffffffu;
   constexpr uint32_t kZero16 = Key16<T>::kZero >> 16, kInf16 = Key16<T>::kInf >> 16;
@@ -2261,6 +2269,9 @@ __global__ __launch_bounds__(kH16Block) void h16_select_kernel(const OneShard ta
     }
   }
   __builtin_amdgcn_sched_barrier(0);
+  // (the start time -- of the resident rounds' patience -- is taken HERE: reading the clock waits for every scalar load
+  // in flight, the argument loads included, which must not stand between wave 0 and its requests)
+  if (threadIdx.x == 0) ol.t0 = __builtin_amdgcn_s_memrealtime();
   one_stamp(a, 12);
   // ---- clear: the histogram, the window histograms (lh[0] first serves as the sample's histogram), the zero words ----
   {
@@ -2491,8 +2502,20 @@ __global__ __launch_bounds__(kH16Block) void h16_select_kernel(const OneShard ta
   }
   if (wg == 0) n_wg += n - n_packs * kPack;
   // ---- round 1 inline; whatever follows (rare) out of line ----
-  if (h16_round<T, NSEL>(tab, a, wg, nwg, n_wg, 1u, PCT, hist, zero_word, plan, ol, swl, adv))
-    h16_more_rounds<T, NSEL>(tab, a, wg, nwg, n_wg, hist, zero_word, &plan, &ol, &swl, &adv);
+  if (h16_round<T, NSEL>(tab, a, wg, nwg, n_wg, 1u, PCT, hist, zero_word, plan, ol, swl, adv)) {
+    // (copied dword by dword out of the argument block in memory -- layout: x0, n32, nwg32, tab, a, naturally aligned
+    // -- rather than from `tab` / `a`: fields that only this cold path reads would otherwise be fetched at the kernel's
+    // entry, kept alive through it, and spilled to scratch there)
+    __shared__ OneShard tab_l;
+    __shared__ OneArgs a_l;
+    static_assert(alignof(OneShard) == 8 && alignof(OneArgs) == 8 && sizeof(OneShard) % 8 == 0, "argument block layout");
+    constexpr uint32_t kTabOff = 16, kArgsOff = kTabOff + sizeof(OneShard);
+    const uint32_t* kargs = (const uint32_t*)__builtin_amdgcn_kernarg_segment_ptr();  // (C cast: out of address space 4)
+    if (threadIdx.x < sizeof(OneShard) / 4) reinterpret_cast<uint32_t*>(&tab_l)[threadIdx.x] = kargs[kTabOff / 4 + threadIdx.x];
+    if (threadIdx.x < sizeof(OneArgs) / 4) reinterpret_cast<uint32_t*>(&a_l)[threadIdx.x] = kargs[kArgsOff / 4 + threadIdx.x];
+    __syncthreads();
+    h16_more_rounds<T, NSEL>(&tab_l, &a_l, wg, nwg, n_wg, hist, zero_word, &plan, &ol, &swl, &adv);
+  }
   one_stamp(a, 7);
 }
 
@@ -2591,8 +2614,9 @@ int win_h16_launch_t(int n_sel, unsigned grid, hipStream_t st, const void* table
       return true;
     }();
     (void)once;
-    if (n_sel == 1) h16_select_kernel<T, 1, false><<<grid, kH16Block, h16_lds_bytes<1>(), st>>>(t, a);
-    else h16_select_kernel<T, 2, true><<<grid, kH16Block, h16_lds_bytes<2>(), st>>>(t, a);
+    const uint32_t n32 = static_cast<uint32_t>(a.n);
+    if (n_sel == 1) h16_select_kernel<T, 1, false><<<grid, kH16Block, h16_lds_bytes<1>(), st>>>(t.ptr[0], n32, grid, t, a);
+    else h16_select_kernel<T, 2, true><<<grid, kH16Block, h16_lds_bytes<2>(), st>>>(t.ptr[0], n32, grid, t, a);
     return SBQ_OK;
   }
 }

@@ -673,9 +673,12 @@ __global__ __launch_bounds__(kH16Threads) void hist16_kernel(const void* __restr
 #pragma unroll
   for (int m = 0; m < 32; ++m) {
     if (__builtin_amdgcn_ballot_w64(wv[m] != 0u) == 0) continue;
+    // the two keys of a dword are neighbours in the global histogram too: ONE 64-bit add for both counters (their sums
+    // stay below 2^32: no carry from the low counter into the high one)
     const uint32_t key0 = (m * kH16Threads + threadIdx.x) * 2u;
-    if (wv[m] & 0xffffu) atomicAdd(&g[key0], wv[m] & 0xffffu);
-    if (wv[m] >> 16) atomicAdd(&g[key0 + 1u], wv[m] >> 16);
+    if (wv[m])
+      atomicAdd(reinterpret_cast<unsigned long long*>(&g[key0]),
+                static_cast<unsigned long long>(wv[m] & 0xffffu) | (static_cast<unsigned long long>(wv[m] >> 16) << 32));
   }
   // the zeros: one add per WAVE and sign of zero
   const uint32_t zn = dpp_reduce_u32(zw & 0xffffu, 0u, [](uint32_t p, uint32_t q) { return p + q; });

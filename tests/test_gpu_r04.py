@@ -515,3 +515,75 @@ def test_mse_histogram_route_constant_block(ops):
         finally:
             L.set_tuning(2, 0)
     assert np.all(np.abs(out[0] - out[19]) <= 1e-6 * np.abs(out[19]))
+
+
+# --------------------------------------------------------------------------------------
+# GPTQ mat-vec: the branch-free (LEAN) and the 512-thread single-pass (wide) strip kernels
+# --------------------------------------------------------------------------------------
+@pytest.mark.parametrize("bits", [4, 3, 2])
+@pytest.mark.parametrize("batch", [1, 2])
+@pytest.mark.parametrize("in_f,out_f,gs", [
+    (4096, 4096, 128),    # one wide pass, every K lane live
+    (2048, 1024, 128),    # half of the wide workgroup's K lanes are dead (clamped rows, zero activations)
+    (4224, 2048, 128),    # one full wide pass + a 128-channel stub of a second
+    (11008, 4096, 128),   # three wide passes, the last one partial; K split in the 256-thread route
+    (4096, 11008, 0),     # un-grouped (one scale per column)
+    (1152, 96, 128),      # 96 columns: three strips, no XCD swizzle
+    (4096, 4096, 1024),   # groups wider than a K lane's 64 channels
+])
+def test_gptq_lean_and_wide_kernels(ops, bits, batch, in_f, out_f, gs):
+    """the default route (LEAN loads; wide workgroups where the rule of gptq_matmul picks them), the 256-thread LEAN
+    kernels (knob 2 = 25) and the branchy kernels of round 3 (knob 2 = 23) against the oracle -- tolerance 1e-5 of the
+    largest output: the reference adds with atomicAdd, the order of the fp32 sums is not part of its contract
+    (cuda_kernel_4bit.cu:64-81) -- and the same launch twice gives the same bits"""
+    from oracle import oracle as O
+    from sparsebit_amd import lib as L
+
+    if gs and in_f % gs:
+        pytest.skip("group size must divide in_features")
+    g = torch.Generator().manual_seed(bits * 1000 + batch * 100 + in_f % 97)
+    rows = (in_f + 31) // 32 * 3 if bits == 3 else (in_f * bits + 31) // 32
+    groups = in_f // gs if gs else 1
+    qw = torch.randint(-2 ** 31, 2 ** 31 - 1, (rows, out_f), generator=g, dtype=torch.int64).to(torch.int32)
+    sc = torch.rand(out_f, groups, generator=g) * 0.02 + 0.001
+    zr = torch.randint(0, 2 ** bits, (out_f, groups), generator=g).float() * sc
+    x = torch.randn(batch, in_f, generator=g)
+    bias = torch.randn(out_f, generator=g)
+    want = O.vecquantmatmul(x.numpy(), qw.numpy(), bias.numpy(), sc.numpy(), zr.numpy(), gs, bits)
+    tol = 1e-5 * max(1.0, float(np.abs(want).max())) * max(1.0, (in_f / 4096) ** 0.5)
+    dev = torch.device("cuda:0")
+    qwd, scd, zrd, xd = qw.to(dev), sc.to(dev), zr.to(dev), x.to(dev)
+    got = {}
+    try:
+        for knob in (0, 25, 23):
+            L.set_tuning(2, knob)
+            y = bias.repeat(batch, 1).contiguous().to(dev)
+            ops.vecquantmatmul(bits, xd, qwd, y, scd, zrd, gs)
+            y2 = bias.repeat(batch, 1).contiguous().to(dev)
+            ops.vecquantmatmul(bits, xd, qwd, y2, scd, zrd, gs)
+            assert torch.equal(y, y2), "knob %d: two launches differ" % knob
+            got[knob] = y.cpu().numpy()
+            assert np.abs(got[knob] - want).max() <= tol, "knob %d" % knob
+    finally:
+        L.set_tuning(2, 0)
+
+
+def test_gptq_unaligned_activations_take_the_branchy_kernels(ops):
+    """x 4 bytes off a 16-byte boundary: the LEAN kernels' 16-byte activation loads do not apply; same result"""
+    from oracle import oracle as O
+
+    g = torch.Generator().manual_seed(77)
+    in_f, out_f = 4096, 2048
+    qw = torch.randint(-2 ** 31, 2 ** 31 - 1, (in_f // 8, out_f), generator=g, dtype=torch.int64).to(torch.int32)
+    sc = torch.rand(out_f, in_f // 128, generator=g) * 0.02 + 0.001
+    zr = torch.randint(0, 16, (out_f, in_f // 128), generator=g).float() * sc
+    x = torch.randn(1, in_f, generator=g)
+    want = O.vecquantmatmul(x.numpy(), qw.numpy(), np.zeros(out_f, np.float32), sc.numpy(), zr.numpy(), 128, 4)
+    dev = torch.device("cuda:0")
+    buf = torch.zeros(in_f + 8, device=dev)
+    xd = buf[1:1 + in_f].view(1, in_f)
+    xd.copy_(x)
+    assert xd.data_ptr() % 16 == 4 and xd.is_contiguous()
+    y = torch.zeros(1, out_f, device=dev)
+    ops.vecquantmatmul(4, xd, qw.to(dev), y, sc.to(dev), zr.to(dev), 128)
+    assert np.abs(y.cpu().numpy() - want).max() <= 1e-5 * max(1.0, float(np.abs(want).max()))

@@ -99,15 +99,17 @@ __device__ __forceinline__ void minmax_chunk(const void* __restrict__ x, const i
 template <typename T, bool FINAL>
 __global__ __launch_bounds__(kBlock) void stats_minmax_kernel(const void* __restrict__ x, StatPartial* __restrict__ part,
                                                               float* __restrict__ min_out, float* __restrict__ max_out,
-                                                              const ChunkGeom g, uint32_t n_chunks) {
+                                                              uint32_t n_chunks, int64_t inner, const ChunkGeom g) {
+  // (n_chunks and inner in front of the struct: with the pointers they are the argument dwords that arrive preloaded
+  // in SGPRs, and a weight's launch (FINAL) needs nothing else before its first load)
   const int lane = threadIdx.x & (kWave - 1);
   const uint32_t cid = blockIdx.x * kWavesPerBlock + __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);  // wave-uniform
   if (cid >= n_chunks) return;
   // FINAL == one chunk per channel == a [C, inner <= 4096] weight: the chunk is row `cid`, no divisions in front of
   // the first load.  Offsets inside a chunk are 32-bit (a chunk holds at most 4096 elements).
   uint32_t c_out = cid;
-  int64_t first = static_cast<int64_t>(cid) * g.inner;  // element index of the chunk's first element
-  uint32_t len = static_cast<uint32_t>(g.inner);
+  int64_t first = static_cast<int64_t>(cid) * inner;  // element index of the chunk's first element
+  uint32_t len = static_cast<uint32_t>(inner);
   if constexpr (!FINAL) {
     const ChunkPos cp = chunk_pos(g, cid);
     c_out = cp.c;
@@ -908,8 +910,8 @@ int sbq_channel_stats(const void* x, int x_dtype, int64_t outer, int64_t C, int6
   stats_partial_kernel<T, V, F><<<grid, kBlock, 0, st>>>(x, part, min_out, max_out, abssum_out, g, n_chunks)
     if (vec && !abssum_out && knob(2) != 11) {
       // the min-max observer: integer / minimum3 reductions (knob 2 == 11: the general kernel, for A/B runs)
-      if (final_) stats_minmax_kernel<T, true><<<grid, kBlock, 0, st>>>(x, part, min_out, max_out, g, n_chunks);
-      else stats_minmax_kernel<T, false><<<grid, kBlock, 0, st>>>(x, part, min_out, max_out, g, n_chunks);
+      if (final_) stats_minmax_kernel<T, true><<<grid, kBlock, 0, st>>>(x, part, min_out, max_out, n_chunks, g.inner, g);
+      else stats_minmax_kernel<T, false><<<grid, kBlock, 0, st>>>(x, part, min_out, max_out, n_chunks, g.inner, g);
     } else if (vec) { if (final_) SBQ_STATS(true, true); else SBQ_STATS(true, false); }
     else { if (final_) SBQ_STATS(false, true); else SBQ_STATS(false, false); }
 #undef SBQ_STATS

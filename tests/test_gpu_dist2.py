@@ -50,6 +50,27 @@ CASES = [
 ]
 
 
+class _Mix(torch.nn.Module):
+    """stand-in for a convolution between the quantizers of the test models: elementwise torch ops only (per-channel
+    scale, a channel rotation, a bias), with a conv-shaped `weight` for the weight quantizers.  A real Conv2d goes
+    through MIOpen, whose solver choice for a problem is NOT the same in two processes that meet it for the first time on
+    a fresh machine (the second one finds the first one's find-db entry): the ranks then disagree about the activations
+    in the last bit, and "sharded == single process, bit for bit" fails for a reason that is none of this package's
+    -- seen once in eight runs, on the first run on a fresh box."""
+
+    def __init__(self, c_in, c_out):
+        super().__init__()
+        self.weight = torch.nn.Parameter(torch.randn(c_out, c_in, 3, 3) * 0.2)
+        self.bias = torch.nn.Parameter(torch.randn(c_out) * 0.1)
+        self.c_in, self.c_out = c_in, c_out
+
+    def forward(self, x):
+        reps = (self.c_out + self.c_in - 1) // self.c_in
+        xe = x.repeat(1, reps, 1, 1)[:, :self.c_out]
+        w = self.weight.mean(dim=(1, 2, 3)).view(1, -1, 1, 1)
+        return xe * w + torch.roll(xe, 1, dims=1) * 0.5 + self.bias.view(1, -1, 1, 1)
+
+
 class _Net(torch.nn.Module):
     """two quantized operators in the QuantOpr convention (attributes input_quantizer / weight_quantizer / weight)"""
 
@@ -68,8 +89,8 @@ class _Net(torch.nn.Module):
                 return self.fwd(self.input_quantizer(x))
 
         torch.manual_seed(9)
-        self.c1 = Op(torch.nn.Conv2d(3, 8, 3, padding=1))
-        self.c2 = Op(torch.nn.Conv2d(8, 8, 3, padding=1))
+        self.c1 = Op(_Mix(3, 8))
+        self.c2 = Op(_Mix(8, 8))
 
     def forward(self, x):
         return self.c2(torch.relu(self.c1(x)))
@@ -209,7 +230,7 @@ def _worker(rank, world, port, tmp):
                     return torch.relu(self.fwd(self.input_quantizer(x)))
 
             torch.manual_seed(11)
-            self.ops = torch.nn.Sequential(*[Op(torch.nn.Conv2d(3 if i == 0 else 8, 8, 3, padding=1)) for i in range(n_ops)])
+            self.ops = torch.nn.Sequential(*[Op(_Mix(3 if i == 0 else 8, 8)) for i in range(n_ops)])
 
         def forward(self, x):
             return self.ops(x)

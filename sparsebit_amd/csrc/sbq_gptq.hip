@@ -518,7 +518,11 @@ __global__ __launch_bounds__(8 * KL) __attribute__((amdgpu_waves_per_eu(CH == 64
   constexpr int kXLoads = (KL * CH) / (kThreads * 4);  // 16-byte x loads per thread per pass
   constexpr int kXStride = CH + 4;            // skewed LDS row of one K lane
   __shared__ __attribute__((aligned(16))) float xs[kBT][KL * kXStride];
-  __shared__ float red[KL][kBT][kStripCols + 1];
+  // (a mat-vec folds a wave's 8 K lanes by shuffles and hands one partial per WAVE through LDS; more batch rows: one
+  // per K lane -- the shuffles' registers cost the two-row 512-thread kernel its second workgroup per CU)
+  constexpr bool kShuffleFold = kBT == 1;
+  constexpr int kRedRows = kShuffleFold ? kThreads / kWave : KL;
+  __shared__ float red[kRedRows][kBT][kStripCols + 1];
   __shared__ uint32_t s_prev;
   const int cl = threadIdx.x & 7;   // column quad inside the strip
   const int kl = threadIdx.x >> 3;  // K lane
@@ -831,19 +835,37 @@ __global__ __launch_bounds__(8 * KL) __attribute__((amdgpu_waves_per_eu(CH == 64
       if (LEAN || live) strip_compute<BITS, kBT, CH, DEC8, KL * kXStride>(w, &xs[0][0], kl, sc, zr, acc);
   }
   }
-  // fold the K lanes in ascending order
+  // fold the K lanes, in a fixed order.  Mat-vec: a wave holds 8 K lanes x 8 column quads (lane = 8 * (K lane % 8) +
+  // quad), so its K lanes meet through three butterfly shuffles (lanes 8, 16, 32 apart: ((k0 + k1) + (k2 + k3)) + ...),
+  // and only one partial per wave goes through LDS -- 4 or 8 values per column for the final ascending sum instead of
+  // 32 or 64 read one after the other (0.6 us of the 512-thread kernel's 5.3, tools/lab/gptq_stamps.py).  Otherwise:
+  // every K lane's partial through LDS, summed in ascending order.
   GPTQ_STAMP(4);
+  if constexpr (kShuffleFold) {
+#pragma unroll
+    for (int b = 0; b < kBT; ++b)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float v = acc[j][b];
+        v += __shfl_xor(v, 8);
+        v += __shfl_xor(v, 16);
+        v += __shfl_xor(v, 32);
+        acc[j][b] = v;
+      }
+  }
   __syncthreads();  // the previous tile's readers are done with `red`
   GPTQ_STAMP(5);
+  if (!kShuffleFold || (threadIdx.x & (kWave - 1)) < 8) {
 #pragma unroll
-  for (int b = 0; b < kBT; ++b)
+    for (int b = 0; b < kBT; ++b)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) red[kl][b][cl * 4 + j] = acc[j][b];
+      for (int j = 0; j < 4; ++j) red[kShuffleFold ? threadIdx.x / kWave : kl][b][cl * 4 + j] = acc[j][b];
+  }
   __syncthreads();
   if (owner && b0 + ob < g.batch) {
     float t = 0.0f;
 #pragma unroll
-    for (int q = 0; q < KL; ++q) t += red[q][ob][occ];
+    for (int q = 0; q < kRedRows; ++q) t += red[q][ob][occ];
     if (split == 1)  // this workgroup saw all of K: add to out (pre-filled with the bias)
       out[(b0 + ob) * g.out_features + ocol] = out_prev + t;
     else

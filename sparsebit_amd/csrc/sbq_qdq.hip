@@ -120,18 +120,24 @@ struct RowCursor {
   uint32_t d_sl, d_row, d_col, d_c;  // stride of one step (gridDim.x tiles)
 };
 
+// (position and stride separately: the stride needs the grid size, a hidden kernel argument that is not preloaded
+// -- it is computed after the first tile's loads have been issued)
 template <int U>
-__device__ __forceinline__ RowCursor make_cursor(const QdqGeom& g, uint32_t tile, uint32_t step_tiles) {
+__device__ __forceinline__ RowCursor make_cursor(const QdqGeom& g, uint32_t tile) {
   RowCursor k;
   k.sl = tile * U;
   k.row = k.sl / g.slabs_per_row;
   k.col = k.sl - k.row * g.slabs_per_row;
   k.c = k.row % g.C;
+  k.d_sl = k.d_row = k.d_col = k.d_c = 0;
+  return k;
+}
+template <int U>
+__device__ __forceinline__ void set_stride(const QdqGeom& g, RowCursor& k, uint32_t step_tiles) {
   k.d_sl = step_tiles * U;
   k.d_row = k.d_sl / g.slabs_per_row;
   k.d_col = k.d_sl - k.d_row * g.slabs_per_row;
   k.d_c = k.d_row % g.C;
-  return k;
 }
 
 __device__ __forceinline__ void advance(const QdqGeom& g, RowCursor& k) {
@@ -139,13 +145,12 @@ __device__ __forceinline__ void advance(const QdqGeom& g, RowCursor& k) {
   k.col += k.d_col;
   k.row += k.d_row;
   k.c += k.d_c;
-  if (k.col >= g.slabs_per_row) {
-    k.col -= g.slabs_per_row;
-    ++k.row;
-    ++k.c;
-  }
+  const bool carry = k.col >= g.slabs_per_row;  // (selects: see locate)
+  k.col -= carry ? g.slabs_per_row : 0u;
+  k.row += carry ? 1u : 0u;
+  k.c += carry ? 1u : 0u;
   // c < C and d_c < C before, plus a carry of at most 1: c < 2C, one subtraction suffices
-  if (k.c >= g.C) k.c -= g.C;
+  k.c -= k.c >= g.C ? g.C : 0u;
 }
 
 template <bool FLAT, int U, bool SPLIT = false>
@@ -173,24 +178,19 @@ __device__ __forceinline__ void locate(const QdqGeom& g, uint32_t tile, const Ro
       const uint32_t pkc = pk < g.packs_per_row ? pk : g.packs_per_row - 1;
       t.elem[u] = static_cast<int64_t>(row) * g.inner + static_cast<int64_t>(pkc) * kPack;
       }
-      float s_ = uniform_load(scale, c), z_ = uniform_load(zero_point, c);
-      if (g.lsq) {
-        s_ = __builtin_fabsf(s_);
-        z_ = __builtin_amdgcn_fmed3f(z_, g.qlo, g.qhi);
-      }
-      t.s[u] = s_;
-      t.z[u] = __builtin_rintf(z_);
-      // advance to the next slab without dividing; past the end stay on the last one
-      if (sl + 1 < g.n_slabs) {
-        ++sl;
-        if (++col == g.slabs_per_row) {
-          col = 0;
-          ++row;
-          if (++c == g.C) c = 0;
-        }
-      } else {
-        sl = g.n_slabs;
-      }
+      // (requested here, used by settle() AFTER the tile's vector loads have been issued: finishing them here made
+      // every tile's loads wait for a scalar round trip first)
+      t.s[u] = uniform_load(scale, c);
+      t.z[u] = uniform_load(zero_point, c);
+      // advance to the next slab without dividing; past the end stay on the last one.  SELECTS, not branches: with
+      // branches every slab's parameter loads sit in a basic block of their own and the compiler drains the scalar
+      // loads at each join -- four dependent scalar round trips (~1 us) in front of the tile's first vector load.
+      const bool more = sl + 1 < g.n_slabs;
+      const bool wrap = more && col + 1 == g.slabs_per_row;
+      col = more ? (wrap ? 0u : col + 1u) : col;
+      row += wrap ? 1u : 0u;
+      c = wrap ? (c + 1u == g.C ? 0u : c + 1u) : c;
+      sl = more ? sl + 1u : g.n_slabs;
     }
   } else {
 #pragma unroll
@@ -201,14 +201,25 @@ __device__ __forceinline__ void locate(const QdqGeom& g, uint32_t tile, const Ro
       t.elem[u] = static_cast<int64_t>(pkc) * kPack;
       uint32_t c = 0;
       if (g.C != 1) c = (pkc / g.packs_per_row) % g.C;  // per tensor: no division
-      float s_ = scale[c], z_ = zero_point[c];
-      if (g.lsq) {
-        s_ = __builtin_fabsf(s_);
-        z_ = __builtin_amdgcn_fmed3f(z_, g.qlo, g.qhi);
-      }
-      t.s[u] = s_;
-      t.z[u] = __builtin_rintf(z_);
+      t.s[u] = scale[c];
+      t.z[u] = zero_point[c];
     }
+  }
+}
+
+// the tile's raw scale / zero point -> what the arithmetic uses (LSQ: |s|, clamped zero point; zero point to the
+// nearest integer, half to even).  Called after issue_loads: the wait for the parameters overlaps the data's flight.
+template <int U>
+__device__ __forceinline__ void settle(const QdqGeom& g, Tile<U>& t) {
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    float s_ = t.s[u], z_ = t.z[u];
+    if (g.lsq) {
+      s_ = __builtin_fabsf(s_);
+      z_ = __builtin_amdgcn_fmed3f(z_, g.qlo, g.qhi);
+    }
+    t.s[u] = s_;
+    t.z[u] = __builtin_rintf(z_);
   }
 }
 
@@ -263,19 +274,19 @@ __device__ __forceinline__ void finish_tile(void* __restrict__ y, void* __restri
 // under HBM latency instead of adding to it -- the kernel is short (one 4096x4096 weight is
 // ~12 us), there is no steady state to amortise a load->compute->store serialisation.
 //
-// Parameter order matters: the file is built with -amdgpu-kernarg-preload-count=14, so the
-// first 14 dwords of the kernarg segment (x, the tile geometry, y, scale, zero_point) arrive
+// Parameter order matters: the library is built with -amdgpu-kernarg-preload-count=16 (14 fit), so the
+// first 14 dwords of the kernarg segment (x, the tile geometry, scale, zero_point) arrive
 // in SGPRs with the wave instead of through a cold scalar load -- every launch gets a fresh
 // kernarg block, and for a ~12 us kernel one more dependent HBM round trip in front of the
 // first data load is measurable.  The rarely used arguments follow and are loaded normally.
 template <typename Tin, typename Tout, int QT, int MASK, bool FLAT, bool NT, int U, int MATH, bool NTS = NT>
 __global__ __launch_bounds__(kBlock) void qdq_pack_kernel(
     const void* __restrict__ x, uint32_t n_tiles, uint32_t slabs_per_row, uint32_t packs_per_row,
-    uint32_t n_channels, int64_t inner, void* __restrict__ y, const float* __restrict__ scale,
+    uint32_t n_channels, int64_t inner, uint32_t n_slabs, uint32_t total_packs, const float* __restrict__ scale,
     const float* __restrict__ zero_point,
-    // ---- not preloaded ----
-    void* __restrict__ q, const uint8_t* __restrict__ mask, const float* __restrict__ thresh,
-    uint32_t n_slabs, uint32_t total_packs, float qlo, float qhi, uint32_t lsq) {
+    // ---- not preloaded (nothing the first tile's loads need, the mask pointer of the masked variants excepted) ----
+    void* __restrict__ y, void* __restrict__ q, const uint8_t* __restrict__ mask, const float* __restrict__ thresh,
+    float qlo, float qhi, uint32_t lsq) {
   QdqGeom g;
   g.lsq = lsq;
   g.inner = inner;
@@ -294,23 +305,32 @@ __global__ __launch_bounds__(kBlock) void qdq_pack_kernel(
   // output needs 8 consecutive levels per dword and keeps the contiguous pack
   constexpr bool SPLIT = !FLAT && QT != SBQ_Q_I4 && Tout::id == SBQ_F32;
   uint32_t tile = blockIdx.x;
-  const uint32_t G = gridDim.x;
   if (tile >= g.n_tiles) return;
   Tile<U> ta, tb;
   RawPack<Tin> ra[U], rb[U];
   u32x2 ma[U], mb[U];
   RowCursor cur{};
-  if constexpr (!FLAT) cur = make_cursor<U>(g, tile, G);
+  if constexpr (!FLAT) cur = make_cursor<U>(g, tile);
   // fetches happen in tile order (tile, tile+G, tile+2G, ...): one cursor, stepped after each
 #define SBQ_FETCH(T, R, M, IDX)                                     \
   locate<FLAT, U, SPLIT>(g, (IDX), cur, scale, zero_point, T);      \
   issue_loads<Tin, MASK, NT, U, SPLIT>(x, mask, T, R, M);           \
   __builtin_amdgcn_sched_barrier(0); /* nothing of the following FINISH (whose first use waits for the */ \
   /* PREVIOUS tile's loads) may be scheduled above these loads: that would serialise the pipeline */   \
+  settle<U>(g, T);                                                  \
   if constexpr (!FLAT) advance(g, cur)
 #define SBQ_FINISH(T, R, M) \
   finish_tile<Tin, Tout, QT, MASK, FLAT, NTS, U, MATH, SPLIT>(y, q, T, R, M, thr, g.qlo, g.qhi)
-  SBQ_FETCH(ta, ra, ma, tile);
+  // the first tile: as SBQ_FETCH, with the cursor's stride computed behind the loads
+  locate<FLAT, U, SPLIT>(g, tile, cur, scale, zero_point, ta);
+  issue_loads<Tin, MASK, NT, U, SPLIT>(x, mask, ta, ra, ma);
+  __builtin_amdgcn_sched_barrier(0);
+  settle<U>(g, ta);
+  const uint32_t G = gridDim.x;
+  if constexpr (!FLAT) {
+    set_stride<U>(g, cur, G);
+    advance(g, cur);
+  }
   // Steady state: both prefetches are unconditional, so the compiler's vmcnt bookkeeping
   // stays exact (a conditional prefetch merges two scoreboard states at the join and makes
   // every wait drain the prefetched tile too).
@@ -359,7 +379,8 @@ __global__ __launch_bounds__(kBlock) void qdq_batched_kernel(const void* const* 
   auto load_item = [&]() {
     const void* const* e = table + static_cast<size_t>(item) * 4;
     cur = Ptrs{e[0], const_cast<void*>(e[1]), static_cast<const float*>(e[2]), static_cast<const float*>(e[3])};
-    rc = make_cursor<U>(g, lt, G);
+    rc = make_cursor<U>(g, lt);
+    set_stride<U>(g, rc, G);
   };
   load_item();
   auto step_item = [&]() {  // move to the tile G further on
@@ -384,7 +405,8 @@ __global__ __launch_bounds__(kBlock) void qdq_batched_kernel(const void* const* 
   locate<false, U, SPLIT>(g, lt, rc, P.scale, P.zp, T);            \
   issue_loads<Tin, MASK, true, U, SPLIT>(P.x, nullptr, T, R, M);   \
   step_item();                                                     \
-  __builtin_amdgcn_sched_barrier(0) /* nothing of the following FINISH above this tile's loads */
+  __builtin_amdgcn_sched_barrier(0); /* nothing of the following FINISH above this tile's loads */ \
+  settle<U>(g, T)
 #define SBQ_FINISH(P, T, R, M) \
   finish_tile<Tin, Tout, SBQ_Q_NONE, MASK, false, true, U, MATH_FAST, SPLIT>(P.y, nullptr, T, R, M, 0.0f, g.qlo, g.qhi)
   SBQ_FETCH(pa, ta, ra, ma, tile);
@@ -546,8 +568,8 @@ template <typename Tin, typename Tout, int QT, int MASK, bool FLAT, bool NT, int
 void launch_pack(const QdqCall& c, hipStream_t st) {
   const uint32_t grid = auto_grid(c.g.n_tiles);
   qdq_pack_kernel<Tin, Tout, QT, MASK, FLAT, NT, U, MATH, NTS><<<grid, kBlock, 0, st>>>(
-      c.p.x, c.g.n_tiles, c.g.slabs_per_row, c.g.packs_per_row, c.g.C, c.g.inner, c.p.y, c.p.scale, c.p.zp,
-      c.p.q, c.p.mask, c.p.thresh, c.g.n_slabs, c.g.total_packs, c.g.qlo, c.g.qhi, c.g.lsq);
+      c.p.x, c.g.n_tiles, c.g.slabs_per_row, c.g.packs_per_row, c.g.C, c.g.inner, c.g.n_slabs, c.g.total_packs, c.p.scale,
+      c.p.zp, c.p.y, c.p.q, c.p.mask, c.p.thresh, c.g.qlo, c.g.qhi, c.g.lsq);
 }
 
 // variant id (knob 0):  bit0-1: log2(U) (0..2) ; bit2: NT off ; -1 auto

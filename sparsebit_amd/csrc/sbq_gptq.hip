@@ -470,7 +470,7 @@ struct GptqMulti {
 
 // LEAN (host-checked: x rows 16-byte aligned, in_features % 4 == 0): EVERY global load of a pass is unconditional --
 // channels, batch rows, weight rows and groups are clamped to valid ones and what must not count is zeroed by a
-// select afterwards.  A load under a branch makes the compiler wait for everything in flight at the join: the
+// mask afterwards.  A load under a branch makes the compiler wait for everything in flight at the join: the
 // timeline of the branchy version (tools/lab/gptq_stamps.py, profiles/r04_gptq_timeline.txt) showed the weight
 // words of the first pass being REQUESTED 2.3 us after the workgroup started -- behind two full memory round trips
 // (the value added to, then the activations) that the joins had serialised.
@@ -569,9 +569,10 @@ __global__ __launch_bounds__(8 * KL) __attribute__((amdgpu_waves_per_eu(CH == 64
     const int kc = k < in32 ? k : in32 - 4;
     const int rc = brow < batch32 ? brow : batch32 - 1;
     const f32x4 t = *reinterpret_cast<const f32x4*>(at32(x, static_cast<uint32_t>(rc * in32 + kc) * 4u));
-    // zeroed by a MULTIPLY: a select (of a vector, on a scalar condition) becomes a branch, and the load sinks into it
-    const float keep = ((k < in32) & (brow < batch32)) ? 1.0f : 0.0f;
-    return t * keep;
+    // zeroed by a bit MASK: a select (of a vector, on a scalar condition) becomes a branch and the load sinks into it;
+    // a multiply by 0 / 1 would turn an inf or NaN of the clamped element into a NaN of a channel that does not exist
+    const uint32_t keep = ((k < in32) & (brow < batch32)) ? 0xffffffffu : 0u;
+    return __builtin_bit_cast(f32x4, __builtin_bit_cast(u32x4, t) & keep);
   };
   auto lean_group = [&](int k0) -> int {
     const int grp = static_cast<int>(static_cast<uint32_t>(k0) / static_cast<uint32_t>(g.group_size));

@@ -28,6 +28,9 @@
 #include <type_traits>
 
 #include <atomic>
+#ifndef SBQ_POLL_SLEEP
+#define SBQ_POLL_SLEEP 8  // s_sleep units (64 cycles) between two polls of a resident workgroup (A/B: tools/lab/build_variant.py)
+#endif
 #ifndef SBQ_SEL_STAMPS
 #define SBQ_SEL_STAMPS 0  // -DSBQ_SEL_STAMPS=1: development timestamps (tools/lab/build_stamps.py)
 #endif
@@ -1731,7 +1734,7 @@ __device__ __forceinline__ bool win_finish(const Tab& tab, int n_shards, const O
       const unsigned long long limit = 10000ull + 4ull * (t_arr - ol.t0);
       bool may_resign = true;
       for (uint32_t spin = 0;; ++spin) {
-        __builtin_amdgcn_s_sleep(8);
+        __builtin_amdgcn_s_sleep(SBQ_POLL_SLEEP);
         v = __hip_atomic_fetch_add(vp, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if ((v >> 1) == (tag >> 1)) break;
         if (may_resign && (spin & 15u) == 15u && __builtin_amdgcn_s_memrealtime() - t_arr > limit) {

@@ -33,6 +33,8 @@ def timed(fn, iters=200):
     return best
 
 
+if os.environ.get("SBQ_LIB"):
+    L.LIB_PATH = os.environ["SBQ_LIB"]  # a variant library (tools/lab/build_variant.py)
 lib = L.load()
 ws = L.fresh_workspace(lib.sbq_radix_select_workspace_bytes(1, 2), dev)
 out = torch.empty(2, dtype=torch.float32, device=dev)

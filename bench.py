@@ -85,6 +85,9 @@ def main():
     ap.add_argument("--steps", type=int, default=500)
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--reference", default=os.environ.get("SBQ_REFERENCE"),
+                    help="checkout of megvii-research/Sparsebit: the CPU baseline is then the REAL reference's Quantizer "
+                         "(tools/reference_cpu_baseline.py, kind 'reference'); without one, oracle/torch_port.py (kind 'port')")
     ap.add_argument("--quick", action="store_true",
                     help="headline + multi-GPU plumbing only: no config legs, no CPU baseline (tests/test_gpu_bench_n2.py)")
     args = ap.parse_args()
@@ -387,12 +390,42 @@ def main():
         ar_us = timed(lambda i: sbq_dist.allreduce_minmax(mn, mx), 50) if world > 1 else 0.0
         ar_mse_us = timed(lambda i: sbq_dist.allreduce_sum_(sse_t), 50) if world > 1 else 0.0
         ar_hist_us = timed(lambda i: sbq_dist.allreduce_sum_(hist_t), 50) if world > 1 else 0.0
+    ar_bytes = (4 * 4 * ROWS, sse_t.numel() * 8, hist_t.numel() * 8)
+    if world == 1 and not args.quick:
+        # N = 1: the same three collectives on a ONE-rank RCCL communicator (tools/rccl_ws1.py, in a subprocess with a
+        # timeout: a hung rendezvous must not take the benchmark with it) -- the launch + RCCL-kernel floor that the
+        # xGMI hops of N > 1 add to, and the first time RCCL itself runs under sparsebit_amd.dist
+        import subprocess
+
+        ws1 = {"ran": False}
+        try:
+            env = dict(os.environ)
+            env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "rccl_ws1.py")], env=env, capture_output=True,
+                               text=True, timeout=240)
+            lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            if r.returncode == 0 and lines:
+                ws1 = json.loads(lines[-1])
+                ws1["ran"] = True
+                lat = ws1["latency"]
+                ar_us, ar_mse_us, ar_hist_us = (lat["minmax_pack_allreduce_unpack_us"], lat["mse_sum_us"],
+                                                lat["percentile_hist_sum_us"])
+                ar_bytes = (lat["minmax_bytes"], lat["mse_sum_bytes"], lat["percentile_hist_sum_bytes"])
+            else:
+                ws1["error"] = (r.stderr or r.stdout)[-400:]
+        except Exception as e:  # noqa: BLE001  (timeout, missing RCCL: the headline line must still print)
+            ws1["error"] = repr(e)[:400]
+        extras["rccl_world_size_1"] = ws1
+    measured = world > 1 or ar_us > 0.0
     extras["observer_allreduce_us"] = round(ar_us, 2)
-    extras["observer_allreduce_bytes"] = 4 * 4 * ROWS if world > 1 else 0
+    extras["observer_allreduce_bytes"] = ar_bytes[0] if measured else 0
     extras["observer_allreduce_mse_sum_us"] = round(ar_mse_us, 2)
-    extras["observer_allreduce_mse_sum_bytes"] = sse_t.numel() * 8 if world > 1 else 0
+    extras["observer_allreduce_mse_sum_bytes"] = ar_bytes[1] if measured else 0
     extras["observer_allreduce_percentile_hist_sum_us"] = round(ar_hist_us, 2)
-    extras["observer_allreduce_percentile_hist_sum_bytes"] = hist_t.numel() * 8 if world > 1 else 0
+    extras["observer_allreduce_percentile_hist_sum_bytes"] = ar_bytes[2] if measured else 0
+    extras["observer_allreduce_what"] = (
+        "RCCL all-reduce over %d rank(s): MAX of the packed [max, -min, nan flags] fp32 buffer for C = 4096 incl. the pack / "
+        "unpack kernels; SUM of the fp64 [C, 80] squared-error table; SUM of one int64 [1, 2, 2048] histogram" % world)
 
     # ---- config 3 across ranks: DeiT-small's percentile calibration with the batches SHARDED over the GPUs ----------
     # every rank holds its own 4 batches of 64 x 197 x 384 (bf16) for each of 12 activation quantizers (one per block);
@@ -504,7 +537,7 @@ def main():
             "config1_resnet18_minmax_trt": BC.config1_resnet18_minmax(ctx),
             "config2_mse_per_channel": BC.config2_mse(ctx),
             "config3_percentile": BC.config3_percentile(ctx),
-            "config4_gptq_4bit_g128_B1": BC.config4_gptq(ctx),
+            "config4_gptq_4bit_g128": BC.config4_gptq(ctx),
             "config5_mask_lsq_4bit": BC.config5_mask_lsq(ctx),
         }
         extras["model_wide_calibration"] = BC.model_wide_calibration(ctx)
@@ -560,6 +593,33 @@ def main():
                       "%.1f ms" % (reps, best * 1e3),
             "matches_gpu_output": same,
         }
+        if args.reference and os.path.isdir(os.path.join(args.reference, "sparsebit")):
+            # the REAL reference: build_quantizer(cfg) -> update_observer -> calc_qparams -> forward of its own CPU path,
+            # GPUs hidden, in a subprocess (tools/reference_cpu_baseline.py); the port above stays beside it
+            import subprocess
+            import zlib
+
+            try:
+                r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "reference_cpu_baseline.py"), "--reference",
+                                    args.reference, "--seed", str(1000 * rank), "--budget-s", "20"], capture_output=True,
+                                   text=True, timeout=300)
+                ref = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+                gpu_crc = zlib.crc32(ys[0].cpu().view(torch.int16).numpy().tobytes()) & 0xFFFFFFFF
+                s_crc = zlib.crc32(scale.reshape(-1).float().cpu().numpy().tobytes()) & 0xFFFFFFFF
+                port = cpu_baseline
+                cpu_baseline = {
+                    "value": ref["value"], "unit": "elements/s", "cores": ref["cores"], "host_cores": ref["host_cores"],
+                    "kind": "reference",
+                    "sample": "full 4096x4096 weight (fp32 upcast of the same bf16 data) through the reference's own "
+                              "build_quantizer(cfg) -> update_observer -> calc_qparams -> Quantizer.forward (%s), GPUs hidden, best "
+                              "of %d forwards over thread counts {all,64,32,16}, %.1f ms; calibration %.1f ms"
+                              % (ref["quantizer"], ref["runs"], ref["forward_ms"], ref["calibration_ms"]),
+                    "matches_gpu_output": bool(ref["out_bf16_crc32"] == gpu_crc),
+                    "scale_matches_gpu": bool(ref["scale_crc32"] == s_crc),
+                    "port_value": port["value"], "port_cores": port["cores"],
+                }
+            except Exception as e:  # noqa: BLE001
+                cpu_baseline["reference_error"] = repr(e)[:300]
         # the other CPU legs of BASELINE.md 3, same host, the thread count that was best for the QDQ, one timed run
         # each after a warm-up on a quarter of the data (bounded: the MSE observer is 80 passes over its input)
         torch.set_num_threads(best_threads)
@@ -620,6 +680,18 @@ def main():
         except (OSError, ValueError):
             traffic = None
 
+    # the same fraction from the COMMITTED rocprofv3 --kernel-trace --stats summary (profiles/pmc_latest.json:
+    # rocprof_kernel_avg_ns of this kernel on the box that profile was taken on): reproducible from profiles/ alone
+    frac_rocprof = rocprof_avg_us = None
+    try:
+        with open(pmc_path) as f:
+            pmc_ = json.load(f)
+        if str(pmc_.get("kernel")).replace("sbq::", "") == kernel_name.replace("sbq::", "") and pmc_.get("rocprof_kernel_avg_ns"):
+            rocprof_avg_us = float(pmc_["rocprof_kernel_avg_ns"]) / 1e3
+            frac_rocprof = round(n_elem * BYTES_PER_ELEM / rocprof_avg_us / 1e3 / HBM_PEAK_GBS, 4)
+    except (OSError, ValueError):
+        pass
+
     if rank == 0:
         line = {
             "metric": "per-channel int8 QDQ throughput, 4096x4096 bf16 weight",
@@ -657,6 +729,11 @@ def main():
                 "kernel_avg_us_windows_min": round(around[0], 3),
                 "kernel_avg_us_windows_max": round(around[-1], 3),
                 "frac_1024_window_median": round(achieved / HBM_PEAK_GBS, 4),
+                "frac_rocprof": frac_rocprof,
+                "rocprof_kernel_avg_us": None if rocprof_avg_us is None else round(rocprof_avg_us, 3),
+                "frac_rocprof_what": "algorithmic bytes / the committed rocprofv3 --kernel-trace --stats average of this kernel "
+                                     "(profiles/pmc_latest.json, taken on the builder's box) / 8 TB/s; `frac` is the same bytes "
+                                     "over this run's own HIP-event windows",
                 "frac_windows_min": round(n_elem * BYTES_PER_ELEM / around[-1] / 1e3 / HBM_PEAK_GBS, 4),
                 "frac_windows_max": round(n_elem * BYTES_PER_ELEM / around[0] / 1e3 / HBM_PEAK_GBS, 4),
                 # the K timed launches alone (events around the timed region), and the wall clock of the timed region

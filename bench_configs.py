@@ -484,6 +484,39 @@ def config4_gptq(c):
         out[name] = _entry(us, nbytes, ok, "y == oracle(cuda_kernel_4bit.cu:36-180) at rtol = atol = 1e-5 (x max|y|), the "
                            "reference test's tolerance", weight_copies_in_rotation=copies,
                            cache_resident_us=round(us_warm, 3), max_abs_err=float(np.abs(got - ref).max()))
+        # ---- the same matrix at B = 8 and B = 32 (SURVEY.md 8(d) M-gptq: B in {1, 8, 32}; the reference's multi-batch
+        #      cases, test_cuda_kernel.py:81-126).  The weight stream is read once per call whatever B is, so the HBM
+        #      fraction falls with B while the arithmetic (2 * B * in * out flops on the fp32 vector ALU: the contract is
+        #      fp32 FMA on int nibbles, no MFMA) grows: both fractions are reported.
+        gx = torch.Generator().manual_seed(900 + in_f % 89)
+        for B in (8, 32):
+            xb = torch.randn(B, in_f, generator=gx).float()
+            xbd = xb.to(c.dev)
+            yb = torch.zeros(B, out_f, dtype=torch.float32, device=c.dev)
+            wsb = L.fresh_workspace(max(lib.sbq_gptq_workspace_bytes(B, in_f, out_f), 16), c.dev)
+            argb = [(L.ptr(xbd), L.ptr(qws[j]), L.ptr(yb), L.ptr(scs[j]), L.ptr(zrs[j])) for j in range(copies)]
+
+            def run_b(i):
+                a = argb[i % copies]
+                return lib.sbq_vecquant4matmul(a[0], a[1], a[2], a[3], a[4], B, in_f, out_f, 128, L.ptr(wsb), wsb.numel(), c.st)
+
+            us_b = c.timed(run_b, 200, warm=20)
+            yb.zero_()
+            L.check(run_b(0))
+            torch.cuda.synchronize(c.dev)
+            ref = O.vecquantmatmul(xb.numpy(), qws[0].cpu().numpy(), np.zeros(out_f, np.float32), scs[0].cpu().numpy(),
+                                   zrs[0].cpu().numpy(), 128, 4)
+            got = yb.cpu().numpy()
+            tol = 1e-5 * max(1.0, float(np.abs(ref).max()))
+            ok_b = bool(np.all(np.abs(got - ref) <= tol + 1e-5 * np.abs(ref)))
+            nbytes_b = w_bytes + 2 * out_f * groups * 4 + B * (in_f + 2 * out_f) * 4
+            flops = 2.0 * B * in_f * out_f
+            out.setdefault("B%d" % B, {})[name] = _entry(
+                us_b, nbytes_b, ok_b, "y [%d, %d] == oracle(cuda_kernel_4bit.cu:36-180) at the reference test's rtol = atol = "
+                "1e-5 (x max|y|)" % (B, out_f), batch=B, weight_copies_in_rotation=copies, max_abs_err=float(np.abs(got - ref).max()),
+                valu_tflops=round(flops / us_b / 1e6, 2), frac_of_fp32_vector_peak=round(flops / us_b / 1e6 / FP32_VECTOR_PEAK_TFLOPS, 4),
+                us_per_row_of_x=round(us_b / B, 3))
+            del xbd, yb, wsb
         del qws, scs, zrs
     # ---- a decoder layer's projections that share their input, as ONE launch each (quant.py:262-278 issues one
     #      mat-vec per QuantLinear): q / k / v = 3 x (4096 -> 4096); gate + up = 2 x (4096 -> 11008)

@@ -1,5 +1,7 @@
 // sbq_core.hip -- status strings, launch checking and tuning knobs of libsbq.
 #include <atomic>
+#include <climits>
+#include <cstdint>
 #include <cstring>
 
 #include "sbq_common.hpp"
@@ -12,7 +14,11 @@ namespace {
 thread_local char g_last_hip_error[128] = "";
 // Tuning knobs are per calling THREAD (benchmarks / A-B runs set them around their own calls): a host with several
 // threads cannot have one thread's experiment change the kernels another thread's calls dispatch.
-thread_local int g_knobs[4] = {-1, 0, 0, 0};
+// A thread that never set a knob sees the PROCESS default (sbq_set_tuning(knob | SBQ_TUNING_PROCESS, v)): autograd runs
+// backward kernels on its own threads, which a setting made on the Python main thread would otherwise never reach.
+constexpr int kKnobUnset = INT32_MIN;
+thread_local int g_knobs[4] = {kKnobUnset, kKnobUnset, kKnobUnset, kKnobUnset};
+std::atomic<int> g_knob_defaults[4] = {{-1}, {0}, {0}, {0}};
 
 // ---- zero-contract workspaces ---------------------------------------------------------------------------------
 // The whole-tensor selection engine and the GPTQ mat-vec keep arrival counters / histogram copies in caller memory
@@ -40,8 +46,14 @@ int workspace_guard(void* region, size_t bytes, hipStream_t st) {
   (void)hipGetDevice(&dev);
   char* begin = static_cast<char*>(region);
   std::lock_guard<std::mutex> lock(g_ws_mutex);
-  for (WsEntry& e : g_ws) {
+  // (the entry this thread hit last is tried first: a decode loop calls with the same region every time)
+  thread_local size_t last_hit = 0;
+  const size_t n_ws = g_ws.size();
+  for (size_t probe = 0; probe < n_ws; ++probe) {
+    const size_t idx = probe == 0 ? (last_hit < n_ws ? last_hit : 0) : (probe <= last_hit && last_hit < n_ws ? probe - 1 : probe);
+    WsEntry& e = g_ws[idx];
     if (e.dev != dev || e.begin != begin) continue;
+    last_hit = idx;
     if (e.stream != st) {
       if (hipStreamQuery(e.stream) == hipErrorNotReady) return SBQ_ERR_BUSY;
       (void)hipGetLastError();  // (a stream that no longer exists is idle too)
@@ -76,7 +88,10 @@ int check_launch() {
   return SBQ_ERR_LAUNCH;
 }
 
-int knob(int which) { return g_knobs[which & 3]; }
+int knob(int which) {
+  const int v = g_knobs[which & 3];
+  return v != kKnobUnset ? v : g_knob_defaults[which & 3].load(std::memory_order_relaxed);
+}
 
 // compute units of the current device (cached per device ordinal; 256 on an MI355X)
 uint32_t cu_count() {
@@ -118,8 +133,11 @@ const char* sbq_strerror(int status) {
 const char* sbq_last_hip_error(void) { return sbq::g_last_hip_error; }
 
 int sbq_set_tuning(int knob, int value) {
+  const bool process = (knob & SBQ_TUNING_PROCESS) != 0;
+  knob &= ~SBQ_TUNING_PROCESS;
   if (knob < 0 || knob > 3) return SBQ_ERR_ARG;
-  sbq::g_knobs[knob] = value;
+  if (process) sbq::g_knob_defaults[knob].store(value, std::memory_order_relaxed);
+  else sbq::g_knobs[knob] = value;
   return SBQ_OK;
 }
 

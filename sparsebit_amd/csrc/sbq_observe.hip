@@ -593,7 +593,9 @@ __global__ __launch_bounds__(kH16Threads) void hist16_kernel(const void* __restr
     const uint32_t pk = (wg + static_cast<uint32_t>(j / 2) * nwg) * 2048u + (j % 2) * kH16Threads + threadIdx.x;
     const bool there = pk < n_packs;
     okmask |= there ? 1u << j : 0u;
-    raw[j] = load_raw<T, true>(x, static_cast<int64_t>((there ? pk : n_packs - 1u) * static_cast<uint32_t>(kPack))).d[0];
+    // (a pack that is not there re-reads the last one that is; the host never launches with n < 8: sbq_mse_accumulate folds
+    // a rest shorter than one pack into the launch before it -- the clamp below only keeps the address inside x)
+    raw[j] = load_raw<T, true>(x, static_cast<int64_t>((there ? pk : (n_packs ? n_packs - 1u : 0u)) * static_cast<uint32_t>(kPack))).d[0];
   }
   __builtin_amdgcn_sched_barrier(0);
   {
@@ -636,11 +638,14 @@ __global__ __launch_bounds__(kH16Threads) void hist16_kernel(const void* __restr
       }
     }
   }
-  if (wg == 0 && wid == 1) {  // the tensor's last n % 8 elements
+  if (wg == 0 && wid == 1) {
+    // the launch's last n % 8 elements: straight into the global histogram (copy 0), NOT into this workgroup's LDS
+    // counts -- the single-key carry fallback below credits everything the workgroup counted to one key, and must
+    // therefore cover whole packs only
     const uint32_t e = n_packs * kPack + lane;
     if (e < n) {
       const uint32_t k = Key16<T>::pack2(static_cast<const uint16_t*>(x)[e], 0xffffffffu) & 0xffffu;
-      atomicAdd(&hist[k >> 1], (k & 1u) ? 0x10000u : 1u);
+      atomicAdd(&ghist[k], 1u);
     }
   }
   if (threadIdx.x == 0) s_first = first_key;
@@ -652,7 +657,6 @@ __global__ __launch_bounds__(kH16Threads) void hist16_kernel(const void* __restr
     const uint32_t p0 = (wg + static_cast<uint32_t>(j) * nwg) * 2048u, p1 = p0 + 2048u;
     if (p0 < n_packs) n_wg += ((p1 < n_packs ? p1 : n_packs) - p0) * kPack;
   }
-  if (wg == 0) n_wg += n - n_packs * kPack;
   uint32_t wv[32], total = 0;
 #pragma unroll
   for (int m = 0; m < 32; ++m) {
@@ -1098,8 +1102,11 @@ int sbq_mse_accumulate(const void* x, int x_dtype, int64_t outer, int64_t C, int
     const int64_t numel = outer * C * inner;
     const int64_t per_launch = static_cast<int64_t>(kH16Elems) * cu_count();
     int rc16 = SBQ_OK;
-    for (int64_t done = 0; done < numel && rc16 == SBQ_OK; done += per_launch) {
-      const int64_t cnt = numel - done < per_launch ? numel - done : per_launch;
+    for (int64_t done = 0; done < numel && rc16 == SBQ_OK;) {
+      int64_t cnt = numel - done < per_launch ? numel - done : per_launch;
+      // a rest shorter than one 8-element pack rides with this launch (one more workgroup's worth of slab indices, no
+      // launch of its own: hist16_kernel reads whole packs and takes n % 8 elements as the ragged end of workgroup 0)
+      if (numel - done - cnt < kPack) cnt = numel - done;
       const uint32_t wgs = static_cast<uint32_t>(ceil_div(cnt, static_cast<int64_t>(kH16Elems)));
       const void* xp = static_cast<const char*>(x) + done * 2;
       rc16 = dispatch_dtype(x_dtype, [&](auto tag) {
@@ -1113,6 +1120,7 @@ int sbq_mse_accumulate(const void* x, int x_dtype, int64_t outer, int64_t C, int
           hist16_kernel<T><<<wgs, kH16Threads, 131072, st>>>(xp, static_cast<uint32_t>(cnt), ghist);
         }
       });
+      done += cnt;
     }
     if (rc16 != SBQ_OK) return rc16;
     rc16 = dispatch_dtype(x_dtype, [&](auto tag) {

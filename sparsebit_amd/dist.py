@@ -23,6 +23,7 @@ import torch.distributed as dist
 
 _sync_enabled = False
 _group = None
+_even_alone = False
 
 
 def enable(group=None):
@@ -47,12 +48,38 @@ def sharded_calibration(group=None):
         disable()
 
 
+def collectives_even_alone(flag=True):
+    """Issue the collectives on a ONE-rank communicator too (default: a lone rank skips them).  Every wire format
+    then crosses RCCL on a single leased GPU -- tests/test_gpu_rccl_ws1.py, and the N = 1 point of bench.py's
+    observer all-reduce latencies.  Results are unchanged by construction: a reduction over one rank is the identity."""
+    global _even_alone
+    _even_alone = bool(flag)
+
+
 def active():
-    return _sync_enabled and dist.is_available() and dist.is_initialized() and dist.get_world_size(_group) > 1
+    if not (_sync_enabled and dist.is_available() and dist.is_initialized()):
+        return False
+    return _even_alone or dist.get_world_size(_group) > 1
 
 
 def world_size():
     return dist.get_world_size(_group) if active() else 1
+
+
+def init_single_rank_rccl(device):
+    """A one-rank RCCL communicator on `device` (file-store rendezvous: no port, no environment) -- what a one-GPU
+    lease can still put under the collective path.  Returns True when THIS call created the default group."""
+    import os
+    import tempfile
+
+    if dist.is_initialized():
+        return False
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    fd, path = tempfile.mkstemp(prefix="sbq_rccl_ws1_")
+    os.close(fd)
+    os.unlink(path)  # (FileStore creates it)
+    dist.init_process_group("nccl", init_method="file://" + path, world_size=1, rank=0, device_id=device)
+    return True
 
 
 def allreduce_minmax(min_val, max_val):
@@ -181,12 +208,16 @@ def run_lockstep(gens):
                     if len(ts) == 1:
                         _all_reduce(ts[0], dist.ReduceOp.SUM)
                     else:
+                        # one gather launch, one collective, one scatter launch (a copy_ per member was a launch per
+                        # observer: 12 of them behind a ~20 us collective on DeiT-small)
                         flat = torch.cat([t.reshape(-1) for t in ts])
                         _all_reduce(flat, dist.ReduceOp.SUM)
-                        o = 0
-                        for t in ts:
-                            t.copy_(flat[o:o + t.numel()].reshape(t.shape))
-                            o += t.numel()
+                        parts = list(flat.split([t.numel() for t in ts]))
+                        if all(t.is_contiguous() for t in ts):
+                            torch._foreach_copy_([t.view(-1) for t in ts], parts)
+                        else:
+                            for t, part in zip(ts, parts):
+                                t.copy_(part.reshape(t.shape))
                 for i, t in zip(members, ts):
                     answers[i] = t
             elif kind == "host":

@@ -314,5 +314,10 @@ def device_guard(device):
     return torch.cuda.device(device)
 
 
-def set_tuning(knob, value):
-    check(load().sbq_set_tuning(knob, value))
+TUNING_PROCESS = 0x100  # SBQ_TUNING_PROCESS
+
+
+def set_tuning(knob, value, process=False):
+    """per calling thread by default; process=True sets the default every thread without a setting of its own sees
+    (autograd's backward threads never see the main thread's per-thread setting)"""
+    check(load().sbq_set_tuning(knob | (TUNING_PROCESS if process else 0), value))

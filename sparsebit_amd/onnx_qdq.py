@@ -129,13 +129,22 @@ def _constants(name, rec):
     """initializers of one record's scale / zero point (and levels) -> (list of TensorProto bytes, q elem type)"""
     signed = bool(rec.signed)
     q_type = (INT4 if signed else UINT4) if rec.packed else (INT8 if signed else UINT8)
-    z_type = INT8 if signed else UINT8
+    # DequantizeLinear requires x and x_zero_point to share a type: 4-bit levels take a 4-bit zero point (two per byte,
+    # low nibble first -- ONNX's packing of INT4 / UINT4 raw_data -- the last byte padded with 0)
+    z_type = q_type
     per_channel = rec.axis is not None
     scale = _np(rec.scale.float()).reshape(-1)
     zp = _np(rec.zero_point).reshape(-1).astype(np.int8 if signed else np.uint8)
     sdims = [scale.size] if per_channel else []
+    if rec.packed:
+        nib = zp.astype(np.uint8) & 0xF
+        if nib.size % 2:
+            nib = np.concatenate([nib, np.zeros(1, np.uint8)])
+        zraw = (nib[0::2] | (nib[1::2] << 4)).astype(np.uint8).tobytes()
+    else:
+        zraw = zp.tobytes()
     ts = [_tensor(name + "_scale", FLOAT, sdims, scale.astype("<f4").tobytes()),
-          _tensor(name + "_zero_point", z_type, sdims, zp.tobytes())]
+          _tensor(name + "_zero_point", z_type, sdims, zraw)]
     return ts, q_type
 
 
@@ -234,12 +243,22 @@ def load_qdq_onnx(path):
             continue
         qn, sn, zn = n["input"]
         scale, sdims, _ = array(sn)
-        zp, _, zt = array(zn)
+        zp, zdims, zt = array(zn)
+        if zt in (INT4, UINT4):  # two zero points per byte, low nibble first -> one int8 / uint8 value each
+            count = 1
+            for d in zdims:
+                count *= d
+            b = zp.numpy()
+            nib = np.stack([b & 0xF, b >> 4], axis=1).reshape(-1)[:count].astype(np.int16)
+            if zt == INT4:
+                nib = np.where(nib >= 8, nib - 16, nib)
+            zp = torch.from_numpy(nib.astype(np.int8 if zt == INT4 else np.uint8).reshape(zdims if zdims else ()))
         axis = n["attrs"].get("axis") if sdims else None
         bits = n["attrs"].get("bits", 8)
-        signed = zt == INT8
+        signed = zt in (INT8, INT4)
         if qn in tensors:  # stored levels: a weight
             q, qdims, qt = array(qn)
+            signed = qt in (INT8, INT4)  # the levels' own type decides (the zero point shares it in a valid file)
             out["weights"][n["output"][0]] = QDQTensor(q, scale, zp, axis, bits, qdims, signed, qt in (INT4, UINT4))
         else:  # produced by the QuantizeLinear in front of it: an activation's constants
             name = qn[:-2] if qn.endswith("_q") else qn

@@ -1112,15 +1112,23 @@ class HipWindowBackend:
 
     def __init__(self, dtype):
         self.dtype = dtype
-        self.dtype_id = _DTYPE_IDS[dtype]
+        try:
+            self.dtype_id = _DTYPE_IDS[dtype]
+        except KeyError:
+            raise L.SbqError("libsbq: Kernel Failure, Invalid dtype of Input tensor: %s" % (dtype,))
 
     def expected_rounds(self):
         return 2 if self.dtype == torch.float32 else 1  # a sweep resolves 11 key bits below the sample's window
 
+    def _chunks(self):
+        """this rank's shards in library calls of <= SBQ_MAX_BATCH: the sample histogram and a round's record are SUMS
+        over shards (that is what lets the ranks all-reduce them), so a rank with more cached batches than one call
+        takes adds the calls' outputs -- every rank runs the SAME exchange sequence whatever its batch count"""
+        sh = self.shards
+        return [sh[i:i + L.MAX_BATCH] for i in range(0, len(sh), L.MAX_BATCH)] or [[]]
+
     def _tables(self, shards):
         n = len(shards)
-        if n > L.MAX_BATCH:
-            raise L.SbqError("a windowed selection takes at most %d shards per rank" % L.MAX_BATCH)
         ptrs = (ctypes.c_void_p * max(n, 1))()
         counts = (ctypes.c_int64 * max(n, 1))()
         for i, x in enumerate(shards):
@@ -1132,12 +1140,15 @@ class HipWindowBackend:
     def sample(self, shards, use_abs, device):
         dev = L.require_device(*shards) if shards else device
         self.shards = [x.contiguous() for x in shards]
-        out = torch.empty(L.DIST_SAMPLE_WORDS, dtype=torch.int64, device=dev)
-        ptrs, counts, n = self._tables(self.shards)
-        with L.device_guard(dev):
-            rc = L.load().sbq_dist_select_sample(ptrs, counts, n, self.dtype_id, int(bool(use_abs)), L.ptr(out), L.stream_ptr(dev))
-        L.check(rc)
-        return out
+        total = None
+        for part in self._chunks():
+            out = torch.empty(L.DIST_SAMPLE_WORDS, dtype=torch.int64, device=dev)
+            ptrs, counts, n = self._tables(part)
+            with L.device_guard(dev):
+                rc = L.load().sbq_dist_select_sample(ptrs, counts, n, self.dtype_id, int(bool(use_abs)), L.ptr(out), L.stream_ptr(dev))
+            L.check(rc)
+            total = out if total is None else total.add_(out)
+        return total
 
     def plan(self, sample, n_sel, percentile_alpha, ranks, device):
         lib = L.load()
@@ -1158,13 +1169,16 @@ class HipWindowBackend:
 
     def sweep(self, sel, shards, use_abs, count_signs):
         dev = sel["dev"]
-        rec = torch.empty(L.DIST_ROUND_WORDS, dtype=torch.int64, device=dev)
-        ptrs, counts, n = self._tables(self.shards)
-        with L.device_guard(dev):
-            rc = L.load().sbq_dist_select_sweep(ptrs, counts, n, self.dtype_id, int(bool(use_abs)), sel["n_sel"], int(bool(count_signs)),
-                                                L.ptr(sel["ws"]), sel["ws"].numel(), L.ptr(rec), L.stream_ptr(dev))
-        L.check(rc)
-        return rec
+        total = None
+        for part in self._chunks():
+            rec = torch.empty(L.DIST_ROUND_WORDS, dtype=torch.int64, device=dev)
+            ptrs, counts, n = self._tables(part)
+            with L.device_guard(dev):
+                rc = L.load().sbq_dist_select_sweep(ptrs, counts, n, self.dtype_id, int(bool(use_abs)), sel["n_sel"], int(bool(count_signs)),
+                                                    L.ptr(sel["ws"]), sel["ws"].numel(), L.ptr(rec), L.stream_ptr(dev))
+            L.check(rc)
+            total = rec if total is None else total.add_(rec)
+        return total
 
     def advance(self, sel, rec):
         dev = sel["dev"]

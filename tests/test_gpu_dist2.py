@@ -96,16 +96,24 @@ class _Net(torch.nn.Module):
         return self.c2(torch.relu(self.c1(x)))
 
 
-def _worker(rank, world, port, tmp):
+def _worker(rank, world, port, tmp, backend="gloo"):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    dist.init_process_group("gloo", rank=rank, world_size=world)
     from sparsebit_amd import dist as sd
 
     dev = torch.device("cuda:0")
     torch.cuda.set_device(dev)
+    if backend == "nccl":
+        # tests/test_gpu_rccl_ws1.py: the same product call sites over a ONE-rank RCCL communicator on the leased GPU
+        # (every collective is issued although the rank is alone: dist.collectives_even_alone)
+        assert world == 1
+        sd.init_single_rank_rccl(dev)
+        sd.collectives_even_alone(True)
+        assert dist.get_backend() == "nccl"
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     g = torch.Generator().manual_seed(2024)  # the same stream on every rank: identical "global" data
     batches = [(torch.randn(8, 16, 14, 14, generator=g) * (1 + 0.3 * i)).to(dev) for i in range(4)]
     mine = batches[rank::world]

@@ -541,6 +541,11 @@ def main():
             "config5_mask_lsq_4bit": BC.config5_mask_lsq(ctx),
         }
         extras["model_wide_calibration"] = BC.model_wide_calibration(ctx)
+        e2e = BC.e2e_resnet20(ctx)
+        extras["e2e_resnet20_b16_forward"] = e2e
+        extras["e2e_resnet20_b16_forward_eager_us"] = e2e["eager_us"]
+        extras["e2e_resnet20_b16_forward_plan_us"] = e2e["plan_us"]
+        extras["e2e_resnet20_b16_forward_graph_us"] = e2e["graph_us"]
 
         def _gates(d):
             for v in d.values():
@@ -550,7 +555,7 @@ def main():
                     yield from _gates(v)  # (a leg may carry a nested leg of its own)
 
         extras["all_config_gates_pass"] = all(g for g in _gates(extras["configs"]) if g is not None) and all(
-            g for g in _gates(extras["model_wide_calibration"]) if g is not None)
+            g for g in _gates(extras["model_wide_calibration"]) if g is not None) and bool(e2e["parity"])
 
     # ---- CPU baseline: the reference's CPU fake-quant ops on this box's host cores -----------
     cpu_baseline = None

@@ -779,3 +779,19 @@ def model_wide_calibration(c):
                                     "tensors; three of them == numpy partition" % len(ws), one_by_one_us=round(us_1, 1),
                                     launches_grouped=2)
     return out
+
+
+# ------------------------------------------------------------------------------------------------------
+# end to end: a quantized ResNet-20 forward (batch 16) with the host in and out of the way
+# ------------------------------------------------------------------------------------------------------
+def e2e_resnet20(c):
+    """62 quantizer calls per forward around 22 convolutions / 1 linear / 9 adds (examples/resnet20_quantopr.py, the
+    reference's QuantOpr convention: modules/conv.py:37-42 -> quantizers/base.py:55-64).  Host wall clock per forward:
+    the generic Python route per call (what round 4 shipped), launch plans (sparsebit_amd.plan), one captured hipGraph
+    (sparsebit_amd.graph); outputs compared bit for bit."""
+    from examples import resnet20_quantopr as R
+
+    rec = R.measure(c.dev, iters=200)
+    rec["parity"] = bool(rec["plan_equals_eager"] and rec["graph_equals_eager"])
+    rec["gate"] = "logits of the planned and of the replayed forward == the generic route's, bit for bit"
+    return rec

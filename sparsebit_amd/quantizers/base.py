@@ -14,9 +14,14 @@ import warnings
 import torch
 from torch import nn
 
+from .. import plan as sbq_plan
 from ..observers import build_observer
 from .quant_descriptor import QuantDescriptor
-from .quant_tensor import torch_fake_quant
+from .quant_tensor import _default_out, torch_fake_quant
+
+# attributes whose re-binding changes what a forward does: every assignment moves the quantizer's structure version
+# (`_sv`: launch plans, sparsebit_amd.plan) and the process-wide epoch (captured graphs, sparsebit_amd.graph)
+_STRUCTURAL = frozenset(("scale", "zero_point", "use_quant", "fake_fused", "export_onnx", "backend", "keep_input_dtype"))
 
 
 def _default_device():
@@ -32,6 +37,9 @@ class Quantizer(nn.Module):
         # in that MRO super() would be the reference base, whose __init__ takes the config and builds
         # its own observer
         nn.Module.__init__(self)
+        self.__dict__["_sv"] = 0
+        self.__dict__["_plans"] = sbq_plan.PlanCache()
+        self.__dict__["_planned"] = None  # lazily: does this class take the planned forward at all?
         self.cfg = config
         self.qdesc = QuantDescriptor(config)
         self.device = _default_device()
@@ -41,10 +49,27 @@ class Quantizer(nn.Module):
         self.dims = None  # rank of the observed tensor; set by update_observer
         self._pregrouped = None  # (source tensor, result) handed in by group.WeightQuantGroup.attach
         self.use_quant = self.export_onnx = self.fake_fused = False
+        # output dtype: None = the process default (quant_tensor.keep_input_dtype, fp32 like the reference unless changed),
+        # True = the input's dtype (bf16 in -> bf16 out), False = fp32 whatever the default says
+        self.keep_input_dtype = None
         if config.QUANTIZER.DISABLE:
             self.set_fake_fused()
         if self.qdesc.bit == 0:
             warnings.warn("used bit==0 to disable quantizer is deprecated, please use a flag: QUANTIZER.DISABLE")
+
+    def __setattr__(self, name, value):
+        if name in _STRUCTURAL:
+            d = self.__dict__
+            d["_sv"] = d.get("_sv", 0) + 1
+            sbq_plan.bump_epoch()
+        nn.Module.__setattr__(self, name, value)
+
+    def _out_keeps_dtype(self):
+        k = self.keep_input_dtype
+        return sbq_plan.keep_default() if k is None else bool(k)
+
+    def _out_dtype(self, x):
+        return _default_out(x, self.keep_input_dtype)
 
     # ---- scale / zero_point state ---------------------------------------------------------
     def _identity(self):
@@ -135,12 +160,31 @@ class Quantizer(nn.Module):
     def _forward(self, x, scale, zero_point):
         raise NotImplementedError(type(self).__name__)
 
+    def _takes_plan(self):
+        """the planned forward replaces exactly: base `_qparams_preprocess` + the uniform quantizer's `_forward`
+        (subclasses that transform their input or their qparams -- PACT, DoReFa, LSQ+ -- keep the generic route)"""
+        from .uniform import Quantizer as Uniform
+
+        cls = type(self)
+        ok = cls._forward is Uniform._forward and cls._qparams_preprocess is Quantizer._qparams_preprocess
+        self.__dict__["_planned"] = ok
+        return ok
+
     def forward(self, x):
-        if not self.is_enable:
+        if not self.use_quant or self.fake_fused:
             return x
         pre = self._pregrouped
         if pre is not None and x is pre[0]:  # already quantized by the model-wide launch of this forward
             return pre[1]
+        if not self.export_onnx:
+            planned = self._planned
+            if planned is None:
+                planned = self._takes_plan()
+            if planned and not (torch.is_grad_enabled() and (x.requires_grad or self.scale.requires_grad
+                                                              or self.zero_point.requires_grad)):
+                p = self._plans.lookup(self, x)  # sparsebit_amd.plan: one allocation + one foreign call
+                if p is not None:
+                    return p(x)
         scale, zero_point = self._qparams_preprocess(x)
         if self.export_onnx:  # tracing for QDQ-ONNX: torch builtins only, the HIP kernel is never traced
             return torch_fake_quant(x, scale, zero_point, self.qdesc)
@@ -173,7 +217,7 @@ class Quantizer(nn.Module):
         self.export_onnx = False
 
     def set_bit(self, bit):
-        self.qdesc.set_bit(bit)
+        self.qdesc.set_bit(bit)  # (moves the descriptor's version: launch plans and captured graphs are rebuilt)
 
     # ---- read-only views ------------------------------------------------------------------------
     is_enable = property(lambda self: self.use_quant and not self.fake_fused)

@@ -28,4 +28,4 @@ class Quantizer(BaseQuantizer):
 
     def _forward(self, x, scale, zero_point):
         # like the reference, the stored parameters are used, not the preprocessed ones
-        return STE.apply(_squash(x), self.scale, self.zero_point, self.qdesc, self.backend)
+        return STE.apply(_squash(x), self.scale, self.zero_point, self.qdesc, self.backend, self._out_dtype(x))

@@ -39,12 +39,12 @@ class LsqSTE(torch.autograd.Function):
     of as abs / clamp / gs_scaling tensor ops and autograd nodes around the STE (lsq.py:13-21,61-76)."""
 
     @staticmethod
-    def forward(ctx, x, scale, zero_point, qdesc, ratio):
+    def forward(ctx, x, scale, zero_point, qdesc, ratio, out_dtype=None):
         ctx.save_for_backward(x, scale, zero_point)
         ctx.qdesc, ctx.ratio = qdesc, ratio
         qmin, qmax = qdesc.qrange
         return ops.lsq_fake_quant(x, scale.detach(), zero_point.detach(), qmin, qmax, qdesc.ch_axis,
-                                  out_dtype=_default_out(x))
+                                  out_dtype=out_dtype or _default_out(x))
 
     @staticmethod
     def backward(ctx, gout):
@@ -54,7 +54,7 @@ class LsqSTE(torch.autograd.Function):
                                              ctx.needs_input_grad[1], ctx.ratio, gx_dtype=x.dtype)
         if gs is not None:
             gs = gs.reshape(scale.shape)
-        return gx if ctx.needs_input_grad[0] else None, gs, None, None, None
+        return gx if ctx.needs_input_grad[0] else None, gs, None, None, None, None
 
 
 @register_quantizer
@@ -119,10 +119,15 @@ class Quantizer(BaseQuantizer):
             if pre is not None and x is pre[0]:
                 return pre[1]
             if not (torch.is_grad_enabled() and (x.requires_grad or self.scale.requires_grad)):
-                qmin, qmax = self.qdesc.qrange  # nothing asks for a gradient: the forward alone, no autograd node
+                # nothing asks for a gradient: the forward alone, no autograd node -- through the launch plan
+                # (sparsebit_amd.plan) when there is one for this input
+                p = self._plans.lookup(self, x, lsq=True)
+                if p is not None:
+                    return p(x)
+                qmin, qmax = self.qdesc.qrange
                 return ops.lsq_fake_quant(x, self.scale.detach(), self.zero_point, qmin, qmax, self.qdesc.ch_axis,
-                                          out_dtype=_default_out(x))
-            return LsqSTE.apply(x, self.scale, self.zero_point, self.qdesc, self._gs_ratio(x))
+                                          out_dtype=self._out_dtype(x))
+            return LsqSTE.apply(x, self.scale, self.zero_point, self.qdesc, self._gs_ratio(x), self._out_dtype(x))
         return super().forward(x)
 
     def _gs_ratio(self, x):
@@ -136,7 +141,7 @@ class Quantizer(BaseQuantizer):
         scale = gs_scaling.apply(scale, ratio)
         if zero_point.requires_grad:  # only LSQ+ learns its zero point (lsq_plus.py:90-92)
             zero_point = gs_scaling.apply(zero_point, ratio)
-        return STE.apply(x, scale, zero_point, self.qdesc, self.backend)
+        return STE.apply(x, scale, zero_point, self.qdesc, self.backend, self._out_dtype(x))
 
     def forward_masked(self, x, mask=None, thresh=None, out_dtype=None):
         """Inference-side fused `quantizer(x * mask)`: one kernel, one read of x

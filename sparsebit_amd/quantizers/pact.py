@@ -72,4 +72,4 @@ class Quantizer(BaseQuantizer):
 
     def _forward(self, x, scale, zero_point=None):
         x_clamp = torch.clamp(x, self.lower, self.alpha)  # differentiable w.r.t. alpha
-        return STE.apply(x_clamp, scale, zero_point, self.qdesc, self.backend)
+        return STE.apply(x_clamp, scale, zero_point, self.qdesc, self.backend, self._out_dtype(x_clamp))

@@ -6,6 +6,7 @@ set_bit, set_symmetric.
 """
 import torch
 
+from .. import plan as sbq_plan
 from ..common import get_qscheme
 
 _SYMMETRIC = (torch.per_channel_symmetric, torch.per_tensor_symmetric)
@@ -39,6 +40,10 @@ class QuantDescriptor:
 
     def _refresh_range(self):
         self._qmin, self._qmax, self._type = self.calc_qmin_qmax(self._bit, self._scheme)
+        # the integer range is baked into launch plans (plan.QdqPlan keeps the version it was built for) and captured
+        # graphs (the process-wide epoch): set_bit / set_symmetric on the descriptor itself invalidate both
+        self.version = getattr(self, "version", 0) + 1
+        sbq_plan.bump_epoch()
 
     def set_bit(self, bit):
         self._bit = bit

@@ -11,6 +11,7 @@ import torch
 
 from .. import fake_quant as fake_quant_kernel  # noqa: F401  (the name the reference's module exposes)
 from .. import ops
+from .. import plan
 from ..common import Backend
 
 
@@ -50,19 +51,21 @@ def trt_fake_quant(x_f, scale, zero_point, qdesc, out_dtype=None):
     return ops.fake_quant(x_f, scale, zero_point, qmin, qmax, qdesc.ch_axis, out_dtype=out_dtype or _default_out(x_f))
 
 
-_keep_dtype = False
-
-
 def keep_input_dtype(flag=True):
     """Perf mode: return the dequantized tensor in the input dtype (bf16 in -> bf16 out,
     = RNE cast of the fp32 result, 4 B/element of HBM traffic instead of 6).  Default
-    off: the reference always returns fp32."""
-    global _keep_dtype
-    _keep_dtype = bool(flag)
+    off: the reference always returns fp32.
+
+    This is the PROCESS default; a quantizer's own `keep_input_dtype` attribute (None = follow the default, True /
+    False = its own choice) overrides it, so two models in one process can differ."""
+    plan.set_keep_default(flag)
 
 
-def _default_out(x):
-    return x.dtype if _keep_dtype else torch.float32
+def _default_out(x, keep=None):
+    """output dtype of a quantizer call: `keep` is the quantizer's own setting (None: the process default)"""
+    if keep is None:
+        keep = plan.keep_default()
+    return x.dtype if keep else torch.float32
 
 
 fake_quant_factory = {
@@ -73,11 +76,12 @@ fake_quant_factory = {
 
 
 class STE(torch.autograd.Function):
-    """quant_tensor.py:74-125; backward through sbq_quant_*_backward."""
+    """quant_tensor.py:74-125; backward through sbq_quant_*_backward.  (out_dtype: the calling quantizer's output
+    dtype, None = the process default.)"""
 
     @staticmethod
-    def forward(ctx, x, scale, zero_point, qdesc, backend):
-        x_fq = fake_quant_factory[backend](x, scale, zero_point, qdesc)
+    def forward(ctx, x, scale, zero_point, qdesc, backend, out_dtype=None):
+        x_fq = fake_quant_factory[backend](x, scale, zero_point, qdesc, out_dtype)
         ctx.save_for_backward(x, scale, zero_point)
         ctx.qdesc = qdesc
         return x_fq
@@ -96,15 +100,15 @@ class STE(torch.autograd.Function):
             gs = gs.reshape(scale.shape)
         if gzp is not None:
             gzp = gzp.reshape(zero_point.shape)
-        return gx, gs, gzp, None, None
+        return gx, gs, gzp, None, None, None
 
 
-def ste_fake_quant(x, scale, zero_point, qdesc, backend):
+def ste_fake_quant(x, scale, zero_point, qdesc, backend, out_dtype=None):
     """STE.apply, or -- when nothing asks for a gradient (PTQ calibration / evaluation, no_grad) -- the forward
     alone without an autograd node: the quantizer calls of an inference pass are host-bound."""
     if torch.is_grad_enabled() and (x.requires_grad or scale.requires_grad or zero_point.requires_grad):
-        return STE.apply(x, scale, zero_point, qdesc, backend)
-    return fake_quant_factory[backend](x, scale, zero_point, qdesc)
+        return STE.apply(x, scale, zero_point, qdesc, backend, out_dtype)
+    return fake_quant_factory[backend](x, scale, zero_point, qdesc, out_dtype)
 
 
 def trt_dqrange(scale, zero_point, qdesc):

@@ -14,7 +14,7 @@ class Quantizer(BaseQuantizer):
     TYPE = "uniform"
 
     def _forward(self, x_f, scale, zero_point):
-        return ste_fake_quant(x_f, scale, zero_point, self.qdesc, self.backend)
+        return ste_fake_quant(x_f, scale, zero_point, self.qdesc, self.backend, self._out_dtype(x_f))
 
     @torch.no_grad()
     def quantize_to_int(self, x, dtype=None):

@@ -155,16 +155,26 @@ def measure(device, iters=200):
     fwd = sbq_graph.capture(model, x)
     y_graph = fwd(x).clone()
     graph_us = time_forward(lambda: fwd(x), iters)
-    # the float model (quantizers off): what the layers themselves cost through the same Python
+    fwd_frozen = sbq_graph.capture(model, x, freeze_weights=True)
+    y_frozen = fwd_frozen(x).clone()
+    frozen_us = time_forward(lambda: fwd_frozen(x), iters)
+    # the float model (quantizers off): what the layers themselves cost -- through the same Python, and as a graph of its
+    # own (the floor no quantizer path can go below: torch's / MIOpen's kernels and their boundaries)
     for q in quantizers(model):
         q.disable_quant()
     with torch.no_grad():
         float_us = time_forward(lambda: model(x), iters)
+    fwd_float = sbq_graph.capture(model, x)
+    float_graph_us = time_forward(lambda: fwd_float(x), iters)
     for q in quantizers(model):
         q.enable_quant()
     return {
         "eager_us": round(eager_us, 1), "plan_us": round(plan_us, 1), "graph_us": round(graph_us, 1),
-        "float_model_eager_us": round(float_us, 1),
+        "graph_frozen_weights_us": round(frozen_us, 1),
+        "float_model_eager_us": round(float_us, 1), "float_model_graph_us": round(float_graph_us, 1),
+        "quantizers_cost_in_graph_us": round(graph_us - float_graph_us, 1),
+        "quantizers_cost_in_graph_frozen_weights_us": round(frozen_us - float_graph_us, 1),
+        "frozen_equals_eager": bool(torch.equal(y_frozen, y_eager)),
         "quantizer_calls_per_forward": n_q + 9,  # (a QAdd's quantizer runs twice)
         "plan_equals_eager": bool(torch.equal(y_plan, y_eager)), "graph_equals_eager": bool(torch.equal(y_graph, y_eager)),
         "graph_speedup_vs_eager": round(eager_us / graph_us, 2),

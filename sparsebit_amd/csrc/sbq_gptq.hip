@@ -400,7 +400,7 @@ __device__ __forceinline__ void glds16s(const void* sbase, uint32_t voff, uint32
 
 // The cross-workgroup half of the K split (shared by the strip kernels): publish, count the arrival, and the last
 // workgroup of the strip folds the S partials in index order.
-template <int kThreads>
+template <int kThreads, int kStripCols = 32>
 __device__ __forceinline__ void strip_fold_partials(uint32_t strip, int split, const GptqGeom& g,
                                                     float* __restrict__ part, float* __restrict__ out,
                                                     uint32_t* __restrict__ arrivals, uint32_t& s_prev) {
@@ -1108,6 +1108,265 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 }
 
 // out[b,n] += sum over K blocks, ascending
+// 16-byte accesses at the device-coherent level (sc1: write-through / L2-bypassing, what the agent-scope atomic
+// dword accesses of strip_fold_partials carry); the load is asynchronous -- the caller waits (s_waitcnt vmcnt) before
+// it touches the result
+__device__ __forceinline__ void st16_sc1(float* p, f32x4 v) {
+  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ f32x4 ld16_sc1(const float* p) {
+  f32x4 v;
+  asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
+
+// ---- batched mat-mul, 5 <= B <= 32, 4-bit: the batch rows through the matrix cores ----------------------------------
+// The reference's kernel takes any batch in one launch (cuda_kernel_4bit.cu:36-81; test_cuda_kernel.py:81-126 runs
+// B = 8 .. 32).  With B rows per weight the op stops being a weight STREAM: B = 32 on 4096 x 4096 is 1.07 GFLOP against
+// 8.4 MB -- 6.8 us at the fp32 peak, 1.2 us of HBM.  The strip kernels tile the batch four rows at a time and re-read and
+// re-decode the strip per tile, and every lane fetches its activations from LDS (two ds_read_b128 per sixteen packed
+// FMAs: the LDS pipe is as busy as the vector ALU): 17 us at B = 8, 55 us at B = 32 (0.10 - 0.17 of the fp32 peak).
+// Here the contraction runs on v_mfma_f32_16x16x4_f32 -- TRUE fp32 operands and accumulation (the contract is fp32 FMA
+// on int nibbles; the fp32 matrix peak equals the vector peak, what the MFMA buys is operand delivery): a lane
+// supplies ONE activation and ONE dequantized weight per instruction and the 16 x 16 x 4 products happen inside the
+// core, so nothing is broadcast through LDS and the vector ALU is left with the decode (one cvt per two levels and one
+// FMA per weight -- a quarter of the MFMA pipe's time).
+//   wave tile   64 output columns x 16 (MT = 1) or 32 (MT = 2) batch rows; K in chunks of BPC 128-channel blocks.
+//   lane (kg = lane / 16, j = lane % 16) loads ONE 16-byte qweight word per 4 rows: row (4 s + kg), columns n0 + 4 j ..
+//   + 3 -- sixteen lanes read 256 contiguous bytes of a row -- i.e. 8 channels of 4 columns = 32 weights = 32 MFMAs:
+//   step i of column t multiplies A[m = j][k = kg] = x[row m][channel 8 row + i] with B[k = kg][n = j] = w[that
+//   channel][column n0 + 4 j + t].  C[m = 4 kg + c][n = j] of column tile t sits in acc[t][c]: the lane's four
+//   accumulators of one batch row are four ADJACENT output columns (one 16-byte store).
+//   The four waves of a workgroup take four K chunks of the same columns and meet through LDS in wave order; K blocks
+//   beyond that (gridDim.y) publish partial tiles and the last arriver folds them in index order (strip_fold_partials:
+//   deterministic, no float atomics).
+// Requirements (host): out_features % 64 == 0, in_features % 128 == 0, 16-byte aligned qweight / x rows.
+template <int MT>
+__global__ __launch_bounds__(256) void gptq_mfma_kernel(const float* __restrict__ x, const int32_t* __restrict__ qw,
+                                                        const float* __restrict__ scales, const float* __restrict__ zeros,
+                                                        float* __restrict__ out, float* __restrict__ part,
+                                                        uint32_t* __restrict__ arrivals, const GptqGeom g, int bpc) {
+  constexpr int kTileCols = 64;
+  __shared__ __attribute__((aligned(16))) f32x4 red[4][MT][4][kWave];  // [wave][batch tile][c][lane]: 16 KB x MT
+  __shared__ uint32_t s_prev;
+  GPTQ_STAMP_INIT();
+  GPTQ_STAMP(0);
+  const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
+  const int kg = lane >> 4, j = lane & 15;
+  // XCD-aware tile order (as the strip kernels): the workgroups that run side by side on one XCD read adjacent
+  // 256-byte pieces of the same rows
+  uint32_t tile = blockIdx.x;
+  if (g.xcd_swizzle) tile = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  const uint32_t out32 = static_cast<uint32_t>(g.out_features), in32 = static_cast<uint32_t>(g.in_features);
+  const uint32_t col = tile * kTileCols + 4u * j;  // this lane's four columns
+  const int nblk = static_cast<int>(in32 / 128u);  // 128-channel blocks (16 qweight rows) of K
+  const int chunk = static_cast<int>(blockIdx.y) * 4 + wid;
+  const int blk_begin = chunk * bpc, blk_end = blk_begin + bpc < nblk ? blk_begin + bpc : nblk;
+  // batch rows of this lane's A operand, clamped (rows >= batch are computed on a valid row and never stored).
+  // 32-bit element offsets throughout (host-checked: every tensor below 4 GB)
+  uint32_t xrow[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int b = mt * 16 + j;
+    xrow[mt] = static_cast<uint32_t>(b < g.batch ? b : static_cast<int>(g.batch) - 1) * in32;
+  }
+  const uint32_t groups32 = static_cast<uint32_t>(g.groups);
+  const uint32_t col_lane = (tile * kTileCols + static_cast<uint32_t>(lane)) * groups32;  // scale / zero: ONE column per lane
+  f32x4 tot[MT][4];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) tot[mt][t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+
+  // One 128-channel block = 4 weight words + 4 x 8 activations per batch tile per lane, and the group's scale / zero'
+  // of ONE column per lane (lane L: column L of the tile; the four columns a lane works on come by shuffle -- a load of
+  // four scattered dwords per lane touches 64 cache lines per instruction, eight such instructions per block were
+  // a third of the 3 us this kernel took to ISSUE its first loads).
+  // Every load is unconditional (a block index past the chunk's end is clamped to its last block and the result
+  // ignored: a load under a branch makes the compiler wait for everything in flight at the join) and the NEXT block's
+  // loads are issued before the current block's arithmetic (two register sets, the loop unrolled by two).
+  struct Blk {
+    u32x4 w4[4];
+    f32x4 xa[4][MT][2];
+    float s_lane, z_lane;
+  };
+  const int blk_last = blk_end - 1;
+  auto load_blk = [&](int blk_in, Blk& r) {
+    const uint32_t blk = static_cast<uint32_t>(blk_in < blk_last ? blk_in : blk_last);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const uint32_t row = blk * 16u + 4u * s + kg;
+      r.w4[s] = ld16<true>(qw + (row * out32 + col));
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const float* xp = x + (xrow[mt] + row * 8u);
+        r.xa[s][mt][0] = *reinterpret_cast<const f32x4*>(xp);
+        r.xa[s][mt][1] = *reinterpret_cast<const f32x4*>(xp + 4);
+      }
+    }
+    const uint32_t grp = (blk * 128u) / static_cast<uint32_t>(g.group_size);
+    r.s_lane = scales[col_lane + grp];
+    r.z_lane = zeros[col_lane + grp];
+  };
+  // The block's arithmetic, dequantization factored out of the contraction (as in the strip kernels):
+  //     sum_k (s * lvl_k - z) * x_k  =  s * sum_k lvl_k * x_k  -  z * sum_k x_k
+  // so the B operand of an MFMA is the decoded LEVEL itself -- the output of v_cvt_pk_f32_fp8, no per-weight FMA
+  // in front of the matrix core -- and scale / zero' meet the 16 x 16 tile once per block.  Per word set: the 32 levels
+  // are decoded into 32 DISTINCT registers first, then the 32 x MT MFMAs issue back to back (a VALU write to a
+  // register an MFMA in flight still reads stalls the pipe: the first version of this kernel, one re-used operand
+  // register per MFMA, ran 65 cycles per instruction instead of 32).
+  // live == false (the odd block of a chunk with an odd block count): the block's sums are computed and dropped by a
+  // select -- not branched around (loads that only a conditional block uses are sunk into it and waited for one by
+  // one there), and not multiplied by zero (an inf / NaN of the clamped block must not leak).
+  auto compute_blk = [&](const Blk& r, bool live) {
+    float xsum[MT][4], sc[4], zr[4];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      f32x4 v4 = r.xa[0][mt][0] + r.xa[0][mt][1];
+#pragma unroll
+      for (int s = 1; s < 4; ++s) v4 += r.xa[s][mt][0] + r.xa[s][mt][1];
+      float xs = (v4[0] + v4[1]) + (v4[2] + v4[3]);  // batch row j, this lane's 32 channels of the block
+      xs += __shfl_xor(xs, 16);
+      xs += __shfl_xor(xs, 32);  // ... all 128 channels (the four K sub-lanes kg)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) xsum[mt][c] = __shfl(xs, 4 * kg + c);  // batch row 4 kg + c: where this lane's C values live
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      sc[t] = __shfl(r.s_lane, 4 * j + t) * 512.0f;  // the e4m3 decode yields level * 2^-9 (exact): 2^9 into the scale
+      zr[t] = __shfl(r.z_lane, 4 * j + t);
+    }
+    f32x4 acc[MT][4];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[mt][t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      f32x2 lp[4][4];  // column t: levels (0, 2) (1, 3) (4, 6) (5, 7) of the word
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const uint32_t word = r.w4[s][t];
+        const uint32_t even = word & 0x0f0f0f0fu, odd = (word >> 4) & 0x0f0f0f0fu;
+        lp[t][0] = __builtin_amdgcn_cvt_pk_f32_fp8(even, false);
+        lp[t][1] = __builtin_amdgcn_cvt_pk_f32_fp8(odd, false);
+        lp[t][2] = __builtin_amdgcn_cvt_pk_f32_fp8(even, true);
+        lp[t][3] = __builtin_amdgcn_cvt_pk_f32_fp8(odd, true);
+#pragma unroll
+        for (int p2 = 0; p2 < 4; ++p2) asm volatile("" : "+v"(lp[t][p2]));  // the decoded pair EXISTS here, in registers of its own
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        // channel i of the word: pair (i >> 2) * 2 + (i & 1), half (i >> 1) & 1
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const float lv = lp[t][(i >> 2) * 2 + (i & 1)][(i >> 1) & 1];
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) {
+            const float xe = r.xa[s][mt][i >> 2][i & 3];
+            acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(xe, lv, acc[mt][t], 0, 0, 0);
+          }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const float v = tot[mt][t][c] + __builtin_fmaf(sc[t], acc[mt][t][c], -(zr[t] * xsum[mt][c]));
+          tot[mt][t][c] = live ? v : tot[mt][t][c];
+        }
+  };
+  if (blk_begin < blk_end) {  // (uniform per wave; a wave past the end of K only takes part in the fold)
+    Blk ra, rb;
+    load_blk(blk_begin, ra);
+    int blk = blk_begin;
+    // steady state (three or more blocks left): both prefetches are real
+    for (; blk + 2 < blk_end; blk += 2) {
+      load_blk(blk + 1, rb);
+      __builtin_amdgcn_sched_barrier(0);
+      compute_blk(ra, true);
+      __builtin_amdgcn_sched_barrier(0);
+      load_blk(blk + 2, ra);
+      __builtin_amdgcn_sched_barrier(0);
+      compute_blk(rb, true);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // the last one or two blocks: nothing is requested that nobody will use (the clamped re-load of the last block
+    // cost the two-block chunks of 4096 x 4096 twenty load instructions -- ~1 us of issue -- in front of their
+    // second block)
+    load_blk(blk + 1, rb);  // (clamped to the last block when only one is left: ignored then)
+    __builtin_amdgcn_sched_barrier(0);
+    GPTQ_STAMP(1);
+    compute_blk(ra, true);
+    __builtin_amdgcn_sched_barrier(0);
+    GPTQ_STAMP(2);
+    compute_blk(rb, blk + 1 < blk_end);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  GPTQ_STAMP(3);
+  // the four waves' K chunks, in wave order.  tot[mt][t][c] = row (mt * 16 + 4 kg + c), column (col + t): transposed to
+  // one 16-byte value per (row, lane) on the way into LDS
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) red[wid][mt][c][lane] = f32x4{tot[mt][0][c], tot[mt][1][c], tot[mt][2][c], tot[mt][3][c]};
+  __syncthreads();
+  const int split = static_cast<int>(gridDim.y);
+  // wave `wid` finishes c = wid of every batch tile
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const f32x4 t = ((red[0][mt][wid][lane] + red[1][mt][wid][lane]) + red[2][mt][wid][lane]) + red[3][mt][wid][lane];
+    const int b = mt * 16 + 4 * kg + wid;
+    if (b < g.batch) {
+      if (split == 1) {
+        float* o = out + static_cast<size_t>(b) * out32 + col;
+        const f32x4 prev = *reinterpret_cast<const f32x4*>(o);
+        *reinterpret_cast<f32x4*>(o) = prev + t;
+      } else {
+        // publish write-through (sc1): the reader is a workgroup of another XCD, behind another L2
+        st16_sc1(part + (static_cast<size_t>(blockIdx.y) * g.batch + b) * out32 + col, t);
+      }
+    }
+  }
+  GPTQ_STAMP(4);
+  if (split == 1) return;
+  // arrival protocol of strip_fold_partials (see there: no agent-scope fence; every access of the protocol goes to the
+  // device-coherent level by itself); the fold below differs: 16-byte accesses, and the partials of FOUR K blocks are
+  // requested before any is added -- one memory round trip per four instead of one per K block (the scalar fold spent
+  // ~1 us per partial: 4 of this kernel's 15 us at 4096 x 4096)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_s_waitcnt(0);
+  __syncthreads();
+  if (threadIdx.x == 0) s_prev = __hip_atomic_fetch_add(&arrivals[tile], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  GPTQ_STAMP(5);
+  if (s_prev != static_cast<uint32_t>(split - 1)) return;
+  const size_t slab = static_cast<size_t>(g.batch) * out32;  // floats per K block
+  for (int e = threadIdx.x; e < static_cast<int>(g.batch) * (kTileCols / 4); e += 256) {
+    const size_t o = static_cast<size_t>(e >> 4) * out32 + tile * kTileCols + 4u * (e & 15);
+    const f32x4 prev = *reinterpret_cast<const f32x4*>(out + o);
+    f32x4 total = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (int s0 = 0; s0 < split; s0 += 4) {  // (uniform)
+      f32x4 p[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) p[u] = ld16_sc1(part + static_cast<size_t>(s0 + u < split ? s0 + u : split - 1) * slab + o);
+      // (the loaded values flow THROUGH the wait: nothing that uses them can be scheduled above it)
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3])::"memory");
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (s0 + u < split) total += p[u];  // index order: the sum does not depend on who arrived last
+    }
+    *reinterpret_cast<f32x4*>(out + o) = prev + total;
+  }
+  GPTQ_STAMP(6);
+  if (threadIdx.x == 0) __hip_atomic_store(&arrivals[tile], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 __global__ __launch_bounds__(kBlock) void gptq_fold_kernel(const float* __restrict__ part,
                                                             float* __restrict__ out, int64_t bn,
                                                             int kblocks) {
@@ -1239,6 +1498,29 @@ int gptq_matmul(const float* x, const int32_t* qweight, float* out, const float*
   // batch rows per register tile, half-group K lanes only (register budget)
   // ... and so do batches up to 32 (the reference's kernel takes any batch in one launch,
   // cuda_kernel_4bit.cu:36-81): tiles of four rows, the strip's weights re-read per tile out of the caches
+  if constexpr (BITS == 4) {
+    // 5 <= B <= 32: the batch rows through the fp32 matrix cores (gptq_mfma_kernel; knob 2 == 26: the strip tiles of four
+    // rows instead, for A/B runs)
+    if (vec && batch >= 5 && batch <= 32 && out_features % 64 == 0 && in_features % 128 == 0 && group_size % 128 == 0 &&
+        aligned16(x) && out_features / 64 <= kMaxStrips && g.H * out_features * 4 < (1ll << 32) &&
+        out_features * g.groups < (1ll << 30) &&
+        batch * in_features < (1ll << 30) && knob(2) != 26 && knob(2) != 9) {
+      const int64_t tiles64 = out_features / 64, nblk = in_features / 128;
+      // blocks per wave: about one wave per SIMD on the whole chip, at most 16 K blocks of four waves
+      int64_t bpc = (nblk * tiles64) / (4 * static_cast<int64_t>(cu_count()));
+      if (bpc < 1) bpc = 1;
+      if (bpc > 1 && (bpc & 1)) --bpc;  // (the kernel walks a chunk two blocks at a time)
+      while (ceil_div(ceil_div(nblk, bpc), 4) > kStripMaxSplit) bpc += bpc > 1 ? 2 : 1;
+      const int64_t ksplit = ceil_div(ceil_div(nblk, bpc), 4);
+      g.xcd_swizzle = (tiles64 % 8 == 0 && knob(2) != 8) ? 1 : 0;
+      const dim3 grid(static_cast<uint32_t>(tiles64), static_cast<uint32_t>(ksplit));
+      if (batch <= 16)
+        gptq_mfma_kernel<1><<<grid, 256, 0, st>>>(x, qweight, scales, zeros, out, part, arrivals, g, static_cast<int>(bpc));
+      else
+        gptq_mfma_kernel<2><<<grid, 256, 0, st>>>(x, qweight, scales, zeros, out, part, arrivals, g, static_cast<int>(bpc));
+      return check_launch();
+    }
+  }
   if (vec && out_features % kStripCols == 0 && batch >= 3 && batch <= 32 && !half_slices && strips <= kMaxStrips &&
       knob(2) != 9) {
     int64_t split = ceil_div(in_features, 32 * (kSliceK / 2));

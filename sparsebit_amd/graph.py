@@ -20,6 +20,13 @@ What makes a replay valid, and how it is kept valid:
     a replay compares ONE integer and re-captures (default) or raises (on_stale="raise") when it moved;
   * the model must be in eval mode and its forward free of host-side data dependence (the usual CUDA-graph contract).
 Outputs live in the graph's static memory: they are valid until the next replay (clone=True returns copies).
+
+freeze_weights=True additionally takes the WEIGHT quantizers out of the replay: every operator's
+`weight_quantizer(weight)` is evaluated once, before the capture, and handed to the operator through the quantizer's
+`_pregrouped` slot (the mechanism of group.WeightQuantGroup.attach) while the forward is recorded -- an inference
+forward re-quantizes constants on every call otherwise (modules/conv.py:37-42 does).  The fake-quantized weights then
+are constants OF THE CAPTURE: an in-place change of a weight or of a weight step size is not seen until the next
+capture (structural changes still move the epoch and re-capture).
 """
 import torch
 
@@ -53,12 +60,13 @@ def _tensors(obj, out):
 
 
 class CapturedForward:
-    def __init__(self, model, *example_inputs, warmup=3, on_stale="recapture", clone=False, pool=None):
+    def __init__(self, model, *example_inputs, warmup=3, on_stale="recapture", clone=False, pool=None, freeze_weights=False):
         if on_stale not in ("recapture", "raise"):
             raise ValueError("on_stale must be 'recapture' or 'raise'")
         if model.training:
             raise RuntimeError("capture() records an inference forward: call model.eval() first")
         self.model, self.warmup, self.on_stale, self.clone, self.pool = model, int(warmup), on_stale, clone, pool
+        self.freeze_weights = bool(freeze_weights)
         self.captures = 0
         self._static_in = _map(example_inputs, lambda t: t.detach().clone())
         flat = _tensors(self._static_in, [])
@@ -67,19 +75,40 @@ class CapturedForward:
         self._flat_in = flat
         self._capture()
 
+    def _freeze(self):
+        """[(quantizer, weight, fake-quantized weight)] of every operator in the QuantOpr convention"""
+        frozen = []
+        with torch.no_grad():
+            for m in self.model.modules():
+                q, w = getattr(m, "weight_quantizer", None), getattr(m, "weight", None)
+                if q is None or not isinstance(w, torch.Tensor) or not getattr(q, "is_enable", False) or q.export_onnx:
+                    continue
+                if not hasattr(q, "_pregrouped") or q._pregrouped is not None:
+                    continue  # not one of ours, or already served by a WeightQuantGroup
+                frozen.append((q, w, q(w)))
+        return frozen
+
     def _capture(self):
         dev = self._flat_in[0].device
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
-        with torch.no_grad(), torch.cuda.stream(side):
-            for _ in range(max(self.warmup, 1)):  # plans built, workspaces of THIS stream allocated, host checks resolved
-                self.model(*self._static_in)
-        torch.cuda.current_stream(dev).wait_stream(side)
-        torch.cuda.synchronize(dev)
-        epoch = sbq_plan.epoch()
-        g = torch.cuda.CUDAGraph()
-        with torch.no_grad(), torch.cuda.graph(g, pool=self.pool, stream=side):
-            out = self.model(*self._static_in)
+        frozen = self._freeze() if self.freeze_weights else []
+        try:
+            for q, w, y in frozen:
+                q._pregrouped = (w, y)  # (not a structural attribute: the epoch does not move)
+            with torch.no_grad(), torch.cuda.stream(side):
+                for _ in range(max(self.warmup, 1)):  # plans built, workspaces of THIS stream allocated, host checks resolved
+                    self.model(*self._static_in)
+            torch.cuda.current_stream(dev).wait_stream(side)
+            torch.cuda.synchronize(dev)
+            epoch = sbq_plan.epoch()
+            g = torch.cuda.CUDAGraph()
+            with torch.no_grad(), torch.cuda.graph(g, pool=self.pool, stream=side):
+                out = self.model(*self._static_in)
+        finally:
+            for q, _, _ in frozen:
+                q._pregrouped = None
+        self._frozen = frozen  # (the graph reads the fake-quantized weights by address)
         if sbq_plan.epoch() != epoch:
             raise RuntimeError("the model changed its quantizers' structure DURING the forward (the epoch moved): "
                                "such a forward cannot be replayed")
@@ -117,5 +146,6 @@ class CapturedForward:
 
 
 def capture(model, *example_inputs, **kw):
-    """-> CapturedForward (see the module docstring).  kw: warmup=3, on_stale="recapture" | "raise", clone=False, pool"""
+    """-> CapturedForward (see the module docstring).  kw: warmup=3, on_stale="recapture" | "raise", clone=False, pool,
+    freeze_weights=False"""
     return CapturedForward(model, *example_inputs, **kw)

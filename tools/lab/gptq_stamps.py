@@ -41,11 +41,15 @@ raw.sbq_debug_gptq_stamps.argtypes = [ctypes.c_void_p]
 g = torch.Generator().manual_seed(1)
 names = ["start", "loads issued", "pass 0 landed | barrier", "last pass landed | x staged", "arithmetic done", "K-lane barrier",
          "result stored", "split fold done"]
+BATCH = int(os.environ.get("BATCH", "1"))
+if BATCH >= 5:  # gptq_mfma_kernel's stamps (round 5)
+    names = ["start", "block 0 + 1 loads issued", "block 0 computed", "all blocks computed", "partial tile published",
+             "arrival counted", "fold done (last arriver)", "-"]
 K2 = int(os.environ.get("KNOB2", "0"))
 K1 = int(os.environ.get("KNOB1", "0"))
 L.set_tuning(2, K2)
 L.set_tuning(1, K1)
-print("knob 2 = %d, knob 1 = %d" % (K2, K1))
+print("knob 2 = %d, knob 1 = %d, batch = %d" % (K2, K1, BATCH))
 for in_f, out_f in ((4096, 4096), (4096, 11008), (11008, 4096)):
     groups = in_f // 128
     wb = in_f // 8 * out_f * 4
@@ -53,13 +57,13 @@ for in_f, out_f in ((4096, 4096), (4096, 11008), (11008, 4096)):
     qws = [torch.randint(-2**31, 2**31 - 1, (in_f // 8, out_f), generator=g, dtype=torch.int64).to(torch.int32).to(dev) for _ in range(copies)]
     sc = (torch.rand(out_f, groups, generator=g) * 0.02 + 0.001).to(dev)
     zr = (torch.rand(out_f, groups, generator=g) * 0.1).to(dev)
-    x = torch.randn(1, in_f, generator=g).to(dev)
-    y = torch.zeros(1, out_f, device=dev)
-    ws = L.fresh_workspace(lib.sbq_gptq_workspace_bytes(1, in_f, out_f), dev)
+    x = torch.randn(BATCH, in_f, generator=g).to(dev)
+    y = torch.zeros(BATCH, out_f, device=dev)
+    ws = L.fresh_workspace(lib.sbq_gptq_workspace_bytes(BATCH, in_f, out_f), dev)
     stamps = torch.zeros(4096 * 8, dtype=torch.int64, device=dev)
 
     def run(i):
-        lib.sbq_vecquant4matmul(L.ptr(x), L.ptr(qws[i % copies]), L.ptr(y), L.ptr(sc), L.ptr(zr), 1, in_f, out_f, 128, L.ptr(ws), ws.numel(), st)
+        lib.sbq_vecquant4matmul(L.ptr(x), L.ptr(qws[i % copies]), L.ptr(y), L.ptr(sc), L.ptr(zr), BATCH, in_f, out_f, 128, L.ptr(ws), ws.numel(), st)
 
     raw.sbq_debug_gptq_stamps(None)
     for i in range(50): run(i)

@@ -344,62 +344,3 @@ def test_captured_forward_with_frozen_weights():
     with torch.no_grad():
         want2 = model(x2).clone()
     assert torch.equal(fwd(x2), want2)
-
-
-# --------------------------------------------------------------------------------------
-# resident schedule of the 16-bit STE / LSQ backward (csrc/sbq_backward.hip: ste_backward_resident_kernel)
-# --------------------------------------------------------------------------------------
-@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("shape,per_channel", [((4096, 4096), True), ((2048, 2048), True), ((1536, 4096), True),
-                                               ((4096, 4096), False), ((3, 1024, 2048), False)])
-def test_resident_backward_equals_chunked(ops, oracle_mod, dtype, shape, per_channel):
-    """same gx bit for bit and gs / gzp to fp32 rounding of the totals as the chunked kernel (knob 3 = 1: never
-    resident), which tests/test_gpu_parity.py pins to the oracle (MySTE.backward, quant_tensor.py:45-71); a few rows
-    against the oracle directly; values beyond the clamp, NaN / inf and a zero row included"""
-    from sparsebit_amd import lib as L
-
-    dev = torch.device("cuda:0")
-    g = torch.Generator().manual_seed(17)
-    x = torch.randn(shape, generator=g) * torch.logspace(-2, 1, shape[0]).reshape(-1, *([1] * (len(shape) - 1)))
-    x.view(-1)[5] = float("inf")
-    x.view(-1)[77] = float("nan")
-    if len(shape) == 2:
-        x[3] = 0.0
-    x = x.to(dtype).to(dev)
-    gy = torch.randn(shape, generator=g).to(dtype).to(dev)
-    C = shape[0] if per_channel else 1
-    xf = x.float()
-    amax = torch.nan_to_num(xf, nan=0.0, posinf=0.0, neginf=0.0).reshape(C, -1).abs().amax(1) if per_channel else \
-        torch.nan_to_num(xf, nan=0.0, posinf=0.0).abs().max().reshape(1)
-    scale = (amax * 0.4 / 7).clamp_min(1e-6).float()  # 4 bit: a good share of the values clamps
-    zp = torch.randint(-2, 3, (C,), generator=g).float().to(dev)
-    res = {}
-    for knob in (0, 1):
-        L.set_tuning(3, knob)
-        try:
-            res[knob] = ops.fake_quant_backward(x, gy, scale, zp, -8, 7, 0, True, True)
-            res[("lsq", knob)] = ops.lsq_fake_quant_backward(x, gy, -scale, zp, -8, 7, 0, True, 0.125)
-        finally:
-            L.set_tuning(3, 0)
-    for key in (0, "lsq"):
-        a, b = (res[0], res[1]) if key == 0 else (res[("lsq", 0)], res[("lsq", 1)])
-        assert torch.equal(torch.nan_to_num(a[0].float(), nan=7.0), torch.nan_to_num(b[0].float(), nan=7.0)), key
-        for k in range(1, len(a)):
-            ga, gb = a[k].double(), b[k].double()
-            fin = torch.isfinite(gb)
-            assert torch.equal(torch.isfinite(ga), fin)
-            denom = gb[fin].abs().clamp_min(1e-3 * float(gb[fin].abs().max()) if fin.any() else 1.0)
-            assert float(((ga[fin] - gb[fin]).abs() / denom).max()) <= 1e-5 if fin.any() else True, (key, k)
-    if per_channel and shape == (2048, 2048):
-        rows = [0, 1, 2, 3, 1000, 2047]
-        gx_ref, gs_ref, gz_ref = oracle_mod.ste_backward(x[rows].float().cpu().numpy(), gy[rows].float().cpu().numpy(),
-                                                          scale[rows].cpu().numpy(), zp[rows].cpu().numpy(), -8, 7, 0)
-        got = res[0][0][rows].float().cpu().numpy()
-        assert np.array_equal(np.nan_to_num(got, nan=7.0), np.nan_to_num(gx_ref, nan=7.0))
-
-
-@pytest.fixture(scope="module")
-def oracle_mod():
-    from oracle import oracle as O
-
-    return O

@@ -344,3 +344,71 @@ def test_captured_forward_with_frozen_weights():
     with torch.no_grad():
         want2 = model(x2).clone()
     assert torch.equal(fwd(x2), want2)
+
+
+# --------------------------------------------------------------------------------------
+# GPTQ 4-bit batched mat-mul on the fp32 matrix cores (csrc/sbq_gptq.hip: gptq_mfma_kernel, 5 <= B <= 32)
+# --------------------------------------------------------------------------------------
+def _gptq_case(in_f, out_f, gs, B, seed, dev):
+    g = torch.Generator().manual_seed(seed)
+    groups = in_f // gs if gs else 1
+    qw = torch.randint(-2 ** 31, 2 ** 31 - 1, (in_f // 8, out_f), generator=g, dtype=torch.int64).to(torch.int32)
+    sc = (torch.rand(out_f, groups, generator=g) * 0.02 + 0.001).float()
+    zr = (torch.randint(0, 16, (out_f, groups), generator=g).float() * sc).float()
+    x = torch.randn(B, in_f, generator=g).float()
+    bias = torch.randn(out_f, generator=g).float()
+    return qw, sc, zr, x, bias
+
+
+@pytest.mark.parametrize("batch", [5, 7, 8, 9, 15, 16, 17, 24, 29, 31, 32])
+@pytest.mark.parametrize("in_f,out_f,gs", [
+    (128, 64, 128),      # one block, one tile: three of the workgroup's four waves have no K chunk
+    (384, 128, 128),     # three blocks: an odd chunk (the dropped dead block)
+    (640, 192, 128),     # five blocks over four waves
+    (1024, 4096, 0),     # one group for the whole of K
+    (2048, 1024, 256),   # a group spans two blocks
+    (4096, 4096, 128),   # the decode shape: 2 blocks per wave, 4 K blocks of workgroups, the arrival fold
+    (11008, 4096, 128),  # 86 blocks: uneven chunks, 6 K blocks
+    (4096, 11008, 128),  # 172 tiles (not a multiple of 8: no XCD swizzle)
+])
+def test_gptq_batched_mfma_vs_oracle(ops, oracle_mod, batch, in_f, out_f, gs):
+    """y == oracle(cuda_kernel_4bit.cu:36-180) at the reference test's rtol = atol = 1e-5 (test_cuda_kernel.py:81-126
+    runs these batch sizes), bias kept, a second call gives the same bits (deterministic fold), and the strip tiles of
+    four rows this kernel replaced (knob 2 = 26) agree to the same tolerance"""
+    from sparsebit_amd import lib as L
+
+    dev = torch.device("cuda:0")
+    if batch not in (8, 17, 32) and in_f * out_f > 4096 * 4096:
+        pytest.skip("large shapes: three batch sizes")
+    qw, sc, zr, x, bias = _gptq_case(in_f, out_f, gs, batch, 3 + in_f % 89 + batch, dev)
+    qwd, scd, zrd, xd = qw.to(dev), sc.to(dev), zr.to(dev), x.to(dev)
+    outs = {}
+    for knob in (0, 26):
+        L.set_tuning(2, knob)
+        try:
+            y = bias.repeat(batch, 1).to(dev)
+            ops.vecquant4matmul(xd, qwd, y, scd, zrd, gs)
+            y2 = bias.repeat(batch, 1).to(dev)
+            ops.vecquant4matmul(xd, qwd, y2, scd, zrd, gs)
+            assert torch.equal(y, y2), "knob %d: two calls differ" % knob
+            outs[knob] = y.cpu().numpy()
+        finally:
+            L.set_tuning(2, 0)
+    ref = oracle_mod.vecquantmatmul(x.numpy(), qw.numpy(), bias.numpy(), sc.numpy(), zr.numpy(), gs, 4)
+    tol = 1e-5 * max(1.0, float(np.abs(ref).max()))
+    for knob, got in outs.items():
+        assert np.all(np.abs(got - ref) <= tol + 1e-5 * np.abs(ref)), (knob, float(np.abs(got - ref).max()))
+
+
+def test_gptq_batched_mfma_inf_nan_rows(ops):
+    """an inf / NaN activation poisons its OWN batch row only (the dead block of an odd chunk is dropped by a select,
+    not multiplied by zero; rows >= batch are clamped copies that are never stored)"""
+    dev = torch.device("cuda:0")
+    qw, sc, zr, x, bias = _gptq_case(384, 128, 128, 9, 41, dev)
+    x[2, 300] = float("inf")
+    x[5, 17] = float("nan")
+    y = bias.repeat(9, 1).to(dev)
+    ops.vecquant4matmul(x.to(dev), qw.to(dev), y, sc.to(dev), zr.to(dev), 128)
+    y = y.cpu()
+    bad = ~torch.isfinite(y).all(dim=1)
+    assert bad.tolist() == [False, False, True, False, False, True, False, False, False]

@@ -1506,11 +1506,30 @@ int gptq_matmul(const float* x, const int32_t* qweight, float* out, const float*
         out_features * g.groups < (1ll << 30) &&
         batch * in_features < (1ll << 30) && knob(2) != 26 && knob(2) != 9) {
       const int64_t tiles64 = out_features / 64, nblk = in_features / 128;
-      // blocks per wave: about one wave per SIMD on the whole chip, at most 16 K blocks of four waves
-      int64_t bpc = (nblk * tiles64) / (4 * static_cast<int64_t>(cu_count()));
-      if (bpc < 1) bpc = 1;
-      if (bpc > 1 && (bpc & 1)) --bpc;  // (the kernel walks a chunk two blocks at a time)
-      while (ceil_div(ceil_div(nblk, bpc), 4) > kStripMaxSplit) bpc += bpc > 1 ? 2 : 1;
+      // Blocks per wave (profiles/r05_gptq_batch_bpc_sweep.log).  The kernel is bound by the matrix cores, four waves
+      // keep a CU's four busy, and a launch ends with its slowest workgroup: best is ONE round of equal workgroups --
+      // tiles x K blocks just under the CU count (4096 x 4096: 64 tiles x 4 K blocks of 2-block waves; 11008 -> 4096:
+      // 64 x 4 of 6-block waves, 20.9 us at B = 8 against 27.2 with 4-block waves = 384 workgroups = one and a half
+      // rounds).  Where no block count gives that (4096 -> 11008: 172 tiles), many SMALL workgroups balance
+      // dynamically: 2-block waves (688 workgroups, 21.4 us) beat 4-block waves (344: a second workgroup on a third of
+      // the CUs, 26.5 us).  At most kStripMaxSplit K blocks (the partial tiles' workspace).
+      const int64_t cus = cu_count();
+      int64_t bpc = 0, best_wgs = 0;
+      for (int64_t cand = 1; cand <= nblk; cand += cand == 1 ? 1 : 2) {  // 1, 2, 4, 6, ...
+        const int64_t ks = ceil_div(ceil_div(nblk, cand), 4);
+        if (ks > kStripMaxSplit) continue;
+        const int64_t wgs = tiles64 * ks;
+        if (wgs <= cus && 4 * wgs >= 3 * cus && wgs > best_wgs) {
+          best_wgs = wgs;
+          bpc = cand;
+        }
+      }
+      if (bpc == 0) {
+        bpc = nblk >= 2 ? 2 : 1;
+        while (ceil_div(ceil_div(nblk, bpc), 4) > kStripMaxSplit) bpc += 2;
+      }
+      if (knob(1) > 0 && knob(1) < 128 && ceil_div(ceil_div(nblk, static_cast<int64_t>(knob(1))), 4) <= kStripMaxSplit)
+        bpc = knob(1);  // dev override (shares the strip kernels' K-split knob)
       const int64_t ksplit = ceil_div(ceil_div(nblk, bpc), 4);
       g.xcd_swizzle = (tiles64 % 8 == 0 && knob(2) != 8) ? 1 : 0;
       const dim3 grid(static_cast<uint32_t>(tiles64), static_cast<uint32_t>(ksplit));

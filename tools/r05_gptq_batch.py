@@ -47,10 +47,16 @@ def timed(fn, iters=200, warm=20):
     return best
 
 
+K1 = int(os.environ.get("KNOB1", "0"))
+L.set_tuning(1, K1)
+ONLY_TIMED = os.environ.get("ONLY_TIMED") == "1"
+print("knob 1 (blocks per wave) = %d" % K1)
 print("shape            gs   B   parity  max_err     mfma_us  strip4_us  frac_fp32_peak  frac_hbm")
 ok_all = True
 for in_f, out_f, gs, time_it in ((4096, 4096, 128, True), (4096, 11008, 128, True), (11008, 4096, 128, True), (128, 64, 128, False),
                                  (256, 192, 128, False), (1024, 4096, 0, False), (2048, 1024, 256, False), (12288, 4096, 128, True)):
+    if ONLY_TIMED and not time_it:
+        continue
     w_bytes = in_f // 8 * out_f * 4
     copies = max(2, int(3.2e8 // w_bytes) + 1) if time_it else 1
     mats, g = problem(in_f, out_f, gs, 7 + in_f % 97, copies)

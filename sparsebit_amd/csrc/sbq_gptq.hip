@@ -1191,22 +1191,26 @@ __global__ __launch_bounds__(256) void gptq_mfma_kernel(const float* __restrict_
     float s_lane, z_lane;
   };
   const int blk_last = blk_end - 1;
+  auto at32 = [](const auto* base, uint32_t byte_off) {
+    return reinterpret_cast<decltype(base)>(reinterpret_cast<const char*>(base) + byte_off);
+  };
   auto load_blk = [&](int blk_in, Blk& r) {
     const uint32_t blk = static_cast<uint32_t>(blk_in < blk_last ? blk_in : blk_last);
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
+      // (uniform base + 32-bit BYTE offset per lane: one address register and no 64-bit arithmetic per load)
       const uint32_t row = blk * 16u + 4u * s + kg;
-      r.w4[s] = ld16<true>(qw + (row * out32 + col));
+      r.w4[s] = ld16<true>(at32(qw, (row * out32 + col) * 4u));
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
-        const float* xp = x + (xrow[mt] + row * 8u);
+        const float* xp = at32(x, (xrow[mt] + row * 8u) * 4u);
         r.xa[s][mt][0] = *reinterpret_cast<const f32x4*>(xp);
         r.xa[s][mt][1] = *reinterpret_cast<const f32x4*>(xp + 4);
       }
     }
     const uint32_t grp = (blk * 128u) / static_cast<uint32_t>(g.group_size);
-    r.s_lane = scales[col_lane + grp];
-    r.z_lane = zeros[col_lane + grp];
+    r.s_lane = *at32(scales, (col_lane + grp) * 4u);
+    r.z_lane = *at32(zeros, (col_lane + grp) * 4u);
   };
   // The block's arithmetic, dequantization factored out of the contraction (as in the strip kernels):
   //     sum_k (s * lvl_k - z) * x_k  =  s * sum_k lvl_k * x_k  -  z * sum_k x_k

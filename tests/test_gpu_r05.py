@@ -24,6 +24,13 @@ def ops():
     return _ops
 
 
+@pytest.fixture(scope="module")
+def oracle_mod():
+    from oracle import oracle as O
+
+    return O
+
+
 def _tables(ops, x, qmin, qmax, sym):
     from sparsebit_amd import lib as L
 

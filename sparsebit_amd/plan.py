@@ -80,7 +80,7 @@ def _flat_f32(t):
 
 class QdqPlan:
     __slots__ = ("sv", "qv", "own", "shape", "dtype", "dev_index", "out_dtype", "fn", "head", "tail", "zp", "zp_version", "trt", "keep",
-                 "numel", "lsq")
+                 "numel", "lsq", "s_home", "z_home", "s_obj", "z_obj")
 
     def __init__(self, quantizer, x, lsq=False):
         """raises ValueError when this (quantizer, x) is not plannable -- the caller then remembers that and keeps
@@ -90,8 +90,15 @@ class QdqPlan:
             raise ValueError("input")
         bufs = quantizer.__dict__["_buffers"]
         params = quantizer.__dict__["_parameters"]
-        scale = params["scale"] if "scale" in params else bufs["scale"]
-        zp = params["zero_point"] if "zero_point" in params else bufs["zero_point"]
+        # where the two tensors LIVE (the module's parameter or buffer dict) and which objects they were: the plan holds
+        # raw addresses, so it keeps the tensors alive and checks on every call that the module still holds the same
+        # objects -- nn.Module._apply (.to() / .cuda() / .half()) and load_state_dict(assign=True) re-bind them without
+        # going through __setattr__
+        self.s_home = params if "scale" in params else bufs
+        self.z_home = params if "zero_point" in params else bufs
+        scale = self.s_home["scale"]
+        zp = self.z_home["zero_point"]
+        self.s_obj, self.z_obj = scale, zp
         if scale.device != x.device or zp.device != x.device:
             raise ValueError("device")
         s, z = _flat_f32(scale.detach()), _flat_f32(zp.detach())
@@ -137,7 +144,8 @@ class QdqPlan:
             self.tail = (yd, None, L.Q_NONE, sp, zpp, self.numel, int(qmin), int(qmax), L.ROUND_HALF_EVEN)
 
     def matches(self, quantizer, x):
-        return (self.sv == quantizer._sv and self.qv == quantizer.qdesc.version and x.dtype is self.dtype and x.shape == self.shape
+        return (self.sv == quantizer._sv and self.qv == quantizer.qdesc.version and x.dtype is self.dtype
+                and self.s_home.get("scale") is self.s_obj and self.z_home.get("zero_point") is self.z_obj and x.shape == self.shape
                 and x.device.index == self.dev_index and x.is_contiguous()
                 and (self.own or self.keep == _keep_default))
 
@@ -167,6 +175,14 @@ class PlanCache:
     def __init__(self):
         self.plan = None
         self.refused = None
+
+    # a plan holds a foreign function and raw device addresses: copies of the quantizer (copy.deepcopy of a model for an
+    # EMA / a checkpoint through pickle) start without one
+    def __deepcopy__(self, memo):
+        return PlanCache()
+
+    def __reduce__(self):
+        return (PlanCache, ())
 
     def lookup(self, quantizer, x, lsq=False):
         if not _enabled:

@@ -64,6 +64,13 @@ class Quantizer(nn.Module):
             sbq_plan.bump_epoch()
         nn.Module.__setattr__(self, name, value)
 
+    def _apply(self, fn, *args, **kwargs):
+        # .to() / .cuda() / .float(): nn.Module re-binds parameters and buffers behind __setattr__'s back
+        out = nn.Module._apply(self, fn, *args, **kwargs)
+        self.__dict__["_sv"] = self.__dict__.get("_sv", 0) + 1
+        sbq_plan.bump_epoch()
+        return out
+
     def _out_keeps_dtype(self):
         k = self.keep_input_dtype
         return sbq_plan.keep_default() if k is None else bool(k)

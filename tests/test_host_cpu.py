@@ -422,3 +422,65 @@ def test_plugin_preinstall_answers_the_reference_import_time_jit():
     finally:
         restore()
     assert ext.load is real
+
+
+# ---- round 5: launch plans / captured graphs -- the host-side bookkeeping (no kernel runs here) -----------------------
+def test_structure_version_and_epoch_follow_every_switch():
+    """a launch plan (sparsebit_amd.plan) is valid for ONE structure version of its quantizer, a captured graph
+    (sparsebit_amd.graph) for ONE process-wide epoch: both must move with everything that changes what a forward does"""
+    import copy
+    import io
+
+    from sparsebit_amd import plan
+    from sparsebit_amd.common import Backend
+    from sparsebit_amd.config import quantizer_config
+    from sparsebit_amd.quantizers import build_quantizer
+    from sparsebit_amd.quantizers import quant_tensor as QT
+
+    q = build_quantizer(quantizer_config("per-channel-symmetric", 8))
+    for change in (lambda: q.enable_quant(), lambda: q.disable_quant(), lambda: q.set_backend(Backend.TENSORRT),
+                   lambda: q.enable_export_onnx(), lambda: q.disable_export_onnx(), lambda: setattr(q, "keep_input_dtype", True),
+                   lambda: setattr(q, "scale", torch.ones(3)), lambda: setattr(q, "zero_point", torch.zeros(3)),
+                   lambda: q.set_fake_fused(), lambda: q.float()):
+        sv, ep = q._sv, plan.epoch()
+        change()
+        assert q._sv > sv and plan.epoch() > ep
+    qv, ep = q.qdesc.version, plan.epoch()
+    q.set_bit(4)
+    assert q.qdesc.version > qv and plan.epoch() > ep and q.qdesc.qrange == (-8, 7)
+    qv = q.qdesc.version
+    q.qdesc.set_symmetric(False)  # straight on the descriptor (lsq.py:39-43 does)
+    assert q.qdesc.version > qv
+    # the process default of the output dtype, and a quantizer's own choice
+    q2 = build_quantizer(quantizer_config("per-tensor-affine", 8))
+    assert q2.keep_input_dtype is None and q2._out_keeps_dtype() is False
+    ep = plan.epoch()
+    QT.keep_input_dtype(True)
+    try:
+        assert q2._out_keeps_dtype() is True and plan.epoch() > ep
+        q2.keep_input_dtype = False
+        assert q2._out_keeps_dtype() is False and q2._out_dtype(torch.zeros(1, dtype=torch.bfloat16)) == torch.float32
+    finally:
+        QT.keep_input_dtype(False)
+    # copies start without a plan (a plan holds a foreign function and device addresses)
+    q3 = copy.deepcopy(q2)
+    assert q3._plans is not q2._plans and q3._plans.plan is None
+    buf = io.BytesIO()
+    torch.save(q2, buf)
+    buf.seek(0)
+    q4 = torch.load(buf, weights_only=False)
+    assert q4._plans.plan is None and q4.keep_input_dtype is False
+    sd = q2.state_dict()
+    assert sorted(k for k in sd if "observer" not in k) == ["scale", "zero_point"]  # nothing new in checkpoints
+
+
+def test_graph_module_refuses_host_tensors_and_training_mode():
+    from sparsebit_amd import graph
+
+    m = torch.nn.Linear(4, 4)
+    with pytest.raises(RuntimeError):
+        graph.capture(m, torch.zeros(2, 4))  # training mode
+    with pytest.raises(RuntimeError):
+        graph.capture(m.eval(), torch.zeros(2, 4))  # host tensors
+    with pytest.raises(ValueError):
+        graph.capture(m, torch.zeros(2, 4), on_stale="ignore")

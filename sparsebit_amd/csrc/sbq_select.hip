@@ -763,23 +763,43 @@ __global__ __launch_bounds__(kBlock) void sign_count_kernel(const void* __restri
 }
 
 // mask[i] = |x[i]| > thresh   (l1norm.py:24-25)
+// A workgroup takes 1024 consecutive packs, four per thread a quarter apart (every wave instruction reads 1 KiB /
+// writes 512 B of contiguous memory): the four loads are requested before anything else, the four stores follow the
+// four conversions.  For the headline weight that is 2048 workgroups = ONE resident round at eight waves per SIMD --
+// the whole tensor requested at once, read burst then write burst (the grid-stride loop this replaces had one load in
+// flight per thread and iteration: 10.1 us = 0.62 of 8 TB/s for 4096 x 4096 bf16).
+constexpr int kMaskU = 4;
 template <typename T>
 __global__ __launch_bounds__(kBlock) void mask_pack_kernel(const void* __restrict__ x,
                                                            const float* __restrict__ thresh,
                                                            uint8_t* __restrict__ mask, uint32_t packs) {
+  const uint32_t base = blockIdx.x * (kBlock * kMaskU) + threadIdx.x;
+  RawPack<T> raw[kMaskU];
+#pragma unroll
+  for (int u = 0; u < kMaskU; ++u) {
+    const uint32_t p = base + u * kBlock;
+    raw[u] = load_raw<T, true>(x, static_cast<int64_t>(p < packs ? p : packs - 1u) * kPack);  // (clamped: unconditional loads)
+  }
+  __builtin_amdgcn_sched_barrier(0);
   const float thr = *thresh;
-  for (uint32_t p = blockIdx.x * kBlock + threadIdx.x; p < packs; p += gridDim.x * kBlock) {
+  u32x2 w[kMaskU];
+#pragma unroll
+  for (int u = 0; u < kMaskU; ++u) {
     float v[kPack];
-    load_pack<T, true>(x, static_cast<int64_t>(p) * kPack, v);
-    u32x2 w;
+    unpack_raw<T>(raw[u], v);
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       uint32_t acc = 0;
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc |= (__builtin_fabsf(v[4 * h + j]) > thr ? 1u : 0u) << (8 * j);
-      w[h] = acc;
+      w[u][h] = acc;
     }
-    st8<true>(mask + static_cast<int64_t>(p) * kPack, w);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int u = 0; u < kMaskU; ++u) {
+    const uint32_t p = base + u * kBlock;
+    if (p < packs) st8<true>(mask + static_cast<int64_t>(p) * kPack, w[u]);
   }
 }
 
@@ -1083,8 +1103,7 @@ int sbq_mask_from_threshold(const void* x, int x_dtype, int64_t numel, const flo
     using T = decltype(tag);
     if (body > 0) {
       const uint32_t packs = static_cast<uint32_t>(body / kPack);
-      uint32_t grid = (packs + kBlock - 1) / kBlock;
-      if (grid > 4096u) grid = 4096u;
+      const uint32_t grid = (packs + kBlock * kMaskU - 1) / (kBlock * kMaskU);
       mask_pack_kernel<T><<<grid, kBlock, 0, st>>>(x, thresh, mask_out, packs);
     }
     if (body < numel) {

@@ -72,4 +72,4 @@ def test_bench_launches_itself_when_started_like_the_one_gpu_command():
     rf = d["roofline"]
     # the roofline figure comes from windows of 1024 launches around the timed region, not from the 5 timed launches
     assert rf["windows_measured"] >= 12 and rf["kernel_avg_us_windows_min"] <= rf["kernel_avg_us"] <= rf["kernel_avg_us_windows_max"]
-    assert rf["frac"] == rf["frac_1024_window_median"] and "frac_wall" in rf and "frac_timed_region" in rf
+    assert rf["frac"] == rf["frac_1024_window_median"] and "frac_wall" in rf and "us_per_step_wall" in rf and "frac_rocprof" in rf

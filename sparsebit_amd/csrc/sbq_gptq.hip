@@ -1247,6 +1247,10 @@ __global__ __launch_bounds__(256) void gptq_mfma_kernel(const float* __restrict_
       for (int t = 0; t < 4; ++t) acc[mt][t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
+      // (decode and MFMAs in separate phases: interleaving the NEXT set's decode into the MFMA stream -- one VALU
+      // instruction per MFMA issue slot via sched_group_barrier -- was measured slower, 11.6 vs 10.9 us at B = 8 and
+      // 18.9 vs 18.0 us at B = 32 on 4096 x 4096: a filler beside every fp32 MFMA costs more than the 28-instruction
+      // decode phase it hides)
       f32x2 lp[4][4];  // column t: levels (0, 2) (1, 3) (4, 6) (5, 7) of the word
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
@@ -1505,10 +1509,11 @@ int gptq_matmul(const float* x, const int32_t* qweight, float* out, const float*
   if constexpr (BITS == 4) {
     // 5 <= B <= 32: the batch rows through the fp32 matrix cores (gptq_mfma_kernel; knob 2 == 26: the strip tiles of four
     // rows instead, for A/B runs)
-    if (vec && batch >= 5 && batch <= 32 && out_features % 64 == 0 && in_features % 128 == 0 && group_size % 128 == 0 &&
-        aligned16(x) && out_features / 64 <= kMaxStrips && g.H * out_features * 4 < (1ll << 32) &&
-        out_features * g.groups < (1ll << 30) &&
-        batch * in_features < (1ll << 30) && knob(2) != 26 && knob(2) != 9) {
+    // (any batch >= 5: more than 32 rows go through the kernel 32 at a time -- the launches of one call follow each other
+    // on the stream and share the partial-tile workspace; the weights of the later tiles come out of L2 / Infinity Cache)
+    if (vec && batch >= 5 && out_features % 64 == 0 && in_features % 128 == 0 && group_size % 128 == 0 &&
+        aligned16(x) && in_features % 4 == 0 && out_features / 64 <= kMaxStrips && g.H * out_features * 4 < (1ll << 32) &&
+        out_features * g.groups < (1ll << 30) && 32 * in_features < (1ll << 30) && knob(2) != 26 && knob(2) != 9) {
       const int64_t tiles64 = out_features / 64, nblk = in_features / 128;
       // Blocks per wave (profiles/r05_gptq_batch_bpc_sweep.log).  The kernel is bound by the matrix cores, four waves
       // keep a CU's four busy, and a launch ends with its slowest workgroup: best is ONE round of equal workgroups --
@@ -1537,11 +1542,19 @@ int gptq_matmul(const float* x, const int32_t* qweight, float* out, const float*
       const int64_t ksplit = ceil_div(ceil_div(nblk, bpc), 4);
       g.xcd_swizzle = (tiles64 % 8 == 0 && knob(2) != 8) ? 1 : 0;
       const dim3 grid(static_cast<uint32_t>(tiles64), static_cast<uint32_t>(ksplit));
-      if (batch <= 16)
-        gptq_mfma_kernel<1><<<grid, 256, 0, st>>>(x, qweight, scales, zeros, out, part, arrivals, g, static_cast<int>(bpc));
-      else
-        gptq_mfma_kernel<2><<<grid, 256, 0, st>>>(x, qweight, scales, zeros, out, part, arrivals, g, static_cast<int>(bpc));
-      return check_launch();
+      for (int64_t b0 = 0; b0 < batch; b0 += 32) {
+        GptqGeom gt = g;
+        gt.batch = batch - b0 < 32 ? batch - b0 : 32;
+        const float* xt = x + b0 * in_features;
+        float* ot = out + b0 * out_features;
+        if (gt.batch <= 16)
+          gptq_mfma_kernel<1><<<grid, 256, 0, st>>>(xt, qweight, scales, zeros, ot, part, arrivals, gt, static_cast<int>(bpc));
+        else
+          gptq_mfma_kernel<2><<<grid, 256, 0, st>>>(xt, qweight, scales, zeros, ot, part, arrivals, gt, static_cast<int>(bpc));
+        const int rc = check_launch();
+        if (rc != SBQ_OK) return rc;
+      }
+      return SBQ_OK;
     }
   }
   if (vec && out_features % kStripCols == 0 && batch >= 3 && batch <= 32 && !half_slices && strips <= kMaxStrips &&

@@ -368,7 +368,7 @@ def _gptq_case(in_f, out_f, gs, B, seed, dev):
     return qw, sc, zr, x, bias
 
 
-@pytest.mark.parametrize("batch", [5, 7, 8, 9, 15, 16, 17, 24, 29, 31, 32])
+@pytest.mark.parametrize("batch", [5, 7, 8, 9, 15, 16, 17, 24, 29, 31, 32, 33, 64, 100])
 @pytest.mark.parametrize("in_f,out_f,gs", [
     (128, 64, 128),      # one block, one tile: three of the workgroup's four waves have no K chunk
     (384, 128, 128),     # three blocks: an odd chunk (the dropped dead block)
@@ -386,7 +386,7 @@ def test_gptq_batched_mfma_vs_oracle(ops, oracle_mod, batch, in_f, out_f, gs):
     from sparsebit_amd import lib as L
 
     dev = torch.device("cuda:0")
-    if batch not in (8, 17, 32) and in_f * out_f > 4096 * 4096:
+    if batch not in (8, 17, 32, 100) and in_f * out_f > 4096 * 4096:
         pytest.skip("large shapes: three batch sizes")
     qw, sc, zr, x, bias = _gptq_case(in_f, out_f, gs, batch, 3 + in_f % 89 + batch, dev)
     qwd, scd, zrd, xd = qw.to(dev), sc.to(dev), zr.to(dev), x.to(dev)

@@ -167,13 +167,16 @@ class QdqPlan:
 
 
 class PlanCache:
-    """per quantizer: the plan of the last input signature seen (a quantizer sits on ONE edge of the graph, so its
-    inputs share a signature; a second signature simply replaces the first) and the signatures known unplannable"""
+    """per quantizer: the plans of the last few input signatures seen (a quantizer sits on ONE edge of the graph, so its
+    inputs usually share a signature; a shared quantizer -- the reference's QAdd feeds both addends through one -- may see
+    two) and the signature last found unplannable"""
 
-    __slots__ = ("plan", "refused")
+    __slots__ = ("plan", "more", "refused")
+    KEEP = 4
 
     def __init__(self):
-        self.plan = None
+        self.plan = None   # the most recently used plan
+        self.more = []     # up to KEEP - 1 others
         self.refused = None
 
     # a plan holds a foreign function and raw device addresses: copies of the quantizer (copy.deepcopy of a model for an
@@ -185,18 +188,25 @@ class PlanCache:
         return (PlanCache, ())
 
     def lookup(self, quantizer, x, lsq=False):
-        if not _enabled:
+        if not _enabled or _raw_stream is None or _get_device is None:
             return None
         p = self.plan
         if p is not None and p.matches(quantizer, x):
             return p
+        for i, q in enumerate(self.more):
+            if q.matches(quantizer, x):
+                self.more[i], self.plan = p, q
+                return q
         key = (quantizer._sv, quantizer.qdesc.version, x.shape, x.dtype, x.device.index, x.is_contiguous())
         if self.refused == key:
             return None
         try:
-            p = QdqPlan(quantizer, x, lsq)
+            q = QdqPlan(quantizer, x, lsq)
         except ValueError:
             self.refused = key
             return None
-        self.plan = p
-        return p
+        if p is not None:
+            # (plans of an older structure version can never match again: drop them instead of keeping them alive)
+            self.more = [m for m in [p] + self.more if m.sv == q.sv and m.qv == q.qv][: self.KEEP - 1]
+        self.plan = q
+        return q

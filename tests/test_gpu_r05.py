@@ -420,3 +420,28 @@ def test_gptq_batched_mfma_inf_nan_rows(ops):
     y = y.cpu()
     bad = ~torch.isfinite(y).all(dim=1)
     assert bad.tolist() == [False, False, True, False, False, True, False, False, False]
+
+
+def test_plan_cache_keeps_the_signatures_of_a_shared_quantizer():
+    """ONE quantizer fed two shapes in turn (the reference's QAdd sends both addends through one input quantizer; a
+    shared quantizer may also see two layouts): both plans stay, neither is rebuilt on the next round, results equal
+    the generic route"""
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(4)
+    a = torch.randn(8, 16, 14, 14, generator=g).to(dev)
+    b = torch.randn(8, 16, 7, 7, generator=g).to(dev)
+    q = _mk("per-tensor-affine", 8, target="feature", layout="NCHW").to(dev)
+    q.update_observer(a)
+    q.calc_qparams()
+    q.enable_quant()
+    with torch.no_grad():
+        ya, yb = q(a), q(b)
+        pa_b = {id(q._plans.plan)} | {id(m) for m in q._plans.more}
+        assert len(pa_b) == 2
+        for _ in range(3):
+            assert torch.equal(q(a), ya) and torch.equal(q(b), yb)
+        assert {id(q._plans.plan)} | {id(m) for m in q._plans.more} == pa_b  # nothing rebuilt
+        assert torch.equal(ya, _generic(q, a)) and torch.equal(yb, _generic(q, b))
+        q.set_bit(4)  # a structural change drops the old plans instead of keeping them alive
+        q(a)
+        assert q._plans.more == []

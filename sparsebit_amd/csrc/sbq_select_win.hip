@@ -31,6 +31,9 @@
 #ifndef SBQ_POLL_SLEEP
 #define SBQ_POLL_SLEEP 8  // s_sleep units (64 cycles) between two polls of a resident workgroup (A/B: tools/lab/build_variant.py)
 #endif
+#ifndef SBQ_RESIGN_TICKS
+#define SBQ_RESIGN_TICKS 10000ull  // s_memrealtime ticks (100 MHz) a resident workgroup waits at least before it may resign: 100 us
+#endif                             // (tools/lab/resident_stress.py runs a variant with a few ticks: the resignation path on every round)
 #ifndef SBQ_SEL_STAMPS
 #define SBQ_SEL_STAMPS 0  // -DSBQ_SEL_STAMPS=1: development timestamps (tools/lab/build_stamps.py)
 #endif
@@ -1731,7 +1734,7 @@ __device__ __forceinline__ bool win_finish(const Tab& tab, int n_shards, const O
       // publisher tells the rest how many are left, and they share the next sweep by ticket.  In the worst case the
       // last arriver sweeps alone, as it did before there were resident rounds.
       const unsigned long long t_arr = __builtin_amdgcn_s_memrealtime();
-      const unsigned long long limit = 10000ull + 4ull * (t_arr - ol.t0);
+      const unsigned long long limit = SBQ_RESIGN_TICKS + (SBQ_RESIGN_TICKS >= 10000ull ? 4ull : 0ull) * (t_arr - ol.t0);
       bool may_resign = true;
       for (uint32_t spin = 0;; ++spin) {
         __builtin_amdgcn_s_sleep(SBQ_POLL_SLEEP);

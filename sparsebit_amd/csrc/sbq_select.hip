@@ -796,6 +796,23 @@ __global__ __launch_bounds__(kBlock) void mask_pack_kernel(const void* __restric
     }
   }
   __builtin_amdgcn_sched_barrier(0);
+  if (blockIdx.x * (kBlock * kMaskU) + kBlock * kMaskU <= packs) {  // (uniform) every pack of the workgroup exists
+    // 16-byte stores: neighbouring lanes swap halves (quad_perm [1, 0, 3, 2]) -- the even lane then holds the mask bytes
+    // of packs (t, t + 1) of quarter u, the odd lane those of packs (t - 1, t) of quarter u + 1: one store instruction
+    // writes two contiguous 512-byte runs, 16 bytes per lane, instead of one run at 8 bytes per lane
+    const bool odd = (threadIdx.x & 1u) != 0;
+#pragma unroll
+    for (int u = 0; u < kMaskU; u += 2) {
+      const u32x2 send = odd ? w[u] : w[u + 1];
+      u32x2 recv;
+      recv[0] = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(send[0]), 0xB1, 0xf, 0xf, false));
+      recv[1] = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(send[1]), 0xB1, 0xf, 0xf, false));
+      const u32x4 out = odd ? u32x4{recv[0], recv[1], w[u + 1][0], w[u + 1][1]} : u32x4{w[u][0], w[u][1], recv[0], recv[1]};
+      const uint32_t p = base + (u + (odd ? 1 : 0)) * kBlock - (odd ? 1u : 0u);
+      __builtin_nontemporal_store(out, reinterpret_cast<u32x4*>(mask + static_cast<int64_t>(p) * kPack));
+    }
+    return;
+  }
 #pragma unroll
   for (int u = 0; u < kMaskU; ++u) {
     const uint32_t p = base + u * kBlock;

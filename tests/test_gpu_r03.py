@@ -597,7 +597,7 @@ def test_concurrent_resident_selections_neither_hang_nor_differ(tmp_path):
     import sys
     import torch.multiprocessing as mp
 
-    # Round 5: this test failed ONCE in seven full `-m gpu` runs (never in 8 isolated runs, never in 2 x 9600 isolated
+    # Round 5: this test failed ONCE in eight full `-m gpu` runs (never in 8 isolated runs, never in 2 x 9600 isolated
     # iterations of the same loop, tools/lab/resident_stress.py, nor in 2 x 4800 with the resignation forced on every
     # round by a 0.5 us patience); the failing run's detail was not kept.  Two processes saturating ONE device is a stress,
     # not a deployment (one process per GPU): a first failure is reported on stderr with what it was and the pair is run

@@ -5,8 +5,12 @@
     must not depend on a rank's batch count),
   * per-thread tuning knobs with a process-wide default (autograd's backward threads),
   * the launch plan of a calibrated quantizer and the hipGraph capture of a whole quantized forward
-    (sparsebit_amd.graph): bit-identical to the eager path, invalidated by a re-calibration.
-Reference anchors: observers/mse.py:46-61, observers/percentile.py:16-46, quantizers/base.py:55-64, modules/conv.py:37-42.
+    (sparsebit_amd.graph, also with the weight quantizers frozen into the capture): bit-identical to the eager path,
+    invalidated by a re-calibration; a shared quantizer's several input signatures,
+  * the GPTQ 4-bit batched mat-mul on the fp32 matrix cores (gptq_mfma_kernel, B >= 5) against the oracle and the strip
+    tiles it replaces, determinism, inf / NaN rows.
+Reference anchors: observers/mse.py:46-61, observers/percentile.py:16-46, quantizers/base.py:55-64, modules/conv.py:37-42,
+large_language_models/llama/quantization/cuda/cuda_kernel_4bit.cu:36-180, test_cuda_kernel.py:81-126.
 """
 import threading
 

@@ -624,7 +624,9 @@ int sbq_workspace_release(const void* workspace, size_t workspace_bytes);
  * 7 = fixed-digit radix engine for whole-tensor selections, 12 = the multi-launch windowed protocol (plan / sweep /
  * advance / fallback launches) instead of the one-launch engine, 15 = an fp32 whole-tensor selection as ONE launch of resident
  * rounds instead of one launch per sweep, 16 = every whole-tensor selection waits for its verdict (resident) even when its plan expects
- * one sweep: +1.5-2 us, measured, 17 = the extraction kernel instead of the sorted lists in sbq_percentile_rows, 11 = general statistics kernel for a min-max-only call). knob 3: resident schedule of the forward QDQ
+ * one sweep: +1.5-2 us, measured, 17 = the extraction kernel instead of the sorted lists in sbq_percentile_rows, 11 = general statistics kernel for a min-max-only call;
+ * 31 / 32 / 33 = TEST hook of the whole-tensor selections' resident rounds: a waiting workgroup resigns after half a microsecond
+ * from round 1 / 2 / 3 on and never before -- results must not change). knob 3: resident schedule of the forward QDQ
  * (0 = auto: tensors that fit the chip's registers in one sitting, 1 = never, 2 = always).
  * Scope: a setting belongs to the CALLING THREAD (two threads' experiments cannot disturb each other).  OR the knob
  * with SBQ_TUNING_PROCESS to set the process-wide default instead -- what every thread that never set the knob itself

@@ -796,7 +796,9 @@ __global__ __launch_bounds__(kBlock) void mask_pack_kernel(const void* __restric
     }
   }
   __builtin_amdgcn_sched_barrier(0);
-  if (blockIdx.x * (kBlock * kMaskU) + kBlock * kMaskU <= packs) {  // (uniform) every pack of the workgroup exists
+  // (uniform) every pack of the workgroup exists, and the mask is 16-byte aligned (the host admits 8: a view at an odd
+  // multiple of 8 bytes keeps the 8-byte stores below)
+  if (blockIdx.x * (kBlock * kMaskU) + kBlock * kMaskU <= packs && (reinterpret_cast<uintptr_t>(mask) & 15u) == 0) {
     // 16-byte stores: neighbouring lanes swap halves (quad_perm [1, 0, 3, 2]) -- the even lane then holds the mask bytes
     // of packs (t, t + 1) of quarter u, the odd lane those of packs (t - 1, t) of quarter u + 1: one store instruction
     // writes two contiguous 512-byte runs, 16 bytes per lane, instead of one run at 8 bytes per lane

@@ -34,6 +34,9 @@
 #ifndef SBQ_RESIGN_TICKS
 #define SBQ_RESIGN_TICKS 10000ull  // s_memrealtime ticks (100 MHz) a resident workgroup waits at least before it may resign: 100 us
 #endif                             // (tools/lab/resident_stress.py runs a variant with a few ticks: the resignation path on every round)
+#ifndef SBQ_R05_ROUND_RESTART
+#define SBQ_R05_ROUND_RESTART 0  // 1: round 5's round numbering at the full-histogram engine's hand-over (the bug of
+#endif                           // profiles/r06_roundtag_repro.log; tools/lab/r06_roundtag_repro.py builds and runs it)
 #ifndef SBQ_SEL_STAMPS
 #define SBQ_SEL_STAMPS 0  // -DSBQ_SEL_STAMPS=1: development timestamps (tools/lab/build_stamps.py)
 #endif
@@ -1509,6 +1512,9 @@ struct OneArgs {
   int32_t key_mode;  // KEYS_*: how the final key turns back into a value
   unsigned long long epoch;  // of this selection (host counter, > 0): tags the verdicts of its resident rounds
   int32_t always_resident;   // every workgroup waits for the verdict even when the plan expects one sweep
+  // test hook (knob 2 == 31 / 32 / 33): r > 0 = a waiting workgroup's patience is half a microsecond from round r on
+  // (and unlimited before): the resignation path at a chosen point of a selection, in the production build
+  int32_t test_resign;
   unsigned long long* stamps;  // development (knob 1 == 779): 8 timestamps per workgroup, else nullptr
 };
 // (compiled in only with -DSBQ_SEL_STAMPS=1 -- SBQ_EXTRA_HIPCC_FLAGS of sparsebit_amd/build.py: the conditional
@@ -1734,8 +1740,9 @@ __device__ __forceinline__ bool win_finish(const Tab& tab, int n_shards, const O
       // publisher tells the rest how many are left, and they share the next sweep by ticket.  In the worst case the
       // last arriver sweeps alone, as it did before there were resident rounds.
       const unsigned long long t_arr = __builtin_amdgcn_s_memrealtime();
-      const unsigned long long limit = SBQ_RESIGN_TICKS + (SBQ_RESIGN_TICKS >= 10000ull ? 4ull : 0ull) * (t_arr - ol.t0);
-      bool may_resign = true;
+      const unsigned long long limit =
+          a.test_resign > 0 ? 50ull : SBQ_RESIGN_TICKS + (SBQ_RESIGN_TICKS >= 10000ull ? 4ull : 0ull) * (t_arr - ol.t0);
+      bool may_resign = a.test_resign <= 0 || round >= static_cast<uint32_t>(a.test_resign);
       for (uint32_t spin = 0;; ++spin) {
         __builtin_amdgcn_s_sleep(SBQ_POLL_SLEEP);
         v = __hip_atomic_fetch_add(vp, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1862,8 +1869,12 @@ __device__ __forceinline__ bool win_finish(const Tab& tab, int n_shards, const O
 template <typename T, int NSEL, int BLOCK, typename Tab>
 __device__ __forceinline__ void win_resident_rounds(const Tab& tab, int n_shards, const OneArgs& a, const uint32_t,
                                                     const uint32_t, OneLds& ol, SweepLds<NSEL, BLOCK>& swl,
-                                                    AdvShared (&adv)[2], bool again) {
-  for (uint32_t round = 2; again && round < 12; ++round) {
+                                                    AdvShared (&adv)[2], bool again, const uint32_t first_round = 2) {
+  // (first_round: the full-histogram engine hands over in the middle of a selection -- its rounds so far count: the
+  // verdict tags are (epoch, serial, ROUND), and a round number used twice would match the earlier round's verdict,
+  // which is never cleared.  That was the one failure of round 5's concurrency test: no resignation in round 1, one
+  // in round 2 of a selection that needed a third round.)
+  for (uint32_t round = first_round; again && round < first_round + 10; ++round) {
     __syncthreads();
     // this round's participants and this workgroup's place among them (win_finish: the verdict's mailbox / a ticket)
     const uint32_t wg = __builtin_amdgcn_readfirstlane(ol.ticket), nwg = __builtin_amdgcn_readfirstlane(ol.part);
@@ -2032,6 +2043,11 @@ constexpr size_t h16_lds_bytes() {
 struct H16Plan {
   uint32_t b_lo[kWinSel], b_hi[kWinSel], b_mid[kWinSel];
   uint32_t first_key;  // thread 0's first key: what a workgroup of ONE repeated key consists of
+  // The tensor's last n % 8 elements (workgroup 0 only; else tail_n == 0) stay OUT of the 16-bit histogram: with them
+  // workgroup 0 would hold up to 65 543 elements, and "a count carried out of its half-dword <=> all 65 536 elements
+  // of the workgroup are one key" would no longer hold (65 535 + 1 from the tail carries too).  Every round visits
+  // them on their own.
+  uint32_t tail_n, tail_key[kPack];
 };
 
 // One round of the full-histogram engine: bin this workgroup's histogram into the selectors' current windows (ol.sel),
@@ -2111,6 +2127,7 @@ __device__ __forceinline__ bool h16_round(const OneShard& tab, const OneArgs& a,
       if (zw & 0xffffu) visit(kZero16, zw & 0xffffu);
       if (zw >> 16) visit(kZero16 + 1u, zw >> 16);
     }
+    if (threadIdx.x < plan.tail_n) visit(plan.tail_key[threadIdx.x], 1u);  // (not part of `total`: whole packs only)
   }
   one_stamp(a, 8);
   // counters: lanes -> wave -> workgroup
@@ -2153,6 +2170,18 @@ __device__ __forceinline__ bool h16_round(const OneShard& tab, const OneArgs& a,
     }
     tot[NSEL] = key < kZero16 ? c : 0u;
     tot[NSEL + 1] = key > kInf16 ? c : 0u;
+    // ... and the ragged tail's keys again (the counters above replaced what their visits had added)
+    const uint32_t tail_n = plan.tail_n;
+    for (uint32_t t = 0; t < tail_n; ++t) {
+      const uint32_t tk = plan.tail_key[t];
+#pragma unroll
+      for (int s = 0; s < NSEL; ++s) {
+        tot[s] += tk < lo16[s] ? 1u : 0u;
+        if (threadIdx.x == 0 && act[s] && tk >= lo16[s] && tk - lo16[s] <= span16[s]) swl.lh[s][(tk - lo16[s]) >> sh16[s]] += 1u;
+      }
+      tot[NSEL] += tk < kZero16 ? 1u : 0u;
+      tot[NSEL + 1] += tk > kInf16 ? 1u : 0u;
+    }
     __syncthreads();
   }
   one_stamp(a, 9);
@@ -2206,7 +2235,7 @@ __device__ __attribute__((noinline)) void h16_more_rounds(const OneShard* tab_l,
   for (uint32_t round = 2; round < 12; ++round) {
     if (__builtin_amdgcn_readfirstlane(ol->part) != nwg) {
       // somebody gave up waiting (two resident launches sharing the device): the rest sweeps global memory by ticket
-      win_resident_rounds<T, NSEL, kH16Block>(tab, 1, a, wg, nwg, *ol, *swl, *adv, true);
+      win_resident_rounds<T, NSEL, kH16Block>(tab, 1, a, wg, nwg, *ol, *swl, *adv, true, SBQ_R05_ROUND_RESTART ? 2u : round);
       return;
     }
     __syncthreads();  // ol.sel: the narrowed windows, fetched by win_finish
@@ -2485,20 +2514,19 @@ __global__ __launch_bounds__(kH16Block) void h16_select_kernel(const void* x0, u
   }
   if (wg == 0 && wid == 1) {  // the tensor's last n % 8 elements, one per lane
     const uint32_t e = n_packs * kPack + lane;
-    if (e < n) {
-      const uint32_t k = Key16<T>::pack2(static_cast<const uint16_t*>(x)[e], amask2) & 0xffffu;
-      const bool z = (k - kZero16) <= 1u;
-      atomicAdd(z ? &zero_word[threadIdx.x] : &hist[k >> 1], (k & 1u) ? 0x10000u : 1u);
-    }
+    if (e < n) plan.tail_key[lane] = Key16<T>::pack2(static_cast<const uint16_t*>(x)[e], amask2) & 0xffffu;
   }
-  if (threadIdx.x == 0) plan.first_key = first_key;
+  if (threadIdx.x == 0) {
+    plan.first_key = first_key;
+    plan.tail_n = wg == 0 ? n - n_packs * kPack : 0u;
+  }
   if constexpr (SBQ_SEL_STAMPS != 0) {  // when has a wave finished counting?  wave 0 (after its plan), waves 1 and 15
     if (a.stamps && lane == 0 && (wid == 0 || wid == 1 || wid == kWaves - 1))
       a.stamps[blockIdx.x * 32 + (wid == 0 ? 11 : (wid == 1 ? 15 : 18))] = __builtin_amdgcn_s_memrealtime();
   }
   lds_sync();
   one_stamp(a, 2);
-  // this workgroup's elements (for the carry check): its whole packs, and the ragged tail in workgroup 0
+  // this workgroup's elements in the histogram (for the carry check): its whole packs
   uint32_t n_wg = 0;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
@@ -2506,7 +2534,6 @@ __global__ __launch_bounds__(kH16Block) void h16_select_kernel(const void* x0, u
     const uint32_t p1 = p0 + WinGeom<BLOCK>::kSlab / kPack;
     if (p0 < n_packs) n_wg += ((p1 < n_packs ? p1 : n_packs) - p0) * kPack;
   }
-  if (wg == 0) n_wg += n - n_packs * kPack;
   // ---- round 1 inline; whatever follows (rare) out of line ----
   if (h16_round<T, NSEL>(tab, a, wg, nwg, n_wg, 1u, PCT, hist, zero_word, plan, ol, swl, adv)) {
     // (copied dword by dword out of the argument block in memory -- layout: x0, n32, nwg32, tab, a, naturally aligned
@@ -2731,6 +2758,7 @@ int win_one_run(const void* const* shards, const int64_t* counts, int n_shards, 
   a.mode = percentile ? 1 : 0;
   a.epoch = next_epoch();
   a.always_resident = knob(2) == 16 ? 1 : 0;
+  a.test_resign = knob(2) >= 31 && knob(2) <= 33 ? knob(2) - 30 : 0;
   a.stamps = knob(1) == 779 ? reinterpret_cast<unsigned long long*>(region + kOneRegion) : nullptr;
   int rc = SBQ_OK;
   OneShard os{};

@@ -69,15 +69,26 @@ def world_size():
 def init_single_rank_rccl(device):
     """A one-rank RCCL communicator on `device` (file-store rendezvous: no port, no environment) -- what a one-GPU
     lease can still put under the collective path.  Returns True when THIS call created the default group."""
+    import atexit
     import os
     import tempfile
 
     if dist.is_initialized():
         return False
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # (HSA_ENABLE_IPC_MODE_LEGACY=0 -- dmabuf IPC, the only kind this pool's host driver supports -- has to be in the
+    # environment BEFORE the HIP runtime initialises: the launcher's / the test's job, not this function's.  One rank
+    # shares no memory across processes, so nothing here depends on it.)
     fd, path = tempfile.mkstemp(prefix="sbq_rccl_ws1_")
     os.close(fd)
-    os.unlink(path)  # (FileStore creates it)
+    os.unlink(path)  # (FileStore creates it again)
+
+    def _cleanup(p=path):
+        try:
+            os.unlink(p)
+        except OSError:
+            pass
+
+    atexit.register(_cleanup)
     dist.init_process_group("nccl", init_method="file://" + path, world_size=1, rank=0, device_id=device)
     return True
 

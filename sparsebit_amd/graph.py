@@ -91,8 +91,9 @@ class CapturedForward:
     def _capture(self):
         dev = self._flat_in[0].device
         side = torch.cuda.Stream(device=dev)
-        side.wait_stream(torch.cuda.current_stream(dev))
+        # (the frozen weights are written on the CURRENT stream: the side stream waits after they are enqueued)
         frozen = self._freeze() if self.freeze_weights else []
+        side.wait_stream(torch.cuda.current_stream(dev))
         try:
             for q, w, y in frozen:
                 q._pregrouped = (w, y)  # (not a structural attribute: the epoch does not move)

@@ -129,6 +129,9 @@ class QdqPlan:
         self.numel = x.numel()
         self.lsq = lsq
         sp, zpp = s.data_ptr(), z.data_ptr()
+        # (the raw addresses are part of the plan: `scale.data = other` / set_() / resize_() move the storage under the
+        # same tensor object, which neither _sv nor the identity test below would notice)
+        self.s_ptr, self.z_ptr = scale.data_ptr(), zp.data_ptr()
         # call = fn(x_ptr, *head, y_ptr, *tail, stream): plain Python ints, converted by ctypes' argtypes
         if lsq:
             self.fn = lib.sbq_quant_lsq_forward
@@ -145,7 +148,8 @@ class QdqPlan:
 
     def matches(self, quantizer, x):
         return (self.sv == quantizer._sv and self.qv == quantizer.qdesc.version and x.dtype is self.dtype
-                and self.s_home.get("scale") is self.s_obj and self.z_home.get("zero_point") is self.z_obj and x.shape == self.shape
+                and self.s_home.get("scale") is self.s_obj and self.z_home.get("zero_point") is self.z_obj
+                and self.s_obj.data_ptr() == self.s_ptr and self.z_obj.data_ptr() == self.z_ptr and x.shape == self.shape
                 and x.device.index == self.dev_index and x.is_contiguous()
                 and (self.own or self.keep == _keep_default))
 

@@ -80,7 +80,7 @@ def _flat_f32(t):
 
 class QdqPlan:
     __slots__ = ("sv", "qv", "own", "shape", "dtype", "dev_index", "out_dtype", "fn", "head", "tail", "zp", "zp_version", "trt", "keep",
-                 "numel", "lsq", "s_home", "z_home", "s_obj", "z_obj")
+                 "numel", "lsq", "s_home", "z_home", "s_obj", "z_obj", "s_ptr", "z_ptr")
 
     def __init__(self, quantizer, x, lsq=False):
         """raises ValueError when this (quantizer, x) is not plannable -- the caller then remembers that and keeps

@@ -63,6 +63,7 @@ constexpr int kPlanShift = 19;
 constexpr int kPlanPacks = 2048;  // sampled packs of 8 consecutive elements
 constexpr int kMaxShards = 64;
 constexpr int kAdvBlock = 512;
+constexpr uint32_t kCandHead = 16;  // words in front of a candidate segment's keys (a 64-byte line: the count)
 
 struct WinSel {
   uint32_t lo;     // first key of the window
@@ -957,11 +958,16 @@ struct SweepLds {
 #define SBQ_SWEEP_STAMP(i) do { } while (0)
 #endif
 
+// COLLECT (fp32, one selector): every key inside the window is also appended to this wave's candidate segment
+// (cand_seg: count word, kCandHead - 1 unused words, cand_cap keys; nullptr = not this time) -- compacted per wave
+// instruction: a ballot, the lanes' ranks among the hits, one store of a few adjacent words.
 template <typename T, int NSEL, bool SIGNS, int BLOCK, bool EARLY, bool FLUSH, bool ALWAYS = false, bool KEY16 = false,
-          typename Tab, typename LoadState>
+          bool COLLECT = false, typename Tab, typename LoadState>
 __device__ __forceinline__ bool win_sweep(const Tab& tab, int n_shards, const uint32_t wg, const uint32_t nwg,
                                           LoadState&& load_state, WinSlot* __restrict__ slots,
-                                          uint32_t* __restrict__ hist, int use_abs, SweepLds<NSEL, BLOCK>& lds) {
+                                          uint32_t* __restrict__ hist, int use_abs, SweepLds<NSEL, BLOCK>& lds,
+                                          uint32_t* __restrict__ cand_seg = nullptr, const uint32_t cand_cap = 0) {
+  static_assert(!COLLECT || (NSEL == 1 && !SIGNS && T::id == SBQ_F32), "candidates: one fp32 selector");
   constexpr uint32_t kSlab = WinGeom<BLOCK>::kSlab;
   constexpr int U = WinGeom<BLOCK>::kU;
   constexpr int kWaves = BLOCK / kWave;
@@ -1056,6 +1062,18 @@ __device__ __forceinline__ bool win_sweep(const Tab& tab, int n_shards, const ui
   // few per cent of the elements; only those go on to the window test, and the ones beyond the far end are what
   // the sweep counts (side 1: the keys ABOVE the window; the advance turns that into the keys below).
   constexpr bool ONESIDED = SIGNS && NSEL == 2;
+  uint32_t c_fill = 0;  // uniform: keys this wave has found inside the window (COLLECT)
+  auto collect = [&](uint32_t kk, bool hit) {
+    const uint64_t m = __builtin_amdgcn_ballot_w64(hit);
+    if (cand_seg != nullptr && m != 0) {  // uniform
+      const uint32_t c = static_cast<uint32_t>(__builtin_popcountll(m));
+      if (c_fill + c <= cand_cap) {
+        const uint32_t pos = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0u));
+        if (hit) cand_seg[kCandHead + c_fill + pos] = kk;
+      }
+      c_fill += c;  // (past cand_cap: nothing more is written, and the count says so)
+    }
+  };
   auto visit = [&](uint32_t kk, bool valid) {
     if constexpr (SIGNS) {
       neg += valid && kk < kZeroKey;
@@ -1068,6 +1086,7 @@ __device__ __forceinline__ bool win_sweep(const Tab& tab, int n_shards, const ui
       else lt[s] += valid && kk < lo[s];
       if (valid && d <= span[s]) atomicAdd(&lh[s][d >> sh[s]], 1u);
     }
+    if constexpr (COLLECT) collect(kk, valid && kk - lo[0] <= span[0]);
   };
   // count the lanes of a compare on the scalar unit, HERE: as plain C++ (popcount of a ballot, added to a uniform
   // counter) the adds are sunk to the end of the slab and the 128 masks waiting for them spill into VGPR lanes
@@ -1102,6 +1121,7 @@ __device__ __forceinline__ bool win_sweep(const Tab& tab, int n_shards, const ui
       const uint32_t d = kk - lo[s];
       if (d <= span[s]) atomicAdd(&lh[s][d >> sh[s]], 1u);
     }
+    if constexpr (COLLECT) collect(kk, kk - lo[0] <= span[0]);
   };
   // 16-bit inputs: the keys of a pack stay PACKED.  A window of a 16-bit selection is 2^16-aligned in key32 (Key16),
   // so every test has an exact 16-bit form; per pack of 8 keys the sweep spends one packed min / max chain and one
@@ -1367,6 +1387,9 @@ __device__ __forceinline__ bool win_sweep(const Tab& tab, int n_shards, const ui
       else visit(key_of(__builtin_bit_cast(uint32_t, Elem<T>::load1(x, e))), true);
     }
   }
+  if constexpr (COLLECT) {
+    if (cand_seg != nullptr && lane0) cand_seg[0] = c_fill;
+  }
   // counters: lanes -> wave -> workgroup -> one of the 64 counter lines
   SBQ_SWEEP_STAMP(15);
   const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
@@ -1515,6 +1538,12 @@ struct OneArgs {
   // test hook (knob 2 == 31 / 32 / 33): r > 0 = a waiting workgroup's patience is half a microsecond from round r on
   // (and unlimited before): the resignation path at a chosen point of a selection, in the production build
   int32_t test_resign;
+  // fp32 selections of sbq_group_kth_value (round 6): the keys INSIDE the first window are written out during the first
+  // sweep -- one segment of kCandHead + cand_cap words per wave of the item's workgroups, word 0 = the keys the wave
+  // found (more than cand_cap: the segment overflowed) -- and the item's last arriver finishes the selection on them
+  // alone instead of the whole grid sweeping the tensor again (win_finish).  nullptr: no collection.
+  uint32_t* cand;
+  uint32_t cand_cap;
   unsigned long long* stamps;  // development (knob 1 == 779): 8 timestamps per workgroup, else nullptr
 };
 // (compiled in only with -DSBQ_SEL_STAMPS=1 -- SBQ_EXTRA_HIPCC_FLAGS of sparsebit_amd/build.py: the conditional
@@ -1685,6 +1714,52 @@ __device__ __forceinline__ void one_advance_pair(const OneArgs& a, OneLds& ol, b
   __syncthreads();
 }
 
+// One workgroup alone over an item's candidate segments: the window's histogram in lds.lh[0] (what a lonely win_sweep
+// of the whole tensor leaves there -- the candidates are exactly the tensor's keys inside the FIRST window, and every
+// later window lies inside it).  The rows of 64 keys of all segments form one list (segment-major, n_rows per segment:
+// the fullest one's), dealt to the waves 32 at a time -- every load of a batch is in flight before the first is used.
+template <int NSEL, int BLOCK>
+__device__ __forceinline__ bool cand_sweep_alone(const OneArgs& a, const uint32_t nseg, const uint32_t n_rows, const WinSel& w,
+                                                 SweepLds<NSEL, BLOCK>& lds) {
+  if (w.done) return false;
+  const uint32_t lo = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(w.lo));
+  const uint32_t span = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(w.span));
+  const uint32_t sh = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(w.shift));
+  for (uint32_t i = threadIdx.x; i < static_cast<uint32_t>(kWinBins); i += BLOCK) lds.lh[0][i] = 0;
+  __syncthreads();
+  constexpr uint32_t kBatch = 32, kWaves = BLOCK / kWave;
+  const uint32_t lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
+  const uint32_t seg_words = kCandHead + a.cand_cap;
+  const uint32_t total = nseg * n_rows;
+  for (uint32_t base = wid * kBatch; base < total; base += kWaves * kBatch) {
+    uint32_t key[kBatch], cnt[kBatch];
+    const uint32_t seg0 = base / n_rows, row0 = base - seg0 * n_rows;  // (uniform, once per batch)
+    uint32_t seg = seg0, row = row0;
+#pragma unroll
+    for (uint32_t j = 0; j < kBatch; ++j) {
+      // (past the end of the list: the last segment again, counted as empty -- the loads are unconditional)
+      const uint32_t* sp = a.cand + static_cast<size_t>(seg < nseg ? seg : nseg - 1u) * seg_words;
+      cnt[j] = seg < nseg ? sp[0] : 0u;  // (uniform address; only the validity test below waits for it)
+      const uint32_t i = row * kWave + lane;
+      key[j] = sp[kCandHead + (i < a.cand_cap ? i : a.cand_cap - 1u)];
+      if (++row == n_rows) {
+        row = 0;
+        ++seg;
+      }
+    }
+    row = row0;
+#pragma unroll
+    for (uint32_t j = 0; j < kBatch; ++j) {
+      const uint32_t i = row * kWave + lane;
+      const uint32_t d = key[j] - lo;
+      if (i < cnt[j] && d <= span) atomicAdd(&lds.lh[0][d >> sh], 1u);
+      if (++row == n_rows) row = 0;
+    }
+  }
+  __syncthreads();
+  return true;
+}
+
 // arrival + advance.  Returns true when this workgroup is to sweep again with the state in ol (a resident round).
 //
 // A selection's LAST launch must resolve every selector.  When the windows it starts from are already one value per
@@ -1707,8 +1782,10 @@ __device__ __forceinline__ bool win_finish(const Tab& tab, int n_shards, const O
                                            const uint32_t nwg, OneLds& ol, SweepLds<NSEL, BLOCK>& swl,
                                            AdvShared (&adv)[2], bool signs_in_slots, const bool resident,
                                            const uint32_t round) {
-  // this workgroup's adds are acknowledged before its arrival is counted
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  // this workgroup's adds are acknowledged before its arrival is counted (and its candidate keys -- plain stores --
+  // written back from this XCD's L2: the last arriver may run on another)
+  if (a.cand != nullptr) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __builtin_amdgcn_s_waitcnt(0);
   __syncthreads();
   unsigned long long* arrive64 = reinterpret_cast<unsigned long long*>(&a.st->arrivals);  // {arrivals, serial}
@@ -1789,6 +1866,9 @@ __device__ __forceinline__ bool win_finish(const Tab& tab, int n_shards, const O
   if (threadIdx.x == 0)
     __hip_atomic_fetch_add(arrive64, ~static_cast<unsigned long long>(nwg) + 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   one_stamp(a, 5);
+  // (the window the candidates were collected in: selector 0's before the advance replaces it)
+  const uint32_t w0_lo = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(ol.sel[0].lo));
+  const uint32_t w0_span = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(ol.sel[0].span));
   bool pair = false;
   if constexpr (NSEL == 2) pair = !ol.sel[0].done && !ol.sel[1].done;
   if (pair) {
@@ -1850,12 +1930,46 @@ __device__ __forceinline__ bool win_finish(const Tab& tab, int n_shards, const O
   if (!all_done) {
     // rounds nobody planned for, with everybody else gone: this workgroup sweeps alone until every selector is
     // resolved (each round narrows a window 2048-fold or replaces a missed one: at most 1 + ceil(32 / 11) more)
+    // With candidate segments (sbq_group_kth_value, fp32): the keys of the first window are all this needs -- unless
+    // a wave ran out of room (clustered data: a sorted tensor puts the whole window into a few waves) or the window
+    // missed its rank (the sample lied); then it is the tensor again, as before.
+    bool on_cand = false;
+    uint32_t n_rows = 0;
+    if constexpr (NSEL == 1 && T::id == SBQ_F32) {
+      if (a.cand != nullptr && round == 1u) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // (the other workgroups' plain stores: not out of a stale line)
+        const uint32_t nseg = nwg * (BLOCK / kWave);
+        uint32_t worst = 0;
+        for (uint32_t i = threadIdx.x; i < nseg; i += BLOCK) {
+          const uint32_t c = a.cand[static_cast<size_t>(i) * (kCandHead + a.cand_cap)];
+          worst = c > worst ? c : worst;
+        }
+        worst = dpp_reduce_u32(worst, 0u, [](uint32_t p, uint32_t q) { return p > q ? p : q; });
+        uint32_t* red = reinterpret_cast<uint32_t*>(&swl.red[0][0]);
+        __syncthreads();
+        if ((threadIdx.x & (kWave - 1)) == 0) red[threadIdx.x / kWave] = worst;
+        __syncthreads();
+        worst = 0;
+#pragma unroll
+        for (int w = 0; w < BLOCK / kWave; ++w) worst = red[w] > worst ? red[w] : worst;
+        __syncthreads();
+        const WinSel w1 = ol.sel[0];
+        const bool inside = w1.lo >= w0_lo && static_cast<uint64_t>(w1.lo) + w1.span <= static_cast<uint64_t>(w0_lo) + w0_span;
+        on_cand = worst <= a.cand_cap && inside;
+        n_rows = (worst + kWave - 1) / kWave;  // rows of 64 keys in the fullest segment
+      }
+    }
     for (int r = 0; r < 8; ++r) {
       __syncthreads();
-      const bool live = win_sweep<T, NSEL, false, BLOCK, false, false, true, true>(tab, n_shards, 0u, 1u, [&](WinSel (&sel)[NSEL]) {
+      bool live;
+      if (on_cand) {
+        live = cand_sweep_alone<NSEL, BLOCK>(a, nwg * (BLOCK / kWave), n_rows, ol.sel[0], swl);
+      } else {
+        live = win_sweep<T, NSEL, false, BLOCK, false, false, true, true>(tab, n_shards, 0u, 1u, [&](WinSel (&sel)[NSEL]) {
 #pragma unroll
-        for (int s = 0; s < NSEL; ++s) sel[s] = ol.sel[s];
-      }, a.slots, a.hist, a.use_abs, swl);
+          for (int s = 0; s < NSEL; ++s) sel[s] = ol.sel[s];
+        }, a.slots, a.hist, a.use_abs, swl);
+      }
       if (!live) break;
       __syncthreads();
 #pragma unroll
@@ -1900,7 +2014,8 @@ __device__ __forceinline__ bool win_is_resident(const OneArgs& a, const OneLds& 
   bool r = false;
 #pragma unroll
   for (int s = 0; s < NSEL; ++s) r |= ol.sel[s].done == 0 && (ol.sel[s].shift > a.min_shift || (ol.sel[s].side & 8u) != 0);
-  return a.final_round && (r || a.always_resident);
+  // (with candidate segments nobody waits: the last arriver finishes on them alone)
+  return a.final_round && (r || a.always_resident) && a.cand == nullptr;
 }
 
 // (wg of nwg: this workgroup's place among those that work on THIS selection -- the whole grid, or one item's share of
@@ -1932,7 +2047,13 @@ __device__ __forceinline__ void win_one_body(const Tab& tab, int n_shards, const
   one_stamp(a, 12);
   // ... then the slabs (win_sweep, EARLY), and the plan while they fly
   constexpr bool SIGNS = PCT && NSEL == 2;
-  win_sweep<T, NSEL, SIGNS, BLOCK, true, true, true, true>(tab, n_shards, wg, nwg, [&](WinSel (&sel)[NSEL]) {
+  constexpr bool COLLECT = T::id == SBQ_F32 && NSEL == 1 && !PCT;
+  uint32_t* cand_seg = nullptr;
+  if constexpr (COLLECT) {
+    if (a.cand != nullptr)  // this wave's segment: (workgroup, wave) of the item
+      cand_seg = a.cand + static_cast<size_t>(wg * (BLOCK / kWave) + threadIdx.x / kWave) * (kCandHead + a.cand_cap);
+  }
+  win_sweep<T, NSEL, SIGNS, BLOCK, true, true, true, true, COLLECT>(tab, n_shards, wg, nwg, [&](WinSel (&sel)[NSEL]) {
     one_stamp(a, 13);
     one_stamp(a, 1);
     plan_compute<T, BLOCK, true>(plan, sm, n_packs, a.mode, NSEL, a.use_abs, a.k0, a.k1, a.n, a.alpha, a.min_shift, ol.sel,
@@ -1966,7 +2087,7 @@ __device__ __forceinline__ void win_one_body(const Tab& tab, int n_shards, const
       w.side = __builtin_amdgcn_readfirstlane(w.side);
       sel[s] = w;
     }
-  }, a.slots, a.hist, a.use_abs, swl);
+  }, a.slots, a.hist, a.use_abs, swl, cand_seg, a.cand_cap);
   one_stamp(a, 3);
   const bool resident = win_is_resident<NSEL>(a, ol);
   const bool again = win_finish<T, NSEL, BLOCK>(tab, n_shards, a, wg, nwg, ol, swl, adv, SIGNS, resident, 1u);
@@ -2269,7 +2390,7 @@ __global__ __launch_bounds__(kH16Block) void h16_select_kernel(const void* x0, u
   const uint32_t n = n32;
   const uint32_t n_packs = n / kPack;  // >= 1
   const uint32_t amask2 = a.use_abs ? 0x7fff7fffu : 0xffffffffu;
-  constexpr uint32_t kZero16 = Key16<T>::kZero >> 16, kInf16 = Key16<T>::kInf >> 16;
+  constexpr uint32_t kZero16 = Key16<T>::kZero >> 16;
   static_assert((kZero16 & 1u) == 0 && (kZero16 & ((1u << kH16MiniShift) - 1u)) == 0, "-0 / +0 share a dword; -0 starts a sample bin");
   // ---- requests: the sample (wave 0 only, in front of its slabs: a wave's loads return in order), then four slabs ----
   const uint32_t s_packs = n_packs < static_cast<uint32_t>(kH16SamplePacks) ? n_packs : static_cast<uint32_t>(kH16SamplePacks);
@@ -2563,6 +2684,8 @@ struct KthItemArg {
   int64_t n, k;
   uint32_t n_lean, n_rag;  // whole 16 Ki-element slabs / the ragged rest (0 or 1)
   uint32_t wg_begin, nwg;
+  uint64_t cand_off;   // the item's candidate segments: word offset into the launch's candidate area
+  uint32_t cand_cap, pad;  // keys per segment (0: no collection for this item)
 };
 struct KthItems {
   KthItemArg it[kKthItemsPerLaunch];
@@ -2570,7 +2693,7 @@ struct KthItems {
 template <typename T, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void group_kth_kernel(const KthItems items, int n_items, char* regions, size_t region_bytes,
                                                           float* out, int use_abs, uint32_t min_shift, int round,
-                                                          int final_round, unsigned long long epoch) {
+                                                          int final_round, unsigned long long epoch, uint32_t* cand_area) {
   // the item of this workgroup: last one whose first workgroup is <= blockIdx.x (uniform: scalar loads)
   int lo = 0, hi = n_items - 1;
   while (lo < hi) {
@@ -2602,6 +2725,8 @@ __global__ __launch_bounds__(BLOCK) void group_kth_kernel(const KthItems items, 
   a.key_mode = T::id == SBQ_BF16 ? KEYS_BF16_RAW : (T::id == SBQ_F16 ? KEYS_F16_RAW : KEYS_F32);
   a.stamps = nullptr;
   a.epoch = epoch;
+  a.cand = cand_area != nullptr && me.cand_cap != 0 ? cand_area + me.cand_off : nullptr;
+  a.cand_cap = me.cand_cap;
   if (round == 0) win_one_body<T, 1, false, BLOCK>(tab, 1, a, blockIdx.x - me.wg_begin, me.nwg);
   else win_round_body<T, 1, BLOCK>(tab, 1, a, blockIdx.x - me.wg_begin, me.nwg);
 }
@@ -2656,9 +2781,9 @@ int win_h16_launch_t(int n_sel, unsigned grid, hipStream_t st, const void* table
 template <typename T>
 int win_group_launch_t(const void* items, int cnt, char* regions, size_t region_bytes, float* out, int use_abs,
                        uint32_t min_shift, int round, int final_round, unsigned long long epoch, unsigned grid,
-                       hipStream_t st) {
+                       hipStream_t st, uint32_t* cand_area) {
   group_kth_kernel<T, 1024><<<grid, 1024, 0, st>>>(*static_cast<const KthItems*>(items), cnt, regions, region_bytes, out,
-                                                  use_abs, min_shift, round, final_round, epoch);
+                                                  use_abs, min_shift, round, final_round, epoch, cand_area);
   return SBQ_OK;
 }
 
@@ -2675,7 +2800,7 @@ constexpr size_t kHistBytes = static_cast<size_t>(kCopies) * kWinSel * kWinBins 
 #define SBQ_WIN_ENGINE_ARGS int r, int n_sel, unsigned grid, hipStream_t st, const void* table, int single, int n_shards, const void* args
 #define SBQ_WIN_GROUP_ARGS                                                                                             \
   const void* items, int cnt, char* regions, size_t region_bytes, float* out, int use_abs, uint32_t min_shift, int round, \
-      int final_round, unsigned long long epoch, unsigned grid, hipStream_t st
+      int final_round, unsigned long long epoch, unsigned grid, hipStream_t st, uint32_t* cand_area
 int win_engine_launch_f32(SBQ_WIN_ENGINE_ARGS);
 int win_engine_launch_bf16(SBQ_WIN_ENGINE_ARGS);
 int win_engine_launch_f16(SBQ_WIN_ENGINE_ARGS);
@@ -2688,19 +2813,19 @@ int win_h16_launch_f16(SBQ_WIN_H16_ARGS);
 #if SBQ_WIN_PART == 0
 int win_engine_launch_f32(SBQ_WIN_ENGINE_ARGS) { return win_engine_launch_t<F32>(r, n_sel, grid, st, table, single, n_shards, args); }
 int win_group_launch_f32(SBQ_WIN_GROUP_ARGS) {
-  return win_group_launch_t<F32>(items, cnt, regions, region_bytes, out, use_abs, min_shift, round, final_round, epoch, grid, st);
+  return win_group_launch_t<F32>(items, cnt, regions, region_bytes, out, use_abs, min_shift, round, final_round, epoch, grid, st, cand_area);
 }
 #elif SBQ_WIN_PART == 1
 int win_h16_launch_bf16(SBQ_WIN_H16_ARGS) { return win_h16_launch_t<BF16>(n_sel, grid, st, table, args); }
 int win_engine_launch_bf16(SBQ_WIN_ENGINE_ARGS) { return win_engine_launch_t<BF16>(r, n_sel, grid, st, table, single, n_shards, args); }
 int win_group_launch_bf16(SBQ_WIN_GROUP_ARGS) {
-  return win_group_launch_t<BF16>(items, cnt, regions, region_bytes, out, use_abs, min_shift, round, final_round, epoch, grid, st);
+  return win_group_launch_t<BF16>(items, cnt, regions, region_bytes, out, use_abs, min_shift, round, final_round, epoch, grid, st, cand_area);
 }
 #else
 int win_h16_launch_f16(SBQ_WIN_H16_ARGS) { return win_h16_launch_t<F16>(n_sel, grid, st, table, args); }
 int win_engine_launch_f16(SBQ_WIN_ENGINE_ARGS) { return win_engine_launch_t<F16>(r, n_sel, grid, st, table, single, n_shards, args); }
 int win_group_launch_f16(SBQ_WIN_GROUP_ARGS) {
-  return win_group_launch_t<F16>(items, cnt, regions, region_bytes, out, use_abs, min_shift, round, final_round, epoch, grid, st);
+  return win_group_launch_t<F16>(items, cnt, regions, region_bytes, out, use_abs, min_shift, round, final_round, epoch, grid, st, cand_area);
 }
 #endif
 
@@ -3058,6 +3183,52 @@ int sbq_dist_select_advance(const int64_t* round_record, int x_dtype, int n_sel,
 }  // extern "C"
 
 namespace sbq {
+namespace {
+// The grid of one grouped launch (at most kKthItemsPerLaunch items): four slabs per workgroup (all of them in flight
+// before the windows are known) is what every item WANTS -- but the launch as a whole must fit the chip in one
+// sitting (one 1024-thread workgroup per compute unit): win_finish's resident rounds wait for an item's other
+// workgroups, and a waiting workgroup holds its compute unit, so workgroups that are not yet dispatched could only
+// start after the 100 us resignation.  When the wishes add up to more than the chip, every item keeps one workgroup
+// and the rest is shared out in proportion (a workgroup then walks more than four slabs: the sweep is grid-stride).
+// cand (fp32): every wave of an item's workgroups gets a candidate segment with room for a QUARTER of the keys it
+// sweeps (the first window holds a few per cent of a tensor: +-6 sigma of the sample's rank error) and at least 256.
+struct GroupPlan {
+  uint32_t nwg[kKthItemsPerLaunch];
+  uint32_t cand_cap[kKthItemsPerLaunch];
+  uint64_t cand_off[kKthItemsPerLaunch];  // words
+  uint64_t cand_words;
+  uint32_t grid;
+};
+GroupPlan group_plan(const sbq_kth_item* items, int cnt, int64_t cus, bool cand) {
+  constexpr int64_t slab = WinGeom<1024>::kSlab;
+  GroupPlan p{};
+  int64_t want[kKthItemsPerLaunch], extra_wanted = 0;
+  for (int j = 0; j < cnt; ++j) {
+    const int64_t slabs = ceil_div(items[j].numel, slab);
+    const int64_t nwg = ceil_div(slabs, static_cast<int64_t>(4));
+    want[j] = nwg < 1 ? 1 : (nwg > cus ? cus : nwg);
+    extra_wanted += want[j] - 1;
+  }
+  const int64_t budget = cus > cnt ? cus - cnt : 0;  // (cnt <= 64 <= any part's compute units)
+  for (int j = 0; j < cnt; ++j) {
+    int64_t nwg = want[j];
+    if (extra_wanted > budget) nwg = 1 + (want[j] - 1) * budget / extra_wanted;
+    p.nwg[j] = static_cast<uint32_t>(nwg);
+    p.grid += p.nwg[j];
+    if (cand) {
+      const int64_t slabs = ceil_div(items[j].numel, slab);
+      const int64_t per_wave = (ceil_div(slabs, nwg) + 1) * (slab / (1024 / kWave));  // keys a wave sweeps, at most
+      int64_t cap = per_wave / 4;
+      cap = cap < 256 ? 256 : cap;
+      cap = (cap + 15) / 16 * 16;
+      p.cand_cap[j] = static_cast<uint32_t>(cap);
+      p.cand_off[j] = p.cand_words;
+      p.cand_words += static_cast<uint64_t>(nwg) * (1024 / kWave) * (kCandHead + static_cast<uint64_t>(cap));
+    }
+  }
+  return p;
+}
+}  // namespace
 }  // namespace sbq
 
 extern "C" {
@@ -3065,6 +3236,21 @@ extern "C" {
 size_t sbq_group_kth_workspace_bytes(int n_items) {
   if (n_items <= 0) return 0;
   return static_cast<size_t>(n_items) * sbq::kOneRegion;
+}
+
+size_t sbq_group_kth_workspace_bytes_for(const sbq_kth_item* items, int n_items, int x_dtype) {
+  using namespace sbq;
+  if (n_items <= 0 || !items) return 0;
+  size_t bytes = sbq_group_kth_workspace_bytes(n_items);
+  if (x_dtype != SBQ_F32) return bytes;
+  const int64_t cus = cu_count();
+  uint64_t worst = 0;  // (the launches of a call run one after the other on one stream: they share the area)
+  for (int first = 0; first < n_items; first += kKthItemsPerLaunch) {
+    const int cnt = n_items - first < kKthItemsPerLaunch ? n_items - first : kKthItemsPerLaunch;
+    const GroupPlan p = group_plan(items + first, cnt, cus, true);
+    worst = p.cand_words > worst ? p.cand_words : worst;
+  }
+  return bytes + 256 + static_cast<size_t>(worst) * 4;
 }
 
 int sbq_group_kth_value(const sbq_kth_item* items, int n_items, int x_dtype, int use_abs, float* values_out,
@@ -3089,30 +3275,23 @@ int sbq_group_kth_value(const sbq_kth_item* items, int n_items, int x_dtype, int
     if (rc != SBQ_OK) return rc;
   }
   const uint32_t min_shift = x_dtype == SBQ_F32 ? 0u : 16u;
-  // fp32: TWO launches -- the second one resident, so a tensor whose rank needs a third sweep gets it inside that launch
-  // (measured on ResNet-50's 53 weights: 80 us against 89 for three launches; knob 2 == 21: three, for A/B runs.  A
-  // single fp32 selection keeps its three launches: 72 us against 79.)
-  const int expected = min_shift > 0 || knob(2) == 15 ? 1 : (knob(2) == 21 ? 3 : 2);
+  // fp32 with room for the candidate segments (sbq_group_kth_workspace_bytes_for; round 6): ONE launch -- the first
+  // sweep writes the keys inside the first window out, and each item's last arriver finishes on them alone (win_finish).
+  // Without that room (a workspace sized by sbq_group_kth_workspace_bytes; knob 2 == 34 for A/B runs): TWO launches,
+  // the second one resident, so a tensor whose rank needs a third sweep gets it inside that launch (round 3: 80 us on
+  // ResNet-50's 53 weights against 89 for three launches; knob 2 == 21: three.  A single fp32 selection keeps its
+  // three launches: 72 us against 79.)
+  const bool cand = x_dtype == SBQ_F32 && knob(2) != 34 && knob(2) != 21 && knob(2) != 15 &&
+                    workspace_bytes >= sbq_group_kth_workspace_bytes_for(items, n_items, x_dtype);
+  const int expected = min_shift > 0 || knob(2) == 15 || cand ? 1 : (knob(2) == 21 ? 3 : 2);
   const int64_t cus = cu_count();
+  const size_t cand_start = (sbq_group_kth_workspace_bytes(n_items) + 255) / 256 * 256;
+  uint32_t* cand_area = cand ? reinterpret_cast<uint32_t*>(static_cast<char*>(workspace) + cand_start) : nullptr;
   for (int first = 0; first < n_items; first += kKthItemsPerLaunch) {
     const int cnt = n_items - first < kKthItemsPerLaunch ? n_items - first : kKthItemsPerLaunch;
     KthItems args{};
+    const GroupPlan p = group_plan(items + first, cnt, cus, cand);
     uint32_t grid = 0;
-    // four slabs per workgroup (all of them in flight before the windows are known) is what every item WANTS -- but the
-    // launch as a whole must fit the chip in one sitting (one 1024-thread workgroup per compute unit): win_finish's
-    // resident rounds wait for an item's other workgroups, and a waiting workgroup holds its compute unit, so
-    // workgroups that are not yet dispatched could only start after the 100 us resignation.  When the wishes add up
-    // to more than the chip, every item keeps one workgroup and the rest is shared out in proportion (a workgroup then
-    // walks more than four slabs: the sweep is grid-stride).
-    int64_t want[kKthItemsPerLaunch], extra_wanted = 0;
-    for (int j = 0; j < cnt; ++j) {
-      const sbq_kth_item& it = items[first + j];
-      const int64_t slabs = it.numel / slab + (it.numel % slab ? 1 : 0);
-      int64_t nwg = ceil_div(slabs, static_cast<int64_t>(4));
-      want[j] = nwg < 1 ? 1 : (nwg > cus ? cus : nwg);
-      extra_wanted += want[j] - 1;
-    }
-    const int64_t budget = cus > cnt ? cus - cnt : 0;  // (cnt <= 64 <= any part's compute units)
     for (int j = 0; j < cnt; ++j) {
       const sbq_kth_item& it = items[first + j];
       KthItemArg& d = args.it[j];
@@ -3121,10 +3300,10 @@ int sbq_group_kth_value(const sbq_kth_item* items, int n_items, int x_dtype, int
       d.k = it.k;
       d.n_lean = static_cast<uint32_t>(it.numel / slab);
       d.n_rag = it.numel % slab ? 1u : 0u;
-      int64_t nwg = want[j];
-      if (extra_wanted > budget) nwg = 1 + (want[j] - 1) * budget / extra_wanted;
       d.wg_begin = grid;
-      d.nwg = static_cast<uint32_t>(nwg);
+      d.nwg = p.nwg[j];
+      d.cand_off = p.cand_off[j];
+      d.cand_cap = p.cand_cap[j];
       grid += d.nwg;
     }
     char* regions = static_cast<char*>(workspace) + static_cast<size_t>(first) * kOneRegion;
@@ -3132,7 +3311,7 @@ int sbq_group_kth_value(const sbq_kth_item* items, int n_items, int x_dtype, int
     for (int r = 0; r < expected; ++r) {
       auto fn = x_dtype == SBQ_F32 ? win_group_launch_f32 : (x_dtype == SBQ_BF16 ? win_group_launch_bf16 : win_group_launch_f16);
       int rc = fn(&args, cnt, regions, kOneRegion, values_out + first, use_abs, min_shift, r, r == expected - 1 ? 1 : 0, epoch,
-                  grid, st);
+                  grid, st, cand_area);
       if (rc != SBQ_OK) return rc;
     }
   }

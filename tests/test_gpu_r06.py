@@ -323,3 +323,91 @@ def test_concurrent_resident_selections_neither_hang_nor_differ(tmp_path, knob):
                 if r["first"] is not None:
                     f.write("  first mismatch: %r\n" % (r["first"],))
     assert [r["bad"] for r in res] == [0, 0], [r["first"] for r in res]
+
+
+# ---- grouped fp32 selection: candidate segments (sbq_group_kth_workspace_bytes_for) ------------------------------------
+def _group_cases(seed):
+    g = torch.Generator().manual_seed(seed)
+    xs, names = [], []
+
+    def add(name, t):
+        names.append(name)
+        xs.append(t.float().contiguous())
+
+    for n in (8, 9, 40, 1000, 16384, 16385, 70001, 300000, 16384 * 9, (1 << 20) + 3, 2359296):
+        add("gauss%d" % n, torch.randn(n, generator=g) * 0.02)
+    add("sorted", torch.sort(torch.randn(700000, generator=g))[0])          # the whole window in a few waves: overflow
+    add("reversed", torch.sort(torch.randn(500000, generator=g), descending=True)[0])
+    add("constant", torch.full((200000,), 0.37))
+    add("two_values", (torch.rand(300001, generator=g) < 0.5).float() * 2 - 1)
+    t = torch.randn(400000, generator=g)
+    t[:200000] = 0.25
+    add("half_tied", t[torch.randperm(400000, generator=g)])
+    add("heavy_tail", torch.randn(250000, generator=g) * torch.exp(3 * torch.randn(250000, generator=g)))
+    add("tiny_values", torch.randn(100000, generator=g) * 1e-30)
+    add("pruned", torch.randn(600000, generator=g) * (torch.rand(600000, generator=g) < 0.5))
+    t = torch.randn(123457, generator=g)
+    t[::1000] = float("nan")
+    add("nans", t)
+    stride = 300000 // 16384
+    t = torch.randn(300000, generator=g)
+    t[::stride] = 1000.0  # every sampled element is an outlier: the sample sees a constant, the window misses
+    add("period_eq_stride", t)
+    return names, xs
+
+
+@pytest.mark.parametrize("use_abs", [False, True])
+@pytest.mark.parametrize("which", ["half", "low", "high", "first", "last"])
+def test_group_kth_value_fp32_candidates(ops, use_abs, which):
+    """every item against a sort; the launch WITHOUT candidate segments (knob 2 = 34: round 5's two launches) agrees"""
+    from sparsebit_amd import lib as L
+
+    names, xs = _group_cases(11)
+    xd = [x.cuda() for x in xs]
+    ks = []
+    for x in xs:
+        n = x.numel()
+        ks.append({"half": max(n // 2, 1), "low": max(n // 1000, 1), "high": n - n // 1000, "first": 1, "last": n}[which])
+    got = ops.group_kth_value(xd, ks, use_abs).cpu().numpy()
+    L.set_tuning(2, 34)
+    try:
+        old = ops.group_kth_value(xd, ks, use_abs).cpu().numpy()
+    finally:
+        L.set_tuning(2, 0)
+    for i, x in enumerate(xs):
+        a = np.abs(x.numpy()) if use_abs else x.numpy()
+        want = np.sort(a, kind="stable")[ks[i] - 1]  # (NaN sorts last, as in torch.sort)
+        assert got[i] == want or (np.isnan(got[i]) and np.isnan(want)), (names[i], ks[i], got[i], want)
+        assert old[i] == want or (np.isnan(old[i]) and np.isnan(want)), ("knob 34", names[i], ks[i], old[i], want)
+
+
+def test_group_kth_value_fp32_more_items_than_one_launch(ops):
+    """150 items (64 per launch): the launches of a call share the candidate area one after the other"""
+    g = torch.Generator().manual_seed(3)
+    xs = [(torch.randn(20000 + 977 * i, generator=g) * (1 + 0.1 * i)).cuda() for i in range(150)]
+    ks = [1 + (x.numel() * (i % 7 + 1)) // 9 for i, x in enumerate(xs)]
+    for rep in range(3):  # (the workspace is reused: stale segments of the call before)
+        got = ops.group_kth_value(xs, ks, True).cpu().numpy()
+        for i, x in enumerate(xs):
+            want = np.sort(np.abs(x.cpu().numpy()))[ks[i] - 1]
+            assert got[i] == want, (rep, i, got[i], want)
+
+
+def test_group_kth_value_fp32_resnet50_thresholds(ops):
+    """the shapes of bench_configs' model-wide L1 thresholds (53 conv / fc weights of ResNet-50, ratio 0.5)"""
+    g = torch.Generator().manual_seed(50)
+    shapes = [(64, 3, 7, 7)]
+    inp = 64
+    for width, blocks in ((64, 3), (128, 4), (256, 6), (512, 3)):
+        for b in range(blocks):
+            shapes += [(width, inp, 1, 1), (width, width, 3, 3), (width * 4, width, 1, 1)]
+            if b == 0:
+                shapes.append((width * 4, inp, 1, 1))
+            inp = width * 4
+    shapes.append((1000, 2048))
+    xs = [(torch.randn(*s, generator=g) * (2.0 / (s[1] * (s[2] * s[3] if len(s) == 4 else 1))) ** 0.5).cuda() for s in shapes]
+    ks = [min(int(x.numel() * 0.5), x.numel() - 1) + 1 for x in xs]
+    got = ops.group_kth_value([x.reshape(-1) for x in xs], ks, True).cpu().numpy()
+    for i, x in enumerate(xs):
+        want = np.sort(np.abs(x.cpu().numpy().reshape(-1)))[ks[i] - 1]
+        assert got[i] == want, (shapes[i], got[i], want)

@@ -775,9 +775,9 @@ def model_wide_calibration(c):
         same = same and float(got[j].item()) == float(np.partition(a, ks[j] - 1)[ks[j] - 1])
     us_1 = sync_time(one_by_one_kth, 5)
     us_g = sync_time(lambda: ops.group_kth_value(ws, ks, True), 30)
-    out["mask_thresholds"] = _entry(us_g, nbytes, same, "grouped (ONE launch: the first window's keys collected, each item finished on them by its last arriver) == per-tensor sbq_kth_value on all %d "
+    out["mask_thresholds"] = _entry(us_g, nbytes, same, "grouped (2 launches: the first collects the keys inside each first window, the second -- resident -- finishes on those) == per-tensor sbq_kth_value on all %d "
                                     "tensors; three of them == numpy partition" % len(ws), one_by_one_us=round(us_1, 1),
-                                    launches_grouped=1)
+                                    launches_grouped=2)
     return out
 
 

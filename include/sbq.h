@@ -475,9 +475,9 @@ typedef struct {
 } sbq_kth_item;
 size_t sbq_group_kth_workspace_bytes(int n_items);
 /* fp32 items, round 6: a workspace of this size (instead of the one above, which stays valid) also holds the items'
- * CANDIDATE SEGMENTS -- the first sweep writes the keys inside each item's first window there (a few per cent of the
- * tensor; room for a quarter), and the selection is finished on them: ONE launch and one read of the tensors instead of
- * two launches and up to three reads.  The segment area needs no zeroing.  16-bit items: same size as above. */
+ * CANDIDATE SEGMENTS -- the first launch's sweep writes the keys inside each item's first window there (a tenth of the
+ * tensor; room for a quarter), and the second launch finishes the selection on them: one read of the tensors instead of
+ * two or three.  The segment area needs no zeroing.  16-bit items: same size as above (one launch anyway). */
 size_t sbq_group_kth_workspace_bytes_for(const sbq_kth_item* items, int n_items, int x_dtype);
 int sbq_group_kth_value(const sbq_kth_item* items, int n_items, int x_dtype, int use_abs, float* values_out,
                         void* workspace, size_t workspace_bytes, void* stream);

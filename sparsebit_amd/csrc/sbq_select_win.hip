@@ -966,7 +966,8 @@ template <typename T, int NSEL, bool SIGNS, int BLOCK, bool EARLY, bool FLUSH, b
 __device__ __forceinline__ bool win_sweep(const Tab& tab, int n_shards, const uint32_t wg, const uint32_t nwg,
                                           LoadState&& load_state, WinSlot* __restrict__ slots,
                                           uint32_t* __restrict__ hist, int use_abs, SweepLds<NSEL, BLOCK>& lds,
-                                          uint32_t* __restrict__ cand_seg = nullptr, const uint32_t cand_cap = 0) {
+                                          uint32_t* __restrict__ cand_seg = nullptr, const uint32_t cand_cap = 0,
+                                          unsigned long long* cand_over = nullptr, const unsigned long long cand_tag = 0) {
   static_assert(!COLLECT || (NSEL == 1 && !SIGNS && T::id == SBQ_F32), "candidates: one fp32 selector");
   constexpr uint32_t kSlab = WinGeom<BLOCK>::kSlab;
   constexpr int U = WinGeom<BLOCK>::kU;
@@ -1062,16 +1063,34 @@ __device__ __forceinline__ bool win_sweep(const Tab& tab, int n_shards, const ui
   // few per cent of the elements; only those go on to the window test, and the ones beyond the far end are what
   // the sweep counts (side 1: the keys ABOVE the window; the advance turns that into the keys below).
   constexpr bool ONESIDED = SIGNS && NSEL == 2;
-  uint32_t c_fill = 0;  // uniform: keys this wave has found inside the window (COLLECT)
+  // COLLECT: the hits of a wave instruction are compacted into the wave's staging ring in LDS (the pack queue of the
+  // 16-bit sweeps, idle here: 128 words) and leave it as whole rows of 64 keys -- one 256-byte store per row instead of
+  // a few scattered words per instruction.  Plain stores: the readers are the workgroups of the NEXT launch (the kernel
+  // boundary writes this XCD's L2 back and invalidates theirs).  (Read in the same launch by another XCD's workgroup
+  // -- a first version let each item's last arriver finish on them alone -- they need agent-scope write-through
+  // stores / loads, a release fence at agent scope writes back the WHOLE L2 once per workgroup: 100 us per launch, and
+  // one workgroup reading an item's megabyte of candidates took 50 us.)
+  uint32_t c_rows = 0, q_fill = 0, q_head = 0;  // uniform: rows written, keys staged, the ring's first key
+  uint32_t* const stage = reinterpret_cast<uint32_t*>(&lds.queue[threadIdx.x / kWave][0]);
+  auto put_row = [&](uint32_t n_keys) {  // the first n_keys (<= 64) staged keys become row c_rows of the segment
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t l = threadIdx.x & (kWave - 1);
+    const uint32_t v = stage[(q_head + l) & 127u];
+    if (c_rows * kWave + kWave <= cand_cap && l < n_keys) cand_seg[kCandHead + c_rows * kWave + l] = v;
+    __builtin_amdgcn_wave_barrier();
+  };
   auto collect = [&](uint32_t kk, bool hit) {
     const uint64_t m = __builtin_amdgcn_ballot_w64(hit);
     if (cand_seg != nullptr && m != 0) {  // uniform
-      const uint32_t c = static_cast<uint32_t>(__builtin_popcountll(m));
-      if (c_fill + c <= cand_cap) {
-        const uint32_t pos = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0u));
-        if (hit) cand_seg[kCandHead + c_fill + pos] = kk;
+      const uint32_t pos = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0u));
+      if (hit) stage[(q_head + q_fill + pos) & 127u] = kk;
+      q_fill += static_cast<uint32_t>(__builtin_popcountll(m));
+      if (q_fill >= kWave) {
+        put_row(kWave);
+        ++c_rows;  // (past cand_cap: nothing more is written, and the count says so)
+        q_head = (q_head + kWave) & 127u;
+        q_fill -= kWave;
       }
-      c_fill += c;  // (past cand_cap: nothing more is written, and the count says so)
     }
   };
   auto visit = [&](uint32_t kk, bool valid) {
@@ -1363,6 +1382,26 @@ __device__ __forceinline__ bool win_sweep(const Tab& tab, int n_shards, const ui
     const int64_t begin = static_cast<int64_t>(local) * kSlab;
     const int64_t end = begin + kSlab < n ? begin + kSlab : n;
     int64_t vend = begin;
+    if constexpr (COLLECT) {
+      // (the candidates are compacted by whole waves -- collect() -- so every lane walks the same number of steps here
+      // and brings a validity flag along; one fp32 selector, no RAW16)
+      if ((reinterpret_cast<uintptr_t>(x) & 15u) == 0) {
+        vend = begin + ((end - begin) / kPack) * kPack;
+        for (int64_t e0 = begin; e0 < vend; e0 += static_cast<int64_t>(BLOCK) * kPack) {
+          const int64_t e = e0 + static_cast<int64_t>(threadIdx.x) * kPack;
+          const bool there = e < vend;
+          float v[kPack];
+          load_pack<T, true>(x, there ? e : vend - kPack, v);
+#pragma unroll
+          for (int q = 0; q < kPack; ++q) visit(key_of(__builtin_bit_cast(uint32_t, v[q])), there);
+        }
+      }
+      for (int64_t e0 = vend; e0 < end; e0 += BLOCK) {
+        const int64_t e = e0 + threadIdx.x;
+        const bool there = e < end;
+        visit(key_of(__builtin_bit_cast(uint32_t, Elem<T>::load1(x, there ? e : end - 1))), there);
+      }
+    } else {
     if ((reinterpret_cast<uintptr_t>(x) & 15u) == 0) {
       vend = begin + ((end - begin) / kPack) * kPack;
       for (int64_t e = begin + static_cast<int64_t>(threadIdx.x) * kPack; e < vend; e += static_cast<int64_t>(BLOCK) * kPack) {
@@ -1386,9 +1425,17 @@ __device__ __forceinline__ bool win_sweep(const Tab& tab, int n_shards, const ui
       if constexpr (RAW16) visit(Key16<T>::one(static_cast<const uint16_t*>(x)[e], use_abs != 0), true);
       else visit(key_of(__builtin_bit_cast(uint32_t, Elem<T>::load1(x, e))), true);
     }
+    }
   }
   if constexpr (COLLECT) {
-    if (cand_seg != nullptr && lane0) cand_seg[0] = c_fill;
+    if (cand_seg != nullptr) {
+      if (q_fill) put_row(q_fill);
+      const uint32_t found = c_rows * kWave + q_fill;
+      if (lane0) cand_seg[0] = found;
+      // a segment that ran out of room (clustered data: a sorted tensor puts the whole window into a few waves) tells
+      // the item: its later launches sweep the tensor, as they did before there were candidates
+      if (lane0 && found > cand_cap) __hip_atomic_store(cand_over, cand_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
   // counters: lanes -> wave -> workgroup -> one of the 64 counter lines
   SBQ_SWEEP_STAMP(15);
@@ -1544,6 +1591,7 @@ struct OneArgs {
   // alone instead of the whole grid sweeping the tensor again (win_finish).  nullptr: no collection.
   uint32_t* cand;
   uint32_t cand_cap;
+  uint32_t cand_dbg;  // lab (knob 2 == 35 / 36): 1 = later launches ignore the candidates, 2 = the first launch stores none
   unsigned long long* stamps;  // development (knob 1 == 779): 8 timestamps per workgroup, else nullptr
 };
 // (compiled in only with -DSBQ_SEL_STAMPS=1 -- SBQ_EXTRA_HIPCC_FLAGS of sparsebit_amd/build.py: the conditional
@@ -1561,6 +1609,7 @@ struct OneLds {
   unsigned long long t0;  // s_memrealtime at the kernel's start (100 MHz)
   unsigned long long serial;  // st->serial as this workgroup's arrival found it
   uint32_t part, ticket;  // resident rounds: participants of the next round, this workgroup's index among them
+  uint32_t on_cand, n_seg;  // this launch sweeps the item's candidate segments (n_seg of them) instead of its tensor
 };
 template <typename V>
 __device__ __forceinline__ V one_take(V* p) {  // read and clear, at the memory side
@@ -1714,50 +1763,65 @@ __device__ __forceinline__ void one_advance_pair(const OneArgs& a, OneLds& ol, b
   __syncthreads();
 }
 
-// One workgroup alone over an item's candidate segments: the window's histogram in lds.lh[0] (what a lonely win_sweep
-// of the whole tensor leaves there -- the candidates are exactly the tensor's keys inside the FIRST window, and every
-// later window lies inside it).  The rows of 64 keys of all segments form one list (segment-major, n_rows per segment:
-// the fullest one's), dealt to the waves 32 at a time -- every load of a batch is in flight before the first is used.
+// A sweep over an item's candidate segments instead of its tensor (launches after the first of a grouped fp32
+// selection): the window's histogram, flushed like win_sweep's.  The candidates are exactly the tensor's keys inside
+// the FIRST window, and every later window lies inside it, so the histogram is the one a sweep of the tensor would
+// give.  Segment s belongs to (workgroup s / 16, wave s % 16) of the launch that wrote it; here wave `wid` of workgroup
+// `wg` of `nwg` takes segments wg * 16 + wid, + nwg * 16, ... -- with the first launch's grid that is its own segment,
+// one round trip: the count and the first kCandRows rows are requested together.
+constexpr uint32_t kCandRows = 12;
 template <int NSEL, int BLOCK>
-__device__ __forceinline__ bool cand_sweep_alone(const OneArgs& a, const uint32_t nseg, const uint32_t n_rows, const WinSel& w,
-                                                 SweepLds<NSEL, BLOCK>& lds) {
-  if (w.done) return false;
+__device__ __forceinline__ void cand_sweep(const OneArgs& a, const uint32_t nseg, const uint32_t wg, const uint32_t nwg,
+                                           const WinSel& w, SweepLds<NSEL, BLOCK>& lds) {
+  constexpr uint32_t kWaves = BLOCK / kWave;
   const uint32_t lo = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(w.lo));
   const uint32_t span = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(w.span));
   const uint32_t sh = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(w.shift));
-  for (uint32_t i = threadIdx.x; i < static_cast<uint32_t>(kWinBins); i += BLOCK) lds.lh[0][i] = 0;
-  __syncthreads();
-  constexpr uint32_t kBatch = 32, kWaves = BLOCK / kWave;
+  const bool act = __builtin_amdgcn_readfirstlane(w.done) == 0;
   const uint32_t lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
   const uint32_t seg_words = kCandHead + a.cand_cap;
-  const uint32_t total = nseg * n_rows;
-  for (uint32_t base = wid * kBatch; base < total; base += kWaves * kBatch) {
-    uint32_t key[kBatch], cnt[kBatch];
-    const uint32_t seg0 = base / n_rows, row0 = base - seg0 * n_rows;  // (uniform, once per batch)
-    uint32_t seg = seg0, row = row0;
+  // (the first segment's requests in front of the histogram's clearing)
+  uint32_t seg = wg * kWaves + wid;
+  auto request = [&](uint32_t sg, uint32_t& cnt, uint32_t (&key)[kCandRows]) {
+    const uint32_t* sp = a.cand + static_cast<size_t>(sg < nseg ? sg : nseg - 1u) * seg_words;
+    // (plain loads: written by the launch before)
+    cnt = sp[0];
 #pragma unroll
-    for (uint32_t j = 0; j < kBatch; ++j) {
-      // (past the end of the list: the last segment again, counted as empty -- the loads are unconditional)
-      const uint32_t* sp = a.cand + static_cast<size_t>(seg < nseg ? seg : nseg - 1u) * seg_words;
-      cnt[j] = seg < nseg ? sp[0] : 0u;  // (uniform address; only the validity test below waits for it)
-      const uint32_t i = row * kWave + lane;
-      key[j] = sp[kCandHead + (i < a.cand_cap ? i : a.cand_cap - 1u)];
-      if (++row == n_rows) {
-        row = 0;
-        ++seg;
-      }
+    for (uint32_t r = 0; r < kCandRows; ++r) {
+      const uint32_t i = r * kWave + lane;
+      key[r] = sp[kCandHead + (i < a.cand_cap ? i : a.cand_cap - 1u)];
     }
-    row = row0;
+  };
+  uint32_t cnt, key[kCandRows];
+  request(seg, cnt, key);
+  for (uint32_t i = threadIdx.x; i < static_cast<uint32_t>(NSEL * kWinBins); i += BLOCK) (&lds.lh[0][0])[i] = 0;
+  if (threadIdx.x < NSEL + 2) lds.tot[threadIdx.x] = 0;
+  lds_sync();
+  while (seg < nseg) {  // (wave-uniform)
+    if (!act) cnt = 0;
 #pragma unroll
-    for (uint32_t j = 0; j < kBatch; ++j) {
-      const uint32_t i = row * kWave + lane;
-      const uint32_t d = key[j] - lo;
-      if (i < cnt[j] && d <= span) atomicAdd(&lds.lh[0][d >> sh], 1u);
-      if (++row == n_rows) row = 0;
+    for (uint32_t r = 0; r < kCandRows; ++r) {
+      const uint32_t d = key[r] - lo;
+      if (r * kWave + lane < cnt && d <= span) atomicAdd(&lds.lh[0][d >> sh], 1u);
     }
+    const uint32_t* sp = a.cand + static_cast<size_t>(seg) * seg_words;
+    for (uint32_t i = kCandRows * kWave + lane; i < cnt; i += kWave) {  // a segment fuller than kCandRows rows
+      const uint32_t d = sp[kCandHead + i] - lo;
+      if (d <= span) atomicAdd(&lds.lh[0][d >> sh], 1u);
+    }
+    seg += nwg * kWaves;
+    if (seg < nseg) request(seg, cnt, key);
   }
   __syncthreads();
-  return true;
+  one_stamp(a, 28);
+  if (act) {
+    uint32_t* gh = a.hist + static_cast<size_t>(wg % kCopies) * kWinSel * kWinBins;
+    const uint32_t nb = (span >> sh) + 1u;
+    for (uint32_t i = threadIdx.x; i < nb; i += BLOCK) {
+      const uint32_t v = lds.lh[0][i];
+      if (v) atomicAdd(&gh[i], v);
+    }
+  }
 }
 
 // arrival + advance.  Returns true when this workgroup is to sweep again with the state in ol (a resident round).
@@ -1782,10 +1846,8 @@ __device__ __forceinline__ bool win_finish(const Tab& tab, int n_shards, const O
                                            const uint32_t nwg, OneLds& ol, SweepLds<NSEL, BLOCK>& swl,
                                            AdvShared (&adv)[2], bool signs_in_slots, const bool resident,
                                            const uint32_t round) {
-  // this workgroup's adds are acknowledged before its arrival is counted (and its candidate keys -- plain stores --
-  // written back from this XCD's L2: the last arriver may run on another)
-  if (a.cand != nullptr) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-  else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  // this workgroup's adds (and its candidate keys: write-through stores) are acknowledged before its arrival is counted
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __builtin_amdgcn_s_waitcnt(0);
   __syncthreads();
   unsigned long long* arrive64 = reinterpret_cast<unsigned long long*>(&a.st->arrivals);  // {arrivals, serial}
@@ -1886,6 +1948,12 @@ __device__ __forceinline__ bool win_finish(const Tab& tab, int n_shards, const O
       a.st->n = a.n;
       a.st->pad_neg = ol.neg;
       a.st->pad_nan = ol.nan;
+      // the window this launch's candidates were collected in, tagged with the selection's epoch (never cleared: a
+      // word of another selection matches nothing)
+      if (a.cand != nullptr && round == 1u) {
+        a.st->pad0[1] = static_cast<unsigned long long>(w0_lo) | (static_cast<unsigned long long>(w0_span) << 32);
+        a.st->pad0[2] = a.epoch;
+      }
     }
     return false;
   }
@@ -1930,46 +1998,12 @@ __device__ __forceinline__ bool win_finish(const Tab& tab, int n_shards, const O
   if (!all_done) {
     // rounds nobody planned for, with everybody else gone: this workgroup sweeps alone until every selector is
     // resolved (each round narrows a window 2048-fold or replaces a missed one: at most 1 + ceil(32 / 11) more)
-    // With candidate segments (sbq_group_kth_value, fp32): the keys of the first window are all this needs -- unless
-    // a wave ran out of room (clustered data: a sorted tensor puts the whole window into a few waves) or the window
-    // missed its rank (the sample lied); then it is the tensor again, as before.
-    bool on_cand = false;
-    uint32_t n_rows = 0;
-    if constexpr (NSEL == 1 && T::id == SBQ_F32) {
-      if (a.cand != nullptr && round == 1u) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // (the other workgroups' plain stores: not out of a stale line)
-        const uint32_t nseg = nwg * (BLOCK / kWave);
-        uint32_t worst = 0;
-        for (uint32_t i = threadIdx.x; i < nseg; i += BLOCK) {
-          const uint32_t c = a.cand[static_cast<size_t>(i) * (kCandHead + a.cand_cap)];
-          worst = c > worst ? c : worst;
-        }
-        worst = dpp_reduce_u32(worst, 0u, [](uint32_t p, uint32_t q) { return p > q ? p : q; });
-        uint32_t* red = reinterpret_cast<uint32_t*>(&swl.red[0][0]);
-        __syncthreads();
-        if ((threadIdx.x & (kWave - 1)) == 0) red[threadIdx.x / kWave] = worst;
-        __syncthreads();
-        worst = 0;
-#pragma unroll
-        for (int w = 0; w < BLOCK / kWave; ++w) worst = red[w] > worst ? red[w] : worst;
-        __syncthreads();
-        const WinSel w1 = ol.sel[0];
-        const bool inside = w1.lo >= w0_lo && static_cast<uint64_t>(w1.lo) + w1.span <= static_cast<uint64_t>(w0_lo) + w0_span;
-        on_cand = worst <= a.cand_cap && inside;
-        n_rows = (worst + kWave - 1) / kWave;  // rows of 64 keys in the fullest segment
-      }
-    }
     for (int r = 0; r < 8; ++r) {
       __syncthreads();
-      bool live;
-      if (on_cand) {
-        live = cand_sweep_alone<NSEL, BLOCK>(a, nwg * (BLOCK / kWave), n_rows, ol.sel[0], swl);
-      } else {
-        live = win_sweep<T, NSEL, false, BLOCK, false, false, true, true>(tab, n_shards, 0u, 1u, [&](WinSel (&sel)[NSEL]) {
+      const bool live = win_sweep<T, NSEL, false, BLOCK, false, false, true, true>(tab, n_shards, 0u, 1u, [&](WinSel (&sel)[NSEL]) {
 #pragma unroll
-          for (int s = 0; s < NSEL; ++s) sel[s] = ol.sel[s];
-        }, a.slots, a.hist, a.use_abs, swl);
-      }
+        for (int s = 0; s < NSEL; ++s) sel[s] = ol.sel[s];
+      }, a.slots, a.hist, a.use_abs, swl);
       if (!live) break;
       __syncthreads();
 #pragma unroll
@@ -1992,6 +2026,13 @@ __device__ __forceinline__ void win_resident_rounds(const Tab& tab, int n_shards
     __syncthreads();
     // this round's participants and this workgroup's place among them (win_finish: the verdict's mailbox / a ticket)
     const uint32_t wg = __builtin_amdgcn_readfirstlane(ol.ticket), nwg = __builtin_amdgcn_readfirstlane(ol.part);
+    if constexpr (NSEL == 1 && T::id == SBQ_F32) {
+      if (a.cand != nullptr && __builtin_amdgcn_readfirstlane(ol.on_cand) != 0) {
+        cand_sweep<NSEL, BLOCK>(a, __builtin_amdgcn_readfirstlane(ol.n_seg), wg, nwg, ol.sel[0], swl);
+        again = win_finish<T, NSEL, BLOCK>(tab, n_shards, a, wg, nwg, ol, swl, adv, false, true, round);
+        continue;
+      }
+    }
     win_sweep<T, NSEL, false, BLOCK, true, true, true, true>(tab, n_shards, wg, nwg, [&](WinSel (&sel)[NSEL]) {
 #pragma unroll
       for (int s = 0; s < NSEL; ++s) {
@@ -2014,8 +2055,7 @@ __device__ __forceinline__ bool win_is_resident(const OneArgs& a, const OneLds& 
   bool r = false;
 #pragma unroll
   for (int s = 0; s < NSEL; ++s) r |= ol.sel[s].done == 0 && (ol.sel[s].shift > a.min_shift || (ol.sel[s].side & 8u) != 0);
-  // (with candidate segments nobody waits: the last arriver finishes on them alone)
-  return a.final_round && (r || a.always_resident) && a.cand == nullptr;
+  return a.final_round && (r || a.always_resident);
 }
 
 // (wg of nwg: this workgroup's place among those that work on THIS selection -- the whole grid, or one item's share of
@@ -2087,7 +2127,7 @@ __device__ __forceinline__ void win_one_body(const Tab& tab, int n_shards, const
       w.side = __builtin_amdgcn_readfirstlane(w.side);
       sel[s] = w;
     }
-  }, a.slots, a.hist, a.use_abs, swl, cand_seg, a.cand_cap);
+  }, a.slots, a.hist, a.use_abs, swl, cand_seg, a.cand_dbg == 2u ? 0u : a.cand_cap, &a.st->pad0[0], a.epoch ^ (a.cand_dbg == 2u ? 1ull : 0ull));
   one_stamp(a, 3);
   const bool resident = win_is_resident<NSEL>(a, ol);
   const bool again = win_finish<T, NSEL, BLOCK>(tab, n_shards, a, wg, nwg, ol, swl, adv, SIGNS, resident, 1u);
@@ -2107,7 +2147,38 @@ __device__ __forceinline__ void win_round_body(const Tab& tab, int n_shards, con
   __shared__ AdvShared adv[2];
   __shared__ OneLds ol;
   __shared__ SweepLds<NSEL, BLOCK> swl;
-  if (threadIdx.x == 0) ol.t0 = __builtin_amdgcn_s_memrealtime();
+  if (threadIdx.x == 0) {
+    ol.t0 = __builtin_amdgcn_s_memrealtime();
+    ol.on_cand = 0;
+  }
+  one_stamp(a, 24);
+  bool on_cand = false;  // uniform
+  if constexpr (NSEL == 1 && T::id == SBQ_F32) {
+    if (a.cand != nullptr) {
+      // (all of it written by the launch before: plain loads.)  The candidates serve when the first launch left its
+      // window here (tagged with this selection's epoch), no segment ran out of room, and the mailbox's window lies
+      // inside that first one -- a window that missed its rank is replaced by `everything beyond it`.
+      const WinSel w = a.st->sel[0];
+      const unsigned long long w0 = a.st->pad0[1];
+      const uint32_t w0_lo = static_cast<uint32_t>(w0), w0_span = static_cast<uint32_t>(w0 >> 32);
+      on_cand = a.cand_dbg != 1u && a.st->pad0[2] == a.epoch && a.st->pad0[0] != a.epoch && w.lo >= w0_lo &&
+                static_cast<uint64_t>(w.lo) + w.span <= static_cast<uint64_t>(w0_lo) + w0_span;
+      if (on_cand) {
+        if (threadIdx.x == 0) {
+          ol.sel[0] = w;
+          ol.neg = a.st->pad_neg;
+          ol.nan = a.st->pad_nan;
+          ol.on_cand = 1;
+          ol.n_seg = nwg * (BLOCK / kWave);
+        }
+        __syncthreads();
+        one_stamp(a, 25);
+        cand_sweep<NSEL, BLOCK>(a, nwg * (BLOCK / kWave), wg, nwg, ol.sel[0], swl);
+        one_stamp(a, 26);
+      }
+    }
+  }
+  if (!on_cand)
   win_sweep<T, NSEL, false, BLOCK, true, true, true, true>(tab, n_shards, wg, nwg, [&](WinSel (&sel)[NSEL]) {
 #pragma unroll
     for (int s = 0; s < NSEL; ++s) sel[s] = a.st->sel[s];  // the previous launch's mailbox
@@ -2123,6 +2194,7 @@ __device__ __forceinline__ void win_round_body(const Tab& tab, int n_shards, con
   const bool resident = win_is_resident<NSEL>(a, ol);
   const bool again = win_finish<T, NSEL, BLOCK>(tab, n_shards, a, wg, nwg, ol, swl, adv, false, resident, 1u);
   if (a.final_round) win_resident_rounds<T, NSEL, BLOCK>(tab, n_shards, a, wg, nwg, ol, swl, adv, again);
+  one_stamp(a, 27);
 }
 template <typename T, int NSEL, int BLOCK, typename Tab>
 __global__ __launch_bounds__(BLOCK) void win_round_kernel(const Tab tab, int n_shards, const OneArgs a) {
@@ -2689,6 +2761,8 @@ struct KthItemArg {
 };
 struct KthItems {
   KthItemArg it[kKthItemsPerLaunch];
+  uint64_t stamp_off;  // development timestamps (SBQ_SEL_STAMPS builds): word offset into the candidate area
+  uint32_t cand_dbg, pad;
 };
 template <typename T, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void group_kth_kernel(const KthItems items, int n_items, char* regions, size_t region_bytes,
@@ -2724,9 +2798,14 @@ __global__ __launch_bounds__(BLOCK) void group_kth_kernel(const KthItems items, 
   a.final_round = final_round;
   a.key_mode = T::id == SBQ_BF16 ? KEYS_BF16_RAW : (T::id == SBQ_F16 ? KEYS_F16_RAW : KEYS_F32);
   a.stamps = nullptr;
+#if SBQ_SEL_STAMPS != 0
+  // development: 32 stamps per workgroup behind the candidate area (tools/lab/r06_group_stamps.py)
+  if (cand_area != nullptr) a.stamps = reinterpret_cast<unsigned long long*>(cand_area + items.stamp_off);
+#endif
   a.epoch = epoch;
   a.cand = cand_area != nullptr && me.cand_cap != 0 ? cand_area + me.cand_off : nullptr;
   a.cand_cap = me.cand_cap;
+  a.cand_dbg = items.cand_dbg;
   if (round == 0) win_one_body<T, 1, false, BLOCK>(tab, 1, a, blockIdx.x - me.wg_begin, me.nwg);
   else win_round_body<T, 1, BLOCK>(tab, 1, a, blockIdx.x - me.wg_begin, me.nwg);
 }
@@ -3250,7 +3329,7 @@ size_t sbq_group_kth_workspace_bytes_for(const sbq_kth_item* items, int n_items,
     const GroupPlan p = group_plan(items + first, cnt, cus, true);
     worst = p.cand_words > worst ? p.cand_words : worst;
   }
-  return bytes + 256 + static_cast<size_t>(worst) * 4;
+  return bytes + 256 + static_cast<size_t>(worst) * 4 + (SBQ_SEL_STAMPS != 0 ? 2048 * 32 * 8 : 0);
 }
 
 int sbq_group_kth_value(const sbq_kth_item* items, int n_items, int x_dtype, int use_abs, float* values_out,
@@ -3275,15 +3354,15 @@ int sbq_group_kth_value(const sbq_kth_item* items, int n_items, int x_dtype, int
     if (rc != SBQ_OK) return rc;
   }
   const uint32_t min_shift = x_dtype == SBQ_F32 ? 0u : 16u;
-  // fp32 with room for the candidate segments (sbq_group_kth_workspace_bytes_for; round 6): ONE launch -- the first
-  // sweep writes the keys inside the first window out, and each item's last arriver finishes on them alone (win_finish).
-  // Without that room (a workspace sized by sbq_group_kth_workspace_bytes; knob 2 == 34 for A/B runs): TWO launches,
-  // the second one resident, so a tensor whose rank needs a third sweep gets it inside that launch (round 3: 80 us on
-  // ResNet-50's 53 weights against 89 for three launches; knob 2 == 21: three.  A single fp32 selection keeps its
-  // three launches: 72 us against 79.)
+  // fp32: TWO launches -- the second one resident, so a tensor whose rank needs a third sweep gets it inside that launch
+  // (round 3: 80 us on ResNet-50's 53 weights against 89 for three launches; knob 2 == 21: three.  A single fp32
+  // selection keeps its three launches: 72 us against 79.)  With room for the candidate segments
+  // (sbq_group_kth_workspace_bytes_for; round 6) the first launch's sweep also writes the keys inside each item's first
+  // window out -- a tenth of the tensor -- and the second launch reads THOSE instead of the tensors (cand_sweep).
+  // knob 2 == 34: without, for A/B runs.
   const bool cand = x_dtype == SBQ_F32 && knob(2) != 34 && knob(2) != 21 && knob(2) != 15 &&
                     workspace_bytes >= sbq_group_kth_workspace_bytes_for(items, n_items, x_dtype);
-  const int expected = min_shift > 0 || knob(2) == 15 || cand ? 1 : (knob(2) == 21 ? 3 : 2);
+  const int expected = min_shift > 0 || knob(2) == 15 ? 1 : (knob(2) == 21 ? 3 : 2);
   const int64_t cus = cu_count();
   const size_t cand_start = (sbq_group_kth_workspace_bytes(n_items) + 255) / 256 * 256;
   uint32_t* cand_area = cand ? reinterpret_cast<uint32_t*>(static_cast<char*>(workspace) + cand_start) : nullptr;
@@ -3306,6 +3385,8 @@ int sbq_group_kth_value(const sbq_kth_item* items, int n_items, int x_dtype, int
       d.cand_cap = p.cand_cap[j];
       grid += d.nwg;
     }
+    args.stamp_off = (p.cand_words + 1) / 2 * 2;
+    args.cand_dbg = knob(2) == 35 ? 1u : (knob(2) == 36 ? 2u : 0u);
     char* regions = static_cast<char*>(workspace) + static_cast<size_t>(first) * kOneRegion;
     const unsigned long long epoch = next_epoch();
     for (int r = 0; r < expected; ++r) {

@@ -474,11 +474,6 @@ typedef struct {
   int64_t k;
 } sbq_kth_item;
 size_t sbq_group_kth_workspace_bytes(int n_items);
-/* fp32 items, round 6: a workspace of this size (instead of the one above, which stays valid) also holds the items'
- * CANDIDATE SEGMENTS -- the first launch's sweep writes the keys inside each item's first window there (a tenth of the
- * tensor; room for a quarter), and the second launch finishes the selection on them: one read of the tensors instead of
- * two or three.  The segment area needs no zeroing.  16-bit items: same size as above (one launch anyway). */
-size_t sbq_group_kth_workspace_bytes_for(const sbq_kth_item* items, int n_items, int x_dtype);
 int sbq_group_kth_value(const sbq_kth_item* items, int n_items, int x_dtype, int use_abs, float* values_out,
                         void* workspace, size_t workspace_bytes, void* stream);
 
@@ -630,7 +625,7 @@ int sbq_workspace_release(const void* workspace, size_t workspace_bytes);
  * advance / fallback launches) instead of the one-launch engine, 15 = an fp32 whole-tensor selection as ONE launch of resident
  * rounds instead of one launch per sweep, 16 = every whole-tensor selection waits for its verdict (resident) even when its plan expects
  * one sweep: +1.5-2 us, measured, 17 = the extraction kernel instead of the sorted lists in sbq_percentile_rows, 11 = general statistics kernel for a min-max-only call;
- * 34 = the grouped fp32 selection without candidate segments (two launches, every launch sweeps the tensors),
+ * 34 = the grouped fp32 selection without its candidate store (two launches, each sweeps the tensors),
  * 31 / 32 / 33 = TEST hook of the whole-tensor selections' resident rounds: a waiting workgroup resigns after half a microsecond
  * from round 1 / 2 / 3 on and never before -- results must not change). knob 3: resident schedule of the forward QDQ
  * (0 = auto: tensors that fit the chip's registers in one sitting, 1 = never, 2 = always).

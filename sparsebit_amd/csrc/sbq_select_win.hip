@@ -63,7 +63,6 @@ constexpr int kPlanShift = 19;
 constexpr int kPlanPacks = 2048;  // sampled packs of 8 consecutive elements
 constexpr int kMaxShards = 64;
 constexpr int kAdvBlock = 512;
-constexpr uint32_t kCandHead = 16;  // words in front of a candidate segment's keys (a 64-byte line: the count)
 
 struct WinSel {
   uint32_t lo;     // first key of the window
@@ -958,16 +957,18 @@ struct SweepLds {
 #define SBQ_SWEEP_STAMP(i) do { } while (0)
 #endif
 
-// COLLECT (fp32, one selector): every key inside the window is also appended to this wave's candidate segment
-// (cand_seg: count word, kCandHead - 1 unused words, cand_cap keys; nullptr = not this time) -- compacted per wave
-// instruction: a ballot, the lanes' ranks among the hits, one store of a few adjacent words.
+// COLLECT (fp32, one selector; sbq_group_kth_value): every key inside the window is also KEPT -- appended to this wave's
+// segment of LDS (cand_seg, room for cand_cap keys; nullptr = not this time), compacted per wave instruction: a ballot,
+// the lanes' ranks among the hits, one LDS write.  *cand_found = the keys the wave found (more than cand_cap: it ran
+// out of room, and what it kept is incomplete).  The rounds after the first re-bin these keys instead of reading the
+// tensor again (win_one_body).
 template <typename T, int NSEL, bool SIGNS, int BLOCK, bool EARLY, bool FLUSH, bool ALWAYS = false, bool KEY16 = false,
           bool COLLECT = false, typename Tab, typename LoadState>
 __device__ __forceinline__ bool win_sweep(const Tab& tab, int n_shards, const uint32_t wg, const uint32_t nwg,
                                           LoadState&& load_state, WinSlot* __restrict__ slots,
                                           uint32_t* __restrict__ hist, int use_abs, SweepLds<NSEL, BLOCK>& lds,
-                                          uint32_t* __restrict__ cand_seg = nullptr, const uint32_t cand_cap = 0,
-                                          unsigned long long* cand_over = nullptr, const unsigned long long cand_tag = 0) {
+                                          uint32_t* cand_seg = nullptr, const uint32_t cand_cap = 0,
+                                          uint32_t* cand_found = nullptr) {
   static_assert(!COLLECT || (NSEL == 1 && !SIGNS && T::id == SBQ_F32), "candidates: one fp32 selector");
   constexpr uint32_t kSlab = WinGeom<BLOCK>::kSlab;
   constexpr int U = WinGeom<BLOCK>::kU;
@@ -1063,34 +1064,16 @@ __device__ __forceinline__ bool win_sweep(const Tab& tab, int n_shards, const ui
   // few per cent of the elements; only those go on to the window test, and the ones beyond the far end are what
   // the sweep counts (side 1: the keys ABOVE the window; the advance turns that into the keys below).
   constexpr bool ONESIDED = SIGNS && NSEL == 2;
-  // COLLECT: the hits of a wave instruction are compacted into the wave's staging ring in LDS (the pack queue of the
-  // 16-bit sweeps, idle here: 128 words) and leave it as whole rows of 64 keys -- one 256-byte store per row instead of
-  // a few scattered words per instruction.  Plain stores: the readers are the workgroups of the NEXT launch (the kernel
-  // boundary writes this XCD's L2 back and invalidates theirs).  (Read in the same launch by another XCD's workgroup
-  // -- a first version let each item's last arriver finish on them alone -- they need agent-scope write-through
-  // stores / loads, a release fence at agent scope writes back the WHOLE L2 once per workgroup: 100 us per launch, and
-  // one workgroup reading an item's megabyte of candidates took 50 us.)
-  uint32_t c_rows = 0, q_fill = 0, q_head = 0;  // uniform: rows written, keys staged, the ring's first key
-  uint32_t* const stage = reinterpret_cast<uint32_t*>(&lds.queue[threadIdx.x / kWave][0]);
-  auto put_row = [&](uint32_t n_keys) {  // the first n_keys (<= 64) staged keys become row c_rows of the segment
-    __builtin_amdgcn_wave_barrier();
-    const uint32_t l = threadIdx.x & (kWave - 1);
-    const uint32_t v = stage[(q_head + l) & 127u];
-    if (c_rows * kWave + kWave <= cand_cap && l < n_keys) cand_seg[kCandHead + c_rows * kWave + l] = v;
-    __builtin_amdgcn_wave_barrier();
-  };
+  uint32_t c_fill = 0;  // uniform: keys this wave has found inside the window (COLLECT)
   auto collect = [&](uint32_t kk, bool hit) {
     const uint64_t m = __builtin_amdgcn_ballot_w64(hit);
     if (cand_seg != nullptr && m != 0) {  // uniform
-      const uint32_t pos = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0u));
-      if (hit) stage[(q_head + q_fill + pos) & 127u] = kk;
-      q_fill += static_cast<uint32_t>(__builtin_popcountll(m));
-      if (q_fill >= kWave) {
-        put_row(kWave);
-        ++c_rows;  // (past cand_cap: nothing more is written, and the count says so)
-        q_head = (q_head + kWave) & 127u;
-        q_fill -= kWave;
+      const uint32_t c = static_cast<uint32_t>(__builtin_popcountll(m));
+      if (c_fill + c <= cand_cap) {
+        const uint32_t pos = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0u));
+        if (hit) cand_seg[c_fill + pos] = kk;
       }
+      c_fill += c;  // (past cand_cap: nothing more is kept, and the count says so)
     }
   };
   auto visit = [&](uint32_t kk, bool valid) {
@@ -1402,40 +1385,33 @@ __device__ __forceinline__ bool win_sweep(const Tab& tab, int n_shards, const ui
         visit(key_of(__builtin_bit_cast(uint32_t, Elem<T>::load1(x, there ? e : end - 1))), there);
       }
     } else {
-    if ((reinterpret_cast<uintptr_t>(x) & 15u) == 0) {
-      vend = begin + ((end - begin) / kPack) * kPack;
-      for (int64_t e = begin + static_cast<int64_t>(threadIdx.x) * kPack; e < vend; e += static_cast<int64_t>(BLOCK) * kPack) {
-        if constexpr (RAW16) {
-          const RawPack<T> r = load_raw<T, true>(x, e);
+      if ((reinterpret_cast<uintptr_t>(x) & 15u) == 0) {
+        vend = begin + ((end - begin) / kPack) * kPack;
+        for (int64_t e = begin + static_cast<int64_t>(threadIdx.x) * kPack; e < vend; e += static_cast<int64_t>(BLOCK) * kPack) {
+          if constexpr (RAW16) {
+            const RawPack<T> r = load_raw<T, true>(x, e);
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const uint32_t k2 = Key16<T>::pack2(r.d[0][q], amask2);
-            visit(k2 << 16, true);
-            visit(k2 & 0xffff0000u, true);
+            for (int q = 0; q < 4; ++q) {
+              const uint32_t k2 = Key16<T>::pack2(r.d[0][q], amask2);
+              visit(k2 << 16, true);
+              visit(k2 & 0xffff0000u, true);
+            }
+          } else {
+            float v[kPack];
+            load_pack<T, true>(x, e, v);
+#pragma unroll
+            for (int q = 0; q < kPack; ++q) visit(key_of(__builtin_bit_cast(uint32_t, v[q])), true);
           }
-        } else {
-          float v[kPack];
-          load_pack<T, true>(x, e, v);
-#pragma unroll
-          for (int q = 0; q < kPack; ++q) visit(key_of(__builtin_bit_cast(uint32_t, v[q])), true);
         }
       }
-    }
-    for (int64_t e = vend + threadIdx.x; e < end; e += BLOCK) {
-      if constexpr (RAW16) visit(Key16<T>::one(static_cast<const uint16_t*>(x)[e], use_abs != 0), true);
-      else visit(key_of(__builtin_bit_cast(uint32_t, Elem<T>::load1(x, e))), true);
-    }
+      for (int64_t e = vend + threadIdx.x; e < end; e += BLOCK) {
+        if constexpr (RAW16) visit(Key16<T>::one(static_cast<const uint16_t*>(x)[e], use_abs != 0), true);
+        else visit(key_of(__builtin_bit_cast(uint32_t, Elem<T>::load1(x, e))), true);
+      }
     }
   }
   if constexpr (COLLECT) {
-    if (cand_seg != nullptr) {
-      if (q_fill) put_row(q_fill);
-      const uint32_t found = c_rows * kWave + q_fill;
-      if (lane0) cand_seg[0] = found;
-      // a segment that ran out of room (clustered data: a sorted tensor puts the whole window into a few waves) tells
-      // the item: its later launches sweep the tensor, as they did before there were candidates
-      if (lane0 && found > cand_cap) __hip_atomic_store(cand_over, cand_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    if (cand_found != nullptr) *cand_found = c_fill;
   }
   // counters: lanes -> wave -> workgroup -> one of the 64 counter lines
   SBQ_SWEEP_STAMP(15);
@@ -1585,13 +1561,10 @@ struct OneArgs {
   // test hook (knob 2 == 31 / 32 / 33): r > 0 = a waiting workgroup's patience is half a microsecond from round r on
   // (and unlimited before): the resignation path at a chosen point of a selection, in the production build
   int32_t test_resign;
-  // fp32 selections of sbq_group_kth_value (round 6): the keys INSIDE the first window are written out during the first
-  // sweep -- one segment of kCandHead + cand_cap words per wave of the item's workgroups, word 0 = the keys the wave
-  // found (more than cand_cap: the segment overflowed) -- and the item's last arriver finishes the selection on them
-  // alone instead of the whole grid sweeping the tensor again (win_finish).  nullptr: no collection.
-  uint32_t* cand;
+  // sbq_group_kth_value, fp32 (round 6): keys per wave of the workgroup's candidate store in (dynamic) LDS -- the first
+  // sweep keeps the keys inside the first window there, the rounds after it re-bin those instead of reading the
+  // tensor again (win_one_body).  0: no candidate store (every other caller).
   uint32_t cand_cap;
-  uint32_t cand_dbg;  // lab (knob 2 == 35 / 36): 1 = later launches ignore the candidates, 2 = the first launch stores none
   unsigned long long* stamps;  // development (knob 1 == 779): 8 timestamps per workgroup, else nullptr
 };
 // (compiled in only with -DSBQ_SEL_STAMPS=1 -- SBQ_EXTRA_HIPCC_FLAGS of sparsebit_amd/build.py: the conditional
@@ -1609,7 +1582,7 @@ struct OneLds {
   unsigned long long t0;  // s_memrealtime at the kernel's start (100 MHz)
   unsigned long long serial;  // st->serial as this workgroup's arrival found it
   uint32_t part, ticket;  // resident rounds: participants of the next round, this workgroup's index among them
-  uint32_t on_cand, n_seg;  // this launch sweeps the item's candidate segments (n_seg of them) instead of its tensor
+  uint32_t cand_bad;      // a wave of this workgroup ran out of room for its candidates
 };
 template <typename V>
 __device__ __forceinline__ V one_take(V* p) {  // read and clear, at the memory side
@@ -1763,67 +1736,6 @@ __device__ __forceinline__ void one_advance_pair(const OneArgs& a, OneLds& ol, b
   __syncthreads();
 }
 
-// A sweep over an item's candidate segments instead of its tensor (launches after the first of a grouped fp32
-// selection): the window's histogram, flushed like win_sweep's.  The candidates are exactly the tensor's keys inside
-// the FIRST window, and every later window lies inside it, so the histogram is the one a sweep of the tensor would
-// give.  Segment s belongs to (workgroup s / 16, wave s % 16) of the launch that wrote it; here wave `wid` of workgroup
-// `wg` of `nwg` takes segments wg * 16 + wid, + nwg * 16, ... -- with the first launch's grid that is its own segment,
-// one round trip: the count and the first kCandRows rows are requested together.
-constexpr uint32_t kCandRows = 12;
-template <int NSEL, int BLOCK>
-__device__ __forceinline__ void cand_sweep(const OneArgs& a, const uint32_t nseg, const uint32_t wg, const uint32_t nwg,
-                                           const WinSel& w, SweepLds<NSEL, BLOCK>& lds) {
-  constexpr uint32_t kWaves = BLOCK / kWave;
-  const uint32_t lo = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(w.lo));
-  const uint32_t span = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(w.span));
-  const uint32_t sh = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(w.shift));
-  const bool act = __builtin_amdgcn_readfirstlane(w.done) == 0;
-  const uint32_t lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
-  const uint32_t seg_words = kCandHead + a.cand_cap;
-  // (the first segment's requests in front of the histogram's clearing)
-  uint32_t seg = wg * kWaves + wid;
-  auto request = [&](uint32_t sg, uint32_t& cnt, uint32_t (&key)[kCandRows]) {
-    const uint32_t* sp = a.cand + static_cast<size_t>(sg < nseg ? sg : nseg - 1u) * seg_words;
-    // (plain loads: written by the launch before)
-    cnt = sp[0];
-#pragma unroll
-    for (uint32_t r = 0; r < kCandRows; ++r) {
-      const uint32_t i = r * kWave + lane;
-      key[r] = sp[kCandHead + (i < a.cand_cap ? i : a.cand_cap - 1u)];
-    }
-  };
-  uint32_t cnt, key[kCandRows];
-  request(seg, cnt, key);
-  for (uint32_t i = threadIdx.x; i < static_cast<uint32_t>(NSEL * kWinBins); i += BLOCK) (&lds.lh[0][0])[i] = 0;
-  if (threadIdx.x < NSEL + 2) lds.tot[threadIdx.x] = 0;
-  lds_sync();
-  while (seg < nseg) {  // (wave-uniform)
-    if (!act) cnt = 0;
-#pragma unroll
-    for (uint32_t r = 0; r < kCandRows; ++r) {
-      const uint32_t d = key[r] - lo;
-      if (r * kWave + lane < cnt && d <= span) atomicAdd(&lds.lh[0][d >> sh], 1u);
-    }
-    const uint32_t* sp = a.cand + static_cast<size_t>(seg) * seg_words;
-    for (uint32_t i = kCandRows * kWave + lane; i < cnt; i += kWave) {  // a segment fuller than kCandRows rows
-      const uint32_t d = sp[kCandHead + i] - lo;
-      if (d <= span) atomicAdd(&lds.lh[0][d >> sh], 1u);
-    }
-    seg += nwg * kWaves;
-    if (seg < nseg) request(seg, cnt, key);
-  }
-  __syncthreads();
-  one_stamp(a, 28);
-  if (act) {
-    uint32_t* gh = a.hist + static_cast<size_t>(wg % kCopies) * kWinSel * kWinBins;
-    const uint32_t nb = (span >> sh) + 1u;
-    for (uint32_t i = threadIdx.x; i < nb; i += BLOCK) {
-      const uint32_t v = lds.lh[0][i];
-      if (v) atomicAdd(&gh[i], v);
-    }
-  }
-}
-
 // arrival + advance.  Returns true when this workgroup is to sweep again with the state in ol (a resident round).
 //
 // A selection's LAST launch must resolve every selector.  When the windows it starts from are already one value per
@@ -1846,7 +1758,7 @@ __device__ __forceinline__ bool win_finish(const Tab& tab, int n_shards, const O
                                            const uint32_t nwg, OneLds& ol, SweepLds<NSEL, BLOCK>& swl,
                                            AdvShared (&adv)[2], bool signs_in_slots, const bool resident,
                                            const uint32_t round) {
-  // this workgroup's adds (and its candidate keys: write-through stores) are acknowledged before its arrival is counted
+  // this workgroup's adds are acknowledged before its arrival is counted
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __builtin_amdgcn_s_waitcnt(0);
   __syncthreads();
@@ -1928,9 +1840,6 @@ __device__ __forceinline__ bool win_finish(const Tab& tab, int n_shards, const O
   if (threadIdx.x == 0)
     __hip_atomic_fetch_add(arrive64, ~static_cast<unsigned long long>(nwg) + 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   one_stamp(a, 5);
-  // (the window the candidates were collected in: selector 0's before the advance replaces it)
-  const uint32_t w0_lo = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(ol.sel[0].lo));
-  const uint32_t w0_span = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(ol.sel[0].span));
   bool pair = false;
   if constexpr (NSEL == 2) pair = !ol.sel[0].done && !ol.sel[1].done;
   if (pair) {
@@ -1948,12 +1857,6 @@ __device__ __forceinline__ bool win_finish(const Tab& tab, int n_shards, const O
       a.st->n = a.n;
       a.st->pad_neg = ol.neg;
       a.st->pad_nan = ol.nan;
-      // the window this launch's candidates were collected in, tagged with the selection's epoch (never cleared: a
-      // word of another selection matches nothing)
-      if (a.cand != nullptr && round == 1u) {
-        a.st->pad0[1] = static_cast<unsigned long long>(w0_lo) | (static_cast<unsigned long long>(w0_span) << 32);
-        a.st->pad0[2] = a.epoch;
-      }
     }
     return false;
   }
@@ -1985,8 +1888,10 @@ __device__ __forceinline__ bool win_finish(const Tab& tab, int n_shards, const O
                               __HIP_MEMORY_SCOPE_AGENT);
       if (threadIdx.x == kSelWords) __hip_atomic_exchange(&a.st->pad_neg, ol.neg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (threadIdx.x == kSelWords + 1) __hip_atomic_exchange(&a.st->pad_nan, ol.nan, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      // (the exchanges return: they have been performed when their results are here)
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      // (the exchanges return: they have been performed -- at the memory side, where the pollers' own read-modify-writes
+      // will find them -- when their results are here.  An agent-scope release fence in this place wrote back this
+      // XCD's whole L2 before the verdict could go out: 25 us of every resident round, measured in round 6.)
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       __builtin_amdgcn_s_waitcnt(0);
       __syncthreads();
     }
@@ -2026,13 +1931,6 @@ __device__ __forceinline__ void win_resident_rounds(const Tab& tab, int n_shards
     __syncthreads();
     // this round's participants and this workgroup's place among them (win_finish: the verdict's mailbox / a ticket)
     const uint32_t wg = __builtin_amdgcn_readfirstlane(ol.ticket), nwg = __builtin_amdgcn_readfirstlane(ol.part);
-    if constexpr (NSEL == 1 && T::id == SBQ_F32) {
-      if (a.cand != nullptr && __builtin_amdgcn_readfirstlane(ol.on_cand) != 0) {
-        cand_sweep<NSEL, BLOCK>(a, __builtin_amdgcn_readfirstlane(ol.n_seg), wg, nwg, ol.sel[0], swl);
-        again = win_finish<T, NSEL, BLOCK>(tab, n_shards, a, wg, nwg, ol, swl, adv, false, true, round);
-        continue;
-      }
-    }
     win_sweep<T, NSEL, false, BLOCK, true, true, true, true>(tab, n_shards, wg, nwg, [&](WinSel (&sel)[NSEL]) {
 #pragma unroll
       for (int s = 0; s < NSEL; ++s) {
@@ -2088,10 +1986,12 @@ __device__ __forceinline__ void win_one_body(const Tab& tab, int n_shards, const
   // ... then the slabs (win_sweep, EARLY), and the plan while they fly
   constexpr bool SIGNS = PCT && NSEL == 2;
   constexpr bool COLLECT = T::id == SBQ_F32 && NSEL == 1 && !PCT;
+  extern __shared__ __attribute__((aligned(16))) uint32_t cand_lds[];  // (COLLECT: a.cand_cap keys per wave)
   uint32_t* cand_seg = nullptr;
+  uint32_t cand_found = 0;
   if constexpr (COLLECT) {
-    if (a.cand != nullptr)  // this wave's segment: (workgroup, wave) of the item
-      cand_seg = a.cand + static_cast<size_t>(wg * (BLOCK / kWave) + threadIdx.x / kWave) * (kCandHead + a.cand_cap);
+    if (a.cand_cap != 0) cand_seg = cand_lds + (threadIdx.x / kWave) * a.cand_cap;
+    if (threadIdx.x == 0) ol.cand_bad = 0;
   }
   win_sweep<T, NSEL, SIGNS, BLOCK, true, true, true, true, COLLECT>(tab, n_shards, wg, nwg, [&](WinSel (&sel)[NSEL]) {
     one_stamp(a, 13);
@@ -2127,11 +2027,72 @@ __device__ __forceinline__ void win_one_body(const Tab& tab, int n_shards, const
       w.side = __builtin_amdgcn_readfirstlane(w.side);
       sel[s] = w;
     }
-  }, a.slots, a.hist, a.use_abs, swl, cand_seg, a.cand_dbg == 2u ? 0u : a.cand_cap, &a.st->pad0[0], a.epoch ^ (a.cand_dbg == 2u ? 1ull : 0ull));
+  }, a.slots, a.hist, a.use_abs, swl, cand_seg, a.cand_cap, &cand_found);
   one_stamp(a, 3);
   const bool resident = win_is_resident<NSEL>(a, ol);
-  const bool again = win_finish<T, NSEL, BLOCK>(tab, n_shards, a, wg, nwg, ol, swl, adv, SIGNS, resident, 1u);
-  if (a.final_round) win_resident_rounds<T, NSEL, BLOCK>(tab, n_shards, a, wg, nwg, ol, swl, adv, again);
+  // (the window the candidates were kept for: every workgroup holds the plan's)
+  const uint32_t w0_lo = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(ol.sel[0].lo));
+  const uint32_t w0_span = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(ol.sel[0].span));
+  if constexpr (COLLECT) {
+    if (cand_seg != nullptr && (threadIdx.x & (kWave - 1)) == 0 && cand_found > a.cand_cap) ol.cand_bad = 1;  // (before win_finish's barriers)
+  }
+  bool again = win_finish<T, NSEL, BLOCK>(tab, n_shards, a, wg, nwg, ol, swl, adv, SIGNS, resident, 1u);
+  uint32_t round = 2;
+  if constexpr (COLLECT) {
+    // The rounds after the first, out of LDS: while every workgroup of the selection is still there (nobody resigned:
+    // win_finish) each one re-bins the keys it kept -- they are exactly its elements inside the FIRST window, and a
+    // narrowed window lies inside it -- flushes and arrives; a round costs the arrival / placement / verdict chain, no
+    // memory traffic.  A workgroup with a wave that ran out of room (clustered data: a sorted tensor puts the whole
+    // window into a few waves), or any workgroup when the window MISSED its rank (the sample lied: the new window is
+    // everything beyond the old one), sweeps its own slabs again instead -- the same elements, the same histogram.
+    if (cand_seg != nullptr) {
+      for (; again && round < 12; ++round) {
+        if (static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(ol.part)) != nwg) break;  // tickets over the tensor: below
+        __syncthreads();  // ol.sel: the narrowed window, fetched by win_finish
+        const uint32_t lo = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(ol.sel[0].lo));
+        const uint32_t span = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(ol.sel[0].span));
+        const uint32_t sh = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(ol.sel[0].shift));
+        const bool inside = lo >= w0_lo && static_cast<uint64_t>(lo) + span <= static_cast<uint64_t>(w0_lo) + w0_span;
+        if (inside && __builtin_amdgcn_readfirstlane(ol.cand_bad) == 0) {
+          for (uint32_t i = threadIdx.x; i < static_cast<uint32_t>(kWinBins); i += BLOCK) swl.lh[0][i] = 0;
+          if (threadIdx.x < NSEL + 2) swl.tot[threadIdx.x] = 0;
+          lds_sync();
+          for (uint32_t i = threadIdx.x & (kWave - 1); i < cand_found; i += kWave) {
+            const uint32_t d = cand_seg[i] - lo;
+            if (d <= span) atomicAdd(&swl.lh[0][d >> sh], 1u);
+          }
+          lds_sync();
+          uint32_t* gh = a.hist + static_cast<size_t>(wg % kCopies) * kWinSel * kWinBins;
+          const uint32_t nb = (span >> sh) + 1u;
+          for (uint32_t i = threadIdx.x; i < nb; i += BLOCK) {
+            const uint32_t v = swl.lh[0][i];
+            if (v) atomicAdd(&gh[i], v);
+          }
+        } else {
+          win_sweep<T, NSEL, false, BLOCK, true, true, true, true>(tab, n_shards, wg, nwg, [&](WinSel (&sel)[NSEL]) {
+#pragma unroll
+            for (int s = 0; s < NSEL; ++s) {
+              WinSel w = ol.sel[s];
+              w.lo = __builtin_amdgcn_readfirstlane(w.lo);
+              w.shift = __builtin_amdgcn_readfirstlane(w.shift);
+              w.span = __builtin_amdgcn_readfirstlane(w.span);
+              w.done = __builtin_amdgcn_readfirstlane(w.done);
+              w.fresh = __builtin_amdgcn_readfirstlane(w.fresh);
+              w.side = __builtin_amdgcn_readfirstlane(w.side);
+              sel[s] = w;
+            }
+          }, a.slots, a.hist, a.use_abs, swl);
+        }
+        one_stamp(a, 22 + (round < 5 ? round : 5));  // 24, 25, 26: flushed round 2, 3, 4
+        again = win_finish<T, NSEL, BLOCK>(tab, n_shards, a, wg, nwg, ol, swl, adv, false, true, round);
+      }
+    }
+  }
+  if constexpr (SBQ_SEL_STAMPS != 0) {
+    if (a.stamps && threadIdx.x == 0) a.stamps[blockIdx.x * 32 + 28] = (static_cast<unsigned long long>(round) << 32) | (ol.cand_bad << 16) | (again ? 1u : 0u);
+    if (a.stamps && threadIdx.x == 0) a.stamps[blockIdx.x * 32 + 23] = cand_found;
+  }
+  if (a.final_round) win_resident_rounds<T, NSEL, BLOCK>(tab, n_shards, a, wg, nwg, ol, swl, adv, again, round);
   one_stamp(a, 7);
 }
 template <typename T, int NSEL, bool PCT, int BLOCK, typename Tab>
@@ -2147,38 +2108,7 @@ __device__ __forceinline__ void win_round_body(const Tab& tab, int n_shards, con
   __shared__ AdvShared adv[2];
   __shared__ OneLds ol;
   __shared__ SweepLds<NSEL, BLOCK> swl;
-  if (threadIdx.x == 0) {
-    ol.t0 = __builtin_amdgcn_s_memrealtime();
-    ol.on_cand = 0;
-  }
-  one_stamp(a, 24);
-  bool on_cand = false;  // uniform
-  if constexpr (NSEL == 1 && T::id == SBQ_F32) {
-    if (a.cand != nullptr) {
-      // (all of it written by the launch before: plain loads.)  The candidates serve when the first launch left its
-      // window here (tagged with this selection's epoch), no segment ran out of room, and the mailbox's window lies
-      // inside that first one -- a window that missed its rank is replaced by `everything beyond it`.
-      const WinSel w = a.st->sel[0];
-      const unsigned long long w0 = a.st->pad0[1];
-      const uint32_t w0_lo = static_cast<uint32_t>(w0), w0_span = static_cast<uint32_t>(w0 >> 32);
-      on_cand = a.cand_dbg != 1u && a.st->pad0[2] == a.epoch && a.st->pad0[0] != a.epoch && w.lo >= w0_lo &&
-                static_cast<uint64_t>(w.lo) + w.span <= static_cast<uint64_t>(w0_lo) + w0_span;
-      if (on_cand) {
-        if (threadIdx.x == 0) {
-          ol.sel[0] = w;
-          ol.neg = a.st->pad_neg;
-          ol.nan = a.st->pad_nan;
-          ol.on_cand = 1;
-          ol.n_seg = nwg * (BLOCK / kWave);
-        }
-        __syncthreads();
-        one_stamp(a, 25);
-        cand_sweep<NSEL, BLOCK>(a, nwg * (BLOCK / kWave), wg, nwg, ol.sel[0], swl);
-        one_stamp(a, 26);
-      }
-    }
-  }
-  if (!on_cand)
+  if (threadIdx.x == 0) ol.t0 = __builtin_amdgcn_s_memrealtime();
   win_sweep<T, NSEL, false, BLOCK, true, true, true, true>(tab, n_shards, wg, nwg, [&](WinSel (&sel)[NSEL]) {
 #pragma unroll
     for (int s = 0; s < NSEL; ++s) sel[s] = a.st->sel[s];  // the previous launch's mailbox
@@ -2194,7 +2124,6 @@ __device__ __forceinline__ void win_round_body(const Tab& tab, int n_shards, con
   const bool resident = win_is_resident<NSEL>(a, ol);
   const bool again = win_finish<T, NSEL, BLOCK>(tab, n_shards, a, wg, nwg, ol, swl, adv, false, resident, 1u);
   if (a.final_round) win_resident_rounds<T, NSEL, BLOCK>(tab, n_shards, a, wg, nwg, ol, swl, adv, again);
-  one_stamp(a, 27);
 }
 template <typename T, int NSEL, int BLOCK, typename Tab>
 __global__ __launch_bounds__(BLOCK) void win_round_kernel(const Tab tab, int n_shards, const OneArgs a) {
@@ -2751,23 +2680,26 @@ __global__ __launch_bounds__(kH16Block) void h16_select_kernel(const void* x0, u
 // selection of its own (own sample, own windows, own region of the workspace, own arrival counter and last arriver)
 // and a share of the grid's workgroups proportional to its size; the items of a launch live in the kernel arguments.
 constexpr int kKthItemsPerLaunch = 64;
+// keys per wave of a workgroup's candidate store: 16 waves x 1344 x 4 B = 84 KB of dynamic LDS next to the kernel's
+// 73 KB of static LDS (160 KB per compute unit).  A wave sweeps up to 8 slabs of 1024 keys in a model-wide launch and
+// the first window holds a tenth of them (+-12 sigma of the sample's rank error).
+constexpr uint32_t kGroupCandCap = 1344;
 struct KthItemArg {
   const void* x;
   int64_t n, k;
   uint32_t n_lean, n_rag;  // whole 16 Ki-element slabs / the ragged rest (0 or 1)
   uint32_t wg_begin, nwg;
-  uint64_t cand_off;   // the item's candidate segments: word offset into the launch's candidate area
-  uint32_t cand_cap, pad;  // keys per segment (0: no collection for this item)
 };
 struct KthItems {
   KthItemArg it[kKthItemsPerLaunch];
-  uint64_t stamp_off;  // development timestamps (SBQ_SEL_STAMPS builds): word offset into the candidate area
-  uint32_t cand_dbg, pad;
+  uint32_t cand_cap, pad;  // fp32: keys per wave of every workgroup's candidate store (dynamic LDS); 0 = none
 };
-template <typename T, int BLOCK>
+// ONE: the launch is a selection's only one (fp32 with the candidate store) -- without win_round_body's 42 KB of static
+// LDS the store gets 86 KB next to win_one_body's 75 KB.
+template <typename T, int BLOCK, bool ONE>
 __global__ __launch_bounds__(BLOCK) void group_kth_kernel(const KthItems items, int n_items, char* regions, size_t region_bytes,
                                                           float* out, int use_abs, uint32_t min_shift, int round,
-                                                          int final_round, unsigned long long epoch, uint32_t* cand_area) {
+                                                          int final_round, unsigned long long epoch) {
   // the item of this workgroup: last one whose first workgroup is <= blockIdx.x (uniform: scalar loads)
   int lo = 0, hi = n_items - 1;
   while (lo < hi) {
@@ -2799,15 +2731,17 @@ __global__ __launch_bounds__(BLOCK) void group_kth_kernel(const KthItems items, 
   a.key_mode = T::id == SBQ_BF16 ? KEYS_BF16_RAW : (T::id == SBQ_F16 ? KEYS_F16_RAW : KEYS_F32);
   a.stamps = nullptr;
 #if SBQ_SEL_STAMPS != 0
-  // development: 32 stamps per workgroup behind the candidate area (tools/lab/r06_group_stamps.py)
-  if (cand_area != nullptr) a.stamps = reinterpret_cast<unsigned long long*>(cand_area + items.stamp_off);
+  // development: 32 stamps per workgroup behind the items' regions (tools/lab/r06_group_stamps.py)
+  a.stamps = reinterpret_cast<unsigned long long*>(regions + static_cast<size_t>(n_items) * region_bytes);
 #endif
   a.epoch = epoch;
-  a.cand = cand_area != nullptr && me.cand_cap != 0 ? cand_area + me.cand_off : nullptr;
-  a.cand_cap = me.cand_cap;
-  a.cand_dbg = items.cand_dbg;
-  if (round == 0) win_one_body<T, 1, false, BLOCK>(tab, 1, a, blockIdx.x - me.wg_begin, me.nwg);
-  else win_round_body<T, 1, BLOCK>(tab, 1, a, blockIdx.x - me.wg_begin, me.nwg);
+  a.cand_cap = items.cand_cap;
+  if constexpr (ONE) {
+    win_one_body<T, 1, false, BLOCK>(tab, 1, a, blockIdx.x - me.wg_begin, me.nwg);
+  } else {
+    if (round == 0) win_one_body<T, 1, false, BLOCK>(tab, 1, a, blockIdx.x - me.wg_begin, me.nwg);
+    else win_round_body<T, 1, BLOCK>(tab, 1, a, blockIdx.x - me.wg_begin, me.nwg);
+  }
 }
 
 // The engine's launches for ONE input type (see SBQ_WIN_PART at the top).  table: OneShard / PassTable, args: OneArgs,
@@ -2860,9 +2794,24 @@ int win_h16_launch_t(int n_sel, unsigned grid, hipStream_t st, const void* table
 template <typename T>
 int win_group_launch_t(const void* items, int cnt, char* regions, size_t region_bytes, float* out, int use_abs,
                        uint32_t min_shift, int round, int final_round, unsigned long long epoch, unsigned grid,
-                       hipStream_t st, uint32_t* cand_area) {
-  group_kth_kernel<T, 1024><<<grid, 1024, 0, st>>>(*static_cast<const KthItems*>(items), cnt, regions, region_bytes, out,
-                                                  use_abs, min_shift, round, final_round, epoch, cand_area);
+                       hipStream_t st) {
+  const KthItems& it = *static_cast<const KthItems*>(items);
+  const size_t lds = static_cast<size_t>(it.cand_cap) * (1024 / kWave) * sizeof(uint32_t);  // (fp32 only: the candidate store)
+  if constexpr (T::id == SBQ_F32) {
+    if (lds != 0) {
+      static bool once = [] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(group_kth_kernel<T, 1024, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  static_cast<int>(kGroupCandCap * (1024 / kWave) * sizeof(uint32_t)));
+        return true;
+      }();
+      (void)once;
+      group_kth_kernel<T, 1024, true><<<grid, 1024, lds, st>>>(it, cnt, regions, region_bytes, out, use_abs, min_shift, round,
+                                                              final_round, epoch);
+      return SBQ_OK;
+    }
+  }
+  group_kth_kernel<T, 1024, false><<<grid, 1024, 0, st>>>(it, cnt, regions, region_bytes, out, use_abs, min_shift, round, final_round,
+                                                         epoch);
   return SBQ_OK;
 }
 
@@ -2879,7 +2828,7 @@ constexpr size_t kHistBytes = static_cast<size_t>(kCopies) * kWinSel * kWinBins 
 #define SBQ_WIN_ENGINE_ARGS int r, int n_sel, unsigned grid, hipStream_t st, const void* table, int single, int n_shards, const void* args
 #define SBQ_WIN_GROUP_ARGS                                                                                             \
   const void* items, int cnt, char* regions, size_t region_bytes, float* out, int use_abs, uint32_t min_shift, int round, \
-      int final_round, unsigned long long epoch, unsigned grid, hipStream_t st, uint32_t* cand_area
+      int final_round, unsigned long long epoch, unsigned grid, hipStream_t st
 int win_engine_launch_f32(SBQ_WIN_ENGINE_ARGS);
 int win_engine_launch_bf16(SBQ_WIN_ENGINE_ARGS);
 int win_engine_launch_f16(SBQ_WIN_ENGINE_ARGS);
@@ -2892,19 +2841,19 @@ int win_h16_launch_f16(SBQ_WIN_H16_ARGS);
 #if SBQ_WIN_PART == 0
 int win_engine_launch_f32(SBQ_WIN_ENGINE_ARGS) { return win_engine_launch_t<F32>(r, n_sel, grid, st, table, single, n_shards, args); }
 int win_group_launch_f32(SBQ_WIN_GROUP_ARGS) {
-  return win_group_launch_t<F32>(items, cnt, regions, region_bytes, out, use_abs, min_shift, round, final_round, epoch, grid, st, cand_area);
+  return win_group_launch_t<F32>(items, cnt, regions, region_bytes, out, use_abs, min_shift, round, final_round, epoch, grid, st);
 }
 #elif SBQ_WIN_PART == 1
 int win_h16_launch_bf16(SBQ_WIN_H16_ARGS) { return win_h16_launch_t<BF16>(n_sel, grid, st, table, args); }
 int win_engine_launch_bf16(SBQ_WIN_ENGINE_ARGS) { return win_engine_launch_t<BF16>(r, n_sel, grid, st, table, single, n_shards, args); }
 int win_group_launch_bf16(SBQ_WIN_GROUP_ARGS) {
-  return win_group_launch_t<BF16>(items, cnt, regions, region_bytes, out, use_abs, min_shift, round, final_round, epoch, grid, st, cand_area);
+  return win_group_launch_t<BF16>(items, cnt, regions, region_bytes, out, use_abs, min_shift, round, final_round, epoch, grid, st);
 }
 #else
 int win_h16_launch_f16(SBQ_WIN_H16_ARGS) { return win_h16_launch_t<F16>(n_sel, grid, st, table, args); }
 int win_engine_launch_f16(SBQ_WIN_ENGINE_ARGS) { return win_engine_launch_t<F16>(r, n_sel, grid, st, table, single, n_shards, args); }
 int win_group_launch_f16(SBQ_WIN_GROUP_ARGS) {
-  return win_group_launch_t<F16>(items, cnt, regions, region_bytes, out, use_abs, min_shift, round, final_round, epoch, grid, st, cand_area);
+  return win_group_launch_t<F16>(items, cnt, regions, region_bytes, out, use_abs, min_shift, round, final_round, epoch, grid, st);
 }
 #endif
 
@@ -3262,74 +3211,13 @@ int sbq_dist_select_advance(const int64_t* round_record, int x_dtype, int n_sel,
 }  // extern "C"
 
 namespace sbq {
-namespace {
-// The grid of one grouped launch (at most kKthItemsPerLaunch items): four slabs per workgroup (all of them in flight
-// before the windows are known) is what every item WANTS -- but the launch as a whole must fit the chip in one
-// sitting (one 1024-thread workgroup per compute unit): win_finish's resident rounds wait for an item's other
-// workgroups, and a waiting workgroup holds its compute unit, so workgroups that are not yet dispatched could only
-// start after the 100 us resignation.  When the wishes add up to more than the chip, every item keeps one workgroup
-// and the rest is shared out in proportion (a workgroup then walks more than four slabs: the sweep is grid-stride).
-// cand (fp32): every wave of an item's workgroups gets a candidate segment with room for a QUARTER of the keys it
-// sweeps (the first window holds a few per cent of a tensor: +-6 sigma of the sample's rank error) and at least 256.
-struct GroupPlan {
-  uint32_t nwg[kKthItemsPerLaunch];
-  uint32_t cand_cap[kKthItemsPerLaunch];
-  uint64_t cand_off[kKthItemsPerLaunch];  // words
-  uint64_t cand_words;
-  uint32_t grid;
-};
-GroupPlan group_plan(const sbq_kth_item* items, int cnt, int64_t cus, bool cand) {
-  constexpr int64_t slab = WinGeom<1024>::kSlab;
-  GroupPlan p{};
-  int64_t want[kKthItemsPerLaunch], extra_wanted = 0;
-  for (int j = 0; j < cnt; ++j) {
-    const int64_t slabs = ceil_div(items[j].numel, slab);
-    const int64_t nwg = ceil_div(slabs, static_cast<int64_t>(4));
-    want[j] = nwg < 1 ? 1 : (nwg > cus ? cus : nwg);
-    extra_wanted += want[j] - 1;
-  }
-  const int64_t budget = cus > cnt ? cus - cnt : 0;  // (cnt <= 64 <= any part's compute units)
-  for (int j = 0; j < cnt; ++j) {
-    int64_t nwg = want[j];
-    if (extra_wanted > budget) nwg = 1 + (want[j] - 1) * budget / extra_wanted;
-    p.nwg[j] = static_cast<uint32_t>(nwg);
-    p.grid += p.nwg[j];
-    if (cand) {
-      const int64_t slabs = ceil_div(items[j].numel, slab);
-      const int64_t per_wave = (ceil_div(slabs, nwg) + 1) * (slab / (1024 / kWave));  // keys a wave sweeps, at most
-      int64_t cap = per_wave / 4;
-      cap = cap < 256 ? 256 : cap;
-      cap = (cap + 15) / 16 * 16;
-      p.cand_cap[j] = static_cast<uint32_t>(cap);
-      p.cand_off[j] = p.cand_words;
-      p.cand_words += static_cast<uint64_t>(nwg) * (1024 / kWave) * (kCandHead + static_cast<uint64_t>(cap));
-    }
-  }
-  return p;
-}
-}  // namespace
 }  // namespace sbq
 
 extern "C" {
 
 size_t sbq_group_kth_workspace_bytes(int n_items) {
   if (n_items <= 0) return 0;
-  return static_cast<size_t>(n_items) * sbq::kOneRegion;
-}
-
-size_t sbq_group_kth_workspace_bytes_for(const sbq_kth_item* items, int n_items, int x_dtype) {
-  using namespace sbq;
-  if (n_items <= 0 || !items) return 0;
-  size_t bytes = sbq_group_kth_workspace_bytes(n_items);
-  if (x_dtype != SBQ_F32) return bytes;
-  const int64_t cus = cu_count();
-  uint64_t worst = 0;  // (the launches of a call run one after the other on one stream: they share the area)
-  for (int first = 0; first < n_items; first += kKthItemsPerLaunch) {
-    const int cnt = n_items - first < kKthItemsPerLaunch ? n_items - first : kKthItemsPerLaunch;
-    const GroupPlan p = group_plan(items + first, cnt, cus, true);
-    worst = p.cand_words > worst ? p.cand_words : worst;
-  }
-  return bytes + 256 + static_cast<size_t>(worst) * 4 + (SBQ_SEL_STAMPS != 0 ? 2048 * 32 * 8 : 0);
+  return static_cast<size_t>(n_items) * sbq::kOneRegion + (SBQ_SEL_STAMPS != 0 ? 2048 * 32 * 8 : 0);
 }
 
 int sbq_group_kth_value(const sbq_kth_item* items, int n_items, int x_dtype, int use_abs, float* values_out,
@@ -3354,23 +3242,34 @@ int sbq_group_kth_value(const sbq_kth_item* items, int n_items, int x_dtype, int
     if (rc != SBQ_OK) return rc;
   }
   const uint32_t min_shift = x_dtype == SBQ_F32 ? 0u : 16u;
-  // fp32: TWO launches -- the second one resident, so a tensor whose rank needs a third sweep gets it inside that launch
-  // (round 3: 80 us on ResNet-50's 53 weights against 89 for three launches; knob 2 == 21: three.  A single fp32
-  // selection keeps its three launches: 72 us against 79.)  With room for the candidate segments
-  // (sbq_group_kth_workspace_bytes_for; round 6) the first launch's sweep also writes the keys inside each item's first
-  // window out -- a tenth of the tensor -- and the second launch reads THOSE instead of the tensors (cand_sweep).
-  // knob 2 == 34: without, for A/B runs.
-  const bool cand = x_dtype == SBQ_F32 && knob(2) != 34 && knob(2) != 21 && knob(2) != 15 &&
-                    workspace_bytes >= sbq_group_kth_workspace_bytes_for(items, n_items, x_dtype);
-  const int expected = min_shift > 0 || knob(2) == 15 ? 1 : (knob(2) == 21 ? 3 : 2);
+  // fp32 (round 6): ONE launch -- its sweep keeps the keys inside each item's first window (a tenth of the tensor) in
+  // LDS, and the rounds after it are resident rounds on those (win_one_body): one read of the tensors.
+  // knob 2 == 34: round 3's TWO launches (the second one resident, so a tensor whose rank needs a third sweep gets it
+  // inside that launch: 80 us on ResNet-50's 53 weights against 89 for three launches; knob 2 == 21: three).  A
+  // single fp32 selection keeps its three launches: 72 us against 79.
+  const bool keep = x_dtype == SBQ_F32 && knob(2) != 34 && knob(2) != 21;
+  const int expected = min_shift > 0 || knob(2) == 15 || keep ? 1 : (knob(2) == 21 ? 3 : 2);
   const int64_t cus = cu_count();
-  const size_t cand_start = (sbq_group_kth_workspace_bytes(n_items) + 255) / 256 * 256;
-  uint32_t* cand_area = cand ? reinterpret_cast<uint32_t*>(static_cast<char*>(workspace) + cand_start) : nullptr;
   for (int first = 0; first < n_items; first += kKthItemsPerLaunch) {
     const int cnt = n_items - first < kKthItemsPerLaunch ? n_items - first : kKthItemsPerLaunch;
     KthItems args{};
-    const GroupPlan p = group_plan(items + first, cnt, cus, cand);
+    args.cand_cap = keep ? kGroupCandCap : 0u;
     uint32_t grid = 0;
+    // four slabs per workgroup (all of them in flight before the windows are known) is what every item WANTS -- but the
+    // launch as a whole must fit the chip in one sitting (one 1024-thread workgroup per compute unit): win_finish's
+    // resident rounds wait for an item's other workgroups, and a waiting workgroup holds its compute unit, so
+    // workgroups that are not yet dispatched could only start after the 100 us resignation.  When the wishes add up
+    // to more than the chip, every item keeps one workgroup and the rest is shared out in proportion (a workgroup then
+    // walks more than four slabs: the sweep is grid-stride).
+    int64_t want[kKthItemsPerLaunch], extra_wanted = 0;
+    for (int j = 0; j < cnt; ++j) {
+      const sbq_kth_item& it = items[first + j];
+      const int64_t slabs = it.numel / slab + (it.numel % slab ? 1 : 0);
+      int64_t nwg = ceil_div(slabs, static_cast<int64_t>(4));
+      want[j] = nwg < 1 ? 1 : (nwg > cus ? cus : nwg);
+      extra_wanted += want[j] - 1;
+    }
+    const int64_t budget = cus > cnt ? cus - cnt : 0;  // (cnt <= 64 <= any part's compute units)
     for (int j = 0; j < cnt; ++j) {
       const sbq_kth_item& it = items[first + j];
       KthItemArg& d = args.it[j];
@@ -3379,20 +3278,18 @@ int sbq_group_kth_value(const sbq_kth_item* items, int n_items, int x_dtype, int
       d.k = it.k;
       d.n_lean = static_cast<uint32_t>(it.numel / slab);
       d.n_rag = it.numel % slab ? 1u : 0u;
+      int64_t nwg = want[j];
+      if (extra_wanted > budget) nwg = 1 + (want[j] - 1) * budget / extra_wanted;
       d.wg_begin = grid;
-      d.nwg = p.nwg[j];
-      d.cand_off = p.cand_off[j];
-      d.cand_cap = p.cand_cap[j];
+      d.nwg = static_cast<uint32_t>(nwg);
       grid += d.nwg;
     }
-    args.stamp_off = (p.cand_words + 1) / 2 * 2;
-    args.cand_dbg = knob(2) == 35 ? 1u : (knob(2) == 36 ? 2u : 0u);
     char* regions = static_cast<char*>(workspace) + static_cast<size_t>(first) * kOneRegion;
     const unsigned long long epoch = next_epoch();
     for (int r = 0; r < expected; ++r) {
       auto fn = x_dtype == SBQ_F32 ? win_group_launch_f32 : (x_dtype == SBQ_BF16 ? win_group_launch_bf16 : win_group_launch_f16);
       int rc = fn(&args, cnt, regions, kOneRegion, values_out + first, use_abs, min_shift, r, r == expected - 1 ? 1 : 0, epoch,
-                  grid, st, cand_area);
+                  grid, st);
       if (rc != SBQ_OK) return rc;
     }
   }

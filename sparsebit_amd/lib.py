@@ -130,7 +130,6 @@ _SIGNATURES = {
     "sbq_group_bwd_table_build": (c_int, [c_vp, c_int, c_vp, c_sz, c_vp, c_vp, c_vp, c_vp]),
     "sbq_quant_group_backward": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "sbq_group_kth_workspace_bytes": (c_sz, [c_int]),
-    "sbq_group_kth_workspace_bytes_for": (c_sz, [ctypes.POINTER(KthItem), c_int, c_int]),
     "sbq_group_kth_value": (c_int, [c_vp, c_int, c_int, c_int, c_vp, c_vp, c_sz, c_vp]),
     "sbq_calib_table_build": (c_int, [c_vp, c_int, c_vp, c_sz, c_vp, c_vp, c_vp]),
     "sbq_group_minmax_qparams": (c_int, [c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),

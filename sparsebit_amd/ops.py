@@ -1020,8 +1020,7 @@ def group_kth_value(tensors, ks, use_abs=False):
         items = (L.KthItem * len(idx))()
         for j, i in enumerate(idx):
             items[j] = L.KthItem(tensors[i].data_ptr(), tensors[i].numel(), int(ks[i]))
-        # (fp32: with room for the items' candidate segments -- the second launch reads those, not the tensors again)
-        nbytes = lib.sbq_group_kth_workspace_bytes_for(items, len(idx), L.dtype_id(tensors[idx[0]]))
+        nbytes = lib.sbq_group_kth_workspace_bytes(len(idx))
         key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
         ws = _group_kth_workspaces.get(key)
         if ws is None or ws.numel() < nbytes:

@@ -29,11 +29,7 @@ torch.cuda.synchronize()
 key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
 wsb = ops._group_kth_workspaces[key]
 nb = 2048 * 32 * 8
-items = (L.KthItem * len(ws))()
-for j, w in enumerate(ws):
-    items[j] = L.KthItem(w.data_ptr(), w.numel(), int(ks[j]))
-total = L.load().sbq_group_kth_workspace_bytes_for(items, len(ws), L.dtype_id(ws[0]))  # (the stamps are its last nb bytes)
-wsb = wsb[:total]
+total = wsb.numel()
 wsb[-nb:].zero_()
 ops.group_kth_value(ws, ks, True)
 torch.cuda.synchronize()
@@ -46,12 +42,17 @@ for i in np.where(anyst & ~used)[0]:
 print("rows present: first %d, last %d, missing inside: %r" % (np.where(anyst)[0].min(), np.where(anyst)[0].max(), sorted(set(range(int(np.where(anyst)[0].max()) + 1)) - set(np.where(anyst)[0].tolist()))))
 st = st[used]
 t0 = st[:, 0].min()
-t2 = st[:, 24][st[:, 24] > 0].min() if (st[:, 24] > 0).any() else t0
-print("second launch starts %.1f us after the first" % ((t2 - t0) / 100.0))
+info = st[:, 28].copy()
+found = st[:, 23].copy()
+st[:, 28] = 0
+st[:, 23] = 0
+print("rounds entered (next round number) histogram: %r; workgroups with a full wave store: %d; still unresolved after the LDS rounds: %d" % (
+    np.unique(info >> 32, return_counts=True), int(((info >> 16) & 1).sum()), int((info & 1).sum())))
+print("keys kept by wave 0 of each workgroup: median %d, max %d" % (np.median(found), found.max()))
 us = lambda a: (a - t0) / 100.0  # noqa: E731
 print("workgroups with stamps: %d" % len(st))
 cols = [(0, "start"), (11, "smp_req"), (12, "sample"), (13, "slabs_req"), (8, "plan8"), (9, "plan9"), (10, "plan10"), (2, "plan"), (15, "sw15"), (3, "swept"), (4, "arrived"), (5, "last:begin"), (6, "last:adv"), (20, "alone1"), (21, "alone2"),
-        (22, "alone3"), (7, "end"), (24, "L2:start"), (25, "L2:decided"), (28, "L2:binned"), (26, "L2:flushed"), (27, "L2:end")]
+        (22, "alone3"), (24, "r2:flushed"), (25, "r3:flushed"), (26, "r4:flushed"), (7, "end")]
 # (the second launch's stamps 4 / 5 / 6 overwrite the first's: with candidates, "arrived" .. "last:adv" are the second launch's)
 for c, name in cols:
     v = st[:, c]
@@ -61,6 +62,6 @@ for c, name in cols:
         print("%-11s n=%4d  min %6.1f  median %6.1f  p90 %6.1f  max %6.1f us" % (name, ok.sum(), u.min(), np.median(u), np.percentile(u, 90), u.max()))
 # the slowest last arrivers
 last = np.where(st[:, 5] > 0)[0]
-order = np.argsort(-st[:, 27])[:6] if (st[:, 27] > 0).any() else last[np.argsort(-st[last, 7])][:8]
+order = np.argsort(-st[:, 7])[:6]
 for i in order:
     print("wg row %4d: " % i + "  ".join("%s %.1f" % (n, us(st[i, c])) for c, n in cols if st[i, c] > 0))

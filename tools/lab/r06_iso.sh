@@ -2,7 +2,7 @@
 # 35 = collect but sweep the tensors again, 36 = collect nothing / read the (stale) segments)
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-for K in 0 34 35 36; do
+for K in 0 34; do
   rm -rf /tmp/iso_trace
   SBQ_KNOB2=$K timeout 200 rocprofv3 --kernel-trace --output-format csv -d /tmp/iso_trace -o iso -- python $R/tools/lab/r06_group_stamps.py > /tmp/iso.log 2>&1
   python - <<PY

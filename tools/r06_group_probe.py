@@ -34,7 +34,7 @@ def timed(iters):
 
 
 ref = torch.stack([ops.kth_value(w, k, True) for w, k in zip(ws, ks)])
-for knob, name in ((0, "candidate segments (2 launches)"), (34, "round 5: 2 launches")):
+for knob, name in ((0, "candidate store in LDS, 1 launch"), (34, "round 5: 2 launches")):
     L.set_tuning(2, knob)
     got = ops.group_kth_value(ws, ks, True)
     us = timed(200)

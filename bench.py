@@ -575,18 +575,27 @@ def main():
         xcpu = host.float()
         s_cpu = scale.cpu().reshape(-1, 1)
         z_cpu = zp.cpu().reshape(-1, 1)
+        # (round 6: the reported rate is the best MEDIAN of 5 over the thread counts -- best-of-20 swung 2.8 x between
+        # boxes; the single best run stays beside it.  OMP_PROC_BIND / OMP_PLACES, when the launcher sets them, pin
+        # torch's OpenMP threads; they cannot be changed once the runtime is up, so this process only reports them.)
         best, best_threads, reps = float("inf"), ncpu, 0
+        best_single = float("inf")
+        per_threads = {}
         t_begin = time.perf_counter()
         for threads in sorted({ncpu, min(ncpu, 64), min(ncpu, 32), min(ncpu, 16)}, reverse=True):
             torch.set_num_threads(threads)
             torch_port.ort_fake_quant_cpu(xcpu, s_cpu, z_cpu, QMIN, QMAX)  # warm-up
+            dts = []
             for _ in range(5):
                 a = time.perf_counter()
                 out = torch_port.ort_fake_quant_cpu(xcpu, s_cpu, z_cpu, QMIN, QMAX)
-                dt = time.perf_counter() - a
+                dts.append(time.perf_counter() - a)
                 reps += 1
-                if dt < best:
-                    best, best_threads = dt, threads
+            med = sorted(dts)[len(dts) // 2]
+            per_threads[threads] = round(med * 1e3, 2)
+            best_single = min(best_single, min(dts))
+            if med < best:
+                best, best_threads = med, threads
             if time.perf_counter() - t_begin > 20.0:
                 break
         torch.set_num_threads(best_threads)
@@ -599,9 +608,12 @@ def main():
             "cores": best_threads,
             "host_cores": ncpu,
             "kind": "port",
-            "sample": "full 4096x4096 weight (fp32 upcast of the same bf16 data), best of %d runs over thread "
-                      "counts {all,64,32,16} of the reference's CPU ops (quant_tensor.py:182-184) in torch, "
+            "sample": "full 4096x4096 weight (fp32 upcast of the same bf16 data), best MEDIAN-of-5 over thread "
+                      "counts {all,64,32,16} (%d runs) of the reference's CPU ops (quant_tensor.py:182-184) in torch, "
                       "%.1f ms" % (reps, best * 1e3),
+            "median_ms_per_thread_count": per_threads,
+            "value_best_single_run": round(n_elem / best_single, 1),
+            "omp_proc_bind": os.environ.get("OMP_PROC_BIND"),
             "matches_gpu_output": same,
         }
         if args.reference and os.path.isdir(os.path.join(args.reference, "sparsebit")):
@@ -704,6 +716,40 @@ def main():
         pass
 
     if rank == 0:
+        # what a reader of the DRIVER's record must be able to verify sits in `config` / `roofline` (the driver's parse
+        # keeps those; `extras` is dropped and its tail truncated): gates, the N = 1 RCCL floor, the worst leg
+        verify = {}
+        hg = extras.get("headline_gates") or {}
+        if hg:
+            verify["headline_gates_all"] = bool(hg.get("all"))
+            verify["headline_gate_rows_checked"] = hg.get("rows_checked")
+        if "all_config_gates_pass" in extras:
+            verify["all_config_gates_pass"] = bool(extras["all_config_gates_pass"])
+        ws1_ = extras.get("rccl_world_size_1") or {}
+        if ws1_.get("ran"):
+            lat_ = ws1_.get("latency", {})
+            verify["rccl_n1_allreduce_us"] = {"minmax_MAX_pack_unpack": lat_.get("minmax_pack_allreduce_unpack_us"),
+                                              "mse_fp64_SUM": lat_.get("mse_sum_us"),
+                                              "percentile_int64_SUM": lat_.get("percentile_hist_sum_us")}
+        elif world > 1:
+            verify["rccl_allreduce_us"] = {"minmax_MAX_pack_unpack": extras.get("observer_allreduce_us"),
+                                           "mse_fp64_SUM": extras.get("observer_allreduce_mse_sum_us"),
+                                           "percentile_int64_SUM": extras.get("observer_allreduce_percentile_hist_sum_us")}
+        worst = None
+
+        def _legs(d, path):
+            for k_, v_ in d.items():
+                if isinstance(v_, dict):
+                    if "us" in v_ and "frac" in v_ and v_.get("bound", "hbm") == "hbm":
+                        yield (path + k_, v_["frac"], v_["us"])
+                    yield from _legs(v_, path + k_ + ".")
+
+        for src in ("configs", "model_wide_calibration"):
+            for name_, frac_, us_ in _legs(extras.get(src) or {}, src + "."):
+                if worst is None or frac_ < worst[1]:
+                    worst = (name_, frac_, us_)
+        if worst is not None:
+            verify["worst_hbm_leg"] = {"name": worst[0], "frac": worst[1], "us": worst[2]}
         line = {
             "metric": "per-channel int8 QDQ throughput, 4096x4096 bf16 weight",
             "value": value,
@@ -723,6 +769,7 @@ def main():
                             % (NBUF, NBUF * 2 * n_elem * 2 // 2 ** 20),
                 "elements_per_step_per_gpu": n_elem,
                 "parallelism": "replicated weights, %d rank(s), no data-path collective" % world,
+                "verify": verify,
             },
             "roofline": {
                 "bound": "hbm",

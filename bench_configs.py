@@ -749,14 +749,27 @@ def model_wide_calibration(c):
     ref = one_by_one_mse()
     s_m, z_m, i_m = grp.mse_qparams()
     torch.cuda.synchronize(c.dev)
-    same = all(torch.equal(a[0].reshape(-1), s_m[i]) and torch.equal(a[2].reshape(-1), i_m[i]) for i, a in enumerate(ref))
-    _, _, b_o, _ = O.mse(ws[k].cpu().numpy().reshape(ws[k].shape[0], -1)[:64], -128, 127, True, 0, True)
-    same = same and bool(np.array_equal(i_m[k][:64].cpu().numpy(), b_o))
+    # (round 6: the grouped launch has a summation tree of its own; rows whose index differs from the per-tensor kernel's
+    # must be ties of the two candidates' losses in the oracle's fp64 sums -- oracle.mse_index_disagreements)
+    same, differing = True, 0
+    for i, a in enumerate(ref):
+        eq = a[2].reshape(-1) == i_m[i]
+        n_diff = int((~eq).sum())
+        differing += n_diff
+        same = same and torch.equal(a[0].reshape(-1)[eq], s_m[i][eq])
+        if n_diff:
+            rows = ws[i].reshape(ws[i].shape[0], -1).cpu().numpy()
+            same = same and O.mse_index_disagreements(rows, i_m[i].cpu().numpy(), a[2].reshape(-1).cpu().numpy(), -128, 127, True) == []
+    rows_k = ws[k].cpu().numpy().reshape(ws[k].shape[0], -1)[:64]
+    _, _, b_o, _ = O.mse(rows_k, -128, 127, True, 0, True)
+    same = same and O.mse_index_disagreements(rows_k, i_m[k][:64].cpu().numpy(), b_o, -128, 127, True) == []
     us_1 = sync_time(one_by_one_mse, 3)
     us_g = sync_time(grp.launch_mse, 20)
     evals = n_elem * L.MSE_CANDIDATES
-    out["mse_qparams"] = _entry(us_g, nbytes, same, "grouped (4 launches) == per-tensor calls: scale and argmin index of every "
-                                "channel of all %d tensors; 64 rows of tensor %d == oracle index" % (len(ws), k),
+    out["mse_qparams"] = _entry(us_g, nbytes, same, "grouped (4 launches; a lane per (row, candidate)) vs per-tensor calls: argmin index "
+                                "and scale of every channel of all %d tensors -- equal, or the two candidates' losses tie within 2e-6 in "
+                                "the oracle's fp64 sums (%d such rows); 64 rows of tensor %d vs the oracle's index likewise"
+                                % (len(ws), differing, k),
                                 bound="valu", one_by_one_us=round(us_1, 1), launches_grouped=4,
                                 valu_tflops=round(evals * MSE_FLOPS_PER_EVAL / us_g / 1e6, 1))
     # ---- L1 mask thresholds at 50 % ----

@@ -135,6 +135,27 @@ def mse(x, qmin, qmax, symmetric, ch_axis=0, per_channel=True):
     return s, z, b, sse
 
 
+def mse_index_disagreements(x_rows, idx_a, idx_b, qmin, qmax, symmetric, rel=2e-6):
+    """Two argmin indices per row of the MSE search (observers/mse.py:46-61) that were found with DIFFERENT summation
+    trees may name different candidates where two losses tie to the rounding of an fp32 mean (the reference's own
+    answer on such a row depends on torch's summation order, i.e. on its thread count).  -> the rows where idx_a and
+    idx_b differ AND this oracle's fp64 sums of the two candidates differ by more than `rel` (relative): real
+    disagreements.  x_rows: [R, inner] fp32 (only the rows that differ are evaluated)."""
+    x_rows = _f32(x_rows)
+    a = np.asarray(idx_a).reshape(-1)
+    b = np.asarray(idx_b).reshape(-1)
+    bad = []
+    for r in np.nonzero(a != b)[0]:
+        if a[r] < 0 or b[r] < 0:
+            bad.append(int(r))
+            continue
+        _, _, _, sse = mse(x_rows[r:r + 1], qmin, qmax, symmetric, 0, True)
+        la, lb = float(sse[0, a[r]]), float(sse[0, b[r]])
+        if not abs(la - lb) <= rel * max(abs(la), abs(lb)):
+            bad.append(int(r))
+    return bad
+
+
 def channel_first(x, ch_axis):
     """DataCache.get_data_for_calibration(CHANNELWISE) for ONE cached tensor
     (observers/base.py:27-31): [C, everything else]."""

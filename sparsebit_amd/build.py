@@ -48,6 +48,10 @@ def _hipcc():
 EXTRA_FLAGS = {
     "sbq_qdq.hip": ["-mllvm", "-amdgpu-kernarg-preload-count=14"],
     "sbq_qdq_resident.hip": ["-mllvm", "-amdgpu-kernarg-preload-count=14"],
+    # calib_mse_lanes_kernel: left alone, the SLP vectoriser pairs the loop's fmas into v_pk_fma_f32 and pays six
+    # v_mov per eight evaluations to line the operands up -- packed fp32 issues at 6-8 cycles against 4 for two plain
+    # ones (tools/lab/valu_rate.hip), so the pairing is a loss here
+    "sbq_calib.hip": ["-fno-slp-vectorize"],
 }
 # files compiled more than once: (object suffix, extra flags) per additional unit.  sbq_select_win.hip instantiates
 # the one-launch selection engine per input type in a unit of its own (SBQ_WIN_PART, see the top of that file): the

@@ -35,13 +35,15 @@ struct CalibItemDev {  // 64 bytes, read through the scalar unit
   uint32_t flags;
   uint32_t part_begin;     // first MSE partial record of the item
   uint32_t mse_waves;      // 0: a workgroup per 4096-element chunk; 1 / 2 / 4: a WAVE per row of <= 512 / 1024 / 2048
-                           // elements, holding that many of the per-tensor kernel's waves' shares
+                           // elements, holding that many of the per-tensor kernel's waves' shares (round 3; knob 2 == 37);
+                           // 8: a LANE per (row, candidate), four rows per workgroup (round 6: calib_mse_lanes_kernel)
 };
 static_assert(sizeof(CalibItemDev) == 64, "device table layout");
 
 struct CalibHeader {  // 64 bytes
   uint32_t n_items, n_seg_wgs, n_rows, n_chunks, n_segs, max_chunks_per_row, n_parts;
-  uint32_t pad[9];
+  uint32_t n_lane_chunks;  // the first n_lane_chunks MSE chunks are workgroups of calib_mse_lanes_kernel (round 6)
+  uint32_t pad[8];
 };
 static_assert(sizeof(CalibHeader) == 64, "device table layout");
 
@@ -253,14 +255,16 @@ template <typename T>
 __global__ __launch_bounds__(kBlock) void calib_mse_kernel(const CalibItemDev* __restrict__ items,
                                                            const uint32_t* __restrict__ chunk_item,
                                                            const float* __restrict__ min_base,
-                                                           const float* __restrict__ max_base, double* __restrict__ part) {
+                                                           const float* __restrict__ max_base, double* __restrict__ part,
+                                                           const uint32_t first_chunk) {
   __shared__ MseLds lds_w[kWavesPerBlock];
   MseLds& lds = lds_w[0];
-  const uint32_t idx = uread(chunk_item + blockIdx.x);
+  const uint32_t bid = blockIdx.x + first_chunk;  // (the table's chunk list starts with the lane kernel's workgroups)
+  const uint32_t idx = uread(chunk_item + bid);
   const CalibItemDev* it = items + idx;
   const uint32_t mode = uread(&it->mse_waves);
   if (mode != 0) {  // workgroup-uniform: a wave per row
-    const uint32_t row = (blockIdx.x - uread(&it->chunk_begin)) * kWavesPerBlock + threadIdx.x / kWave;
+    const uint32_t row = (bid - uread(&it->chunk_begin)) * kWavesPerBlock + threadIdx.x / kWave;
     if (mode == 1) mse_wave_rows<T, 1>(lds_w, it, row, min_base, max_base, part);
     else if (mode == 2) mse_wave_rows<T, 2>(lds_w, it, row, min_base, max_base, part);
     else mse_wave_rows<T, 4>(lds_w, it, row, min_base, max_base, part);
@@ -268,7 +272,7 @@ __global__ __launch_bounds__(kBlock) void calib_mse_kernel(const CalibItemDev* _
   }
   const uint32_t inner = uread(&it->inner);
   const uint32_t cpr = (inner + kMseChunk - 1) / kMseChunk;
-  const uint32_t ch = blockIdx.x - uread(&it->chunk_begin);
+  const uint32_t ch = bid - uread(&it->chunk_begin);
   const uint32_t row = cpr == 1 ? ch : udiv24(ch, cpr);
   const uint32_t k = ch - row * cpr;
   const int64_t begin = static_cast<int64_t>(k) * kMseChunk;
@@ -279,6 +283,110 @@ __global__ __launch_bounds__(kBlock) void calib_mse_kernel(const CalibItemDev* _
                                            max_base[off], qhi - qlo, qlo, qhi, (uread(&it->flags) & SBQ_CALIB_SYMMETRIC) != 0);
   if (threadIdx.x < SBQ_MSE_CANDIDATES)
     part[(static_cast<size_t>(uread(&it->part_begin)) + ch) * SBQ_MSE_CANDIDATES + threadIdx.x] = t;
+}
+
+// ---- round 6: a LANE per (row, candidate) ----------------------------------------------------------------------
+// The wave-per-row form above spends 9.8 wave instructions per 64 evaluations (the per-tensor kernel: 5.8): a wave
+// reduction, an exec-masked fp64 store, three LDS reads and two branches PER CANDIDATE for 8 ... 32 evaluations per lane,
+// and a 64-element row still occupies a whole wave.  Here the roles are turned round: four rows per workgroup of 320
+// threads, thread t = (row t / 80, candidate t % 80) -- five full waves, no idle lane whatever the row length -- and
+// every thread walks ITS candidate over ITS row's elements, which the workgroup stages in LDS tile by tile (a wave reads
+// at most two rows: the reads are broadcasts).  Per four elements: one ds_read_b128 and 4 x (mul, rndne, med3, fma,
+// fma) -- 5.25 instructions per evaluation, no cross-lane traffic at all, nothing per candidate.  The sum of squares
+// runs in four interleaved fp32 accumulators per tile of 1024 elements and in fp64 across tiles: a different (and
+// tighter) summation tree than the per-tensor kernel's, so the two may name neighbouring candidates where their losses
+// tie to fp32 rounding -- the gate is the argmin index with such ties allowed (tests/test_gpu_r06.py), as SURVEY 7
+// prescribes, not bit-identity of the sums.
+constexpr int kLaneRows = 4;
+constexpr int kLaneBlock = kLaneRows * SBQ_MSE_CANDIDATES;  // 320
+constexpr uint32_t kLaneTile = 1024;                        // elements of each row staged at a time (16 KB)
+constexpr uint32_t kLaneMaxInner = 16384;                   // longer rows (a per-tensor item): the chunk form above
+static_assert(kLaneBlock % kWave == 0, "whole waves");
+template <typename T>
+__global__ __launch_bounds__(kLaneBlock) void calib_mse_lanes_kernel(const CalibItemDev* __restrict__ items,
+                                                                    const uint32_t* __restrict__ chunk_item,
+                                                                    const float* __restrict__ min_base,
+                                                                    const float* __restrict__ max_base, double* __restrict__ part) {
+  // (+ 4 floats per row: the rows a wave straddles sit in different banks -- 4 KB apart they would share every bank)
+  __shared__ __attribute__((aligned(16))) float xs[kLaneRows][kLaneTile + 4];
+  const uint32_t idx = uread(chunk_item + blockIdx.x);
+  const CalibItemDev* it = items + idx;
+  const uint32_t inner = uread(&it->inner), C = uread(&it->C);
+  const uint32_t row0 = (blockIdx.x - uread(&it->chunk_begin)) * kLaneRows;
+  const uint32_t r = threadIdx.x / SBQ_MSE_CANDIDATES, cand = threadIdx.x - r * SBQ_MSE_CANDIDATES;
+  const uint32_t row = row0 + r;
+  const bool live = row < C;
+  const uint64_t off = uread(&it->out_off) + (live ? row : row0);
+  const float qlo = uread(&it->qlo), qhi = uread(&it->qhi);
+  float s, z;
+  mse_candidate(min_base[off], max_base[off], static_cast<int>(cand), qhi - qlo, (uread(&it->flags) & SBQ_CALIB_SYMMETRIC) != 0, s, z);
+  const bool fast = fast_div_ok(s);
+  const float y = fast ? 1.0f / s : 0.0f;
+  // every candidate of the workgroup's rows on the fast division with zero point 0 (any symmetric scheme on ordinary
+  // data): the branch-free loop.  (mse_chunk_body's three forms of one element's error, operation for operation.)
+  const bool plain = __syncthreads_and(fast && z == 0.0f) != 0;
+  const void* x = uread(&it->x);
+  const float* xr = xs[r];
+  double total = 0.0;
+  for (uint32_t t0 = 0; t0 < inner; t0 += kLaneTile) {  // (uniform)
+    const uint32_t n = inner - t0 < kLaneTile ? inner - t0 : kLaneTile;  // a multiple of 8 (the host admits whole packs)
+    const uint32_t ppr = n / kPack;                                      // packs per row in this tile
+    for (uint32_t p = threadIdx.x; p < kLaneRows * ppr; p += kLaneBlock) {
+      const uint32_t rr = p / ppr, pp = p - rr * ppr;
+      const uint32_t src_row = row0 + rr < C ? row0 + rr : row0;  // (rows past the item's last: a copy of row0, never stored)
+      float v[kPack];
+      load_pack<T, true>(x, static_cast<int64_t>(src_row) * inner + t0 + pp * kPack, v);
+      float4* dst = reinterpret_cast<float4*>(&xs[rr][pp * kPack]);
+      dst[0] = float4{v[0], v[1], v[2], v[3]};
+      dst[1] = float4{v[4], v[5], v[6], v[7]};
+    }
+    __syncthreads();
+    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+    if (plain) {
+#pragma unroll 2
+      for (uint32_t j = 0; j < n; j += 4) {
+        const float4 v = *reinterpret_cast<const float4*>(xr + j);
+        const float l0 = __builtin_amdgcn_fmed3f(__builtin_rintf(v.x * y), qlo, qhi);
+        const float l1 = __builtin_amdgcn_fmed3f(__builtin_rintf(v.y * y), qlo, qhi);
+        const float l2 = __builtin_amdgcn_fmed3f(__builtin_rintf(v.z * y), qlo, qhi);
+        const float l3 = __builtin_amdgcn_fmed3f(__builtin_rintf(v.w * y), qlo, qhi);
+        const float d0 = __builtin_fmaf(-l0, s, v.x), d1 = __builtin_fmaf(-l1, s, v.y);
+        const float d2 = __builtin_fmaf(-l2, s, v.z), d3 = __builtin_fmaf(-l3, s, v.w);
+        a0 = __builtin_fmaf(d0, d0, a0);
+        a1 = __builtin_fmaf(d1, d1, a1);
+        a2 = __builtin_fmaf(d2, d2, a2);
+        a3 = __builtin_fmaf(d3, d3, a3);
+      }
+    } else {
+      for (uint32_t j = 0; j < n; j += 4) {
+        const float4 v4 = *reinterpret_cast<const float4*>(xr + j);
+        const float v[4] = {v4.x, v4.y, v4.z, v4.w};
+        float e[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          if (fast) {
+            if (z == 0.0f) {
+              const float lv = __builtin_amdgcn_fmed3f(__builtin_rintf(v[q] * y), qlo, qhi);
+              e[q] = __builtin_fmaf(-lv, s, v[q]);
+            } else {
+              const float lv = __builtin_amdgcn_fmed3f(__builtin_rintf(v[q] * y) + z, qlo, qhi);
+              e[q] = __builtin_fmaf(-(lv - z), s, v[q]);
+            }
+          } else {
+            const float lv = quant_level<SBQ_ROUND_HALF_EVEN>(v[q], s, z, qlo, qhi);
+            e[q] = v[q] - dequant_level(lv, s, z);
+          }
+        }
+        a0 = __builtin_fmaf(e[0], e[0], a0);
+        a1 = __builtin_fmaf(e[1], e[1], a1);
+        a2 = __builtin_fmaf(e[2], e[2], a2);
+        a3 = __builtin_fmaf(e[3], e[3], a3);
+      }
+    }
+    total += static_cast<double>((a0 + a1) + (a2 + a3));
+    __syncthreads();  // (the tile is read; the next one may be staged)
+  }
+  if (live) part[(static_cast<size_t>(uread(&it->part_begin)) + row) * SBQ_MSE_CANDIDATES + cand] = total;
 }
 
 // Three rows per workgroup, a thread per (row, candidate): the row's chunks are summed in the per-tensor path's
@@ -540,9 +648,19 @@ int sbq_calib_table_build(const sbq_calib_item* items, int n_items, void* host_t
   if (n_items == 0) return SBQ_ERR_EMPTY;
   if (!items) return SBQ_ERR_NULL;
   uint64_t seg_wgs = 0, segs = 0, rows = 0, chunks = 0, max_cpr = 0, parts = 0;
-  auto mse_mode = [](int64_t inner) -> uint32_t {  // virtual waves of a wave-per-row item, 0: workgroup per chunk
+  // 8: a lane per (row, candidate) (round 6; rows of at most kLaneMaxInner elements); knob 2 == 37: round 3's forms --
+  // 1 / 2 / 4 virtual waves of a wave-per-row item, 0: workgroup per chunk
+  const bool lanes = knob(2) != 37;
+  auto mse_mode = [lanes](int64_t inner) -> uint32_t {
+    if (lanes && inner <= static_cast<int64_t>(kLaneMaxInner)) return 8u;
     return inner <= 512 ? 1u : (inner <= 1024 ? 2u : (inner <= 2048 ? 4u : 0u));
   };
+  auto mse_chunks = [&](const sbq_calib_item& it, uint32_t mode) -> uint64_t {
+    if (mode == 8u) return ceil_div(it.C, static_cast<int64_t>(kLaneRows));
+    if (mode != 0u) return ceil_div(it.C, static_cast<int64_t>(kWavesPerBlock));
+    return it.C * ceil_div(it.inner, static_cast<int64_t>(kMseChunk));
+  };
+  uint64_t lane_chunks = 0;
   for (int i = 0; i < n_items; ++i) {
     const sbq_calib_item& it = items[i];
     if (!it.x) return SBQ_ERR_NULL;
@@ -556,14 +674,11 @@ int sbq_calib_table_build(const sbq_calib_item* items, int n_items, void* host_t
     seg_wgs += ceil_div(static_cast<int64_t>(it.C * spr), static_cast<int64_t>(kWavesPerBlock));
     segs += it.C * spr;
     rows += it.C;
-    if (mse_mode(it.inner)) {
-      chunks += ceil_div(it.C, static_cast<int64_t>(kWavesPerBlock));
-      parts += it.C;
-    } else {
-      chunks += it.C * cpr;
-      parts += it.C * cpr;
-    }
-    max_cpr = cpr > max_cpr ? cpr : max_cpr;
+    const uint32_t mode = mse_mode(it.inner);
+    chunks += mse_chunks(it, mode);
+    if (mode == 8u) lane_chunks += mse_chunks(it, mode);
+    parts += mode ? it.C : it.C * cpr;
+    if (mode == 0u) max_cpr = cpr > max_cpr ? cpr : max_cpr;
   }
   if (seg_wgs >= (1ull << 31) || chunks >= (1ull << 31) || rows >= (1ull << 31)) return SBQ_ERR_ARG;
   const size_t bytes = sizeof(CalibHeader) + static_cast<size_t>(n_items) * sizeof(CalibItemDev) + (seg_wgs + chunks) * 4;
@@ -586,7 +701,9 @@ int sbq_calib_table_build(const sbq_calib_item* items, int n_items, void* host_t
   h->n_segs = static_cast<uint32_t>(segs);
   h->max_chunks_per_row = static_cast<uint32_t>(max_cpr);
   h->n_parts = static_cast<uint32_t>(parts);
-  uint32_t wg = 0, sg = 0, rw = 0, ck = 0, pt = 0;
+  h->n_lane_chunks = static_cast<uint32_t>(lane_chunks);
+  // (the MSE chunk list: the lane kernel's workgroups first, then the chunk kernel's -- two launches, two block sizes)
+  uint32_t wg = 0, sg = 0, rw = 0, ck_lane = 0, ck_rest = static_cast<uint32_t>(lane_chunks), pt = 0;
   for (int i = 0; i < n_items; ++i) {
     const sbq_calib_item& it = items[i];
     CalibItemDev d{};
@@ -598,9 +715,10 @@ int sbq_calib_table_build(const sbq_calib_item* items, int n_items, void* host_t
     d.seg_wg_begin = wg;
     d.seg_begin = sg;
     d.row_begin = rw;
+    d.mse_waves = mse_mode(it.inner);
+    uint32_t& ck = d.mse_waves == 8u ? ck_lane : ck_rest;
     d.chunk_begin = ck;
     d.part_begin = pt;
-    d.mse_waves = mse_mode(it.inner);
     d.qlo = static_cast<float>(it.qmin);
     d.qhi = static_cast<float>(it.qmax);
     d.flags = it.flags;
@@ -609,7 +727,7 @@ int sbq_calib_table_build(const sbq_calib_item* items, int n_items, void* host_t
     const uint32_t n_wg = (n_seg + kWavesPerBlock - 1) / kWavesPerBlock;
     for (uint32_t k = 0; k < n_wg; ++k) wg_item[wg + k] = static_cast<uint32_t>(i);
     const uint32_t cpr = static_cast<uint32_t>(ceil_div(it.inner, static_cast<int64_t>(kMseChunk)));
-    const uint32_t n_ck = d.mse_waves ? (d.C + kWavesPerBlock - 1) / kWavesPerBlock : d.C * cpr;
+    const uint32_t n_ck = static_cast<uint32_t>(mse_chunks(it, d.mse_waves));
     for (uint32_t k = 0; k < n_ck; ++k) chunk_item[ck + k] = static_cast<uint32_t>(i);
     wg += n_wg;
     sg += n_seg;
@@ -675,7 +793,10 @@ int sbq_group_mse_qparams(const void* device_table, const void* host_table, int 
   double* part = static_cast<double*>(workspace);
   rc = dispatch_dtype(x_dtype, [&](auto tag) {
     using T = decltype(tag);
-    calib_mse_kernel<T><<<h.n_chunks, kBlock, 0, st>>>(items, chunk_item, min_base, max_base, part);
+    if (h.n_lane_chunks) calib_mse_lanes_kernel<T><<<h.n_lane_chunks, kLaneBlock, 0, st>>>(items, chunk_item, min_base, max_base, part);
+    if (h.n_chunks > h.n_lane_chunks)
+      calib_mse_kernel<T><<<h.n_chunks - h.n_lane_chunks, kBlock, 0, st>>>(items, chunk_item, min_base, max_base, part,
+                                                                          h.n_lane_chunks);
   });
   if (rc != SBQ_OK) return rc;
   rc = check_launch();

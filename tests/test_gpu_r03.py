@@ -229,11 +229,16 @@ def test_group_calibration_equals_per_tensor(oracle, ops, dtype, symmetric, qmin
         sse = torch.zeros(C, L.MSE_CANDIDATES, dtype=torch.float64, device="cuda")
         ops.mse_accumulate(w, rmn, rmx, qmin, qmax, symmetric, sse, 0, per_channel[i])
         rs, rz, ri = ops.mse_select(sse, w.numel() // C, rmn, rmx, qmin, qmax, symmetric)
-        assert torch.equal(idx[i], ri.reshape(-1)), i
-        assert torch.equal(s[i], rs.reshape(-1)) and torch.equal(z[i], rz.reshape(-1)), i
+        # (round 6: the grouped launch sums in a tree of its own -- a lane per (row, candidate) -- so where two candidates'
+        # losses tie to fp32 rounding it may name the neighbour: such rows are checked against the oracle's fp64 sums)
+        same = (idx[i] == ri.reshape(-1))
+        rows = w.float().reshape(C, -1).cpu().numpy()
+        assert oracle.mse_index_disagreements(rows, idx[i].cpu().numpy(), ri.reshape(-1).cpu().numpy(), qmin, qmax, symmetric) == [], i
+        assert torch.equal(s[i][same], rs.reshape(-1)[same]) and torch.equal(z[i][same], rz.reshape(-1)[same]), i
     k = 1
-    _, _, b_ref, _ = oracle.mse(ws[k].float().cpu().numpy().reshape(ws[k].shape[0], -1), qmin, qmax, symmetric, 0, True)
-    assert np.array_equal(idx[k].cpu().numpy(), b_ref)
+    rows_k = ws[k].float().cpu().numpy().reshape(ws[k].shape[0], -1)
+    _, _, b_ref, _ = oracle.mse(rows_k, qmin, qmax, symmetric, 0, True)
+    assert oracle.mse_index_disagreements(rows_k, idx[k].cpu().numpy(), b_ref, qmin, qmax, symmetric) == []
 
 
 @pytest.mark.parametrize("dtype", DTYPES)

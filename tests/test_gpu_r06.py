@@ -411,3 +411,36 @@ def test_group_kth_value_fp32_resnet50_thresholds(ops):
     for i, x in enumerate(xs):
         want = np.sort(np.abs(x.cpu().numpy().reshape(-1)))[ks[i] - 1]
         assert got[i] == want, (shapes[i], got[i], want)
+
+
+# ---- model-wide MSE calibration: a lane per (row, candidate) (calib_mse_lanes_kernel) -----------------------------------
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
+@pytest.mark.parametrize("symmetric,qmin,qmax", [(True, -128, 127), (False, 0, 255), (True, -8, 7), (False, 0, 15)])
+def test_group_mse_lanes_vs_oracle(ops, dtype, symmetric, qmin, qmax):
+    """every row of every tensor against the oracle's argmin (observers/mse.py:46-61), ties of two candidates' losses within
+    fp32 rounding allowed (oracle.mse_index_disagreements); round 3's wave-per-row form (knob 2 = 37) likewise; rows of
+    8 ... 16 384 elements, row counts that are not multiples of four, an all-zero row, a row with one huge outlier"""
+    from oracle import oracle as O
+    from sparsebit_amd import lib as L
+
+    g = torch.Generator().manual_seed(61)
+    shapes = [(64, 8), (3, 64), (5, 576), (1000, 512), (7, 1024 + 8), (4, 4608), (2, 16384), (9, 2048), (1, 1024)]
+    ws = [(torch.randn(s, generator=g) * (0.05 + 0.3 * i)).to(dtype) for i, s in enumerate(shapes)]
+    ws[1][1] = 0.0
+    ws[2][3, 17] = 300.0
+    wd = [w.cuda() for w in ws]
+    for knob in (0, 37):
+        L.set_tuning(2, knob)
+        try:
+            grp = ops.GroupCalibration([(w, qmin, qmax, symmetric, True) for w in wd])
+        finally:
+            L.set_tuning(2, 0)
+        s, z, idx = grp.mse_qparams()
+        torch.cuda.synchronize()
+        for i, w in enumerate(ws):
+            rows = w.float().numpy()
+            so, zo, bo, _ = O.mse(rows, qmin, qmax, symmetric, 0, True)
+            got = idx[i].cpu().numpy()
+            assert O.mse_index_disagreements(rows, got, bo, qmin, qmax, symmetric) == [], (knob, shapes[i])
+            eq = got == bo
+            assert np.array_equal(s[i].cpu().numpy()[eq], so[eq]) and np.array_equal(z[i].cpu().numpy()[eq], zo[eq]), (knob, shapes[i])

@@ -2692,7 +2692,8 @@ struct KthItemArg {
 };
 struct KthItems {
   KthItemArg it[kKthItemsPerLaunch];
-  uint32_t cand_cap, pad;  // fp32: keys per wave of every workgroup's candidate store (dynamic LDS); 0 = none
+  uint32_t cand_cap;     // fp32: keys per wave of every workgroup's candidate store (dynamic LDS); 0 = none
+  int32_t test_resign;   // knob 2 == 31 / 32 / 33 (OneArgs::test_resign)
 };
 // ONE: the launch is a selection's only one (fp32 with the candidate store) -- without win_round_body's 42 KB of static
 // LDS the store gets 86 KB next to win_one_body's 75 KB.
@@ -2736,6 +2737,7 @@ __global__ __launch_bounds__(BLOCK) void group_kth_kernel(const KthItems items, 
 #endif
   a.epoch = epoch;
   a.cand_cap = items.cand_cap;
+  a.test_resign = items.test_resign;
   if constexpr (ONE) {
     win_one_body<T, 1, false, BLOCK>(tab, 1, a, blockIdx.x - me.wg_begin, me.nwg);
   } else {
@@ -3254,6 +3256,7 @@ int sbq_group_kth_value(const sbq_kth_item* items, int n_items, int x_dtype, int
     const int cnt = n_items - first < kKthItemsPerLaunch ? n_items - first : kKthItemsPerLaunch;
     KthItems args{};
     args.cand_cap = keep ? kGroupCandCap : 0u;
+    args.test_resign = knob(2) >= 31 && knob(2) <= 33 ? knob(2) - 30 : 0;
     uint32_t grid = 0;
     // four slabs per workgroup (all of them in flight before the windows are known) is what every item WANTS -- but the
     // launch as a whole must fit the chip in one sitting (one 1024-thread workgroup per compute unit): win_finish's

@@ -444,3 +444,24 @@ def test_group_mse_lanes_vs_oracle(ops, dtype, symmetric, qmin, qmax):
             assert O.mse_index_disagreements(rows, got, bo, qmin, qmax, symmetric) == [], (knob, shapes[i])
             eq = got == bo
             assert np.array_equal(s[i].cpu().numpy()[eq], so[eq]) and np.array_equal(z[i].cpu().numpy()[eq], zo[eq]), (knob, shapes[i])
+
+
+@pytest.mark.parametrize("knob", [31, 32, 33])
+def test_group_kth_value_fp32_resignation_forced(ops, knob):
+    """the grouped fp32 selection's rounds out of LDS with a resignation forced from round 1 / 2 / 3 on: the remaining
+    workgroups of an item hand over to the ticket sweeps of the tensor at that round (win_resident_rounds) -- results
+    are those of a sort"""
+    from sparsebit_amd import lib as L
+
+    names, xs = _group_cases(29)
+    xd = [x.cuda() for x in xs]
+    ks = [max(x.numel() // 2, 1) for x in xs]
+    L.set_tuning(2, knob)
+    try:
+        for rep in range(3):
+            got = ops.group_kth_value(xd, ks, True).cpu().numpy()
+            for i, x in enumerate(xs):
+                want = np.sort(np.abs(x.numpy()), kind="stable")[ks[i] - 1]
+                assert got[i] == want or (np.isnan(got[i]) and np.isnan(want)), (knob, rep, names[i], got[i], want)
+    finally:
+        L.set_tuning(2, 0)

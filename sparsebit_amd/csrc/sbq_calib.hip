@@ -306,7 +306,10 @@ template <typename T>
 __global__ __launch_bounds__(kLaneBlock) void calib_mse_lanes_kernel(const CalibItemDev* __restrict__ items,
                                                                     const uint32_t* __restrict__ chunk_item,
                                                                     const float* __restrict__ min_base,
-                                                                    const float* __restrict__ max_base, double* __restrict__ part) {
+                                                                    const float* __restrict__ max_base,
+                                                                    float* __restrict__ scale_base, float* __restrict__ zp_base,
+                                                                    int32_t* __restrict__ index_base) {
+  __shared__ float s_loss[kLaneRows][SBQ_MSE_CANDIDATES];
   // (+ 4 floats per row: the rows a wave straddles sit in different banks -- 4 KB apart they would share every bank)
   __shared__ __attribute__((aligned(16))) float xs[kLaneRows][kLaneTile + 4];
   const uint32_t idx = uread(chunk_item + blockIdx.x);
@@ -386,7 +389,33 @@ __global__ __launch_bounds__(kLaneBlock) void calib_mse_lanes_kernel(const Calib
     total += static_cast<double>((a0 + a1) + (a2 + a3));
     __syncthreads();  // (the tile is read; the next one may be staged)
   }
-  if (live) part[(static_cast<size_t>(uread(&it->part_begin)) + row) * SBQ_MSE_CANDIDATES + cand] = total;
+  // The pick, in the same launch (round 6: a select launch of its own spent 25 us walking 80 losses per row with one
+  // thread, and the table of partial sums went out to memory and came back): mse.py:51-61 keeps the first candidate
+  // whose fp32 loss is strictly smaller than 1e10 and than every earlier one -- the smallest loss, the lowest index
+  // among equals; NaN never wins.  Wave w < 4 takes row w: lane l holds candidates l and 64 + l.
+  s_loss[r][cand] = static_cast<float>(total / static_cast<double>(inner));
+  __syncthreads();
+  const uint32_t wv = threadIdx.x / kWave, ln = threadIdx.x & (kWave - 1);
+  if (wv < static_cast<uint32_t>(kLaneRows) && row0 + wv < C) {  // (wave-uniform)
+    auto key = [](float loss) {  // order-preserving for losses >= 0; everything that cannot win (NaN, >= 1e10) last
+      return loss < 1e10f ? __builtin_bit_cast(uint32_t, loss + 0.0f) : 0xffffffffu;
+    };
+    const uint32_t ka = key(s_loss[wv][ln]);
+    const uint32_t kb = ln + kWave < static_cast<uint32_t>(SBQ_MSE_CANDIDATES) ? key(s_loss[wv][(ln + kWave) % SBQ_MSE_CANDIDATES]) : 0xffffffffu;
+    const uint32_t mine = kb < ka ? kb : ka;
+    const uint32_t mine_i = kb < ka ? ln + kWave : ln;
+    const uint32_t best_k = dpp_reduce_u32(mine, 0xffffffffu, [](uint32_t p, uint32_t q) { return p < q ? p : q; });
+    const uint32_t best_i = dpp_reduce_u32(mine == best_k ? mine_i : 0xffffffffu, 0xffffffffu, [](uint32_t p, uint32_t q) { return p < q ? p : q; });
+    if (ln == 0) {
+      const uint64_t o = uread(&it->out_off) + row0 + wv;
+      const int best = best_k == 0xffffffffu ? -1 : static_cast<int>(best_i);
+      float bs = 1.0f, bz = 0.0f;  // mse.py:34-39 initial values
+      if (best >= 0) mse_candidate(min_base[o], max_base[o], best, qhi - qlo, (uread(&it->flags) & SBQ_CALIB_SYMMETRIC) != 0, bs, bz);
+      scale_base[o] = bs;
+      zp_base[o] = bz;
+      if (index_base) index_base[o] = best;
+    }
+  }
 }
 
 // Three rows per workgroup, a thread per (row, candidate): the row's chunks are summed in the per-tensor path's
@@ -405,12 +434,15 @@ __global__ __launch_bounds__(kBlock) void calib_mse_select_kernel(const CalibIte
   __shared__ float s_loss[kRowsPerFoldWg][SBQ_MSE_CANDIDATES];
   const uint32_t sub = threadIdx.x / SBQ_MSE_CANDIDATES, i = threadIdx.x % SBQ_MSE_CANDIDATES;
   const uint32_t r = blockIdx.x * kRowsPerFoldWg + sub;
-  const bool live = sub < static_cast<uint32_t>(kRowsPerFoldWg) && r < n_rows;
+  bool live = sub < static_cast<uint32_t>(kRowsPerFoldWg) && r < n_rows;
   const CalibItemDev* it = nullptr;
   uint32_t row = 0;
   if (live) {
     it = &item_of_row(items, n_items, r);
     row = r - it->row_begin;
+  }
+  if (live && it->mse_waves == 8u) live = false;  // (picked inside calib_mse_lanes_kernel; uniform per (row, sub): no barrier depends on it)
+  if (live) {
     const uint32_t cpr = it->mse_waves ? 1u : (it->inner + kMseChunk - 1) / kMseChunk;
     const double* p = part + (static_cast<size_t>(it->part_begin) + static_cast<size_t>(row) * cpr) * SBQ_MSE_CANDIDATES + i;
     double t;
@@ -793,7 +825,9 @@ int sbq_group_mse_qparams(const void* device_table, const void* host_table, int 
   double* part = static_cast<double*>(workspace);
   rc = dispatch_dtype(x_dtype, [&](auto tag) {
     using T = decltype(tag);
-    if (h.n_lane_chunks) calib_mse_lanes_kernel<T><<<h.n_lane_chunks, kLaneBlock, 0, st>>>(items, chunk_item, min_base, max_base, part);
+    if (h.n_lane_chunks)
+      calib_mse_lanes_kernel<T><<<h.n_lane_chunks, kLaneBlock, 0, st>>>(items, chunk_item, min_base, max_base, scale_base, zp_base,
+                                                                       index_base);
     if (h.n_chunks > h.n_lane_chunks)
       calib_mse_kernel<T><<<h.n_chunks - h.n_lane_chunks, kBlock, 0, st>>>(items, chunk_item, min_base, max_base, part,
                                                                           h.n_lane_chunks);
@@ -801,8 +835,9 @@ int sbq_group_mse_qparams(const void* device_table, const void* host_table, int 
   if (rc != SBQ_OK) return rc;
   rc = check_launch();
   if (rc != SBQ_OK) return rc;
-  calib_mse_select_kernel<<<(h.n_rows + kRowsPerFoldWg - 1) / kRowsPerFoldWg, kBlock, 0, st>>>(
-      items, h.n_items, h.n_rows, part, min_base, max_base, scale_base, zp_base, index_base);
+  if (h.n_chunks > h.n_lane_chunks)  // (rows of the chunk / wave forms; the lane kernel picks its own)
+    calib_mse_select_kernel<<<(h.n_rows + kRowsPerFoldWg - 1) / kRowsPerFoldWg, kBlock, 0, st>>>(
+        items, h.n_items, h.n_rows, part, min_base, max_base, scale_base, zp_base, index_base);
   return check_launch();
 }
 

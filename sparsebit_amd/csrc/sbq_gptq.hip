@@ -1141,12 +1141,24 @@ __device__ __forceinline__ f32x4 ld16_sc1(const float* p) {
 //   beyond that (gridDim.y) publish partial tiles and the last arriver folds them in index order (strip_fold_partials:
 //   deterministic, no float atomics).
 // Requirements (host): out_features % 64 == 0, in_features % 128 == 0, 16-byte aligned qweight / x rows.
-template <int MT>
+// BITS (round 6): 3- and 2-bit levels through the same kernel.  A lane's unit of work is the fewest qweight rows that hold
+// whole levels -- one row of 8 (4 bit) or 16 (2 bit) levels, three rows of 32 (3 bit: a 96-bit stream, quant.py:230-257)
+// -- so a 128-channel block is 16 / 8 / 4 units, lane kg takes unit 4 s + kg (s < 4 / 2 / 1) and its MFMA step i
+// multiplies x[row m][channel kW unit + i] with level i of the unit; the levels are decoded EIGHT at a time per column
+// (32 registers), then 32 MT MFMAs issue back to back, as before.  4 bit: v_cvt_pk_f32_fp8 of a nibble alone in a byte
+// (level 2^-9, exact); 2 bit: the same on crumbs ((word >> 2 k) & 0x03030303: byte b is level 4 b + k); 3 bit:
+// v_bfe_u32 / v_alignbit (stream_level) + v_cvt_f32_u32.
+template <int MT, int BITS>
 __global__ __launch_bounds__(256) void gptq_mfma_kernel(const float* __restrict__ x, const int32_t* __restrict__ qw,
                                                         const float* __restrict__ scales, const float* __restrict__ zeros,
                                                         float* __restrict__ out, float* __restrict__ part,
                                                         uint32_t* __restrict__ arrivals, const GptqGeom g, int bpc) {
   constexpr int kTileCols = 64;
+  constexpr int kW = BITS == 4 ? 8 : (BITS == 2 ? 16 : 32);  // levels (channels) per unit
+  constexpr int kR = BITS == 3 ? 3 : 1;                      // qweight rows per unit
+  constexpr int kUPB = 128 / kW;                             // units per 128-channel block
+  constexpr int kS = kUPB / 4;                               // units per lane and block
+  constexpr int kXV = kW / 4;                                // 16-byte activation loads per unit
   __shared__ __attribute__((aligned(16))) f32x4 red[4][MT][4][kWave];  // [wave][batch tile][c][lane]: 16 KB x MT
   __shared__ uint32_t s_prev;
   GPTQ_STAMP_INIT();
@@ -1186,8 +1198,8 @@ __global__ __launch_bounds__(256) void gptq_mfma_kernel(const float* __restrict_
   // ignored: a load under a branch makes the compiler wait for everything in flight at the join) and the NEXT block's
   // loads are issued before the current block's arithmetic (two register sets, the loop unrolled by two).
   struct Blk {
-    u32x4 w4[4];
-    f32x4 xa[4][MT][2];
+    u32x4 w4[kS][kR];
+    f32x4 xa[kS][MT][kXV];
     float s_lane, z_lane;
   };
   const int blk_last = blk_end - 1;
@@ -1197,15 +1209,16 @@ __global__ __launch_bounds__(256) void gptq_mfma_kernel(const float* __restrict_
   auto load_blk = [&](int blk_in, Blk& r) {
     const uint32_t blk = static_cast<uint32_t>(blk_in < blk_last ? blk_in : blk_last);
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
+    for (int s = 0; s < kS; ++s) {
       // (uniform base + 32-bit BYTE offset per lane: one address register and no 64-bit arithmetic per load)
-      const uint32_t row = blk * 16u + 4u * s + kg;
-      r.w4[s] = ld16<true>(at32(qw, (row * out32 + col) * 4u));
+      const uint32_t unit = blk * static_cast<uint32_t>(kUPB) + 4u * s + kg;
+#pragma unroll
+      for (int rr = 0; rr < kR; ++rr) r.w4[s][rr] = ld16<true>(at32(qw, ((unit * kR + rr) * out32 + col) * 4u));
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
-        const float* xp = at32(x, (xrow[mt] + row * 8u) * 4u);
-        r.xa[s][mt][0] = *reinterpret_cast<const f32x4*>(xp);
-        r.xa[s][mt][1] = *reinterpret_cast<const f32x4*>(xp + 4);
+        const float* xp = at32(x, (xrow[mt] + unit * static_cast<uint32_t>(kW)) * 4u);
+#pragma unroll
+        for (int v = 0; v < kXV; ++v) r.xa[s][mt][v] = *reinterpret_cast<const f32x4*>(xp + 4 * v);
       }
     }
     const uint32_t grp = (blk * 128u) / static_cast<uint32_t>(g.group_size);
@@ -1228,7 +1241,14 @@ __global__ __launch_bounds__(256) void gptq_mfma_kernel(const float* __restrict_
     for (int mt = 0; mt < MT; ++mt) {
       f32x4 v4 = r.xa[0][mt][0] + r.xa[0][mt][1];
 #pragma unroll
-      for (int s = 1; s < 4; ++s) v4 += r.xa[s][mt][0] + r.xa[s][mt][1];
+      for (int v = 2; v < kXV; ++v) v4 += r.xa[0][mt][v];
+#pragma unroll
+      for (int s = 1; s < kS; ++s) {
+        f32x4 u4 = r.xa[s][mt][0] + r.xa[s][mt][1];
+#pragma unroll
+        for (int v = 2; v < kXV; ++v) u4 += r.xa[s][mt][v];
+        v4 += u4;
+      }
       float xs = (v4[0] + v4[1]) + (v4[2] + v4[3]);  // batch row j, this lane's 32 channels of the block
       xs += __shfl_xor(xs, 16);
       xs += __shfl_xor(xs, 32);  // ... all 128 channels (the four K sub-lanes kg)
@@ -1237,7 +1257,8 @@ __global__ __launch_bounds__(256) void gptq_mfma_kernel(const float* __restrict_
     }
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      sc[t] = __shfl(r.s_lane, 4 * j + t) * 512.0f;  // the e4m3 decode yields level * 2^-9 (exact): 2^9 into the scale
+      // (4 / 2 bit: the e4m3 decode yields level * 2^-9, exact: 2^9 into the scale)
+      sc[t] = __shfl(r.s_lane, 4 * j + t) * (BITS == 3 ? 1.0f : 512.0f);
       zr[t] = __shfl(r.z_lane, 4 * j + t);
     }
     f32x4 acc[MT][4];
@@ -1246,38 +1267,65 @@ __global__ __launch_bounds__(256) void gptq_mfma_kernel(const float* __restrict_
 #pragma unroll
       for (int t = 0; t < 4; ++t) acc[mt][t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
+    for (int s = 0; s < kS; ++s) {
       // (decode and MFMAs in separate phases: interleaving the NEXT set's decode into the MFMA stream -- one VALU
       // instruction per MFMA issue slot via sched_group_barrier -- was measured slower, 11.6 vs 10.9 us at B = 8 and
       // 18.9 vs 18.0 us at B = 32 on 4096 x 4096: a filler beside every fp32 MFMA costs more than the 28-instruction
       // decode phase it hides)
-      f32x2 lp[4][4];  // column t: levels (0, 2) (1, 3) (4, 6) (5, 7) of the word
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const uint32_t word = r.w4[s][t];
-        const uint32_t even = word & 0x0f0f0f0fu, odd = (word >> 4) & 0x0f0f0f0fu;
-        lp[t][0] = __builtin_amdgcn_cvt_pk_f32_fp8(even, false);
-        lp[t][1] = __builtin_amdgcn_cvt_pk_f32_fp8(odd, false);
-        lp[t][2] = __builtin_amdgcn_cvt_pk_f32_fp8(even, true);
-        lp[t][3] = __builtin_amdgcn_cvt_pk_f32_fp8(odd, true);
-#pragma unroll
-        for (int p2 = 0; p2 < 4; ++p2) asm volatile("" : "+v"(lp[t][p2]));  // the decoded pair EXISTS here, in registers of its own
-      }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        // channel i of the word: pair (i >> 2) * 2 + (i & 1), half (i >> 1) & 1
+      for (int ch = 0; ch < kW / 8; ++ch) {  // eight levels of the unit at a time
+        f32x2 lp[4][4];  // column t, levels 8 ch + ...: pairs (0, 2) (1, 3) (4, 6) (5, 7) for 4 bit; see lvl() below
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-          const float lv = lp[t][(i >> 2) * 2 + (i & 1)][(i >> 1) & 1];
+          if constexpr (BITS == 4) {
+            const uint32_t word = r.w4[s][0][t];
+            const uint32_t even = word & 0x0f0f0f0fu, odd = (word >> 4) & 0x0f0f0f0fu;
+            lp[t][0] = __builtin_amdgcn_cvt_pk_f32_fp8(even, false);
+            lp[t][1] = __builtin_amdgcn_cvt_pk_f32_fp8(odd, false);
+            lp[t][2] = __builtin_amdgcn_cvt_pk_f32_fp8(even, true);
+            lp[t][3] = __builtin_amdgcn_cvt_pk_f32_fp8(odd, true);
+          } else if constexpr (BITS == 2) {
+            // crumb k of every byte: byte b of ((word >> 2 k) & 0x03030303) is level 4 b + k; this chunk's bytes are
+            // 2 ch and 2 ch + 1: lp[t][k] = levels (8 ch + k, 8 ch + 4 + k)
+            const uint32_t word = r.w4[s][0][t];
 #pragma unroll
-          for (int mt = 0; mt < MT; ++mt) {
-            const float xe = r.xa[s][mt][i >> 2][i & 3];
-            acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(xe, lv, acc[mt][t], 0, 0, 0);
+            for (int k = 0; k < 4; ++k) {
+              const uint32_t m = (word >> (2 * k)) & 0x03030303u;
+              if (ch == 0) lp[t][k] = __builtin_amdgcn_cvt_pk_f32_fp8(m, false);  // (the selector is an immediate)
+              else lp[t][k] = __builtin_amdgcn_cvt_pk_f32_fp8(m, true);
+            }
+          } else {
+            // lp[t][p] = levels (8 ch + 2 p, 8 ch + 2 p + 1) of the 96-bit stream
+#pragma unroll
+            for (int p2 = 0; p2 < 4; ++p2) {
+              const auto wd = [&](int idx) { return r.w4[s][idx][t]; };
+              lp[t][p2] = f32x2{static_cast<float>(stream_level<3>(wd, 8 * ch + 2 * p2)),
+                                static_cast<float>(stream_level<3>(wd, 8 * ch + 2 * p2 + 1))};
+            }
+          }
+#pragma unroll
+          for (int p2 = 0; p2 < 4; ++p2) asm volatile("" : "+v"(lp[t][p2]));  // the decoded pair EXISTS here, in registers of its own
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            // level 8 ch + i of the unit
+            float lv;
+            if constexpr (BITS == 4) lv = lp[t][(i >> 2) * 2 + (i & 1)][(i >> 1) & 1];  // pair (i >> 2) * 2 + (i & 1), half (i >> 1) & 1
+            else if constexpr (BITS == 2) lv = lp[t][i & 3][i >> 2];
+            else lv = lp[t][i >> 1][i & 1];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+              const int e = 8 * ch + i;  // channel of the unit
+              const float xe = r.xa[s][mt][e >> 2][e & 3];
+              acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(xe, lv, acc[mt][t], 0, 0, 0);
+            }
           }
         }
+        __builtin_amdgcn_sched_barrier(0);
       }
-      __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -1506,9 +1554,10 @@ int gptq_matmul(const float* x, const int32_t* qweight, float* out, const float*
   // batch rows per register tile, half-group K lanes only (register budget)
   // ... and so do batches up to 32 (the reference's kernel takes any batch in one launch,
   // cuda_kernel_4bit.cu:36-81): tiles of four rows, the strip's weights re-read per tile out of the caches
-  if constexpr (BITS == 4) {
+  {
     // 5 <= B <= 32: the batch rows through the fp32 matrix cores (gptq_mfma_kernel; knob 2 == 26: the strip tiles of four
-    // rows instead, for A/B runs)
+    // rows instead, for A/B runs).  3 / 2 bit since round 6 (the reference's multi-batch cases run all three widths,
+    // test_cuda_kernel.py:81-109; before, they took B strip passes)
     // (any batch >= 5: more than 32 rows go through the kernel 32 at a time -- the launches of one call follow each other
     // on the stream and share the partial-tile workspace; the weights of the later tiles come out of L2 / Infinity Cache)
     if (vec && batch >= 5 && out_features % 64 == 0 && in_features % 128 == 0 && group_size % 128 == 0 &&
@@ -1548,9 +1597,9 @@ int gptq_matmul(const float* x, const int32_t* qweight, float* out, const float*
         const float* xt = x + b0 * in_features;
         float* ot = out + b0 * out_features;
         if (gt.batch <= 16)
-          gptq_mfma_kernel<1><<<grid, 256, 0, st>>>(xt, qweight, scales, zeros, ot, part, arrivals, gt, static_cast<int>(bpc));
+          gptq_mfma_kernel<1, BITS><<<grid, 256, 0, st>>>(xt, qweight, scales, zeros, ot, part, arrivals, gt, static_cast<int>(bpc));
         else
-          gptq_mfma_kernel<2><<<grid, 256, 0, st>>>(xt, qweight, scales, zeros, ot, part, arrivals, gt, static_cast<int>(bpc));
+          gptq_mfma_kernel<2, BITS><<<grid, 256, 0, st>>>(xt, qweight, scales, zeros, ot, part, arrivals, gt, static_cast<int>(bpc));
         const int rc = check_launch();
         if (rc != SBQ_OK) return rc;
       }

@@ -465,3 +465,67 @@ def test_group_kth_value_fp32_resignation_forced(ops, knob):
                 assert got[i] == want or (np.isnan(got[i]) and np.isnan(want)), (knob, rep, names[i], got[i], want)
     finally:
         L.set_tuning(2, 0)
+
+
+# ---- GPTQ 3- / 2-bit batched mat-mul on the fp32 matrix cores (gptq_mfma_kernel<MT, BITS>, 5 <= B) ---------------------
+def _gptq_bits_case(bits, in_f, out_f, gs, B, seed):
+    g = torch.Generator().manual_seed(seed)
+    groups = in_f // gs if gs else 1
+    rows = in_f // 32 * 3 if bits == 3 else in_f * bits // 32
+    qw = torch.randint(-2 ** 31, 2 ** 31 - 1, (rows, out_f), generator=g, dtype=torch.int64).to(torch.int32)
+    sc = (torch.rand(out_f, groups, generator=g) * 0.02 + 0.001).float()
+    zr = (torch.randint(0, 2 ** bits, (out_f, groups), generator=g).float() * sc).float()
+    x = torch.randn(B, in_f, generator=g).float()
+    bias = torch.randn(out_f, generator=g).float()
+    return qw, sc, zr, x, bias
+
+
+@pytest.mark.parametrize("bits", [3, 2])
+@pytest.mark.parametrize("batch", [5, 8, 16, 17, 31, 32, 40])
+@pytest.mark.parametrize("in_f,out_f,gs", [(128, 64, 128), (384, 128, 128), (640, 192, 128), (1024, 4096, 0), (2048, 1024, 256),
+                                           (4096, 4096, 128)])
+def test_gptq_batched_mfma_3bit_2bit_vs_oracle(ops, bits, batch, in_f, out_f, gs):
+    """y == oracle(cuda_kernel_3bit.cu:85-199 / cuda_kernel_2bit.cu:86-153) at the reference test's literal rtol = atol =
+    1e-5 (test_cuda_kernel.py:47; its multi-batch cases run all three widths, :81-109), bias kept, two calls give the
+    same bits, and the strip passes this path replaced (knob 2 = 26) agree to the same tolerance"""
+    from oracle import oracle as O
+    from sparsebit_amd import lib as L
+
+    if in_f * out_f >= 4096 * 4096 and batch not in (8, 17, 32):
+        pytest.skip("large shape: three batch sizes")
+    dev = torch.device("cuda:0")
+    qw, sc, zr, x, bias = _gptq_bits_case(bits, in_f, out_f, gs, batch, 11 * bits + in_f % 97 + batch)
+    qwd, scd, zrd, xd = qw.to(dev), sc.to(dev), zr.to(dev), x.to(dev)
+    ref = O.vecquantmatmul(x.numpy(), qw.numpy(), bias.numpy(), sc.numpy(), zr.numpy(), gs, bits)
+    for knob in (0, 26):
+        L.set_tuning(2, knob)
+        try:
+            y = bias.repeat(batch, 1).to(dev)
+            ops.vecquantmatmul(bits, xd, qwd, y, scd, zrd, gs)
+            y2 = bias.repeat(batch, 1).to(dev)
+            ops.vecquantmatmul(bits, xd, qwd, y2, scd, zrd, gs)
+            assert torch.equal(y, y2), "knob %d: two calls differ" % knob
+        finally:
+            L.set_tuning(2, 0)
+        got = y.cpu().numpy()
+        assert np.all(np.abs(got - ref) <= 1e-5 + 1e-5 * np.abs(ref)), (knob, float(np.abs(got - ref).max()))
+
+
+@pytest.mark.parametrize("bits", [3, 2])
+def test_gptq_batched_mfma_3bit_2bit_inf_nan_rows(ops, bits):
+    """an inf / NaN activation poisons its OWN batch row only"""
+    from oracle import oracle as O
+
+    dev = torch.device("cuda:0")
+    in_f, out_f, gs, B = 640, 128, 128, 12
+    qw, sc, zr, x, bias = _gptq_bits_case(bits, in_f, out_f, gs, B, 5 + bits)
+    x[3, 17] = float("inf")
+    x[7, 300] = float("nan")
+    y = bias.repeat(B, 1).to(dev)
+    ops.vecquantmatmul(bits, x.to(dev), qw.to(dev), y, sc.to(dev), zr.to(dev), gs)
+    got = y.cpu().numpy()
+    ref = O.vecquantmatmul(x.numpy(), qw.numpy(), bias.numpy(), sc.numpy(), zr.numpy(), gs, bits)
+    clean = [b for b in range(B) if b not in (3, 7)]
+    assert np.all(np.abs(got[clean] - ref[clean]) <= 1e-5 + 1e-5 * np.abs(ref[clean]))
+    assert (~np.isfinite(got[3])).all()
+    assert np.isnan(got[7]).all()

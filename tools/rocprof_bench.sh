@@ -12,13 +12,13 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 export SBQ_BENCH_SKIP_E2E=1
 CMD="python $REPO/bench.py --no-cpu-baseline --steps 500 --warmup 50"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_trace -o ${TAG} -- $CMD > $OUT/${TAG}_trace.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_trace -o ${TAG} -- $CMD > $OUT/${TAG}_trace.log 2>&1
 find $OUT/${TAG}_trace -name "*kernel_trace.csv" -delete
 # PMC passes (no tracing with them): FETCH_SIZE and WRITE_SIZE do not fit one pass (TCC has 4 slots: 3 + 2)
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_pmc_fetch -o ${TAG} -- $CMD > $OUT/${TAG}_pmc_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_pmc_write -o ${TAG} -- $CMD > $OUT/${TAG}_pmc_write.log 2>&1
+timeout 900 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_pmc_fetch -o ${TAG} -- $CMD > $OUT/${TAG}_pmc_fetch.log 2>&1
+timeout 900 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_pmc_write -o ${TAG} -- $CMD > $OUT/${TAG}_pmc_write.log 2>&1
 # vector-ALU counters (their own pass): the MSE observer is the one VALU-bound kernel of the path
-rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES --output-format csv -d $OUT/${TAG}_pmc_valu -o ${TAG} -- $CMD > $OUT/${TAG}_pmc_valu.log 2>&1
+timeout 900 rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES --output-format csv -d $OUT/${TAG}_pmc_valu -o ${TAG} -- $CMD > $OUT/${TAG}_pmc_valu.log 2>&1
 cd $REPO && python tools/pmc_summary.py ${TAG} > $OUT/${TAG}_pmc_summary.log 2>&1
 mkdir -p $OUT/${TAG}_summary
 cp profiles/${TAG}_* profiles/pmc_latest.json $OUT/${TAG}_summary/ 2>/dev/null

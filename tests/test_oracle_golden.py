@@ -241,3 +241,21 @@ def test_oracle_gptq_find_params_sym_and_mse_vs_reference_golden(oracle):
         s0, z0 = oracle.gptq_find_params(w, bit, gs, sym=sym == "sym", mse=False)
         if sym == "sym":
             assert np.all(z0 == (2 ** bit) / 2)
+
+
+def test_mse_index_disagreements_allows_fp32_ties_only(oracle):
+    """oracle.mse_index_disagreements (the gate of kernels whose summation tree differs from the per-tensor kernel's):
+    equal indices pass, an index whose loss is NOT a tie of the reported one is a disagreement, a true tie (two
+    candidates with identical sums: an all-zero row) passes"""
+    rng = np.random.default_rng(3)
+    rows = (rng.standard_normal((6, 256)) * 0.3).astype(np.float32)
+    rows[4] = 0.0  # every candidate's loss is exactly 0: any index ties with any other
+    _, _, best, sse = oracle.mse(rows, -128, 127, True, 0, True)
+    assert oracle.mse_index_disagreements(rows, best, best, -128, 127, True) == []
+    other = best.copy()
+    far = int(np.argmax(sse[0]))  # the WORST candidate of row 0: not a tie
+    assert sse[0, far] > sse[0, best[0]] * 1.01
+    other[0] = far
+    other[4] = (best[4] + 7) % 80 if best[4] >= 0 else 3
+    got = oracle.mse_index_disagreements(rows, other, best, -128, 127, True)
+    assert 0 in got and (4 not in got or best[4] < 0)

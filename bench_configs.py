@@ -766,11 +766,11 @@ def model_wide_calibration(c):
     us_1 = sync_time(one_by_one_mse, 3)
     us_g = sync_time(grp.launch_mse, 20)
     evals = n_elem * L.MSE_CANDIDATES
-    out["mse_qparams"] = _entry(us_g, nbytes, same, "grouped (4 launches; a lane per (row, candidate)) vs per-tensor calls: argmin index "
+    out["mse_qparams"] = _entry(us_g, nbytes, same, "grouped (3 launches: two for min-max, one for the search and the pick; a lane per (row, candidate)) vs per-tensor calls: argmin index "
                                 "and scale of every channel of all %d tensors -- equal, or the two candidates' losses tie within 2e-6 in "
                                 "the oracle's fp64 sums (%d such rows); 64 rows of tensor %d vs the oracle's index likewise"
                                 % (len(ws), differing, k),
-                                bound="valu", one_by_one_us=round(us_1, 1), launches_grouped=4,
+                                bound="valu", one_by_one_us=round(us_1, 1), launches_grouped=3,
                                 valu_tflops=round(evals * MSE_FLOPS_PER_EVAL / us_g / 1e6, 1))
     # ---- L1 mask thresholds at 50 % ----
     ks = [min(int(w.numel() * 0.5), w.numel() - 1) + 1 for w in ws]

@@ -204,9 +204,14 @@ int sbq_quant_group_backward(const void* device_table, const void* host_table, i
  *      a HOST buffer; copy it to device memory (16-byte aligned) once and keep the host copy;
  *   3. sbq_group_minmax_qparams: min_base / max_base (and, unless NULL, scale_base / zp_base) of every row of every
  *      tensor; sbq_group_mse_qparams: the 80-candidate search on those (min, max) -> scale / zero_point / index.
- * Results are bit-identical to the per-tensor calls (sbq_channel_stats + sbq_qparams_from_minmax; sbq_mse_accumulate +
- * sbq_mse_select): same device code, same summation order.  The MSE launch takes rows of at most 96 x 4096 elements
- * (SBQ_ERR_ARG beyond: such tensors go through the per-tensor entry points). */
+ * The min-max results are bit-identical to the per-tensor calls (sbq_channel_stats + sbq_qparams_from_minmax: same
+ * device code, same summation order).  The MSE search sums each candidate's squared errors in a tree of its own since
+ * round 6 (a lane per (row, candidate), fp64 across tiles of 1024 elements; knob 2 == 37 at table-build time: round 3's
+ * per-tensor tree) and picks the candidate in the same launch: scale / zero_point / index equal those of
+ * sbq_mse_accumulate + sbq_mse_select except where two candidates' losses tie to the rounding of an fp32 mean -- there
+ * either kernel may name either candidate (as the reference's own answer depends on torch's summation order).  Rows of
+ * more than 16 384 elements keep the per-tensor chunk form, at most 96 x 4096 elements (SBQ_ERR_ARG beyond: such tensors
+ * go through the per-tensor entry points). */
 #define SBQ_CALIB_SYMMETRIC 1u
 typedef struct {
   const void* x;
@@ -462,7 +467,8 @@ int sbq_percentile_select(const void* const* shards, const int64_t* outers, int 
 int sbq_kth_value(const void* x, int x_dtype, int64_t numel, int use_abs, int64_t k, float* value_out,
                   void* workspace, size_t workspace_bytes, void* stream);
 
-/* Many whole-tensor selections in ONE launch (three for fp32): the L1 mask thresholds of a whole model
+/* Many whole-tensor selections in ONE launch (fp32 too since round 6: the keys inside each first window stay in LDS for
+ * the later rounds): the L1 mask thresholds of a whole model
  * (sparse/sparse_model.py:107-113 sorts every layer's weight on its own).  items: HOST array; item i is the 1-indexed
  * k-th smallest of x_i (of |x_i| with use_abs), written to values_out[i].  Every item runs the one-launch engine of
  * sbq_kth_value on its own share of the grid and its own region of the workspace, so the results are those of
@@ -625,7 +631,8 @@ int sbq_workspace_release(const void* workspace, size_t workspace_bytes);
  * advance / fallback launches) instead of the one-launch engine, 15 = an fp32 whole-tensor selection as ONE launch of resident
  * rounds instead of one launch per sweep, 16 = every whole-tensor selection waits for its verdict (resident) even when its plan expects
  * one sweep: +1.5-2 us, measured, 17 = the extraction kernel instead of the sorted lists in sbq_percentile_rows, 11 = general statistics kernel for a min-max-only call;
- * 34 = the grouped fp32 selection without its candidate store (two launches, each sweeps the tensors),
+ * 34 = the grouped fp32 selection without its candidate store (two launches, each sweeps the tensors), 37 (read by
+ * sbq_calib_table_build) = round 3's wave-per-row form of the model-wide MSE search,
  * 31 / 32 / 33 = TEST hook of the whole-tensor selections' resident rounds: a waiting workgroup resigns after half a microsecond
  * from round 1 / 2 / 3 on and never before -- results must not change). knob 3: resident schedule of the forward QDQ
  * (0 = auto: tensors that fit the chip's registers in one sitting, 1 = never, 2 = always).

@@ -411,8 +411,10 @@ class GroupCalibration:
 
     entries: list of (weight, qmin, qmax, symmetric, per_channel).  Weights must stay where they are (pointers are
     captured).  `supports(w)` tells which tensors the grouped launch takes (contiguous, 16-byte aligned, rows of
-    whole 8-element packs); the caller calibrates the others one by one.  Results are bit-identical to the
-    per-tensor ops (channel_stats + qparams_from_minmax, mse_accumulate + mse_select)."""
+    whole 8-element packs); the caller calibrates the others one by one.  The min-max results are bit-identical to the
+    per-tensor ops (channel_stats + qparams_from_minmax); the MSE search (round 6: a lane per (row, candidate), the pick
+    in the same launch) equals mse_accumulate + mse_select except where two candidates' losses tie to fp32 rounding --
+    there either may be named (include/sbq.h, section 3)."""
 
     @staticmethod
     def supports(w, per_channel=True):
@@ -470,7 +472,7 @@ class GroupCalibration:
         L.check(rc)
 
     def launch_mse(self):
-        """enqueue the four launches of the MSE calibration; results in self.scale / zp / index"""
+        """enqueue the launches of the MSE calibration (two for min-max, one for the search + pick); results in self.scale / zp / index"""
         lib = L.load()
         self.launch_minmax(want_qparams=False)
         with L.device_guard(self.dev):

@@ -50,6 +50,8 @@ def main():
                 extra = []
                 if "frac_of_fp32_vector_peak" in v:
                     extra.append("%.3f of the fp32 peak" % v["frac_of_fp32_vector_peak"])
+                if "frac_of_fp32_matrix_peak" in v:
+                    extra.append("%.3f of the fp32 matrix peak" % v["frac_of_fp32_matrix_peak"])
                 if "one_launch_per_matrix_us" in v:
                     extra.append("%.2f µs as one launch per matrix" % v["one_launch_per_matrix_us"])
                 if "one_by_one_us" in v:

@@ -6,8 +6,8 @@ import sys
 
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 table = subprocess.check_output([sys.executable, os.path.join(ROOT, "tools", "design_numbers.py"),
-                                 os.path.join(ROOT, "profiles", "r05_bench_line_default.json"),
-                                 os.path.join(ROOT, "profiles", "r05_bench_line_k20.json")], text=True)
+                                 os.path.join(ROOT, "profiles", "r06_bench_line_default.json"),
+                                 os.path.join(ROOT, "profiles", "r06_bench_line_k20.json")], text=True)
 path = os.path.join(ROOT, "DESIGN.md")
 s = open(path).read()
 a = s.index("<!-- numbers:begin")

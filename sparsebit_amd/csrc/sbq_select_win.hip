@@ -283,7 +283,7 @@ __device__ __forceinline__ void plan_compute(PlanLds& L, const PlanSample<T, kT>
                                              uint32_t min_shift, WinSel* out, Stamp stamp = Stamp()) {
   constexpr int kMine = PlanSample<T, kT>::kMine;
   plan_init(L);
-  if constexpr (SBQ_SEL_STAMPS != 0) {  // development build: when has the sample arrived?
+  if constexpr (SBQ_SEL_STAMPS == 2) {  // development build (-DSBQ_SEL_STAMPS=2 only: the wait distorts the plan's timing): when has the sample arrived?
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     stamp(14);
   }

@@ -239,3 +239,80 @@ def test_fuzz_gptq(oracle, seed):
     assert torch.equal(y, ql(x.cuda()))
     ref = oracle.vecquantmatmul(x.numpy(), qw, layer.bias.detach().numpy(), scale, zeros_p, GS, bit)
     assert np.allclose(y.cpu().numpy(), ref, rtol=1e-5, atol=3e-5)
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_fuzz_group_kth_value(seed):
+    """round 6: the grouped whole-tensor selection (fp32: one launch, candidate store in LDS; 16-bit: the full-histogram /
+    windowed engines per item) on random item counts, sizes (ragged tails, sub-slab items, items of many slabs), ranks
+    (both ends, the bulk) and data (ties, two-valued, sorted runs -- the candidate store's overflow path --, outliers,
+    signed zeros, NaN), plain and |x|: every item against a sort"""
+    from sparsebit_amd import ops
+
+    rng = np.random.default_rng(61000 + seed)
+    dtype = DTYPES[seed % 3]
+    n_items = int(rng.choice([1, 2, 5, 17, 70]))
+    xs, ks = [], []
+    for i in range(n_items):
+        n = int(rng.choice([8, 9, 63, 1000, 16384, 16385, 40001, 131072 + 5, 300000, 1 << 20]))
+        if n_items > 20 and n > 131077:
+            n = 40001
+        a = rng.standard_normal(n).astype(np.float32) * float(rng.choice([1e-3, 1.0, 40.0]))
+        kind = int(rng.integers(0, 7))
+        if kind == 0:
+            a = np.sort(a)
+        elif kind == 1:
+            a[rng.random(n) < 0.5] = float(rng.choice([0.0, -0.0, 0.25]))
+        elif kind == 2:
+            a = np.where(rng.random(n) < 0.5, np.float32(1.0), np.float32(-1.0))
+        elif kind == 3:
+            a[rng.integers(0, n, size=max(1, n // 5000))] = np.float32(3e20) * np.float32(rng.choice([-1.0, 1.0]))
+        elif kind == 4 and n > 100:
+            a[rng.integers(0, n, size=3)] = np.float32("nan")
+        t = torch.from_numpy(a).to(dtype)
+        xs.append(t)
+        ks.append(int(rng.choice([1, 2, n, max(n - 1, 1), max(n // 2, 1), max(n // 1000, 1), max((n * 9) // 10, 1)])))
+    xd = [x.cuda() for x in xs]
+    for use_abs in (False, True):
+        got = ops.group_kth_value(xd, ks, use_abs).cpu().numpy()
+        for i, x in enumerate(xs):
+            a = x.float().numpy()
+            want = np.sort(np.abs(a) if use_abs else a, kind="stable")[ks[i] - 1]  # (NaN last, as torch.sort)
+            assert got[i] == want or (np.isnan(got[i]) and np.isnan(want)), (seed, i, x.numel(), ks[i], use_abs, got[i], want)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_fuzz_group_mse(oracle, seed):
+    """round 6: the model-wide MSE search (a lane per (row, candidate); rows longer than 16 384 elements on the chunk form)
+    on random tensor lists, row counts that are not multiples of four, row lengths 8 ... 20 000, symmetric / affine,
+    4 / 8 bit: scale / zero point / index of every row against the oracle, ties of two candidates' losses within fp32
+    rounding allowed (oracle.mse_index_disagreements)"""
+    from sparsebit_amd import ops
+
+    rng = np.random.default_rng(62000 + seed)
+    dtype = DTYPES[seed % 3]
+    symmetric = bool(seed % 2)
+    qmin, qmax = [(-128, 127), (-8, 7)][seed % 2] if symmetric else [(0, 255), (0, 15)][(seed // 2) % 2]
+    ws = []
+    for _ in range(int(rng.integers(1, 9))):
+        C = int(rng.choice([1, 2, 3, 5, 8, 33, 130]))
+        inner = 8 * int(rng.choice([1, 2, 9, 64, 72, 128, 300, 576, 2049, 2500]))
+        if C * inner > 400000:
+            C = max(1, 400000 // inner)
+        a = rng.standard_normal((C, inner)).astype(np.float32) * float(rng.choice([0.02, 1.0, 25.0]))
+        if rng.random() < 0.3:
+            a[int(rng.integers(0, C))] = 0.0
+        if rng.random() < 0.3:
+            a[int(rng.integers(0, C)), int(rng.integers(0, inner))] = 500.0
+        ws.append(torch.from_numpy(a).to(dtype))
+    wd = [w.cuda() for w in ws]
+    grp = ops.GroupCalibration([(w, qmin, qmax, symmetric, True) for w in wd])
+    s, z, idx = grp.mse_qparams()
+    torch.cuda.synchronize()
+    for i, w in enumerate(ws):
+        rows = w.float().numpy()
+        so, zo, bo, _ = oracle.mse(rows, qmin, qmax, symmetric, 0, True)
+        got = idx[i].cpu().numpy()
+        assert oracle.mse_index_disagreements(rows, got, bo, qmin, qmax, symmetric) == [], (seed, i, rows.shape)
+        eq = got == bo
+        assert np.array_equal(s[i].cpu().numpy()[eq], so[eq]) and np.array_equal(z[i].cpu().numpy()[eq], zo[eq]), (seed, i)

@@ -30,5 +30,5 @@ for knob, name in ((0, "lane per (row, candidate)"), (37, "round 3: wave per row
     torch.cuda.synchronize()
     us = a.elapsed_time(b) * 1e3 / 20
     res[knob] = torch.cat([v.clone() for v in grp.views["index"]])
-    print("%-28s %7.1f us  (4 launches)  %.1f TFLOP/s at 7 flop per evaluation" % (name, us, n * 80 * 7 / us / 1e6), flush=True)
+    print("%-28s %7.1f us  (min-max: 2 launches; search: 1 + the pick inside for the lane form, 2 for round 3)  %.1f TFLOP/s at 7 flop per evaluation" % (name, us, n * 80 * 7 / us / 1e6), flush=True)
 print("rows: %d, argmin index differs in %d" % (res[0].numel(), int((res[0] != res[37]).sum())))

@@ -962,8 +962,10 @@ struct SweepLds {
 // the lanes' ranks among the hits, one LDS write.  *cand_found = the keys the wave found (more than cand_cap: it ran
 // out of room, and what it kept is incomplete).  The rounds after the first re-bin these keys instead of reading the
 // tensor again (win_one_body).
+// ABS: -1 = `use_abs` decides at run time (five vector operations per fp32 key); 1 / 0 = known at compile time -- |x| keys
+// are the bits below the sign plus a constant (two operations), signed keys need no mask (four).
 template <typename T, int NSEL, bool SIGNS, int BLOCK, bool EARLY, bool FLUSH, bool ALWAYS = false, bool KEY16 = false,
-          bool COLLECT = false, typename Tab, typename LoadState>
+          bool COLLECT = false, int ABS = -1, typename Tab, typename LoadState>
 __device__ __forceinline__ bool win_sweep(const Tab& tab, int n_shards, const uint32_t wg, const uint32_t nwg,
                                           LoadState&& load_state, WinSlot* __restrict__ slots,
                                           uint32_t* __restrict__ hist, int use_abs, SweepLds<NSEL, BLOCK>& lds,
@@ -1055,9 +1057,13 @@ __device__ __forceinline__ bool win_sweep(const Tab& tab, int n_shards, const ui
   constexpr uint32_t kZeroKey = RAW16 ? Key16<T>::kZero : kKeyZero, kInfKey = RAW16 ? Key16<T>::kInf : kKeyInf;
   const uint32_t amask2 = use_abs ? 0x7fff7fffu : 0xffffffffu;
   auto key_of = [&](uint32_t bits) {
-    const uint32_t b = bits & amask;
-    const uint32_t m = static_cast<uint32_t>(static_cast<int32_t>(b) >> 31) | 0x80000000u;
-    return (b ^ m) - kRot;
+    if constexpr (ABS == 1) {
+      return (bits & 0x7fffffffu) + (0x80000000u - kRot);  // (b | 0x80000000) - kRot with b's sign bit clear
+    } else {
+      const uint32_t b = ABS == 0 ? bits : bits & amask;
+      const uint32_t m = static_cast<uint32_t>(static_cast<int32_t>(b) >> 31) | 0x80000000u;
+      return (b ^ m) - kRot;
+    }
   };
   // The percentile's first sweep (two selectors + sign counts): selector 0's window sits at the bottom of the data,
   // selector 1's at the top (WinSel::side = 0 / 1).  One compare against the window's NEAR end settles all but a
@@ -1958,7 +1964,7 @@ __device__ __forceinline__ bool win_is_resident(const OneArgs& a, const OneLds& 
 
 // (wg of nwg: this workgroup's place among those that work on THIS selection -- the whole grid, or one item's share of
 // a launch that resolves many selections at once, sbq_group_kth_value)
-template <typename T, int NSEL, bool PCT, int BLOCK, typename Tab>
+template <typename T, int NSEL, bool PCT, int BLOCK, int ABS = -1, typename Tab>
 __device__ __forceinline__ void win_one_body(const Tab& tab, int n_shards, const OneArgs& a, const uint32_t wg,
                                              const uint32_t nwg) {
   __shared__ PlanLds plan;
@@ -1993,7 +1999,7 @@ __device__ __forceinline__ void win_one_body(const Tab& tab, int n_shards, const
     if (a.cand_cap != 0) cand_seg = cand_lds + (threadIdx.x / kWave) * a.cand_cap;
     if (threadIdx.x == 0) ol.cand_bad = 0;
   }
-  win_sweep<T, NSEL, SIGNS, BLOCK, true, true, true, true, COLLECT>(tab, n_shards, wg, nwg, [&](WinSel (&sel)[NSEL]) {
+  win_sweep<T, NSEL, SIGNS, BLOCK, true, true, true, true, COLLECT, ABS>(tab, n_shards, wg, nwg, [&](WinSel (&sel)[NSEL]) {
     one_stamp(a, 13);
     one_stamp(a, 1);
     plan_compute<T, BLOCK, true>(plan, sm, n_packs, a.mode, NSEL, a.use_abs, a.k0, a.k1, a.n, a.alpha, a.min_shift, ol.sel,
@@ -2680,6 +2686,7 @@ __global__ __launch_bounds__(kH16Block) void h16_select_kernel(const void* x0, u
 // selection of its own (own sample, own windows, own region of the workspace, own arrival counter and last arriver)
 // and a share of the grid's workgroups proportional to its size; the items of a launch live in the kernel arguments.
 constexpr int kKthItemsPerLaunch = 64;
+constexpr int kKthMapWgs = 512;  // workgroups the launch's workgroup -> item map covers (grid <= compute units)
 // keys per wave of a workgroup's candidate store: 16 waves x 1344 x 4 B = 84 KB of dynamic LDS next to the kernel's
 // 73 KB of static LDS (160 KB per compute unit).  A wave sweeps up to 8 slabs of 1024 keys in a model-wide launch and
 // the first window holds a tenth of them (+-12 sigma of the sample's rank error).
@@ -2694,19 +2701,30 @@ struct KthItems {
   KthItemArg it[kKthItemsPerLaunch];
   uint32_t cand_cap;     // fp32: keys per wave of every workgroup's candidate store (dynamic LDS); 0 = none
   int32_t test_resign;   // knob 2 == 31 / 32 / 33 (OneArgs::test_resign)
+  // workgroup -> item (round 6): ONE scalar load in front of the item's arguments instead of a binary search over
+  // it[].wg_begin -- six DEPENDENT scalar loads out of a cold argument block, 3 us before a workgroup's first request
+  // (tools/lab/r06_group_stamps.py).  has_map == 0 (a grid beyond the map): the search.
+  uint32_t has_map, pad;
+  uint8_t wg_item[kKthMapWgs];
 };
 // ONE: the launch is a selection's only one (fp32 with the candidate store) -- without win_round_body's 42 KB of static
 // LDS the store gets 86 KB next to win_one_body's 75 KB.
-template <typename T, int BLOCK, bool ONE>
+// ABS (ONE only): use_abs at compile time (win_sweep: the key of |x| in two operations instead of five).
+template <typename T, int BLOCK, bool ONE, int ABS = -1>
 __global__ __launch_bounds__(BLOCK) void group_kth_kernel(const KthItems items, int n_items, char* regions, size_t region_bytes,
                                                           float* out, int use_abs, uint32_t min_shift, int round,
                                                           int final_round, unsigned long long epoch) {
   // the item of this workgroup: last one whose first workgroup is <= blockIdx.x (uniform: scalar loads)
-  int lo = 0, hi = n_items - 1;
-  while (lo < hi) {
-    const int mid = (lo + hi + 1) >> 1;
-    if (items.it[mid].wg_begin <= blockIdx.x) lo = mid;
-    else hi = mid - 1;
+  int lo = 0;
+  if (items.has_map) {
+    lo = items.wg_item[blockIdx.x];
+  } else {
+    int hi = n_items - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (items.it[mid].wg_begin <= blockIdx.x) lo = mid;
+      else hi = mid - 1;
+    }
   }
   const KthItemArg me = items.it[lo];
   OneShard tab{};
@@ -2739,7 +2757,7 @@ __global__ __launch_bounds__(BLOCK) void group_kth_kernel(const KthItems items, 
   a.cand_cap = items.cand_cap;
   a.test_resign = items.test_resign;
   if constexpr (ONE) {
-    win_one_body<T, 1, false, BLOCK>(tab, 1, a, blockIdx.x - me.wg_begin, me.nwg);
+    win_one_body<T, 1, false, BLOCK, ABS>(tab, 1, a, blockIdx.x - me.wg_begin, me.nwg);
   } else {
     if (round == 0) win_one_body<T, 1, false, BLOCK>(tab, 1, a, blockIdx.x - me.wg_begin, me.nwg);
     else win_round_body<T, 1, BLOCK>(tab, 1, a, blockIdx.x - me.wg_begin, me.nwg);
@@ -2802,13 +2820,18 @@ int win_group_launch_t(const void* items, int cnt, char* regions, size_t region_
   if constexpr (T::id == SBQ_F32) {
     if (lds != 0) {
       static bool once = [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(group_kth_kernel<T, 1024, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  static_cast<int>(kGroupCandCap * (1024 / kWave) * sizeof(uint32_t)));
+        const int bytes = static_cast<int>(kGroupCandCap * (1024 / kWave) * sizeof(uint32_t));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(group_kth_kernel<T, 1024, true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(group_kth_kernel<T, 1024, true, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
         return true;
       }();
       (void)once;
-      group_kth_kernel<T, 1024, true><<<grid, 1024, lds, st>>>(it, cnt, regions, region_bytes, out, use_abs, min_shift, round,
-                                                              final_round, epoch);
+      if (use_abs)
+        group_kth_kernel<T, 1024, true, 1><<<grid, 1024, lds, st>>>(it, cnt, regions, region_bytes, out, use_abs, min_shift, round,
+                                                                   final_round, epoch);
+      else
+        group_kth_kernel<T, 1024, true, 0><<<grid, 1024, lds, st>>>(it, cnt, regions, region_bytes, out, use_abs, min_shift, round,
+                                                                   final_round, epoch);
       return SBQ_OK;
     }
   }
@@ -3285,8 +3308,10 @@ int sbq_group_kth_value(const sbq_kth_item* items, int n_items, int x_dtype, int
       if (extra_wanted > budget) nwg = 1 + (want[j] - 1) * budget / extra_wanted;
       d.wg_begin = grid;
       d.nwg = static_cast<uint32_t>(nwg);
+      for (uint32_t w = grid; w < grid + d.nwg && w < static_cast<uint32_t>(kKthMapWgs); ++w) args.wg_item[w] = static_cast<uint8_t>(j);
       grid += d.nwg;
     }
+    args.has_map = grid <= static_cast<uint32_t>(kKthMapWgs) ? 1u : 0u;
     char* regions = static_cast<char*>(workspace) + static_cast<size_t>(first) * kOneRegion;
     const unsigned long long epoch = next_epoch();
     for (int r = 0; r < expected; ++r) {

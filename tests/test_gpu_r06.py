@@ -529,3 +529,31 @@ def test_gptq_batched_mfma_3bit_2bit_inf_nan_rows(ops, bits):
     assert np.all(np.abs(got[clean] - ref[clean]) <= 1e-5 + 1e-5 * np.abs(ref[clean]))
     assert (~np.isfinite(got[3])).all()
     assert np.isnan(got[7]).all()
+
+
+def test_group_kth_value_two_streams(ops):
+    """two grouped fp32 selections at once on two streams of one process: both launches are resident (every workgroup
+    waits for its item's verdict) and together they want twice the chip -- the bounded wait + resignation must let both
+    finish, exactly, out of LDS or by ticket over the tensors"""
+    dev = torch.device("cuda:0")
+    lists = []
+    for seed in (71, 72):
+        g = torch.Generator().manual_seed(seed)
+        xs = [(torch.randn(n, generator=g) * 0.05).to(dev) for n in (2359296, 1 << 20, 589824, 262144, 147456, 65536, 36864, 4096)]
+        ks = [x.numel() // 2 for x in xs]
+        want = [float(torch.sort(x.abs())[0][k - 1]) for x, k in zip(xs, ks)]
+        lists.append((xs, ks, want))
+    streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+    for s, (xs, ks, _) in zip(streams, lists):  # each stream's workspace exists (and is zero) before the contention starts
+        with torch.cuda.stream(s):
+            ops.group_kth_value(xs, ks, True)
+    torch.cuda.synchronize()
+    for it in range(max(STRESS_ITERS // 6, 10)):
+        outs = []
+        for rep in range(4):
+            for s, (xs, ks, _) in zip(streams, lists):
+                with torch.cuda.stream(s):
+                    outs.append(ops.group_kth_value(xs, ks, True))
+        torch.cuda.synchronize()
+        for j, o in enumerate(outs):
+            assert o.cpu().tolist() == lists[j % 2][2], (it, j, o.cpu().tolist(), lists[j % 2][2])

@@ -13,7 +13,9 @@ unmodified on top of the HIP kernels:
     (sparsebit_amd quantizer, the reference's `Quantizer` base)
   * OBSERVERS_MAP["minmax"], ["mse"], ["percentile"], ["moving_average"], ["aciq"] -> classes derived
     from (sparsebit_amd observer, the reference's `Observer` base)
-  * SPARSERS_MAP["l1norm"]                        -> (sparsebit_amd sparser, reference `Sparser` base)
+  * SPARSERS_MAP["l1norm"]                        -> (sparsebit_amd sparser, reference `Sparser` base);
+    `SparseModel.calc_params` keeps its per-layer loop (sparse/sparse_model.py:107-113) and finds the L1 thresholds of
+    all unstructured layers already computed, by ONE grouped selection in front of it (`route_sparse_params`)
   * quant_tensor.fake_quant_kernel                -> sparsebit_amd.fake_quant (for the
     reference quantizers that stay, e.g. adaround / quadapter, which call STE.apply)
 
@@ -115,6 +117,12 @@ def install(native_only=False, calibrate=None):
 
         ref_s.SPARSERS_MAP["l1norm"] = _derive(amd_s.SPARSERS_MAP["l1norm"], ref_s.Sparser)
         installed["sparsers"].append("l1norm")
+        # SparseModel.calc_params (sparse/sparse_model.py:107-113) keeps its per-layer loop; the thresholds of all
+        # unstructured layers are computed in ONE launch in front of it (round 6)
+        import sparsebit.sparse.sparse_model as ref_sm
+
+        route_sparse_params(ref_sm.SparseModel)
+        installed["sparsers"].append("calc_params:model-wide")
     except ImportError:
         pass
     if calibrate == "device":
@@ -123,6 +131,33 @@ def install(native_only=False, calibrate=None):
     elif calibrate is not None:
         raise ValueError("calibrate must be None or 'device', not {!r}".format(calibrate))
     return installed
+
+
+def route_sparse_params(sparse_model_cls):
+    """Wrap `sparse_model_cls.calc_params` (the reference's SparseModel, or a look-alike with the same loop): before
+    the original walks the graph calling every SparseOpr's `calc_mask` (each of which asks its sparser for
+    `calc_mask(weight)`: sparse/modules/conv.py:28-29), the L1 thresholds of all unstructured layers are computed by one
+    grouped selection (`sparsers.l1norm.premasks`) and handed out inside the loop.  Masks are those of the per-layer
+    calls, element for element; idempotent."""
+    import torch
+
+    from .sparsers import l1norm
+
+    orig = sparse_model_cls.calc_params
+    if getattr(orig, "_sbq_grouped", False):
+        return
+
+    def calc_params(self):
+        pairs = []
+        for m in self.model.modules():
+            sp, w = getattr(m, "sparser", None), getattr(m, "weight", None)
+            if sp is not None and isinstance(w, torch.Tensor):
+                pairs.append((sp, w))
+        with l1norm.premasks(pairs):
+            return orig(self)
+
+    calc_params._sbq_grouped = True
+    sparse_model_cls.calc_params = calc_params
 
 
 def uninstall_observer_aliases():

@@ -7,7 +7,9 @@ class Sparser(nn.Module):
     STRATEGY = "base"
 
     def __init__(self, config, opr=None):
-        super().__init__()
+        # (not super().__init__(): in a class derived for the reference -- plugin._derive -- the next __init__ in the MRO
+        # is the reference base's, which wants (config, opr) and would set the same attributes)
+        nn.Module.__init__(self)
         spec = config.SPARSER
         self.config, self.opr = config, opr
         self.type, self.strategy, self.ratio = spec.TYPE, spec.STRATEGY, spec.RATIO

@@ -50,6 +50,10 @@ class Sparser(BaseSparser):
         return ops.kth_value(data, thresh_idx + 1, use_abs=True)  # the three radix passes in one call
 
     def calc_mask(self, x):
+        pre = getattr(self, "_premask", None)
+        if pre is not None and pre[0] is x:  # computed model-wide a moment ago (premasks): hand it over once
+            self._premask = None
+            return pre[1]
         if self.ratio == 0.0:
             return torch.ones_like(x)
         if self.type == "unstructed":
@@ -90,3 +94,38 @@ def calc_masks(pairs):
         if masks[i] is None:
             masks[i] = sp.calc_mask(w)
     return masks
+
+
+class premasks:
+    """`with premasks(pairs): <the reference's per-layer loop>` -- the zero-edit form of calc_masks: the L1 thresholds of
+    all unstructured layers of `pairs` ([(sparser, weight), ...]) come out of ONE selection launch up front, and each
+    layer's own `sparser.calc_mask(weight)` inside the block (sparse/modules/conv.py:28-29, called layer by layer from
+    sparse/sparse_model.py:107-113) returns its share instead of selecting again.  Identity check on the weight tensor;
+    whatever is not picked up is dropped at exit.  Layers the grouped launch does not take (structured, ratio 0, CPU
+    weights, a lone tensor of its dtype) are left to their own calc_mask."""
+
+    def __init__(self, pairs):
+        self.pairs = [(sp, w) for sp, w in pairs if isinstance(sp, Sparser)]
+        self.set = []
+
+    def __enter__(self):
+        todo = [i for i, (sp, w) in enumerate(self.pairs) if sp.ratio != 0.0 and sp.type == "unstructed" and w.is_cuda]
+        by_dtype = {}
+        for i in todo:
+            by_dtype.setdefault(self.pairs[i][1].dtype, []).append(i)
+        for idxs in by_dtype.values():
+            if len(idxs) < 2:
+                continue
+            ws = [self.pairs[i][1].detach().contiguous() for i in idxs]
+            ks = [min(int(w.numel() * self.pairs[i][0].ratio), w.numel() - 1) + 1 for i, w in zip(idxs, ws)]
+            thr = ops.group_kth_value(ws, ks, use_abs=True)
+            for j, i in enumerate(idxs):
+                sp, w = self.pairs[i]
+                sp._premask = (w, ops.mask_from_threshold(ws[j], thr[j]))
+                self.set.append(sp)
+        return self
+
+    def __exit__(self, *exc):
+        for sp in self.set:
+            sp._premask = None
+        return False

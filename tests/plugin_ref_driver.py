@@ -220,4 +220,27 @@ with torch.no_grad():
     x = torch.flatten(x, 1)
     want = torch.nn.functional.linear(fq_a(x, fc.input_quantizer), fq_w(fc.weight, fc.weight_quantizer), fc.bias)
 out["export_matches_torch_builtins"] = bool(torch.equal(seen["y"], want))
+
+
+# ---- the sparse side: SparseModel built by the reference, calc_params routed model-wide (round 6) ---------------------
+try:
+    from sparsebit.sparse import SparseModel, parse_sconfig
+
+    with tempfile.NamedTemporaryFile("w", suffix=".yaml", delete=False) as f:
+        f.write("SPARSER:\n  TYPE: unstructed\n  STRATEGY: l1norm\n  RATIO: 0.5\n")
+    import contextlib
+    import io
+
+    with contextlib.redirect_stdout(io.StringIO()):  # (the reference prints the traced graph)
+        sm = SparseModel(Net().eval(), parse_sconfig(f.name))
+    os.unlink(f.name)
+    sparsers = [m.sparser for m in sm.model.modules() if getattr(m, "sparser", None) is not None]
+    out["sparse_sparsers"] = len(sparsers)
+    out["sparse_all_amd"] = all(type(sp).__module__.startswith("sparsebit_amd") for sp in sparsers)
+    out["sparse_calc_params_routed"] = bool(getattr(SparseModel.calc_params, "_sbq_grouped", False))
+    # CPU weights: nothing is grouped, the reference's loop runs and the first layer's sparser reaches the device check
+    out["sparse_calc_params"] = stops_at_device_check(sm.calc_params)
+    out["sparse_premask_left"] = any(getattr(sp, "_premask", None) is not None for sp in sparsers)
+except Exception as e:  # noqa: BLE001
+    out["sparse_error"] = "{}: {}".format(type(e).__name__, e)
 print("PLUGIN_JSON " + json.dumps(out))

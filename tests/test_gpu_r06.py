@@ -557,3 +557,69 @@ def test_group_kth_value_two_streams(ops):
         torch.cuda.synchronize()
         for j, o in enumerate(outs):
             assert o.cpu().tolist() == lists[j % 2][2], (it, j, o.cpu().tolist(), lists[j % 2][2])
+
+
+# ---- SparseModel.calc_params routed model-wide (plugin.route_sparse_params) -------------------------------------------
+def test_sparse_calc_params_routed_through_one_grouped_selection(ops, monkeypatch):
+    """a SparseModel look-alike with the reference's loop (sparse/sparse_model.py:107-113: every SparseOpr's calc_mask in
+    graph order, each asking its sparser for calc_mask(weight), sparse/modules/conv.py:28-29) under
+    plugin.route_sparse_params: ONE grouped selection for all unstructured layers, no per-layer selection, masks equal
+    to the per-layer sparsers' element for element; a structured layer and a ratio-0 layer keep their own path"""
+    import torch.nn as nn
+
+    from sparsebit_amd import plugin
+    from sparsebit_amd.config import sparser_config
+    from sparsebit_amd.sparsers import build_sparser
+    from sparsebit_amd.sparsers import l1norm
+
+    class SConv(nn.Module):  # sparse/modules/conv.py:8-43 in miniature
+        def __init__(self, cout, cin, k, cfg):
+            super().__init__()
+            self.weight = nn.Parameter(torch.randn(cout, cin, k, k) * 0.05)
+            self.register_buffer("w_mask", torch.ones_like(self.weight))
+            self.sparser = build_sparser(cfg, opr="SConv")
+
+        def calc_mask(self, pre_mask=None):
+            self.w_mask = self.sparser.calc_mask(self.weight)
+            return None
+
+    class SparseModelLike(nn.Module):
+        def __init__(self, model):
+            super().__init__()
+            self.model = model
+
+        def calc_params(self):
+            pre = None
+            for m in self.model:
+                if getattr(m, "sparser", None):
+                    pre = m.calc_mask(pre)
+
+    torch.manual_seed(3)
+    layers = [SConv(64, 3, 7, sparser_config(0.5)), SConv(64, 64, 3, sparser_config(0.3)), SConv(128, 64, 1, sparser_config(0.9)),
+              SConv(256, 128, 3, sparser_config(0.5)), SConv(64, 64, 3, sparser_config(0.0)),
+              SConv(64, 64, 3, sparser_config(0.5, type_="structed")), SConv(512, 256, 3, sparser_config(0.75))]
+    net = nn.Sequential(*layers).cuda()
+    sm = SparseModelLike(net)
+    want = [build_sparser(m.sparser.config).calc_mask(m.weight) for m in net]  # fresh sparsers, layer by layer
+    calls = {"group": 0, "kth": 0}
+    g0, k0 = l1norm.ops.group_kth_value, l1norm.ops.kth_value
+
+    def counted_group(*a, **kw):
+        calls["group"] += 1
+        return g0(*a, **kw)
+
+    def counted_kth(*a, **kw):
+        calls["kth"] += 1
+        return k0(*a, **kw)
+
+    monkeypatch.setattr(l1norm.ops, "group_kth_value", counted_group)
+    monkeypatch.setattr(l1norm.ops, "kth_value", counted_kth)
+    plugin.route_sparse_params(SparseModelLike)
+    plugin.route_sparse_params(SparseModelLike)  # idempotent
+    sm.calc_params()
+    assert calls == {"group": 1, "kth": 0}, calls
+    for m, w in zip(net, want):
+        assert m.w_mask.dtype == w.dtype and torch.equal(m.w_mask, w)
+        assert getattr(m.sparser, "_premask", None) is None
+    sm.calc_params()  # a second pass (a new ratio schedule step): again one grouped launch
+    assert calls == {"group": 2, "kth": 0}, calls

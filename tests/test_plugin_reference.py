@@ -67,3 +67,14 @@ def test_device_calibration_routing():
     assert f["calibration_runner"] == "sparsebit_amd.calibration"
     assert f["calibration"] == "device"
     assert f["export_matches_torch_builtins"]
+
+
+def test_reference_sparsemodel_calc_params_is_routed_model_wide(findings):
+    """SparseModel built by the reference: its sparsers are the installed ones, calc_params is wrapped (the L1
+    thresholds of all unstructured layers in one launch in front of the reference's own loop -- with CPU weights
+    nothing is grouped and the loop's first sparser reaches the device check), nothing is left behind"""
+    assert "sparse_error" not in findings, findings.get("sparse_error")
+    assert findings["sparse_sparsers"] >= 2 and findings["sparse_all_amd"]
+    assert findings["sparse_calc_params_routed"]
+    assert findings["sparse_calc_params"] == "device"
+    assert not findings["sparse_premask_left"]

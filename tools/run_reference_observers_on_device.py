@@ -60,6 +60,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reference", default=None)
     ap.add_argument("--host-leg", default=None)
+    ap.add_argument("--runner", default="device", choices=["device", "reference"],
+                    help="device: QuantModel.calc_qparams routed through DeviceCalibrator (plugin.install(calibrate='device')); "
+                         "reference: the reference's own CalibrationRunner (its fx walk) calling the installed observers")
     args = ap.parse_args()
     ref = R.find_reference(args.reference)
     if args.host_leg:
@@ -79,7 +82,7 @@ def main():
 
     plugin.preinstall()
     R.setup(ref)
-    info = plugin.install(calibrate="device")
+    info = plugin.install(calibrate="device" if args.runner == "device" else None)
     print("reference: %s" % ref)
     print("plugin.install:", json.dumps(info))
     ok_all = True

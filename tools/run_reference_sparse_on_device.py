@@ -23,7 +23,8 @@ ROOT = os.path.dirname(HERE)
 sys.path.insert(0, HERE)
 import run_reference_on_device as R  # noqa: E402
 
-YAML = "SPARSER:\n  TYPE: unstructed\n  STRATEGY: l1norm\n  RATIO: 0.5\n"
+YAML = "SPARSER:\n  TYPE: %s\n  STRATEGY: l1norm\n  RATIO: %s\n" % (os.environ.get("SBQ_SPARSE_TYPE", "unstructed"),
+                                                                         os.environ.get("SBQ_SPARSE_RATIO", "0.5"))
 
 
 def make_net():

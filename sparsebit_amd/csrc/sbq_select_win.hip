@@ -2275,7 +2275,12 @@ __device__ __forceinline__ bool h16_round(const OneShard& tab, const OneArgs& a,
   // (LDS-only barriers: __syncthreads() also drains the vector-memory counter, and whatever the compiler spilled
   // to scratch around here would be waited for -- microseconds)
   lds_sync();
+  // every thread needs the workgroup's totals: lane l reads wave (l % 16)'s partial and the wave sums its 64 lanes on DPP
+  // -- four times the total, exactly -- instead of 16 LDS reads and adds per counter and thread (0.6 us of this
+  // kernel's tail, measured as "counters reduced" in profiles/r04_h16_timeline_after_prologue.txt)
+  static_assert(kWaves == 16, "a wave's 64 lanes hold the 16 partials four times");
   uint32_t tot[kCnt];
+#if defined(SBQ_H16_LOOP_COUNTERS)  // (A/B: tools/lab/build_variant.py -DSBQ_H16_LOOP_COUNTERS=1)
 #pragma unroll
   for (int c = 0; c < kCnt; ++c) {
     uint32_t t = 0;
@@ -2283,6 +2288,10 @@ __device__ __forceinline__ bool h16_round(const OneShard& tab, const OneArgs& a,
     for (int w = 0; w < kWaves; ++w) t += red[c * kWaves + w];
     tot[c] = t;
   }
+#else
+#pragma unroll
+  for (int c = 0; c < kCnt; ++c) tot[c] = dpp_reduce_u32(red[c * kWaves + (lane & (kWaves - 1))], 0u, add32) >> 2;
+#endif
   lds_sync();  // (red is read; the next round / win_finish may write it)
   if (tot[NSEL + 2] != n_wg) {
     // every element of this workgroup is ONE key (65 536 of it carried out of their half-dword): redo the binning

@@ -2237,17 +2237,28 @@ __device__ __forceinline__ bool h16_round(const OneShard& tab, const OneArgs& a,
     uint32_t wv[kM];
 #pragma unroll
     for (int m = 0; m < kM; ++m) wv[m] = hist[m * BLOCK + threadIdx.x];
+    // four dwords at a time first: the occupied part of the key space is two or three of a wave's 32 steps, and eight
+    // tests dismiss the rest where thirty-two did (round 6: 0.3-0.5 us of "windows binned"; A/B:
+    // tools/lab/build_variant.py -DSBQ_H16_NO_GROUP_SKIP=1)
 #pragma unroll
-    for (int m = 0; m < kM; ++m) {
-      const uint32_t wq = wv[m];
-      // a UNIFORM skip (scalar branch): as a per-lane condition the compiler predicates the whole body and a wave
-      // walks all 64 key slots of every lane with nothing to do (measured: 2.3 us for 32 empty iterations)
-      if (__builtin_amdgcn_ballot_w64(wq != 0u) == 0) continue;
-      const uint32_t key0 = (m * BLOCK + threadIdx.x) * 2u;
-      const uint32_t c0 = wq & 0xffffu, c1 = wq >> 16;
-      total += c0 + c1;
-      if (c0) visit(key0, c0);
-      if (c1) visit(key0 + 1u, c1);
+    for (int g4 = 0; g4 < kM; g4 += 4) {
+#if !defined(SBQ_H16_NO_GROUP_SKIP)
+      const uint32_t any4 = wv[g4] | wv[g4 + 1] | wv[g4 + 2] | wv[g4 + 3];
+      if (__builtin_amdgcn_ballot_w64(any4 != 0u) == 0) continue;
+#endif
+#pragma unroll
+      for (int mm = 0; mm < 4; ++mm) {
+        const int m = g4 + mm;
+        const uint32_t wq = wv[m];
+        // a UNIFORM skip (scalar branch): as a per-lane condition the compiler predicates the whole body and a wave
+        // walks all 64 key slots of every lane with nothing to do (measured: 2.3 us for 32 empty iterations)
+        if (__builtin_amdgcn_ballot_w64(wq != 0u) == 0) continue;
+        const uint32_t key0 = (m * BLOCK + threadIdx.x) * 2u;
+        const uint32_t c0 = wq & 0xffffu, c1 = wq >> 16;
+        total += c0 + c1;
+        if (c0) visit(key0, c0);
+        if (c1) visit(key0 + 1u, c1);
+      }
     }
     const uint32_t zw = zero_word[threadIdx.x];
     if (zw) {

@@ -2981,6 +2981,29 @@ int win_one_run(const void* const* shards, const int64_t* counts, int n_shards, 
     if (rc != SBQ_OK) return rc;
     return check_launch();
   }
+  // ONE explicit rank of ONE fp32 tensor (the L1 mask threshold of an fp32 weight -- what a reference user's fp32 model
+  // feeds sparse/sparsers/l1norm.py:18-26): the grouped selection's one-launch form with a single item (round 6) --
+  // the first sweep keeps the keys inside the first window in LDS, the later rounds are resident rounds on those -- instead
+  // of three launches that each sweep the tensor.  Up to eight slabs per workgroup (beyond, a wave's share of the
+  // window outgrows its store and every later round would sweep again anyway).  knob 2 == 34 / 20: the launches.
+  if (x_dtype == SBQ_F32 && n_sel == 1 && !percentile && n_shards == 1 && total <= 8 * cus && knob(2) != 34 && knob(2) != 20 &&
+      knob(2) != 15) {
+    KthItems items{};
+    KthItemArg& d = items.it[0];
+    d.x = pt.ptr[0];
+    d.n = n;
+    d.k = k0;
+    d.n_lean = pt.lean_first[1];
+    d.n_rag = pt.rag_first[1];
+    d.wg_begin = 0;
+    d.nwg = grid;
+    items.cand_cap = kGroupCandCap;
+    items.test_resign = knob(2) >= 31 && knob(2) <= 33 ? knob(2) - 30 : 0;
+    items.has_map = grid <= static_cast<uint32_t>(kKthMapWgs) ? 1u : 0u;  // (wg_item: all zero = item 0)
+    rc = win_group_launch_f32(&items, 1, region, kOneRegion, out0, use_abs, min_shift, 0, 1, a.epoch, grid, st);
+    if (rc != SBQ_OK) return rc;
+    return check_launch();
+  }
   for (int r = 0; r < expected && rc == SBQ_OK; ++r) {
     a.final_round = r == expected - 1 ? 1 : 0;
     rc = n_shards == 1 ? launch(os, r) : launch(pt, r);

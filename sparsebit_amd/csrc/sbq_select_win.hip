@@ -957,7 +957,7 @@ struct SweepLds {
 #define SBQ_SWEEP_STAMP(i) do { } while (0)
 #endif
 
-// COLLECT (fp32, one selector; sbq_group_kth_value): every key inside the window is also KEPT -- appended to this wave's
+// COLLECT (fp32; sbq_group_kth_value, sbq_kth_value and -- two selectors -- sbq_percentile_select): every key inside a window is also KEPT -- appended to this wave's
 // segment of LDS (cand_seg, room for cand_cap keys; nullptr = not this time), compacted per wave instruction: a ballot,
 // the lanes' ranks among the hits, one LDS write.  *cand_found = the keys the wave found (more than cand_cap: it ran
 // out of room, and what it kept is incomplete).  The rounds after the first re-bin these keys instead of reading the
@@ -971,7 +971,7 @@ __device__ __forceinline__ bool win_sweep(const Tab& tab, int n_shards, const ui
                                           uint32_t* __restrict__ hist, int use_abs, SweepLds<NSEL, BLOCK>& lds,
                                           uint32_t* cand_seg = nullptr, const uint32_t cand_cap = 0,
                                           uint32_t* cand_found = nullptr) {
-  static_assert(!COLLECT || (NSEL == 1 && !SIGNS && T::id == SBQ_F32), "candidates: one fp32 selector");
+  static_assert(!COLLECT || T::id == SBQ_F32, "candidates: fp32 keys");
   constexpr uint32_t kSlab = WinGeom<BLOCK>::kSlab;
   constexpr int U = WinGeom<BLOCK>::kU;
   constexpr int kWaves = BLOCK / kWave;
@@ -1094,7 +1094,11 @@ __device__ __forceinline__ bool win_sweep(const Tab& tab, int n_shards, const ui
       else lt[s] += valid && kk < lo[s];
       if (valid && d <= span[s]) atomicAdd(&lh[s][d >> sh[s]], 1u);
     }
-    if constexpr (COLLECT) collect(kk, valid && kk - lo[0] <= span[0]);
+    if constexpr (COLLECT) {
+      bool hit = kk - lo[0] <= span[0];
+      if constexpr (NSEL == 2) hit = hit || kk - lo[1] <= span[1];
+      collect(kk, valid && hit);
+    }
   };
   // count the lanes of a compare on the scalar unit, HERE: as plain C++ (popcount of a ballot, added to a uniform
   // counter) the adds are sunk to the end of the slab and the 128 masks waiting for them spill into VGPR lanes
@@ -1119,6 +1123,7 @@ __device__ __forceinline__ bool win_sweep(const Tab& tab, int n_shards, const ui
         if (d <= span[1]) atomicAdd(&lh[1][d >> sh[1]], 1u);
         else ++lt[1];  // above the window
       }
+      if constexpr (COLLECT) collect(kk, kk - lo[0] <= span[0] || kk - lo[1] <= span[1]);
       return;
     }
 #pragma unroll
@@ -1129,7 +1134,11 @@ __device__ __forceinline__ bool win_sweep(const Tab& tab, int n_shards, const ui
       const uint32_t d = kk - lo[s];
       if (d <= span[s]) atomicAdd(&lh[s][d >> sh[s]], 1u);
     }
-    if constexpr (COLLECT) collect(kk, kk - lo[0] <= span[0]);
+    if constexpr (COLLECT) {
+      bool hit = kk - lo[0] <= span[0];
+      if constexpr (NSEL == 2) hit = hit || kk - lo[1] <= span[1];
+      collect(kk, hit);
+    }
   };
   // 16-bit inputs: the keys of a pack stay PACKED.  A window of a 16-bit selection is 2^16-aligned in key32 (Key16),
   // so every test has an exact 16-bit form; per pack of 8 keys the sweep spends one packed min / max chain and one
@@ -1991,7 +2000,7 @@ __device__ __forceinline__ void win_one_body(const Tab& tab, int n_shards, const
   one_stamp(a, 12);
   // ... then the slabs (win_sweep, EARLY), and the plan while they fly
   constexpr bool SIGNS = PCT && NSEL == 2;
-  constexpr bool COLLECT = T::id == SBQ_F32 && NSEL == 1 && !PCT;
+  constexpr bool COLLECT = T::id == SBQ_F32 && (NSEL == 1 ? !PCT : PCT);  // (the instantiations there are: explicit rank, percentile)
   extern __shared__ __attribute__((aligned(16))) uint32_t cand_lds[];  // (COLLECT: a.cand_cap keys per wave)
   uint32_t* cand_seg = nullptr;
   uint32_t cand_found = 0;
@@ -2036,9 +2045,13 @@ __device__ __forceinline__ void win_one_body(const Tab& tab, int n_shards, const
   }, a.slots, a.hist, a.use_abs, swl, cand_seg, a.cand_cap, &cand_found);
   one_stamp(a, 3);
   const bool resident = win_is_resident<NSEL>(a, ol);
-  // (the window the candidates were kept for: every workgroup holds the plan's)
-  const uint32_t w0_lo = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(ol.sel[0].lo));
-  const uint32_t w0_span = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(ol.sel[0].span));
+  // (the windows the candidates were kept for: every workgroup holds the plan's)
+  uint32_t w0_lo[NSEL], w0_span[NSEL];
+#pragma unroll
+  for (int s = 0; s < NSEL; ++s) {
+    w0_lo[s] = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(ol.sel[s].lo));
+    w0_span[s] = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(ol.sel[s].span));
+  }
   if constexpr (COLLECT) {
     if (cand_seg != nullptr && (threadIdx.x & (kWave - 1)) == 0 && cand_found > a.cand_cap) ol.cand_bad = 1;  // (before win_finish's barriers)
   }
@@ -2046,33 +2059,52 @@ __device__ __forceinline__ void win_one_body(const Tab& tab, int n_shards, const
   uint32_t round = 2;
   if constexpr (COLLECT) {
     // The rounds after the first, out of LDS: while every workgroup of the selection is still there (nobody resigned:
-    // win_finish) each one re-bins the keys it kept -- they are exactly its elements inside the FIRST window, and a
-    // narrowed window lies inside it -- flushes and arrives; a round costs the arrival / placement / verdict chain, no
-    // memory traffic.  A workgroup with a wave that ran out of room (clustered data: a sorted tensor puts the whole
-    // window into a few waves), or any workgroup when the window MISSED its rank (the sample lied: the new window is
-    // everything beyond the old one), sweeps its own slabs again instead -- the same elements, the same histogram.
+    // win_finish) each one re-bins the keys it kept -- they are exactly its elements inside the FIRST windows, and a
+    // narrowed window lies inside its first one -- flushes and arrives; a round costs the arrival / placement / verdict
+    // chain, no memory traffic.  A workgroup with a wave that ran out of room (clustered data: a sorted tensor puts the
+    // whole window into a few waves), or any workgroup when a window MISSED its rank (the sample lied: the new window
+    // is everything beyond the old one), sweeps its own slabs again instead -- the same elements, the same histogram.
     if (cand_seg != nullptr) {
       for (; again && round < 12; ++round) {
         if (static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(ol.part)) != nwg) break;  // tickets over the tensor: below
-        __syncthreads();  // ol.sel: the narrowed window, fetched by win_finish
-        const uint32_t lo = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(ol.sel[0].lo));
-        const uint32_t span = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(ol.sel[0].span));
-        const uint32_t sh = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(ol.sel[0].shift));
-        const bool inside = lo >= w0_lo && static_cast<uint64_t>(lo) + span <= static_cast<uint64_t>(w0_lo) + w0_span;
+        __syncthreads();  // ol.sel: the narrowed windows, fetched by win_finish
+        uint32_t lo[NSEL], span[NSEL], sh[NSEL];
+        bool act[NSEL], inside = true;
+#pragma unroll
+        for (int s = 0; s < NSEL; ++s) {
+          lo[s] = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(ol.sel[s].lo));
+          span[s] = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(ol.sel[s].span));
+          sh[s] = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(ol.sel[s].shift));
+          act[s] = __builtin_amdgcn_readfirstlane(ol.sel[s].done) == 0;
+          if (act[s])
+            inside = inside && lo[s] >= w0_lo[s] && static_cast<uint64_t>(lo[s]) + span[s] <= static_cast<uint64_t>(w0_lo[s]) + w0_span[s];
+          else {
+            lo[s] = 0xffffffffu;  // (a finished selector: an empty window, as in win_sweep)
+            span[s] = 0;
+          }
+        }
         if (inside && __builtin_amdgcn_readfirstlane(ol.cand_bad) == 0) {
-          for (uint32_t i = threadIdx.x; i < static_cast<uint32_t>(kWinBins); i += BLOCK) swl.lh[0][i] = 0;
+          for (uint32_t i = threadIdx.x; i < static_cast<uint32_t>(NSEL * kWinBins); i += BLOCK) (&swl.lh[0][0])[i] = 0;
           if (threadIdx.x < NSEL + 2) swl.tot[threadIdx.x] = 0;
           lds_sync();
           for (uint32_t i = threadIdx.x & (kWave - 1); i < cand_found; i += kWave) {
-            const uint32_t d = cand_seg[i] - lo;
-            if (d <= span) atomicAdd(&swl.lh[0][d >> sh], 1u);
+            const uint32_t kk = cand_seg[i];
+#pragma unroll
+            for (int s = 0; s < NSEL; ++s) {
+              const uint32_t d = kk - lo[s];
+              if (act[s] && d <= span[s]) atomicAdd(&swl.lh[s][d >> sh[s]], 1u);
+            }
           }
           lds_sync();
-          uint32_t* gh = a.hist + static_cast<size_t>(wg % kCopies) * kWinSel * kWinBins;
-          const uint32_t nb = (span >> sh) + 1u;
-          for (uint32_t i = threadIdx.x; i < nb; i += BLOCK) {
-            const uint32_t v = swl.lh[0][i];
-            if (v) atomicAdd(&gh[i], v);
+#pragma unroll
+          for (int s = 0; s < NSEL; ++s) {
+            if (!act[s]) continue;
+            uint32_t* gh = a.hist + (static_cast<size_t>(wg % kCopies) * kWinSel + s) * kWinBins;
+            const uint32_t nb = (span[s] >> sh[s]) + 1u;
+            for (uint32_t i = threadIdx.x; i < nb; i += BLOCK) {
+              const uint32_t v = swl.lh[s][i];
+              if (v) atomicAdd(&gh[i], v);
+            }
           }
         } else {
           win_sweep<T, NSEL, false, BLOCK, true, true, true, true>(tab, n_shards, wg, nwg, [&](WinSel (&sel)[NSEL]) {
@@ -2711,6 +2743,8 @@ constexpr int kKthMapWgs = 512;  // workgroups the launch's workgroup -> item ma
 // 73 KB of static LDS (160 KB per compute unit).  A wave sweeps up to 8 slabs of 1024 keys in a model-wide launch and
 // the first window holds a tenth of them (+-12 sigma of the sample's rank error).
 constexpr uint32_t kGroupCandCap = 1344;
+// ... and of the fp32 percentile's (two selectors: win_one_body's static LDS is 81 KB): 16 x 1248 x 4 B = 78 KB
+constexpr uint32_t kPctCandCap = 1248;
 struct KthItemArg {
   const void* x;
   int64_t n, k;
@@ -2792,20 +2826,34 @@ int win_engine_launch_t(int r, int n_sel, unsigned grid, hipStream_t st, const v
                         const void* args) {
   constexpr int kB = 1024;
   const OneArgs& a = *static_cast<const OneArgs*>(args);
+  // fp32 percentile with a candidate store (round 6; a.cand_cap keys per wave in dynamic LDS behind win_one_body's 81 KB)
+  size_t lds = 0;
+  if constexpr (T::id == SBQ_F32) {
+    if (r == 0 && n_sel == 2 && a.cand_cap != 0) {
+      lds = static_cast<size_t>(a.cand_cap) * (kB / kWave) * sizeof(uint32_t);
+      static bool once = [] {
+        const int bytes = static_cast<int>(kPctCandCap * (kB / kWave) * sizeof(uint32_t));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(win_one_kernel<T, 2, true, kB, OneShard>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(win_one_kernel<T, 2, true, kB, PassTable>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        return true;
+      }();
+      (void)once;
+    }
+  }
   // (two EXPLICIT ranks in one selection, or one rank over several shards: nothing in the C ABI asks for them;
   // win_select_run sends such calls to the multi-launch protocol, so these are all the instantiations there are)
   if (single) {
     const OneShard& t = *static_cast<const OneShard*>(table);
     if (r == 0) {
       if (n_sel == 1) win_one_kernel<T, 1, false, kB, OneShard><<<grid, kB, 0, st>>>(t, n_shards, a);
-      else win_one_kernel<T, 2, true, kB, OneShard><<<grid, kB, 0, st>>>(t, n_shards, a);
+      else win_one_kernel<T, 2, true, kB, OneShard><<<grid, kB, lds, st>>>(t, n_shards, a);
     } else {
       if (n_sel == 1) win_round_kernel<T, 1, kB, OneShard><<<grid, kB, 0, st>>>(t, n_shards, a);
       else win_round_kernel<T, 2, kB, OneShard><<<grid, kB, 0, st>>>(t, n_shards, a);
     }
   } else {
     const PassTable& t = *static_cast<const PassTable*>(table);
-    if (r == 0) win_one_kernel<T, 2, true, kB, PassTable><<<grid, kB, 0, st>>>(t, n_shards, a);
+    if (r == 0) win_one_kernel<T, 2, true, kB, PassTable><<<grid, kB, lds, st>>>(t, n_shards, a);
     else win_round_kernel<T, 2, kB, PassTable><<<grid, kB, 0, st>>>(t, n_shards, a);
   }
   return SBQ_OK;
@@ -3001,6 +3049,18 @@ int win_one_run(const void* const* shards, const int64_t* counts, int n_shards, 
     items.test_resign = knob(2) >= 31 && knob(2) <= 33 ? knob(2) - 30 : 0;
     items.has_map = grid <= static_cast<uint32_t>(kKthMapWgs) ? 1u : 0u;  // (wg_item: all zero = item 0)
     rc = win_group_launch_f32(&items, 1, region, kOneRegion, out0, use_abs, min_shift, 0, 1, a.epoch, grid, st);
+    if (rc != SBQ_OK) return rc;
+    return check_launch();
+  }
+  // The fp32 PERCENTILE (observers/percentile.py:16-46 on an fp32 model's cached activations / weights), round 6: ONE
+  // launch -- the first sweep keeps the keys inside the two first windows in LDS and the later rounds are resident rounds
+  // on those -- instead of three launches that each sweep every cached batch.  Up to sixteen slabs per workgroup; a wave
+  // whose share of the windows outgrows its store sweeps its own slabs again in the later rounds (exact either way).
+  // knob 2 == 34 / 20: the launches.
+  if (x_dtype == SBQ_F32 && n_sel == 2 && percentile && total <= 16 * cus && knob(2) != 34 && knob(2) != 20 && knob(2) != 15) {
+    a.cand_cap = kPctCandCap;
+    a.final_round = 1;
+    rc = n_shards == 1 ? launch(os, 0) : launch(pt, 0);
     if (rc != SBQ_OK) return rc;
     return check_launch();
   }

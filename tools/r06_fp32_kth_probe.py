@@ -32,3 +32,42 @@ for n in (4096 * 4096, 2359296, 1 << 20, 300001):
         L.set_tuning(2, 0)
     print("n = %9d fp32: one launch %6.1f us (exact: %s)   three launches %6.1f us (exact: %s)   %5.1f MB" % (
         n, row[0][0], row[0][1], row[1][0], row[1][1], n * 4 / 1e6), flush=True)
+
+# ---- the fp32 percentile (two selectors), one tensor and four cached batches
+import numpy as np  # noqa: E402
+
+
+def pct_ref(parts, alpha):
+    x = np.concatenate([p.float().cpu().numpy().reshape(-1) for p in parts])
+    srt = np.sort(x, kind="stable")
+    n = x.size
+    neg, pos = int((x < 0).sum()), int((x >= 0).sum())
+    kmax = n - max(int(np.rint(pos * alpha)), 0)
+    kmin = max(int(np.rint(neg * alpha)), 1)
+    return float(srt[kmin - 1]) if neg > 0 else 0.0, float(srt[min(max(kmax, 1), n) - 1]) if pos > 0 else 0.0
+
+
+for name, shapes in (("one tensor 4096x4096", [(4096, 4096)]), ("4 batches of 64x64x56x56 (config 1's activations)", [(64, 64, 56, 56)] * 4),
+                     ("4 batches of 64x197x384 (config 3's, fp32)", [(64, 197, 384)] * 4)):
+    sets = [[torch.randn(s, generator=g).to(dev).reshape(1, -1) for s in shapes] for _ in range(3)]
+    for alpha in (1e-3, 1e-5):
+        want = pct_ref(sets[0], alpha)
+        row = []
+        for knob in (0, 34):
+            L.set_tuning(2, knob)
+            mn, mx = ops.percentile_select(sets[0], alpha, per_channel=False)
+            ok = (float(mn), float(mx)) == want
+            for i in range(5):
+                ops.percentile_select(sets[i % 3], alpha, per_channel=False)
+            torch.cuda.synchronize()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for i in range(60):
+                ops.percentile_select(sets[i % 3], alpha, per_channel=False)
+            b.record()
+            torch.cuda.synchronize()
+            row.append((a.elapsed_time(b) * 1e3 / 60, ok))
+            L.set_tuning(2, 0)
+        mb = sum(int(np.prod(s)) for s in shapes) * 4 / 1e6
+        print("percentile alpha %g, %s (%.0f MB): one launch %6.1f us (exact: %s)   three launches %6.1f us (exact: %s)" % (
+            alpha, name, mb, row[0][0], row[0][1], row[1][0], row[1][1]), flush=True)

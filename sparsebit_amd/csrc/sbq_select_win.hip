@@ -2217,15 +2217,13 @@ template <typename T, int NSEL>
 __device__ __forceinline__ bool h16_round(const OneShard& tab, const OneArgs& a, const uint32_t wg, const uint32_t nwg,
                                           const uint32_t n_wg, const uint32_t round, const bool signs,
                                           const uint32_t* __restrict__ hist, const uint32_t* __restrict__ zero_word,
-                                          const H16Plan& plan, OneLds& ol, SweepLds<NSEL, kH16Block>& swl, AdvShared (&adv)[2],
-                                          uint32_t* __restrict__ cnt_tot) {
+                                          const H16Plan& plan, OneLds& ol, SweepLds<NSEL, kH16Block>& swl, AdvShared (&adv)[2]) {
   constexpr int BLOCK = kH16Block;
   constexpr int kWaves = BLOCK / kWave;
   constexpr uint32_t kZero16 = Key16<T>::kZero >> 16, kInf16 = Key16<T>::kInf >> 16;
   const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
   if (round > 1) {  // (the last arriver's placement used lh as its gathering scratch)
     for (uint32_t i = threadIdx.x; i < static_cast<uint32_t>(NSEL * kWinBins); i += BLOCK) (&swl.lh[0][0])[i] = 0;
-    if (threadIdx.x < 8) cnt_tot[threadIdx.x] = 0;
     lds_sync();
   }
   uint32_t lo16[NSEL], span16[NSEL], sh16[NSEL];
@@ -2312,34 +2310,32 @@ __device__ __forceinline__ bool h16_round(const OneShard& tab, const OneArgs& a,
   part[NSEL] = dpp_reduce_u32(neg, 0u, add32);
   part[NSEL + 1] = dpp_reduce_u32(nan, 0u, add32);
   part[NSEL + 2] = dpp_reduce_u32(total, 0u, add32);
-  uint32_t tot[kCnt];
-#if defined(SBQ_H16_TWO_LEVEL_COUNTERS)  // (A/B: tools/lab/build_variant.py -DSBQ_H16_TWO_LEVEL_COUNTERS=1 -- round 6's first cut)
   uint32_t* red = reinterpret_cast<uint32_t*>(&swl.red[0][0]);  // [kCnt][kWaves] u32 (the sweep's scratch: 8-byte slots)
   if (lane == 0) {
 #pragma unroll
     for (int c = 0; c < kCnt; ++c) red[c * kWaves + wid] = part[c];
   }
+  // (LDS-only barriers: __syncthreads() also drains the vector-memory counter, and whatever the compiler spilled
+  // to scratch around here would be waited for -- microseconds)
   lds_sync();
+  // every thread needs the workgroup's totals: lane l reads wave (l % 16)'s partial and the wave sums its 64 lanes on DPP
+  // -- four times the total, exactly -- instead of 16 LDS reads and adds per counter and thread (0.6 us of this
+  // kernel's tail, measured as "counters reduced" in profiles/r04_h16_timeline_after_prologue.txt)
   static_assert(kWaves == 16, "a wave's 64 lanes hold the 16 partials four times");
+  uint32_t tot[kCnt];
+#if defined(SBQ_H16_LOOP_COUNTERS)  // (A/B: tools/lab/build_variant.py -DSBQ_H16_LOOP_COUNTERS=1)
+#pragma unroll
+  for (int c = 0; c < kCnt; ++c) {
+    uint32_t t = 0;
+#pragma unroll
+    for (int w = 0; w < kWaves; ++w) t += red[c * kWaves + w];
+    tot[c] = t;
+  }
+#else
 #pragma unroll
   for (int c = 0; c < kCnt; ++c) tot[c] = dpp_reduce_u32(red[c * kWaves + (lane & (kWaves - 1))], 0u, add32) >> 2;
-  lds_sync();  // (red is read; the next round / win_finish may write it)
-#else
-  // every thread needs the workgroup's totals: each wave adds its own to five LDS words of the kernel's (zero at the
-  // start of every round), ONE barrier, five broadcast reads.  (Round 5: a [counter][wave] table and 16 reads + adds per
-  // counter and thread -- 0.6 us of this kernel's tail, "counters reduced" in profiles/r04_h16_timeline_after_prologue.txt;
-  // round 6's first cut: one read + a DPP reduction per counter, two barriers.)
-  // (LDS-only barrier: __syncthreads() also drains the vector-memory counter, and whatever the compiler spilled to
-  // scratch around here would be waited for -- microseconds)
-  if (lane == 0) {
-#pragma unroll
-    for (int c = 0; c < kCnt; ++c)
-      if (part[c]) atomicAdd(&cnt_tot[c], part[c]);
-  }
-  lds_sync();
-#pragma unroll
-  for (int c = 0; c < kCnt; ++c) tot[c] = cnt_tot[c];
 #endif
+  lds_sync();  // (red is read; the next round / win_finish may write it)
   if (tot[NSEL + 2] != n_wg) {
     // every element of this workgroup is ONE key (65 536 of it carried out of their half-dword): redo the binning
     // for that single key.  (uniform over the workgroup.)
@@ -2413,7 +2409,7 @@ template <typename T, int NSEL>
 __device__ __attribute__((noinline)) void h16_more_rounds(const OneShard* tab_l, const OneArgs* a_l, const uint32_t wg, const uint32_t nwg,
                                                           const uint32_t n_wg, const uint32_t* hist, const uint32_t* zero_word,
                                                           const H16Plan* plan, OneLds* ol, SweepLds<NSEL, kH16Block>* swl,
-                                                          AdvShared (*adv)[2], uint32_t* cnt_tot) {
+                                                          AdvShared (*adv)[2]) {
   const OneShard tab = *tab_l;
   const OneArgs a = *a_l;
   for (uint32_t round = 2; round < 12; ++round) {
@@ -2423,7 +2419,7 @@ __device__ __attribute__((noinline)) void h16_more_rounds(const OneShard* tab_l,
       return;
     }
     __syncthreads();  // ol.sel: the narrowed windows, fetched by win_finish
-    if (!h16_round<T, NSEL>(tab, a, wg, nwg, n_wg, round, false, hist, zero_word, *plan, *ol, *swl, *adv, cnt_tot)) return;
+    if (!h16_round<T, NSEL>(tab, a, wg, nwg, n_wg, round, false, hist, zero_word, *plan, *ol, *swl, *adv)) return;
   }
 }
 
@@ -2442,7 +2438,6 @@ __global__ __launch_bounds__(kH16Block) void h16_select_kernel(const void* x0, u
   __shared__ OneLds ol;
   __shared__ H16Plan plan;
   __shared__ uint32_t zero_word[BLOCK];  // per lane: (-0 count, +0 count) packed like their histogram dword
-  __shared__ uint32_t cnt_tot[8];        // h16_round's workgroup totals (zero at the start of every round)
   const uint32_t wg = blockIdx.x, nwg = nwg32;
   const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
   one_stamp(a, 0);
@@ -2500,7 +2495,6 @@ __global__ __launch_bounds__(kH16Block) void h16_select_kernel(const void* x0, u
     for (int i = 0; i < static_cast<int>(kH16Dwords / 4 / BLOCK); ++i) h4[i * BLOCK + threadIdx.x] = u32x4{0, 0, 0, 0};
     for (uint32_t i = threadIdx.x; i < static_cast<uint32_t>(NSEL * kWinBins); i += BLOCK) (&swl.lh[0][0])[i] = 0;
     zero_word[threadIdx.x] = 0;
-    if (threadIdx.x < 8) cnt_tot[threadIdx.x] = 0;
     if (threadIdx.x == 0) {
       ol.neg = 0;
       ol.nan = 0;
@@ -2721,7 +2715,7 @@ __global__ __launch_bounds__(kH16Block) void h16_select_kernel(const void* x0, u
     if (p0 < n_packs) n_wg += ((p1 < n_packs ? p1 : n_packs) - p0) * kPack;
   }
   // ---- round 1 inline; whatever follows (rare) out of line ----
-  if (h16_round<T, NSEL>(tab, a, wg, nwg, n_wg, 1u, PCT, hist, zero_word, plan, ol, swl, adv, cnt_tot)) {
+  if (h16_round<T, NSEL>(tab, a, wg, nwg, n_wg, 1u, PCT, hist, zero_word, plan, ol, swl, adv)) {
     // (copied dword by dword out of the argument block in memory -- layout: x0, n32, nwg32, tab, a, naturally aligned
     // -- rather than from `tab` / `a`: fields that only this cold path reads would otherwise be fetched at the kernel's
     // entry, kept alive through it, and spilled to scratch there)
@@ -2733,7 +2727,7 @@ __global__ __launch_bounds__(kH16Block) void h16_select_kernel(const void* x0, u
     if (threadIdx.x < sizeof(OneShard) / 4) reinterpret_cast<uint32_t*>(&tab_l)[threadIdx.x] = kargs[kTabOff / 4 + threadIdx.x];
     if (threadIdx.x < sizeof(OneArgs) / 4) reinterpret_cast<uint32_t*>(&a_l)[threadIdx.x] = kargs[kArgsOff / 4 + threadIdx.x];
     __syncthreads();
-    h16_more_rounds<T, NSEL>(&tab_l, &a_l, wg, nwg, n_wg, hist, zero_word, &plan, &ol, &swl, &adv, cnt_tot);
+    h16_more_rounds<T, NSEL>(&tab_l, &a_l, wg, nwg, n_wg, hist, zero_word, &plan, &ol, &swl, &adv);
   }
   one_stamp(a, 7);
 }

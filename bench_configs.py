@@ -427,6 +427,17 @@ def config3_percentile(c):
     mn_ref, mx_ref = O.percentile(c.host.float().numpy()[rows], 1e-3, 0, True)
     ok = bool(np.array_equal(mn[rows].cpu().numpy(), mn_ref) and np.array_equal(mx[rows].cpu().numpy(), mx_ref))
     out["weight_per_channel"] = _entry(us_c, c.n * 2, ok, "(min, max) of %d rows bit-exact vs oracle" % len(rows))
+    # the same four batches as fp32 -- what a reference user's fp32 model caches (round 6: ONE launch, the keys inside the
+    # first windows kept in LDS, instead of three launches that each sweep every batch)
+    fsets = [[b.float() for b in s] for s in dsets]
+    us_f = c.timed(lambda i: ops.percentile_select(fsets[i % 3], 1e-3, 0, False), 20, warm=4)
+    mn, mx = ops.percentile_select(fsets[0], 1e-3, 0, False)
+    torch.cuda.synchronize(c.dev)
+    mn_ref, mx_ref = O.percentile(flat, 1e-3, 0, False)  # (the fp32 values ARE the bf16 ones)
+    ok = bool(np.array_equal(mn.cpu().numpy().reshape(-1), mn_ref) and np.array_equal(mx.cpu().numpy().reshape(-1), mx_ref))
+    out["deit_4_batches_per_tensor_fp32"] = _entry(us_f, n * 4, ok, "(min, max) of the same 4 batches held as fp32, bit-exact vs "
+                                                   "oracle; one launch (candidate store in LDS)", elements=n)
+    del fsets
     return out
 
 
@@ -608,6 +619,20 @@ def config5_mask_lsq(c):
     torch.cuda.synchronize(c.dev)
     out["mask_threshold_kth_value"] = _entry(us, c.n * 2, float(thr.item()) == float(thr_ref),
                                              "threshold == sort(|w|)[n/2] of the oracle, exact")
+    # the same weight held as fp32 -- a reference user's fp32 model (round 6: one launch instead of three)
+    xf = [c.xs[i].float() for i in range(min(nb, 4))]
+    thr_f = torch.empty((), dtype=torch.float32, device=c.dev)
+
+    def kth_f(i):
+        lib.sbq_kth_value(L.ptr(xf[i % len(xf)]), L.F32, c.n, 1, idx + 1, L.ptr(thr_f), L.ptr(ws), ws.numel(), c.st)
+
+    us_f = c.timed(kth_f, 50)
+    kth_f(0)
+    torch.cuda.synchronize(c.dev)
+    out["mask_threshold_kth_value_fp32"] = _entry(us_f, c.n * 4, float(thr_f.item()) == float(thr_ref),
+                                                  "the same weight as fp32: threshold == sort(|w|)[n/2] of the oracle, exact; one "
+                                                  "launch (candidate store in LDS)")
+    del xf
     # -- mask = |w| > thresh (l1norm.py:24-25): all 16.7 M bytes against the oracle's mask
     masks = [torch.empty(ROWS, COLS, dtype=torch.uint8, device=c.dev) for _ in range(nb)]
     us = c.timed(lambda i: lib.sbq_mask_from_threshold(L.ptr(c.xs[i % nb]), L.BF16, c.n, L.ptr(thr), L.ptr(masks[i % nb]), c.st), 100)

@@ -201,7 +201,7 @@ __device__ __forceinline__ RawPack<T> raw_from_elems(const float (&v)[kPack]) {
 // with the stride (a channels-last activation whose channel count divides it) is still sampled across its period.
 // GUARDED (the multi-launch protocol, which takes any shard): unaligned shards, shards shorter than a pack and a
 // shard's ragged end are read element by element, clamped to the shard.
-template <typename T, int kT, bool JITTER, bool GUARDED = false, typename Tab>
+template <typename T, int kT, bool JITTER, bool GUARDED = false, int RUN = 1, typename Tab>
 __device__ __forceinline__ void plan_sample_load(const Tab& tab, int n_shards, int64_t n, int64_t n_packs,
                                                  PlanSample<T, kT>& sm) {
   constexpr int kMine = PlanSample<T, kT>::kMine;
@@ -212,10 +212,24 @@ __device__ __forceinline__ void plan_sample_load(const Tab& tab, int n_shards, i
     // which shard: the table lives in the kernel arguments, so it is walked with a UNIFORM index (scalar loads) and
     // the lane keeps its own pointer / count by selects -- a per-lane index would spill the table to scratch
     const int64_t p = static_cast<int64_t>(threadIdx.x) + m * kT;
-    int64_t e = (p < n_packs ? p : 0) * stride;
-    if constexpr (JITTER) {
-      const uint32_t h = (static_cast<uint32_t>(p) * 2654435761u) >> 4;
-      if (stride > kPack) e += static_cast<int64_t>(h % static_cast<uint32_t>(stride - kPack + 1));
+    int64_t e;
+    if constexpr (RUN > 1) {
+      // RUN consecutive packs (one 128-byte line) per sample position, taken by RUN neighbouring lanes: a wave's load
+      // instruction touches 64 / RUN lines instead of 64
+      const int64_t pp = p < n_packs ? p : 0;
+      const int64_t r = pp / RUN, q = pp % RUN;
+      e = r * (stride * RUN);
+      if constexpr (JITTER) {
+        const uint32_t h = (static_cast<uint32_t>(r) * 2654435761u) >> 4;
+        if (stride > kPack) e += static_cast<int64_t>(h % static_cast<uint32_t>((stride - kPack) * RUN + 1));
+      }
+      e = (e & ~static_cast<int64_t>(kPack - 1)) + q * kPack;
+    } else {
+      e = (p < n_packs ? p : 0) * stride;
+      if constexpr (JITTER) {
+        const uint32_t h = (static_cast<uint32_t>(p) * 2654435761u) >> 4;
+        if (stride > kPack) e += static_cast<int64_t>(h % static_cast<uint32_t>(stride - kPack + 1));
+      }
     }
     sm.e[m] = e;
     base[m] = tab.ptr[0];
@@ -947,6 +961,7 @@ struct SweepLds {
   unsigned long long red[NSEL + 2][BLOCK / kWave];
   unsigned long long tot[NSEL + 2];
   u32x4 queue[BLOCK / kWave][2 * kWave];  // 16-bit sweeps: each wave's packs that await examination
+  uint32_t cand_spare;                    // COLLECT without a segment: where the kept keys go
 #if defined(SBQ_SEL_STAMPS) && SBQ_SEL_STAMPS != 0
   unsigned long long* stamps;  // development build only
 #endif
@@ -1001,9 +1016,22 @@ __device__ __forceinline__ bool win_sweep(const Tab& tab, int n_shards, const ui
     const void* x = tab.ptr[shard];
     const int64_t begin = n_lean ? static_cast<int64_t>(local) * kSlab : 0;
     const uint32_t stride = real ? kPack : 0u;
+#ifndef SBQ_FP32_SPLIT_SLABS
+#define SBQ_FP32_SPLIT_SLABS 1  // (0: round 5's stride-32-byte fp32 loads, for A/B runs)
+#endif
 #pragma unroll
-    for (int u = 0; u < U; ++u)
-      raw[u] = load_raw<T, true>(x, begin + static_cast<int64_t>((u * BLOCK + threadIdx.x) * stride));
+    for (int u = 0; u < U; ++u) {
+      if constexpr (T::id == SBQ_F32 && SBQ_FP32_SPLIT_SLABS != 0) {
+        // a lean slab is whole, and a selection asks for the multiset of keys, not for who holds which: a lane takes
+        // two 4-element runs half a region apart, so that each of its 16-byte loads is part of a contiguous 1 KiB wave
+        // access (sbq_common.hpp: load_raw2) instead of a stride-32-byte one
+        const uint32_t half = real ? 4u : 0u;
+        const int64_t iA = begin + static_cast<int64_t>((u * 2 * BLOCK + threadIdx.x) * half);
+        raw[u] = load_raw2<T, true>(x, iA, iA + static_cast<int64_t>(BLOCK * half));
+      } else {
+        raw[u] = load_raw<T, true>(x, begin + static_cast<int64_t>((u * BLOCK + threadIdx.x) * stride));
+      }
+    }
     __builtin_amdgcn_sched_barrier(0);  // nothing that waits for the other buffer moves above these loads
   };
   // the first slab is requested before anything else: the selector state below comes from a cold scalar load, the
@@ -1011,7 +1039,13 @@ __device__ __forceinline__ bool win_sweep(const Tab& tab, int n_shards, const ui
   // (EARLY == false, the fallback launch: it usually finds nothing to do, so it looks at the state first)
   // FOUR slab buffers: a 16.7 M-element tensor on 256 CUs is four slabs per workgroup, all requested before the
   // selector state is known (the one-launch engine derives it from a sample meanwhile)
-  constexpr int NB = 4;
+#ifndef SBQ_FP32_NB
+#define SBQ_FP32_NB 2  // (4: round 5; slab buffers of an fp32 sweep (16 registers each; the kernels sit at the 128-register cap)
+#endif
+#ifndef SBQ_PCT16_NB
+#define SBQ_PCT16_NB 3  // (4: round 5) the same for the two-selector sweeps of 16-bit inputs (8 registers each)
+#endif
+  constexpr int NB = T::id == SBQ_F32 ? SBQ_FP32_NB : (NSEL == 2 ? SBQ_PCT16_NB : 4);
   RawPack<T> buf[NB][U];
   auto issue_all = [&]() {
 #pragma unroll
@@ -1071,16 +1105,20 @@ __device__ __forceinline__ bool win_sweep(const Tab& tab, int n_shards, const ui
   // the sweep counts (side 1: the keys ABOVE the window; the advance turns that into the keys below).
   constexpr bool ONESIDED = SIGNS && NSEL == 2;
   uint32_t c_fill = 0;  // uniform: keys this wave has found inside the window (COLLECT)
+#ifndef SBQ_COLLECT_FUSED
+#define SBQ_COLLECT_FUSED 1  // (0: round 6's first form, for A/B runs)
+#endif
+  // (the fused form always writes: without a segment, into a spare word)
+  uint32_t* const seg_w = cand_seg != nullptr ? cand_seg : &lds.cand_spare;
+  const uint32_t seg_last = cand_seg != nullptr && cand_cap != 0 ? cand_cap - 1u : 0u;
+  // (c_fill lives in an SGPR: every update is the scalar add of a ballot's population count)
   auto collect = [&](uint32_t kk, bool hit) {
     const uint64_t m = __builtin_amdgcn_ballot_w64(hit);
-    if (cand_seg != nullptr && m != 0) {  // uniform
-      const uint32_t c = static_cast<uint32_t>(__builtin_popcountll(m));
-      if (c_fill + c <= cand_cap) {
-        const uint32_t pos = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0u));
-        if (hit) cand_seg[c_fill + pos] = kk;
-      }
-      c_fill += c;  // (past cand_cap: nothing more is kept, and the count says so)
+    if (hit) {
+      const uint32_t pos = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), c_fill));
+      seg_w[pos < seg_last ? pos : seg_last] = kk;  // (a full segment: its last word, and the count says so)
     }
+    c_fill = __builtin_amdgcn_readfirstlane(c_fill + static_cast<uint32_t>(__builtin_popcountll(m)));
   };
   auto visit = [&](uint32_t kk, bool valid) {
     if constexpr (SIGNS) {
@@ -1124,6 +1162,23 @@ __device__ __forceinline__ bool win_sweep(const Tab& tab, int n_shards, const ui
         else ++lt[1];  // above the window
       }
       if constexpr (COLLECT) collect(kk, kk - lo[0] <= span[0] || kk - lo[1] <= span[1]);
+      return;
+    }
+    if constexpr (COLLECT && NSEL == 1 && SBQ_COLLECT_FUSED != 0) {
+      // one predicated region for a key inside the window: its histogram add and its place in the wave's segment
+      // (rank among the hits on top of the wave's count, clamped to the segment's last word once that is full -- the
+      // count says so, and a segment that overflowed is not used).  As a ballot, a uniform branch, the bound check and a
+      // second predicated region behind the histogram's this was 34 issue slots per key; 21 now.
+      count(w_lt[0], kk <= lom1[0]);
+      const uint32_t d = kk - lo[0];
+      const bool hit = d <= span[0];
+      const uint64_t m = __builtin_amdgcn_ballot_w64(hit);
+      if (hit) {
+        atomicAdd(&lh[0][d >> sh[0]], 1u);
+        const uint32_t pos = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), c_fill));
+        seg_w[pos < seg_last ? pos : seg_last] = kk;
+      }
+      c_fill = __builtin_amdgcn_readfirstlane(c_fill + static_cast<uint32_t>(__builtin_popcountll(m)));
       return;
     }
 #pragma unroll
@@ -1589,6 +1644,16 @@ __device__ __forceinline__ void one_stamp(const OneArgs& a, int i) {
     if (a.stamps && threadIdx.x == 0) a.stamps[blockIdx.x * 32 + i] = __builtin_amdgcn_s_memrealtime();
   }
 }
+// (-DSBQ_SEL_STAMPS=1 -DSBQ_SEL_WAVE_STAMPS=1: the same for the LAST wave of the workgroup -- how far apart do a
+// workgroup's waves run?)
+#ifndef SBQ_SEL_WAVE_STAMPS
+#define SBQ_SEL_WAVE_STAMPS 0
+#endif
+__device__ __forceinline__ void last_wave_stamp(const OneArgs& a, int i) {
+  if constexpr (SBQ_SEL_STAMPS != 0 && SBQ_SEL_WAVE_STAMPS != 0) {
+    if (a.stamps && threadIdx.x == blockDim.x - kWave) a.stamps[blockIdx.x * 32 + i] = __builtin_amdgcn_s_memrealtime();
+  }
+}
 struct OneLds {
   WinSel sel[kWinSel];
   unsigned long long neg, nan;  // sign / NaN counts of the whole selection (the first sweep's)
@@ -1982,15 +2047,21 @@ __device__ __forceinline__ void win_one_body(const Tab& tab, int n_shards, const
   __shared__ SweepLds<NSEL, BLOCK> swl;
   if (threadIdx.x == 0) ol.t0 = __builtin_amdgcn_s_memrealtime();  // (read by thread 0 only: win_finish)
   one_stamp(a, 0);
+  last_wave_stamp(a, 27);
 #if SBQ_SEL_STAMPS != 0
   if (threadIdx.x == 0) swl.stamps = a.stamps;
 #endif
   const int64_t n_packs = a.n / kPack < kPlanPacks ? (a.n / kPack > 0 ? a.n / kPack : 1) : kPlanPacks;
   // the sample first (vector-memory loads return in order: the plan must not wait for the slabs) ...
   PlanSample<T, BLOCK> sm;
-  plan_sample_load<T, BLOCK, true>(tab, n_shards, a.n, n_packs, sm);
+#ifndef SBQ_PLAN_RUN_BYTES
+#define SBQ_PLAN_RUN_BYTES 128  // (32: round 5 -- every pack on a line of its own)
+#endif
+  constexpr int kRun = SBQ_PLAN_RUN_BYTES / (kPack * static_cast<int>(sizeof(typename T::storage))) > 1 ? SBQ_PLAN_RUN_BYTES / (kPack * static_cast<int>(sizeof(typename T::storage))) : 1;
+  plan_sample_load<T, BLOCK, true, false, kRun>(tab, n_shards, a.n, n_packs, sm);
   __builtin_amdgcn_sched_barrier(0);
   one_stamp(a, 11);
+  last_wave_stamp(a, 19);
   for (int i = threadIdx.x; i < kPlanBins; i += BLOCK) plan.hist[i] = 0;
   // ... of EVERY wave before any wave's slabs: the compute unit's memory pipeline serves its waves' requests in
   // order, so a late wave's sample would queue behind the early waves' slabs -- 128 KB per workgroup, 5 us at a
@@ -2008,7 +2079,11 @@ __device__ __forceinline__ void win_one_body(const Tab& tab, int n_shards, const
     if (a.cand_cap != 0) cand_seg = cand_lds + (threadIdx.x / kWave) * a.cand_cap;
     if (threadIdx.x == 0) ol.cand_bad = 0;
   }
-  win_sweep<T, NSEL, SIGNS, BLOCK, true, true, true, true, COLLECT, ABS>(tab, n_shards, wg, nwg, [&](WinSel (&sel)[NSEL]) {
+#ifndef SBQ_FP32_LATE_SLABS
+#define SBQ_FP32_LATE_SLABS 0  // lab: 1 = an fp32 selection requests its slabs AFTER the plan (is the sample starved by them?)
+#endif
+  constexpr bool kEarly = !(SBQ_FP32_LATE_SLABS != 0 && T::id == SBQ_F32);
+  win_sweep<T, NSEL, SIGNS, BLOCK, kEarly, true, true, true, COLLECT, ABS>(tab, n_shards, wg, nwg, [&](WinSel (&sel)[NSEL]) {
     one_stamp(a, 13);
     one_stamp(a, 1);
     plan_compute<T, BLOCK, true>(plan, sm, n_packs, a.mode, NSEL, a.use_abs, a.k0, a.k1, a.n, a.alpha, a.min_shift, ol.sel,

@@ -21,6 +21,9 @@ dev = torch.device("cuda:0")
 g = torch.Generator().manual_seed(50)
 ws = [torch.randn(s, generator=g).to(dev) for s in B.resnet50_weight_shapes()]
 ks = [min(int(w.numel() * 0.5), w.numel() - 1) + 1 for w in ws]
+if os.environ.get("SBQ_ONLY"):  # one tensor of the list only
+    ws, ks = [ws[int(os.environ["SBQ_ONLY"])]], [ks[int(os.environ["SBQ_ONLY"])]]
+    print("only tensor: %d elements" % ws[0].numel())
 if os.environ.get("SBQ_KNOB2"):
     L.set_tuning(2, int(os.environ["SBQ_KNOB2"]))
 for _ in range(5):
@@ -51,7 +54,7 @@ print("rounds entered (next round number) histogram: %r; workgroups with a full 
 print("keys kept by wave 0 of each workgroup: median %d, max %d" % (np.median(found), found.max()))
 us = lambda a: (a - t0) / 100.0  # noqa: E731
 print("workgroups with stamps: %d" % len(st))
-cols = [(0, "start"), (11, "smp_req"), (12, "sample"), (13, "slabs_req"), (8, "plan8"), (9, "plan9"), (10, "plan10"), (2, "plan"), (15, "sw15"), (3, "swept"), (4, "arrived"), (5, "last:begin"), (6, "last:adv"), (20, "alone1"), (21, "alone2"),
+cols = [(0, "start"), (27, "w15:start"), (11, "smp_req"), (19, "w15:smp_req"), (12, "sample"), (13, "slabs_req"), (8, "plan8"), (9, "plan9"), (10, "plan10"), (2, "plan"), (15, "sw15"), (3, "swept"), (4, "arrived"), (5, "last:begin"), (6, "last:adv"), (20, "alone1"), (21, "alone2"),
         (22, "alone3"), (24, "r2:flushed"), (25, "r3:flushed"), (26, "r4:flushed"), (7, "end")]
 # (the second launch's stamps 4 / 5 / 6 overwrite the first's: with candidates, "arrived" .. "last:adv" are the second launch's)
 for c, name in cols:

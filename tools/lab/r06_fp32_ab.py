@@ -41,7 +41,7 @@ acts16 = [a.bfloat16() for a in acts]
 big16 = torch.randn(25_600_000, generator=g).to(dev).bfloat16()
 huge16 = torch.randn(40_000_000, generator=g).to(dev).bfloat16()
 for rep in range(3):
-    print("model-wide thresholds %.1f us | kth 25.6M fp32 %.1f us | kth 1M fp32 %.1f us | percentile 4 x 4.8M fp32 %.1f us | kth 25.6M "
+    print("model-wide thresholds %.1f us | kth 25.6M fp32 %.1f us | kth 32 K fp32 (one workgroup) %.1f us | percentile 4 x 4.8M fp32 %.1f us | kth 25.6M "
           "bf16 %.1f us | kth 40M bf16 %.1f us | percentile 4 x 4.8M bf16 %.1f us | percentile 40M bf16 %.1f us" % (
         timed(lambda: ops.group_kth_value(ws, ks, True)),
         timed(lambda: ops.kth_value(big, 12_800_000, True)),

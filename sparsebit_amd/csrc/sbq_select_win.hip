@@ -1151,6 +1151,22 @@ __device__ __forceinline__ bool win_sweep(const Tab& tab, int n_shards, const ui
       count(w_nan, kk > kInfKey);
     }
     if constexpr (ONESIDED) {
+      if constexpr (COLLECT && SBQ_COLLECT_FUSED != 0) {
+        // the two near-end compares settle all but a per cent of the keys: when NO lane of the wave holds such a key
+        // (half of the wave instructions at alpha = 1e-3) nothing else runs -- not the window tests, not the
+        // compaction's ballot (as separate steps every key paid five more vector operations for `hit`)
+        const bool near0 = kk <= lo[0] + span[0], near1 = kk >= lo[1];
+        if (__builtin_amdgcn_ballot_w64(near0 || near1) != 0) {  // uniform
+          const uint32_t d0 = kk - lo[0], d1 = kk - lo[1];
+          const bool in0 = near0 && d0 <= span[0], in1 = near1 && d1 <= span[1];
+          if (in0) atomicAdd(&lh[0][d0 >> sh[0]], 1u);
+          if (in1) atomicAdd(&lh[1][d1 >> sh[1]], 1u);
+          lt[0] += near0 && !in0;  // wrapped: below the window
+          lt[1] += near1 && !in1;  // above the window
+          collect(kk, in0 || in1);
+        }
+        return;
+      }
       if (kk <= lo[0] + span[0]) {  // at or below the top of the bottom window: rare
         const uint32_t d = kk - lo[0];
         if (d <= span[0]) atomicAdd(&lh[0][d >> sh[0]], 1u);

@@ -1714,9 +1714,11 @@ __device__ __forceinline__ void one_advance(const int s, const OneArgs& a, OneLd
     // bins wide -- a few hundred exchanges instead of 16 K)
     if (threadIdx.x * kPer <= (w.span >> w.shift)) {
       uint32_t v[kCopies][kPer];
+      uint32_t first_bin = threadIdx.x * kPer;  // (not a loop invariant: see one_advance_pair)
+      asm volatile("" : "+v"(first_bin));
 #pragma unroll
       for (int c = 0; c < kCopies; ++c) {
-        uint32_t* src = a.hist + (static_cast<size_t>(c) * kWinSel + s) * kWinBins + threadIdx.x * kPer;
+        uint32_t* src = a.hist + (static_cast<size_t>(c) * kWinSel + s) * kWinBins + first_bin;
 #pragma unroll
         for (int i = 0; i < kPer; ++i) v[c][i] = one_take(src + i);
       }
@@ -1760,6 +1762,12 @@ __device__ __forceinline__ void one_advance_pair(const OneArgs& a, OneLds& ol, b
   const int tid = threadIdx.x - s * NT;
   const WinSel w = ol.sel[s];
   __syncthreads();  // everyone holds w before anyone replaces it
+  // (a value the optimiser cannot see through: inside a loop of rounds the 16 gather addresses of a thread are loop
+  // invariants -- hoisted in front of the loop they stayed live across every sweep of it and were SPILLED: 40 MB of
+  // scratch writes per fp32 percentile launch, measured with WRITE_SIZE)
+  uint32_t* const hist_base = a.hist;
+  uint32_t fresh0 = 0;
+  asm volatile("" : "+v"(fresh0));
   constexpr int kPer = kWinBins / NT;
   unsigned long long bins[kPer];
 #pragma unroll
@@ -1795,8 +1803,8 @@ __device__ __forceinline__ void one_advance_pair(const OneArgs& a, OneLds& ol, b
       unsigned long long v[K];
 #pragma unroll
       for (int j = 0; j < K; ++j) {
-        const uint32_t idx = (base + static_cast<uint32_t>(j * NT + tid)) & (total - 1u);
-        unsigned long long* copy = reinterpret_cast<unsigned long long*>(a.hist + (static_cast<size_t>(idx >> lgw) * kWinSel + s) * kWinBins);
+        const uint32_t idx = (base + static_cast<uint32_t>(j * NT + tid) + fresh0) & (total - 1u);
+        unsigned long long* copy = reinterpret_cast<unsigned long long*>(hist_base + (static_cast<size_t>(idx >> lgw) * kWinSel + s) * kWinBins);
         v[j] = one_take(copy + (idx & ((1u << lgw) - 1u)));
       }
 #pragma unroll

@@ -87,8 +87,12 @@ __device__ __forceinline__ uint32_t pack2(float a, float b) {
 // made ONCE per wave: both fast forms exist as compact straight-line blocks (no branch inside), they only
 // accumulate an "odd element" flag, and a wave that saw one -- or holds a row the fast division does not cover --
 // redoes its tile in a rolled loop through the generic quantize_pack (cold code at the end of the kernel).
-template <int MASK, bool ZP>
-__device__ __forceinline__ void fast_pack(float (&v)[kPack], const u32x2 mk, float thr, float s, float z, float qlo,
+// (yr = 1 / s, correctly rounded: the callers divide ONCE for all of a wave's slabs -- lane u for slab u -- instead of
+// every lane repeating the 12-instruction IEEE sequence for every slab: a sixth of the kernel's vector instructions)
+// (PER_SLAB: the round-5 form -- the division and eight compares inside every slab's block.  The fp32-output kernels
+// keep it: with the shorter form they measured 17.55 -> 18.6 us on the same box, their stores being the longer phase.)
+template <int MASK, bool ZP, bool PER_SLAB = false>
+__device__ __forceinline__ void fast_pack(float (&v)[kPack], const u32x2 mk, float thr, float s, float yr, float z, float qlo,
                                           float qhi, float (&dq)[kPack], bool& odd) {
 #pragma unroll
   for (int j = 0; j < kPack; ++j) {
@@ -99,10 +103,19 @@ __device__ __forceinline__ void fast_pack(float (&v)[kPack], const u32x2 mk, flo
       v[j] = (__builtin_fabsf(v[j]) > thr) ? v[j] : 0.0f;
     }
   }
-  const float yr = 1.0f / s;
   const float bound = s * 0x1p40f;
+  if constexpr (PER_SLAB) {
+    yr = 1.0f / s;
 #pragma unroll
-  for (int j = 0; j < kPack; ++j) odd |= !(__builtin_fabsf(v[j]) < bound);
+    for (int j = 0; j < kPack; ++j) odd |= !(__builtin_fabsf(v[j]) < bound);
+  } else {
+    // NaN, +-inf or |x| >= s * 2^40 anywhere in the pack: one compare on the NaN-propagating maximum of the eight
+    // magnitudes (v_maximum3_f32) instead of eight compares
+    float m = __builtin_fabsf(v[0]);
+#pragma unroll
+    for (int j = 1; j < kPack; ++j) m = __builtin_elementwise_maximum(m, __builtin_fabsf(v[j]));
+    odd |= !(m < bound);
+  }
 #pragma unroll
   for (int j = 0; j < kPack; j += 2) {
     const f32x2 t = fast_div2(f32x2{v[j], v[j + 1]}, s, yr);
@@ -209,6 +222,24 @@ __global__ __launch_bounds__(kResBlock) void qdq_resident_kernel(
     all_fast &= fast_div_ok(sc[u]);
     all_zero &= zp[u] == 0.0f;
   }
+  // the reciprocals of all U scales in one division: lane u holds slab u's
+  constexpr bool PER_SLAB = Tout::id == SBQ_F32;
+  float yr[U];
+  if constexpr (PER_SLAB) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) yr[u] = 0.0f;  // (fast_pack divides)
+  } else {
+    float sv = 1.0f;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      // sv[lane u] = sc[u]: one select under a constant lane mask (sc[u] is the same in every lane)
+      const unsigned long long only_u = 1ull << u;
+      asm("v_cndmask_b32 %0, %0, %1, %2" : "+v"(sv) : "v"(sc[u]), "s"(only_u));
+    }
+    const float yv = 1.0f / sv;
+#pragma unroll
+    for (int u = 0; u < U; ++u) yr[u] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, yv), u));
+  }
   __builtin_amdgcn_sched_barrier(0);
   if (all_fast) {  // wave-uniform
     // same-width input and output: the result overwrites the slab's input registers (an explicit alias: left to
@@ -242,7 +273,7 @@ __global__ __launch_bounds__(kResBlock) void qdq_resident_kernel(
         }
         float v[kPack], dq[kPack];
         unpack_raw<Tin>(raw[u], v);
-        fast_pack<MASK, ZP>(v, mk[u], thr, sc[u], zp[u], qlo, qhi, dq, odd);
+        fast_pack<MASK, ZP, PER_SLAB>(v, mk[u], thr, sc[u], yr[u], zp[u], qlo, qhi, dq, odd);
         OutPack<Tout> o;
         pack_out<Tout>(dq, o);
         out_d0(u) = o.d[0];
@@ -498,12 +529,14 @@ __global__ __launch_bounds__(kResBlock) void qdq_observe_kernel(
       if (max_out) max_out[row] = mx;
     }
   }
-  float sc[U], zp[U];
+  float sc[U], zp[U], yr[U];
   bool all_fast = true;
+  const float my_yr = 1.0f / my_sc;  // (one division for the wave's U slabs: lane u holds slab u's scale)
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     sc[u] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_sc), u));
     zp[u] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_zp), u));
+    yr[u] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_yr), u));
     all_fast &= fast_div_ok(sc[u]);
   }
   __builtin_amdgcn_sched_barrier(0);
@@ -522,7 +555,7 @@ __global__ __launch_bounds__(kResBlock) void qdq_observe_kernel(
         else asm volatile("; observe: symmetric" : "+v"(raw[u].d[0]));
         float v[kPack], dq[kPack];
         unpack_raw<Tin>(raw[u], v);
-        fast_pack<MASK_NONE, ZP>(v, u32x2{0, 0}, 0.0f, sc[u], zp[u], qlo, qhi, dq, odd);
+        fast_pack<MASK_NONE, ZP>(v, u32x2{0, 0}, 0.0f, sc[u], yr[u], zp[u], qlo, qhi, dq, odd);
         OutPack<Tout> o;
         pack_out<Tout>(dq, o);
         const uint32_t sl = sl0 + u * kResSub;

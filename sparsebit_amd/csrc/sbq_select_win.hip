@@ -40,6 +40,29 @@
 #ifndef SBQ_SEL_STAMPS
 #define SBQ_SEL_STAMPS 0  // -DSBQ_SEL_STAMPS=1: development timestamps (tools/lab/build_stamps.py)
 #endif
+// The forms of the fp32 / two-selector sweeps that round 6 replaced, kept behind macros for same-box A/B runs
+// (tools/lab/build_variant.py -D...; profiles/r06_fp32_selection_ab.log was taken with all five at their old values):
+#ifndef SBQ_FP32_NB
+#define SBQ_FP32_NB 2  // slab buffers of an fp32 sweep, 16 registers each (4: round 5 -- the kernels sat at the 128-register cap and spilled)
+#endif
+#ifndef SBQ_PCT16_NB
+#define SBQ_PCT16_NB 3  // the same for the two-selector sweeps of 16-bit inputs, 8 registers each (4: round 5)
+#endif
+#ifndef SBQ_PLAN_RUN_BYTES
+#define SBQ_PLAN_RUN_BYTES 128  // the plan's sample is taken in runs of one 128-byte line (32: round 5 -- every pack on a line of its own)
+#endif
+#ifndef SBQ_FP32_SPLIT_SLABS
+#define SBQ_FP32_SPLIT_SLABS 1  // a lane's two 16-byte loads of a lean fp32 slab half a region apart: contiguous KiB per wave instruction (0: stride 32 bytes)
+#endif
+#ifndef SBQ_COLLECT_FUSED
+#define SBQ_COLLECT_FUSED 1  // histogram add and candidate store in one predicated region (0: round 6's first form)
+#endif
+#ifndef SBQ_FP32_LATE_SLABS
+#define SBQ_FP32_LATE_SLABS 0  // lab: 1 = an fp32 selection requests its slabs AFTER the plan (the sample IS starved by them: plan done at 6.7 us
+#endif                         // instead of 14, but the stream then ends as late as before -- 1.2 us slower overall)
+#ifndef SBQ_SEL_WAVE_STAMPS
+#define SBQ_SEL_WAVE_STAMPS 0  // with SBQ_SEL_STAMPS: stamps of a workgroup's LAST wave too (how far apart do its waves run?)
+#endif
 // This file is compiled THREE times (sparsebit_amd/build.py): the one-launch engine's kernels are the largest of the
 // library -- 2.5 minutes of compilation for the three input types in one translation unit -- so each type's kernels
 // are instantiated in a unit of their own, behind a plain launcher function:
@@ -1016,9 +1039,6 @@ __device__ __forceinline__ bool win_sweep(const Tab& tab, int n_shards, const ui
     const void* x = tab.ptr[shard];
     const int64_t begin = n_lean ? static_cast<int64_t>(local) * kSlab : 0;
     const uint32_t stride = real ? kPack : 0u;
-#ifndef SBQ_FP32_SPLIT_SLABS
-#define SBQ_FP32_SPLIT_SLABS 1  // (0: round 5's stride-32-byte fp32 loads, for A/B runs)
-#endif
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       if constexpr (T::id == SBQ_F32 && SBQ_FP32_SPLIT_SLABS != 0) {
@@ -1039,12 +1059,6 @@ __device__ __forceinline__ bool win_sweep(const Tab& tab, int n_shards, const ui
   // (EARLY == false, the fallback launch: it usually finds nothing to do, so it looks at the state first)
   // FOUR slab buffers: a 16.7 M-element tensor on 256 CUs is four slabs per workgroup, all requested before the
   // selector state is known (the one-launch engine derives it from a sample meanwhile)
-#ifndef SBQ_FP32_NB
-#define SBQ_FP32_NB 2  // (4: round 5; slab buffers of an fp32 sweep (16 registers each; the kernels sit at the 128-register cap)
-#endif
-#ifndef SBQ_PCT16_NB
-#define SBQ_PCT16_NB 3  // (4: round 5) the same for the two-selector sweeps of 16-bit inputs (8 registers each)
-#endif
   constexpr int NB = T::id == SBQ_F32 ? SBQ_FP32_NB : (NSEL == 2 ? SBQ_PCT16_NB : 4);
   RawPack<T> buf[NB][U];
   auto issue_all = [&]() {
@@ -1105,9 +1119,6 @@ __device__ __forceinline__ bool win_sweep(const Tab& tab, int n_shards, const ui
   // the sweep counts (side 1: the keys ABOVE the window; the advance turns that into the keys below).
   constexpr bool ONESIDED = SIGNS && NSEL == 2;
   uint32_t c_fill = 0;  // uniform: keys this wave has found inside the window (COLLECT)
-#ifndef SBQ_COLLECT_FUSED
-#define SBQ_COLLECT_FUSED 1  // (0: round 6's first form, for A/B runs)
-#endif
   // (the fused form always writes: without a segment, into a spare word)
   uint32_t* const seg_w = cand_seg != nullptr ? cand_seg : &lds.cand_spare;
   const uint32_t seg_last = cand_seg != nullptr && cand_cap != 0 ? cand_cap - 1u : 0u;
@@ -1662,9 +1673,6 @@ __device__ __forceinline__ void one_stamp(const OneArgs& a, int i) {
 }
 // (-DSBQ_SEL_STAMPS=1 -DSBQ_SEL_WAVE_STAMPS=1: the same for the LAST wave of the workgroup -- how far apart do a
 // workgroup's waves run?)
-#ifndef SBQ_SEL_WAVE_STAMPS
-#define SBQ_SEL_WAVE_STAMPS 0
-#endif
 __device__ __forceinline__ void last_wave_stamp(const OneArgs& a, int i) {
   if constexpr (SBQ_SEL_STAMPS != 0 && SBQ_SEL_WAVE_STAMPS != 0) {
     if (a.stamps && threadIdx.x == blockDim.x - kWave) a.stamps[blockIdx.x * 32 + i] = __builtin_amdgcn_s_memrealtime();
@@ -2078,9 +2086,6 @@ __device__ __forceinline__ void win_one_body(const Tab& tab, int n_shards, const
   const int64_t n_packs = a.n / kPack < kPlanPacks ? (a.n / kPack > 0 ? a.n / kPack : 1) : kPlanPacks;
   // the sample first (vector-memory loads return in order: the plan must not wait for the slabs) ...
   PlanSample<T, BLOCK> sm;
-#ifndef SBQ_PLAN_RUN_BYTES
-#define SBQ_PLAN_RUN_BYTES 128  // (32: round 5 -- every pack on a line of its own)
-#endif
   constexpr int kRun = SBQ_PLAN_RUN_BYTES / (kPack * static_cast<int>(sizeof(typename T::storage))) > 1 ? SBQ_PLAN_RUN_BYTES / (kPack * static_cast<int>(sizeof(typename T::storage))) : 1;
   plan_sample_load<T, BLOCK, true, false, kRun>(tab, n_shards, a.n, n_packs, sm);
   __builtin_amdgcn_sched_barrier(0);
@@ -2103,9 +2108,6 @@ __device__ __forceinline__ void win_one_body(const Tab& tab, int n_shards, const
     if (a.cand_cap != 0) cand_seg = cand_lds + (threadIdx.x / kWave) * a.cand_cap;
     if (threadIdx.x == 0) ol.cand_bad = 0;
   }
-#ifndef SBQ_FP32_LATE_SLABS
-#define SBQ_FP32_LATE_SLABS 0  // lab: 1 = an fp32 selection requests its slabs AFTER the plan (is the sample starved by them?)
-#endif
   constexpr bool kEarly = !(SBQ_FP32_LATE_SLABS != 0 && T::id == SBQ_F32);
   win_sweep<T, NSEL, SIGNS, BLOCK, kEarly, true, true, true, COLLECT, ABS>(tab, n_shards, wg, nwg, [&](WinSel (&sel)[NSEL]) {
     one_stamp(a, 13);

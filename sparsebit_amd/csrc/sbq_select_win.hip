@@ -57,6 +57,9 @@
 #ifndef SBQ_COLLECT_FUSED
 #define SBQ_COLLECT_FUSED 1  // histogram add and candidate store in one predicated region (0: round 6's first form)
 #endif
+#ifndef SBQ_NARROW_ONE_COPY
+#define SBQ_NARROW_ONE_COPY 1  // the rounds out of LDS flush into -- and are gathered from -- ONE histogram copy (0: all eight)
+#endif
 #ifndef SBQ_FP32_LATE_SLABS
 #define SBQ_FP32_LATE_SLABS 0  // lab: 1 = an fp32 selection requests its slabs AFTER the plan (the sample IS starved by them: plan done at 6.7 us
 #endif                         // instead of 14, but the stream then ends as late as before -- 1.2 us slower overall)
@@ -80,6 +83,7 @@ constexpr int kWinBins = 2048;  // histogram bins per selector
 constexpr int kWinLog = 11;
 constexpr int kWinSel = 2;      // selectors (percentile: min side, max side)
 constexpr int kCopies = 8;      // copies of the global histogram (workgroup b adds to copy b % kCopies)
+constexpr bool kNarrowOneCopy = SBQ_NARROW_ONE_COPY != 0;
 constexpr int kSlots = 64;      // counter lines (workgroup b adds to line b % kSlots)
 constexpr int kPlanBins = 8192;  // plan: top 13 key bits (32 KB of LDS)
 constexpr int kPlanShift = 19;
@@ -1008,7 +1012,9 @@ __device__ __forceinline__ bool win_sweep(const Tab& tab, int n_shards, const ui
                                           LoadState&& load_state, WinSlot* __restrict__ slots,
                                           uint32_t* __restrict__ hist, int use_abs, SweepLds<NSEL, BLOCK>& lds,
                                           uint32_t* cand_seg = nullptr, const uint32_t cand_cap = 0,
-                                          uint32_t* cand_found = nullptr) {
+                                          uint32_t* cand_found = nullptr, const uint32_t copy_mod = kCopies) {
+  // (copy_mod: the histogram copies this sweep's flush spreads over -- 1 in the rounds out of LDS, whose few keys need
+  // no spreading and whose gather then reads one copy instead of eight)
   static_assert(!COLLECT || T::id == SBQ_F32, "candidates: fp32 keys");
   constexpr uint32_t kSlab = WinGeom<BLOCK>::kSlab;
   constexpr int U = WinGeom<BLOCK>::kU;
@@ -1553,7 +1559,7 @@ __device__ __forceinline__ bool win_sweep(const Tab& tab, int n_shards, const ui
 #pragma unroll
   for (int s = 0; s < NSEL; ++s) {
     if (!FLUSH || !act[s]) continue;
-    uint32_t* gh = hist + (static_cast<size_t>(wg % kCopies) * kWinSel + s) * kWinBins;
+    uint32_t* gh = hist + (static_cast<size_t>(wg % copy_mod) * kWinSel + s) * kWinBins;
     for (uint32_t i = threadIdx.x; i < static_cast<uint32_t>(kWinBins); i += BLOCK) {
       const uint32_t v = lh[s][i];
       if (v) atomicAdd(&gh[i], v);
@@ -1701,7 +1707,7 @@ __device__ __forceinline__ V one_take(V* p) {  // read and clear, at the memory 
 // per selector instead of 0.7)
 template <int NSEL, int BLOCK>
 __device__ __forceinline__ void one_advance(const int s, const OneArgs& a, OneLds& ol, const SweepLds<NSEL, BLOCK>* lonely,
-                            bool take_signs, AdvShared& sh) {
+                            bool take_signs, AdvShared& sh, const bool one_copy = false) {
   const WinSel w = ol.sel[s];
   __syncthreads();  // everyone holds w before anyone replaces it
   if (w.done) return;
@@ -1724,16 +1730,22 @@ __device__ __forceinline__ void one_advance(const int s, const OneArgs& a, OneLd
       uint32_t v[kCopies][kPer];
       uint32_t first_bin = threadIdx.x * kPer;  // (not a loop invariant: see one_advance_pair)
       asm volatile("" : "+v"(first_bin));
+      if (one_copy) {  // uniform: a round out of LDS flushed into copy 0 only
+        uint32_t* src = a.hist + static_cast<size_t>(s) * kWinBins + first_bin;
 #pragma unroll
-      for (int c = 0; c < kCopies; ++c) {
-        uint32_t* src = a.hist + (static_cast<size_t>(c) * kWinSel + s) * kWinBins + first_bin;
+        for (int i = 0; i < kPer; ++i) bins[i] = one_take(src + i);
+      } else {
 #pragma unroll
-        for (int i = 0; i < kPer; ++i) v[c][i] = one_take(src + i);
+        for (int c = 0; c < kCopies; ++c) {
+          uint32_t* src = a.hist + (static_cast<size_t>(c) * kWinSel + s) * kWinBins + first_bin;
+#pragma unroll
+          for (int i = 0; i < kPer; ++i) v[c][i] = one_take(src + i);
+        }
+#pragma unroll
+        for (int c = 0; c < kCopies; ++c)
+#pragma unroll
+          for (int i = 0; i < kPer; ++i) bins[i] += v[c][i];
       }
-#pragma unroll
-      for (int c = 0; c < kCopies; ++c)
-#pragma unroll
-        for (int i = 0; i < kPer; ++i) bins[i] += v[c][i];
     }
     if (threadIdx.x < kSlots) {
       c_below = one_take(&a.slots[threadIdx.x].below[s]);
@@ -1763,7 +1775,7 @@ __device__ __forceinline__ void one_advance(const int s, const OneArgs& a, OneLd
 // are still unresolved; the counts of a first sweep (take_signs) are taken by half 0 and handed to half 1.
 template <int BLOCK>
 __device__ __forceinline__ void one_advance_pair(const OneArgs& a, OneLds& ol, bool take_signs, AdvShared (&sh)[2],
-                                                 uint32_t (&acc)[2][kWinBins]) {
+                                                 uint32_t (&acc)[2][kWinBins], const bool one_copy = false) {
   constexpr int NT = BLOCK / 2;
   static_assert(NT % kWave == 0 && NT >= kSlots, "a half is whole waves and holds the counter lines");
   const int s = threadIdx.x / NT;  // wave-uniform
@@ -1802,7 +1814,7 @@ __device__ __forceinline__ void one_advance_pair(const OneArgs& a, OneLds& ol, b
     // (two bins per exchange: the words of a copy share a few cache lines, and read-modify-writes on one line are
     // served one after the other)
     const uint32_t lgw = lg > 0 ? lg - 1u : 0u;  // log2 of the 8-byte words per copy that are touched
-    const uint32_t total = static_cast<uint32_t>(kCopies) << lgw;  // a power of two
+    const uint32_t total = (one_copy ? 1u : static_cast<uint32_t>(kCopies)) << lgw;  // a power of two
     // Every exchange of a batch is issued unconditionally (behind a condition each would wait for the one before:
     // four round trips instead of one).  Slots past the end wrap around -- a word taken twice reads zero the second
     // time -- and the bins between nb and 2^lg were never added to.
@@ -1824,7 +1836,12 @@ __device__ __forceinline__ void one_advance_pair(const OneArgs& a, OneLds& ol, b
         if (hi_) atomicAdd(&acc[s][b + 1u], hi_);
       }
     };
-    if (total <= static_cast<uint32_t>(NT)) batch(std::integral_constant<int, 1>(), 0u);
+    if (total <= static_cast<uint32_t>(NT)) {
+      // one exchange per word, by the first `total` threads only: wrapped around (as the larger batches are), a window
+      // of two bins had every thread of the half take the SAME word -- 512 read-modify-writes on one address, one after
+      // the other: 15 us of the last round of an fp32 percentile (64 per word, 2 us, while there were eight copies)
+      if (static_cast<uint32_t>(tid) < total) batch(std::integral_constant<int, 1>(), 0u);
+    }
     else if (total <= 4u * NT) batch(std::integral_constant<int, 4>(), 0u);
     else
       for (uint32_t base = 0; base < total; base += 16u * NT) batch(std::integral_constant<int, 16>(), base);
@@ -1869,7 +1886,7 @@ template <typename T, int NSEL, int BLOCK, typename Tab>
 __device__ __forceinline__ bool win_finish(const Tab& tab, int n_shards, const OneArgs& a, const uint32_t wg,
                                            const uint32_t nwg, OneLds& ol, SweepLds<NSEL, BLOCK>& swl,
                                            AdvShared (&adv)[2], bool signs_in_slots, const bool resident,
-                                           const uint32_t round) {
+                                           const uint32_t round, const bool one_copy = false) {
   // this workgroup's adds are acknowledged before its arrival is counted
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __builtin_amdgcn_s_waitcnt(0);
@@ -1955,10 +1972,10 @@ __device__ __forceinline__ bool win_finish(const Tab& tab, int n_shards, const O
   bool pair = false;
   if constexpr (NSEL == 2) pair = !ol.sel[0].done && !ol.sel[1].done;
   if (pair) {
-    if constexpr (NSEL == 2) one_advance_pair<BLOCK>(a, ol, signs_in_slots, adv, swl.lh);
+    if constexpr (NSEL == 2) one_advance_pair<BLOCK>(a, ol, signs_in_slots, adv, swl.lh, one_copy);
   } else {
 #pragma unroll
-    for (int s = 0; s < NSEL; ++s) one_advance<NSEL, BLOCK>(s, a, ol, nullptr, signs_in_slots && s == 0, adv[0]);
+    for (int s = 0; s < NSEL; ++s) one_advance<NSEL, BLOCK>(s, a, ol, nullptr, signs_in_slots && s == 0, adv[0], one_copy);
   }
   one_stamp(a, 6);
   if (!a.final_round) {
@@ -2200,7 +2217,9 @@ __device__ __forceinline__ void win_one_body(const Tab& tab, int n_shards, const
 #pragma unroll
           for (int s = 0; s < NSEL; ++s) {
             if (!act[s]) continue;
-            uint32_t* gh = a.hist + (static_cast<size_t>(wg % kCopies) * kWinSel + s) * kWinBins;
+            // (copy 0 only: a round out of LDS adds a handful of keys per workgroup -- nothing to spread -- and the last
+            // arriver then gathers 2048 words per selector instead of 16 384: SBQ_NARROW_ONE_COPY)
+            uint32_t* gh = a.hist + (static_cast<size_t>(kNarrowOneCopy ? 0u : wg % kCopies) * kWinSel + s) * kWinBins;
             const uint32_t nb = (span[s] >> sh[s]) + 1u;
             for (uint32_t i = threadIdx.x; i < nb; i += BLOCK) {
               const uint32_t v = swl.lh[s][i];
@@ -2220,10 +2239,10 @@ __device__ __forceinline__ void win_one_body(const Tab& tab, int n_shards, const
               w.side = __builtin_amdgcn_readfirstlane(w.side);
               sel[s] = w;
             }
-          }, a.slots, a.hist, a.use_abs, swl);
+          }, a.slots, a.hist, a.use_abs, swl, nullptr, 0u, nullptr, kNarrowOneCopy ? 1u : static_cast<uint32_t>(kCopies));
         }
         one_stamp(a, 22 + (round < 5 ? round : 5));  // 24, 25, 26: flushed round 2, 3, 4
-        again = win_finish<T, NSEL, BLOCK>(tab, n_shards, a, wg, nwg, ol, swl, adv, false, true, round);
+        again = win_finish<T, NSEL, BLOCK>(tab, n_shards, a, wg, nwg, ol, swl, adv, false, true, round, kNarrowOneCopy);
       }
     }
   }

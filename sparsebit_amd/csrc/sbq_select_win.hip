@@ -1842,6 +1842,7 @@ __device__ __forceinline__ void one_advance_pair(const OneArgs& a, OneLds& ol, b
       // the other: 15 us of the last round of an fp32 percentile (64 per word, 2 us, while there were eight copies)
       if (static_cast<uint32_t>(tid) < total) batch(std::integral_constant<int, 1>(), 0u);
     }
+    else if (total <= 2u * NT) batch(std::integral_constant<int, 2>(), 0u);  // (total is a power of two: exactly 2 NT -- no word twice)
     else if (total <= 4u * NT) batch(std::integral_constant<int, 4>(), 0u);
     else
       for (uint32_t base = 0; base < total; base += 16u * NT) batch(std::integral_constant<int, 16>(), base);

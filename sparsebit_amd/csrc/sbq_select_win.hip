@@ -60,6 +60,9 @@
 #ifndef SBQ_NARROW_ONE_COPY
 #define SBQ_NARROW_ONE_COPY 1  // the rounds out of LDS flush into -- and are gathered from -- ONE histogram copy (0: all eight)
 #endif
+#ifndef SBQ_PCT_FIRST_COPIES
+#define SBQ_PCT_FIRST_COPIES 2  // histogram copies of the fp32 percentile's FIRST sweep when its windows are sparse (8: round 5)
+#endif
 #ifndef SBQ_FP32_LATE_SLABS
 #define SBQ_FP32_LATE_SLABS 0  // lab: 1 = an fp32 selection requests its slabs AFTER the plan (the sample IS starved by them: plan done at 6.7 us
 #endif                         // instead of 14, but the stream then ends as late as before -- 1.2 us slower overall)
@@ -84,6 +87,7 @@ constexpr int kWinLog = 11;
 constexpr int kWinSel = 2;      // selectors (percentile: min side, max side)
 constexpr int kCopies = 8;      // copies of the global histogram (workgroup b adds to copy b % kCopies)
 constexpr bool kNarrowOneCopy = SBQ_NARROW_ONE_COPY != 0;
+constexpr uint32_t kSparseCopies = SBQ_PCT_FIRST_COPIES;  // copies of a first sweep whose windows hold < 1/64 of the data each
 constexpr int kSlots = 64;      // counter lines (workgroup b adds to line b % kSlots)
 constexpr int kPlanBins = 8192;  // plan: top 13 key bits (32 KB of LDS)
 constexpr int kPlanShift = 19;
@@ -1096,6 +1100,15 @@ __device__ __forceinline__ bool win_sweep(const Tab& tab, int n_shards, const ui
     live |= act[s];
   }
   if (!live) return false;
+  // (copy_mod == 0: windows at the ends of the data -- no selector's bracket is dense, WinSel::side bit 2 -- are spread
+  // over kSparseCopies copies only: win_first_copies, which the caller's gather uses too)
+  uint32_t flush_copies = copy_mod;
+  if (copy_mod == 0) {
+    uint32_t sides = 0;
+#pragma unroll
+    for (int s = 0; s < NSEL; ++s) sides |= act[s] ? sel[s].side : 0u;
+    flush_copies = (sides & 4u) ? static_cast<uint32_t>(kCopies) : kSparseCopies;
+  }
   if (!EARLY && (ALWAYS || n_lean > 0)) issue_all();
   for (uint32_t i = threadIdx.x; i < NSEL * kWinBins; i += BLOCK) (&lh[0][0])[i] = 0;
   lds_sync();  // (not __syncthreads(): the slabs are in flight)
@@ -1559,7 +1572,7 @@ __device__ __forceinline__ bool win_sweep(const Tab& tab, int n_shards, const ui
 #pragma unroll
   for (int s = 0; s < NSEL; ++s) {
     if (!FLUSH || !act[s]) continue;
-    uint32_t* gh = hist + (static_cast<size_t>(wg % copy_mod) * kWinSel + s) * kWinBins;
+    uint32_t* gh = hist + (static_cast<size_t>(wg % flush_copies) * kWinSel + s) * kWinBins;
     for (uint32_t i = threadIdx.x; i < static_cast<uint32_t>(kWinBins); i += BLOCK) {
       const uint32_t v = lh[s][i];
       if (v) atomicAdd(&gh[i], v);
@@ -1707,7 +1720,7 @@ __device__ __forceinline__ V one_take(V* p) {  // read and clear, at the memory 
 // per selector instead of 0.7)
 template <int NSEL, int BLOCK>
 __device__ __forceinline__ void one_advance(const int s, const OneArgs& a, OneLds& ol, const SweepLds<NSEL, BLOCK>* lonely,
-                            bool take_signs, AdvShared& sh, const bool one_copy = false) {
+                            bool take_signs, AdvShared& sh, const uint32_t copies = kCopies) {
   const WinSel w = ol.sel[s];
   __syncthreads();  // everyone holds w before anyone replaces it
   if (w.done) return;
@@ -1730,10 +1743,15 @@ __device__ __forceinline__ void one_advance(const int s, const OneArgs& a, OneLd
       uint32_t v[kCopies][kPer];
       uint32_t first_bin = threadIdx.x * kPer;  // (not a loop invariant: see one_advance_pair)
       asm volatile("" : "+v"(first_bin));
-      if (one_copy) {  // uniform: a round out of LDS flushed into copy 0 only
-        uint32_t* src = a.hist + static_cast<size_t>(s) * kWinBins + first_bin;
+      if (copies != static_cast<uint32_t>(kCopies)) {  // uniform: the sweep flushed into the first `copies` copies only (1: a round out of LDS)
+        for (uint32_t c = 0; c < copies; ++c) {
+          uint32_t* src = a.hist + (static_cast<size_t>(c) * kWinSel + s) * kWinBins + first_bin;
+          uint32_t t[kPer];
 #pragma unroll
-        for (int i = 0; i < kPer; ++i) bins[i] = one_take(src + i);
+          for (int i = 0; i < kPer; ++i) t[i] = one_take(src + i);
+#pragma unroll
+          for (int i = 0; i < kPer; ++i) bins[i] += t[i];
+        }
       } else {
 #pragma unroll
         for (int c = 0; c < kCopies; ++c) {
@@ -1775,7 +1793,7 @@ __device__ __forceinline__ void one_advance(const int s, const OneArgs& a, OneLd
 // are still unresolved; the counts of a first sweep (take_signs) are taken by half 0 and handed to half 1.
 template <int BLOCK>
 __device__ __forceinline__ void one_advance_pair(const OneArgs& a, OneLds& ol, bool take_signs, AdvShared (&sh)[2],
-                                                 uint32_t (&acc)[2][kWinBins], const bool one_copy = false) {
+                                                 uint32_t (&acc)[2][kWinBins], const uint32_t copies = kCopies) {
   constexpr int NT = BLOCK / 2;
   static_assert(NT % kWave == 0 && NT >= kSlots, "a half is whole waves and holds the counter lines");
   const int s = threadIdx.x / NT;  // wave-uniform
@@ -1814,7 +1832,7 @@ __device__ __forceinline__ void one_advance_pair(const OneArgs& a, OneLds& ol, b
     // (two bins per exchange: the words of a copy share a few cache lines, and read-modify-writes on one line are
     // served one after the other)
     const uint32_t lgw = lg > 0 ? lg - 1u : 0u;  // log2 of the 8-byte words per copy that are touched
-    const uint32_t total = (one_copy ? 1u : static_cast<uint32_t>(kCopies)) << lgw;  // a power of two
+    const uint32_t total = copies << lgw;  // a power of two (copies: 1, 2, 4 or 8)
     // Every exchange of a batch is issued unconditionally (behind a condition each would wait for the one before:
     // four round trips instead of one).  Slots past the end wrap around -- a word taken twice reads zero the second
     // time -- and the bins between nb and 2^lg were never added to.
@@ -1887,7 +1905,7 @@ template <typename T, int NSEL, int BLOCK, typename Tab>
 __device__ __forceinline__ bool win_finish(const Tab& tab, int n_shards, const OneArgs& a, const uint32_t wg,
                                            const uint32_t nwg, OneLds& ol, SweepLds<NSEL, BLOCK>& swl,
                                            AdvShared (&adv)[2], bool signs_in_slots, const bool resident,
-                                           const uint32_t round, const bool one_copy = false) {
+                                           const uint32_t round, const uint32_t copies = kCopies) {
   // this workgroup's adds are acknowledged before its arrival is counted
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __builtin_amdgcn_s_waitcnt(0);
@@ -1973,10 +1991,10 @@ __device__ __forceinline__ bool win_finish(const Tab& tab, int n_shards, const O
   bool pair = false;
   if constexpr (NSEL == 2) pair = !ol.sel[0].done && !ol.sel[1].done;
   if (pair) {
-    if constexpr (NSEL == 2) one_advance_pair<BLOCK>(a, ol, signs_in_slots, adv, swl.lh, one_copy);
+    if constexpr (NSEL == 2) one_advance_pair<BLOCK>(a, ol, signs_in_slots, adv, swl.lh, copies);
   } else {
 #pragma unroll
-    for (int s = 0; s < NSEL; ++s) one_advance<NSEL, BLOCK>(s, a, ol, nullptr, signs_in_slots && s == 0, adv[0], one_copy);
+    for (int s = 0; s < NSEL; ++s) one_advance<NSEL, BLOCK>(s, a, ol, nullptr, signs_in_slots && s == 0, adv[0], copies);
   }
   one_stamp(a, 6);
   if (!a.final_round) {
@@ -2127,6 +2145,10 @@ __device__ __forceinline__ void win_one_body(const Tab& tab, int n_shards, const
     if (threadIdx.x == 0) ol.cand_bad = 0;
   }
   constexpr bool kEarly = !(SBQ_FP32_LATE_SLABS != 0 && T::id == SBQ_F32);
+  // the fp32 percentile's first sweep keeps its keys (COLLECT) in windows at the two ends of the data -- a fraction of
+  // a per cent of the elements: its flush needs less spreading than a window in the bulk, and the pair gather reads
+  // `copies` x 2048 words per selector
+  constexpr uint32_t kFirstCopies = COLLECT && NSEL == 2 ? 0u : static_cast<uint32_t>(kCopies);  // (0: by the windows' density)
   win_sweep<T, NSEL, SIGNS, BLOCK, kEarly, true, true, true, COLLECT, ABS>(tab, n_shards, wg, nwg, [&](WinSel (&sel)[NSEL]) {
     one_stamp(a, 13);
     one_stamp(a, 1);
@@ -2161,7 +2183,7 @@ __device__ __forceinline__ void win_one_body(const Tab& tab, int n_shards, const
       w.side = __builtin_amdgcn_readfirstlane(w.side);
       sel[s] = w;
     }
-  }, a.slots, a.hist, a.use_abs, swl, cand_seg, a.cand_cap, &cand_found);
+  }, a.slots, a.hist, a.use_abs, swl, cand_seg, a.cand_cap, &cand_found, kFirstCopies);
   one_stamp(a, 3);
   const bool resident = win_is_resident<NSEL>(a, ol);
   // (the windows the candidates were kept for: every workgroup holds the plan's)
@@ -2174,7 +2196,14 @@ __device__ __forceinline__ void win_one_body(const Tab& tab, int n_shards, const
   if constexpr (COLLECT) {
     if (cand_seg != nullptr && (threadIdx.x & (kWave - 1)) == 0 && cand_found > a.cand_cap) ol.cand_bad = 1;  // (before win_finish's barriers)
   }
-  bool again = win_finish<T, NSEL, BLOCK>(tab, n_shards, a, wg, nwg, ol, swl, adv, SIGNS, resident, 1u);
+  uint32_t first_copies = kFirstCopies;
+  if constexpr (kFirstCopies == 0) {  // the sweep's own rule (win_sweep), on the plan's windows
+    uint32_t sides = 0;
+#pragma unroll
+    for (int s = 0; s < NSEL; ++s) sides |= ol.sel[s].done == 0 ? ol.sel[s].side : 0u;
+    first_copies = (__builtin_amdgcn_readfirstlane(sides) & 4u) ? static_cast<uint32_t>(kCopies) : kSparseCopies;
+  }
+  bool again = win_finish<T, NSEL, BLOCK>(tab, n_shards, a, wg, nwg, ol, swl, adv, SIGNS, resident, 1u, first_copies);
   uint32_t round = 2;
   if constexpr (COLLECT) {
     // The rounds after the first, out of LDS: while every workgroup of the selection is still there (nobody resigned:
@@ -2243,7 +2272,7 @@ __device__ __forceinline__ void win_one_body(const Tab& tab, int n_shards, const
           }, a.slots, a.hist, a.use_abs, swl, nullptr, 0u, nullptr, kNarrowOneCopy ? 1u : static_cast<uint32_t>(kCopies));
         }
         one_stamp(a, 22 + (round < 5 ? round : 5));  // 24, 25, 26: flushed round 2, 3, 4
-        again = win_finish<T, NSEL, BLOCK>(tab, n_shards, a, wg, nwg, ol, swl, adv, false, true, round, kNarrowOneCopy);
+        again = win_finish<T, NSEL, BLOCK>(tab, n_shards, a, wg, nwg, ol, swl, adv, false, true, round, kNarrowOneCopy ? 1u : static_cast<uint32_t>(kCopies));
       }
     }
   }

@@ -38,11 +38,12 @@ def timed(fn, iters=300):
 ref_g = torch.stack([ops.kth_value(w, k, True) for w, k in zip(ws, ks)])
 assert torch.equal(ops.group_kth_value(ws, ks, True), ref_g)
 acts16 = [a.bfloat16() for a in acts]
+w16 = (torch.randn(4096, 4096, generator=g) * torch.logspace(-2, 1, 4096).unsqueeze(1)).to(dev).bfloat16()
 big16 = torch.randn(25_600_000, generator=g).to(dev).bfloat16()
 huge16 = torch.randn(40_000_000, generator=g).to(dev).bfloat16()
 for rep in range(3):
     print("model-wide thresholds %.1f us | kth 25.6M fp32 %.1f us | kth 32 K fp32 (one workgroup) %.1f us | percentile 4 x 4.8M fp32 %.1f us | kth 25.6M "
-          "bf16 %.1f us | kth 40M bf16 %.1f us | percentile 4 x 4.8M bf16 %.1f us | percentile 40M bf16 %.1f us" % (
+          "bf16 %.1f us | kth 40M bf16 %.1f us | percentile 4 x 4.8M bf16 %.1f us | percentile 40M bf16 %.1f us | 4096^2 bf16 (full-histogram engine): kth %.1f us, percentile %.1f us" % (
         timed(lambda: ops.group_kth_value(ws, ks, True)),
         timed(lambda: ops.kth_value(big, 12_800_000, True)),
         timed(lambda: ops.kth_value(ws[10], ks[10], True)),
@@ -50,4 +51,6 @@ for rep in range(3):
         timed(lambda: ops.kth_value(big16, 12_800_000, True)),
         timed(lambda: ops.kth_value(huge16, 20_000_000, True)),
         timed(lambda: ops.percentile_select(acts16, 1e-3, 0, False)),
-        timed(lambda: ops.percentile_select([huge16], 1e-3, 0, False))), flush=True)
+        timed(lambda: ops.percentile_select([huge16], 1e-3, 0, False)),
+        timed(lambda: ops.kth_value(w16, 8_388_609, True)),
+        timed(lambda: ops.percentile_select([w16], 1e-3, 0, False))), flush=True)
